@@ -1,0 +1,144 @@
+/*
+ * polychase_hip.h -- C ABI of the MI355X (gfx950) video-analysis hot path.
+ *
+ * This is the drop-in boundary BELOW the reference's pybind11 module `polychase_core`
+ * (/root/reference/cpp/polychase_pybind.cc:29): the reference has no FFI of its own, its host C++
+ * calls OpenCV directly.  Each entry point below replaces one OpenCV / in-repo call on the path
+ * GenerateOpticalFlowDatabase (cpp/opticalflow.cc:209-321) and cites it.  Plain pointers and sizes
+ * only; no torch / Eigen / OpenCV types.  All functions return 0 on success, a negative PC_E_* code
+ * on failure; pc_last_error() returns the message of the calling thread's last failure.
+ *
+ * Memory: "host" pointers are ordinary (or pinned) CPU memory; "device" pointers are HIP device
+ * memory of the context's GPU (e.g. torch.Tensor.data_ptr()).  Work is enqueued on the context's HIP
+ * stream; functions that return data to the host synchronise that stream themselves.
+ *
+ * There is NO CPU fallback: every function fails with PC_E_NO_DEVICE when no gfx950 device is
+ * usable.
+ */
+#ifndef POLYCHASE_HIP_H_
+#define POLYCHASE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PC_OK 0
+#define PC_E_INVALID (-1)     /* bad argument / unsupported option */
+#define PC_E_NO_DEVICE (-2)   /* no usable HIP device */
+#define PC_E_HIP (-3)         /* a HIP runtime call failed */
+#define PC_E_CAPACITY (-4)    /* caller buffer too small */
+#define PC_E_STATE (-5)       /* call sequence error (e.g. frame has no keypoints) */
+
+#define PC_MAX_TARGETS 8      /* the reference tracks each frame into <= 8 neighbours (opticalflow.cc:76-77) */
+#define PC_MAX_LEVELS 8
+#define PC_MAX_WINDOW 16
+
+typedef struct pc_context pc_context;
+typedef struct pc_frame pc_frame;
+
+/* GFTTOptions, cpp/feature_detection/gftt.h:5-21 (same fields, same defaults) */
+typedef struct pc_gftt_options {
+    double quality_level; /* 0.01 */
+    double min_distance;  /* 5.0 */
+    int block_size;       /* 3   (only 3 is implemented on the device) */
+    int gradient_size;    /* 3   (only 3) */
+    int max_corners;      /* 0 = unlimited */
+    int use_harris;       /* 0   (harris branch not implemented: PC_E_INVALID) */
+    double harris_k;      /* 0.04 */
+    int grid_rows;        /* 4 */
+    int grid_cols;        /* 4 */
+} pc_gftt_options;
+
+/* OpticalFlowOptions, cpp/opticalflow.h:27-33 */
+typedef struct pc_flow_options {
+    int window_size;            /* 10  (3..PC_MAX_WINDOW) */
+    int max_level;              /* 3   (0..PC_MAX_LEVELS-1) */
+    int term_max_iters;         /* 30 */
+    double term_epsilon;        /* 0.01 */
+    double min_eigen_threshold; /* 1e-4 */
+} pc_flow_options;
+
+void pc_gftt_default_options(pc_gftt_options* o);
+void pc_flow_default_options(pc_flow_options* o);
+
+const char* pc_last_error(void);
+/* Library / build identification ("polychase_hip gfx950 ..."). */
+const char* pc_version(void);
+
+/* ---- context: one per GPU (one process per GPU in multi-GPU runs) ---- */
+int pc_context_create(int device_index, pc_context** out);
+void pc_context_destroy(pc_context* ctx);
+int pc_context_synchronize(pc_context* ctx);
+/* hipStream_t the context enqueues on (for callers that time with HIP events / torch streams). */
+void* pc_context_stream(pc_context* ctx);
+/* Timing of the context's kernels with HIP events on the context stream.  While enabled every
+ * kernel class accumulates (launches, total ms).  Classes: see PC_K_* below. */
+int pc_context_enable_timing(pc_context* ctx, int enable);
+int pc_context_get_timing(pc_context* ctx, int kernel_class, int* launches, double* total_ms);
+int pc_context_reset_timing(pc_context* ctx);
+#define PC_K_GRAY 0
+#define PC_K_PYRAMID 1
+#define PC_K_MINEIG 2
+#define PC_K_NMS 3
+#define PC_K_SORT 4
+#define PC_K_SUPPRESS 5
+#define PC_K_LK 6
+#define PC_K_COMPACT 7
+#define PC_K_COUNT 8
+
+/* ---- frame: gray image + LK pyramid (+ Scharr derivative planes) + keypoints, resident in HBM ----
+ * Replaces the per-frame state of cpp/opticalflow.cc:223-226 (frame1_gray, features, frame1_pyramid)
+ * and OpticalFlowCache (:18-37). */
+int pc_frame_create(pc_context* ctx, int width, int height, int window_size, int max_level,
+                    pc_frame** out);
+void pc_frame_destroy(pc_frame* f);
+
+/* cv::cvtColor(COLOR_RGB2GRAY) (opticalflow.cc:259,:298) + cv::buildOpticalFlowPyramid
+ * (opticalflow.cc:180-187) in one call.  rgb: H rows of W*3 bytes, row_pitch bytes apart.
+ * on_device != 0: rgb is a device pointer; otherwise host memory (copied to the GPU first).
+ * Clears the frame's keypoints. */
+int pc_frame_set_rgb(pc_context* ctx, pc_frame* f, const uint8_t* rgb, size_t row_pitch, int on_device);
+/* Same, from an 8-bit gray image (tests / callers that already hold gray). */
+int pc_frame_set_gray(pc_context* ctx, pc_frame* f, const uint8_t* gray, size_t row_pitch, int on_device);
+
+int pc_frame_num_levels(const pc_frame* f); /* = maxLevel returned by buildOpticalFlowPyramid + 1 */
+int pc_frame_level_size(const pc_frame* f, int level, int* width, int* height);
+/* Read-back (tests, debugging).  Layouts are tightly packed, matching OpenCV's padded pyramid:
+ * image  (h + 2*win) x (w + 2*win) u8, REFLECT_101 border;
+ * deriv  (h + 2*win) x (w + 2*win) x 2 int16 (dx,dy interleaved), zero border. */
+int pc_frame_download_gray(pc_context* ctx, const pc_frame* f, uint8_t* out_gray);
+int pc_frame_download_level(pc_context* ctx, const pc_frame* f, int level, uint8_t* out_padded);
+int pc_frame_download_deriv(pc_context* ctx, const pc_frame* f, int level, int16_t* out_padded);
+
+/* GoodFeaturesToTrack (cpp/feature_detection/gftt.cc:14-192, called at opticalflow.cc:160) on the
+ * frame's gray image; keypoints stay on the device, in acceptance order. */
+int pc_frame_detect(pc_context* ctx, pc_frame* f, const pc_gftt_options* opt);
+/* cv::cornerMinEigenVal map of the last pc_frame_detect (gftt.cc:35), w*h floats (tests). */
+int pc_frame_download_min_eig(pc_context* ctx, const pc_frame* f, float* out_eig);
+/* Number of local-maximum candidates of the last pc_frame_detect (gftt.cc:76-86) (tests). */
+int pc_frame_num_candidates(pc_context* ctx, const pc_frame* f, int* out_n);
+int pc_frame_num_keypoints(pc_context* ctx, const pc_frame* f, int* out_n);
+int pc_frame_download_keypoints(pc_context* ctx, const pc_frame* f, float* out_xy, int capacity);
+/* Keypoints read back from the database on resume (opticalflow.cc:168-178). host pointer, n x 2. */
+int pc_frame_set_keypoints(pc_context* ctx, pc_frame* f, const float* xy, int n);
+
+/* cv::calcOpticalFlowPyrLK(frame1 pyramid, target pyramid, frame1 keypoints, ...) (opticalflow.cc:119-125)
+ * for n_targets targets in one launch.  Raw outputs (host pointers), target-major:
+ *   next_xy [n_targets][N][2], status [n_targets][N], err [n_targets][N],  N = keypoints of frame1. */
+int pc_lk_track(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targets, int n_targets,
+                const pc_flow_options* opt, float* next_xy, uint8_t* status, float* err);
+
+/* Same + the status==1 filter of opticalflow.cc:130-147, compacted on the device, ascending
+ * keypoint index.  Host outputs, each with room for n_targets*N rows; rows of target t start at
+ * row_offset[t] (row_offset has n_targets+1 entries; row_offset[n_targets] = total rows). */
+int pc_lk_track_filtered(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targets,
+                         int n_targets, const pc_flow_options* opt, uint32_t* src_indices,
+                         float* tgt_xy, float* flow_err, int64_t* row_offset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLYCHASE_HIP_H_ */

@@ -1,0 +1,733 @@
+// api.hip -- implementation of the C ABI declared in include/polychase_hip.h.
+//
+// Host-side orchestration only: HBM plane layout, stream ordering, read-backs, and the two pieces of
+// GoodFeaturesToTrack that are sequential by definition (greedy min-distance suppression,
+// reference cpp/feature_detection/gftt.cc:100-164).  No pixel arithmetic happens on the CPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../../include/polychase_hip.h"
+#include "kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define PC_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(PC_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+template <typename T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct TimedRange {
+    int cls;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct pc_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // staging of host-provided frames
+    DevBuf<uint8_t> staging;
+    // GFTT scratch
+    DevBuf<float> eig;
+    DevBuf<unsigned long long> keys_in, keys_out;
+    DevBuf<uint32_t> counters;  // [0] candidate counter, [1..] cell max keys
+    DevBuf<uint8_t> sort_temp;
+    PinBuf<unsigned long long> h_keys;
+    PinBuf<float> h_kps;
+    PinBuf<uint32_t> h_counter;
+    const pc_frame* eig_owner = nullptr;
+    // LK scratch
+    DevBuf<float2> lk_xy, lk_cxy;
+    DevBuf<uint8_t> lk_status;
+    DevBuf<float> lk_err, lk_cerr;
+    DevBuf<uint32_t> lk_cidx, lk_block_counts;
+    DevBuf<long long> lk_row_offset;
+    PinBuf<long long> h_row_offset;
+    // timing
+    bool timing = false;
+    std::vector<TimedRange> ranges;
+    std::vector<hipEvent_t> event_pool;
+    int launches[PC_K_COUNT] = {0};
+    double total_ms[PC_K_COUNT] = {0};
+};
+
+struct pc_frame {
+    pc_context* ctx = nullptr;
+    int w = 0, h = 0, win = 0, max_level = 0, nlevels = 0;
+    pc::Level levels[PC_MAX_LEVELS];
+    uint8_t* slab = nullptr;
+    size_t slab_bytes = 0;
+    float2* d_kps = nullptr;
+    int kp_cap = 0;
+    int n_kps = -1;   // -1: none
+    int n_cands = -1;
+};
+
+namespace {
+
+struct ScopedTimer {
+    pc_context* c;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(pc_context* ctx, int k) : c(ctx), cls(k) {
+        if (!c->timing) return;
+        auto get = [&]() {
+            hipEvent_t e = nullptr;
+            if (!c->event_pool.empty()) {
+                e = c->event_pool.back();
+                c->event_pool.pop_back();
+            } else {
+                (void)hipEventCreate(&e);
+            }
+            return e;
+        };
+        a = get();
+        b = get();
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~ScopedTimer() {
+        if (!c->timing || !a) return;
+        (void)hipEventRecord(b, c->stream);
+        c->ranges.push_back({cls, a, b});
+    }
+};
+
+int collect_timing(pc_context* c) {
+    if (c->ranges.empty()) return PC_OK;
+    PC_HIP(hipStreamSynchronize(c->stream));
+    for (auto& r : c->ranges) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            c->launches[r.cls] += 1;
+            c->total_ms[r.cls] += ms;
+        }
+        c->event_pool.push_back(r.a);
+        c->event_pool.push_back(r.b);
+    }
+    c->ranges.clear();
+    return PC_OK;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// greedy min-distance suppression, reference gftt.cc:100-164 (and :165-181 when min_distance < 1).
+// keys: sorted (value desc, linear index desc).  Output: accepted corners in acceptance order.
+int suppress_min_distance(const unsigned long long* keys, size_t total, int w, int h, double min_distance,
+                          int max_corners, std::vector<float>& out_xy) {
+    out_xy.clear();
+    size_t ncorners = 0;
+    if (min_distance >= 1) {
+        const int cell_size = (int)std::lrint(min_distance);  // cvRound
+        const int grid_w = (w + cell_size - 1) / cell_size;
+        const int grid_h = (h + cell_size - 1) / cell_size;
+        std::vector<int32_t> head((size_t)grid_w * grid_h, -1);
+        std::vector<int32_t> next;
+        next.reserve(total / 4 + 16);
+        const double min_dist_sq = min_distance * min_distance;
+        for (size_t i = 0; i < total; i++) {
+            const uint32_t idx = (uint32_t)(keys[i] & 0xffffffffull);
+            const int y = (int)(idx / (uint32_t)w);
+            const int x = (int)(idx - (uint32_t)y * (uint32_t)w);
+            const int xc = x / cell_size, yc = y / cell_size;
+            const int x1 = std::max(xc - 1, 0), y1 = std::max(yc - 1, 0);
+            const int x2 = std::min(xc + 1, grid_w - 1), y2 = std::min(yc + 1, grid_h - 1);
+            bool good = true;
+            for (int yy = y1; yy <= y2 && good; yy++)
+                for (int xx = x1; xx <= x2 && good; xx++)
+                    for (int32_t j = head[(size_t)yy * grid_w + xx]; j >= 0; j = next[j]) {
+                        const float dx = (float)x - out_xy[2 * (size_t)j];
+                        const float dy = (float)y - out_xy[2 * (size_t)j + 1];
+                        if ((double)(dx * dx + dy * dy) < min_dist_sq) {
+                            good = false;
+                            break;
+                        }
+                    }
+            if (good) {
+                out_xy.push_back((float)x);
+                out_xy.push_back((float)y);
+                next.push_back(head[(size_t)yc * grid_w + xc]);
+                head[(size_t)yc * grid_w + xc] = (int32_t)ncorners;
+                ncorners++;
+                if (max_corners > 0 && (int)ncorners == max_corners) break;
+            }
+        }
+    } else {
+        for (size_t i = 0; i < total; i++) {
+            const uint32_t idx = (uint32_t)(keys[i] & 0xffffffffull);
+            const int y = (int)(idx / (uint32_t)w);
+            const int x = (int)(idx - (uint32_t)y * (uint32_t)w);
+            out_xy.push_back((float)x);
+            out_xy.push_back((float)y);
+            ncorners++;
+            if (max_corners > 0 && (int)ncorners == max_corners) break;
+        }
+    }
+    return (int)ncorners;
+}
+
+int ensure_kp_capacity(pc_frame* f, int n) {
+    if (n <= f->kp_cap) return PC_OK;
+    if (f->d_kps) (void)hipFree(f->d_kps);
+    f->d_kps = nullptr;
+    f->kp_cap = 0;
+    const int want = n + n / 4 + 1024;
+    PC_HIP(hipMalloc(reinterpret_cast<void**>(&f->d_kps), (size_t)want * sizeof(float2)));
+    f->kp_cap = want;
+    return PC_OK;
+}
+
+// gray already in level-0 interior -> borders, pyrDown chain, Scharr planes
+void build_pyramid(pc_context* c, pc_frame* f) {
+    ScopedTimer t(c, PC_K_PYRAMID);
+    for (int l = 0; l < f->nlevels; l++) {
+        if (l > 0) pc::launch_pyrdown(f->levels[l - 1], f->levels[l], c->stream);
+        pc::launch_border(f->levels[l], f->win, c->stream);
+        pc::launch_scharr(f->levels[l], c->stream);
+    }
+}
+
+int check_lk_args(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targets, int n_targets,
+                  const pc_flow_options* opt) {
+    if (!ctx || !frame1 || !targets || !opt) return fail(PC_E_INVALID, "null argument");
+    if (n_targets < 1 || n_targets > PC_MAX_TARGETS) return fail(PC_E_INVALID, "n_targets must be in [1,%d]", PC_MAX_TARGETS);
+    if (frame1->n_kps < 0) return fail(PC_E_STATE, "frame1 has no keypoints (call pc_frame_detect or pc_frame_set_keypoints)");
+    if (opt->window_size != frame1->win) return fail(PC_E_INVALID, "window_size %d differs from the frame's pyramid padding %d", opt->window_size, frame1->win);
+    for (int t = 0; t < n_targets; t++) {
+        if (!targets[t]) return fail(PC_E_INVALID, "null target");
+        // cv::calcOpticalFlowPyrLK asserts equal level sizes/types (CV_Assert in lkpyramid.cpp)
+        if (targets[t]->w != frame1->w || targets[t]->h != frame1->h || targets[t]->win != frame1->win)
+            return fail(PC_E_INVALID, "target %d geometry differs from frame1", t);
+    }
+    return PC_OK;
+}
+
+int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targets, int n_targets,
+           const pc_flow_options* opt) {
+    const int n = frame1->n_kps;
+    const size_t rows = (size_t)n * n_targets;
+    PC_HIP(ctx->lk_xy.ensure(rows + 1));
+    PC_HIP(ctx->lk_status.ensure(rows + 1));
+    PC_HIP(ctx->lk_err.ensure(rows + 1));
+    if (n == 0) return PC_OK;
+    pc::LKParams p;
+    std::memset(&p, 0, sizeof(p));
+    int max_level = std::min(opt->max_level, frame1->nlevels - 1);
+    for (int t = 0; t < n_targets; t++) max_level = std::min(max_level, targets[t]->nlevels - 1);
+    if (max_level < 0) max_level = 0;
+    for (int l = 0; l <= max_level; l++) {
+        p.src[l] = frame1->levels[l];
+        for (int t = 0; t < n_targets; t++) p.tgt[t][l] = targets[t]->levels[l].img;
+    }
+    p.n_targets = n_targets;
+    p.max_level = max_level;
+    p.n = n;
+    p.pts = frame1->d_kps;
+    // TermCriteria clamps of calcOpticalFlowPyrLK
+    p.max_iters = std::min(std::max(opt->term_max_iters, 0), 100);
+    const double eps = std::min(std::max(opt->term_epsilon, 0.), 10.);
+    p.eps_sq = eps * eps;
+    p.min_eig_thr = (float)opt->min_eigen_threshold;
+    p.out_xy = ctx->lk_xy.p;
+    p.out_status = ctx->lk_status.p;
+    p.out_err = ctx->lk_err.p;
+    ScopedTimer tm(ctx, PC_K_LK);
+    if (!pc::launch_lk(p, frame1->win, ctx->stream)) return fail(PC_E_INVALID, "unsupported window size %d", frame1->win);
+    return PC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void pc_gftt_default_options(pc_gftt_options* o) {
+    o->quality_level = 0.01;
+    o->min_distance = 5.0;
+    o->block_size = 3;
+    o->gradient_size = 3;
+    o->max_corners = 0;
+    o->use_harris = 0;
+    o->harris_k = 0.04;
+    o->grid_rows = 4;
+    o->grid_cols = 4;
+}
+
+void pc_flow_default_options(pc_flow_options* o) {
+    o->window_size = 10;
+    o->max_level = 3;
+    o->term_max_iters = 30;
+    o->term_epsilon = 0.01;
+    o->min_eigen_threshold = 1e-4;
+}
+
+const char* pc_last_error(void) { return g_err.c_str(); }
+const char* pc_version(void) { return "polychase_hip 0.1 (gfx950, hand-written HIP)"; }
+
+int pc_context_create(int device_index, pc_context** out) {
+    if (!out) return fail(PC_E_INVALID, "null out");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(PC_E_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device_index < 0 || device_index >= count) return fail(PC_E_INVALID, "device index %d out of range [0,%d)", device_index, count);
+    PC_HIP(hipSetDevice(device_index));
+    pc_context* c = new (std::nothrow) pc_context();
+    if (!c) return fail(PC_E_INVALID, "out of host memory");
+    c->device = device_index;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(PC_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return PC_OK;
+}
+
+void pc_context_destroy(pc_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& r : c->ranges) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    c->staging.release();
+    c->eig.release();
+    c->keys_in.release();
+    c->keys_out.release();
+    c->counters.release();
+    c->sort_temp.release();
+    c->h_keys.release();
+    c->h_kps.release();
+    c->h_counter.release();
+    c->lk_xy.release();
+    c->lk_cxy.release();
+    c->lk_status.release();
+    c->lk_err.release();
+    c->lk_cerr.release();
+    c->lk_cidx.release();
+    c->lk_block_counts.release();
+    c->lk_row_offset.release();
+    c->h_row_offset.release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int pc_context_synchronize(pc_context* c) {
+    if (!c) return fail(PC_E_INVALID, "null context");
+    PC_HIP(hipStreamSynchronize(c->stream));
+    return PC_OK;
+}
+
+void* pc_context_stream(pc_context* c) { return c ? (void*)c->stream : nullptr; }
+
+int pc_context_enable_timing(pc_context* c, int enable) {
+    if (!c) return fail(PC_E_INVALID, "null context");
+    int rc = collect_timing(c);
+    c->timing = enable != 0;
+    return rc;
+}
+
+int pc_context_get_timing(pc_context* c, int k, int* launches, double* total_ms) {
+    if (!c || k < 0 || k >= PC_K_COUNT) return fail(PC_E_INVALID, "bad kernel class");
+    int rc = collect_timing(c);
+    if (rc != PC_OK) return rc;
+    if (launches) *launches = c->launches[k];
+    if (total_ms) *total_ms = c->total_ms[k];
+    return PC_OK;
+}
+
+int pc_context_reset_timing(pc_context* c) {
+    if (!c) return fail(PC_E_INVALID, "null context");
+    int rc = collect_timing(c);
+    for (int k = 0; k < PC_K_COUNT; k++) {
+        c->launches[k] = 0;
+        c->total_ms[k] = 0;
+    }
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+int pc_frame_create(pc_context* ctx, int width, int height, int window_size, int max_level, pc_frame** out) {
+    if (!ctx || !out) return fail(PC_E_INVALID, "null argument");
+    *out = nullptr;
+    if (width < 1 || height < 1) return fail(PC_E_INVALID, "bad frame size %dx%d", width, height);
+    // buildOpticalFlowPyramid: CV_Assert(winSize.width > 2 && winSize.height > 2)
+    if (window_size < 3 || window_size > PC_MAX_WINDOW) return fail(PC_E_INVALID, "window_size must be in [3,%d]", PC_MAX_WINDOW);
+    if (max_level < 0 || max_level >= PC_MAX_LEVELS) return fail(PC_E_INVALID, "max_level must be in [0,%d]", PC_MAX_LEVELS - 1);
+    if ((long long)width * height > (1ll << 30)) return fail(PC_E_INVALID, "frame too large");
+    PC_HIP(hipSetDevice(ctx->device));
+    pc_frame* f = new (std::nothrow) pc_frame();
+    if (!f) return fail(PC_E_INVALID, "out of host memory");
+    f->ctx = ctx;
+    f->w = width;
+    f->h = height;
+    f->win = window_size;
+    f->max_level = max_level;
+    // level geometry: stop when the next level would be <= winSize (lkpyramid.cpp)
+    int lw = width, lh = height;
+    size_t total = 0;
+    size_t img_off[PC_MAX_LEVELS], der_off[PC_MAX_LEVELS];
+    for (int l = 0; l <= max_level; l++) {
+        pc::Level& L = f->levels[l];
+        L.w = lw;
+        L.h = lh;
+        L.pitch = (int)align_up((size_t)pc::kPadX + lw + window_size, 64);
+        const size_t rows = (size_t)lh + 2 * window_size;
+        img_off[l] = total;
+        total += align_up(rows * L.pitch, 256);
+        der_off[l] = total;
+        total += align_up(rows * L.pitch * sizeof(int32_t), 256);
+        f->nlevels = l + 1;
+        lw = (lw + 1) / 2;
+        lh = (lh + 1) / 2;
+        if (lw <= window_size || lh <= window_size) break;
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->slab), total);
+    if (e != hipSuccess) {
+        delete f;
+        return fail(PC_E_HIP, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+    }
+    f->slab_bytes = total;
+    // zero once: derivative padding must stay zero (derivBorder = BORDER_CONSTANT)
+    e = hipMemsetAsync(f->slab, 0, total, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(f->slab);
+        delete f;
+        return fail(PC_E_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    }
+    for (int l = 0; l < f->nlevels; l++) {
+        pc::Level& L = f->levels[l];
+        const size_t interior = (size_t)window_size * L.pitch + pc::kPadX;
+        L.img = f->slab + img_off[l] + interior;
+        L.der = reinterpret_cast<int32_t*>(f->slab + der_off[l]) + interior;
+    }
+    int rc = ensure_kp_capacity(f, std::max(4096, (int)((long long)width * height / 16)));
+    if (rc != PC_OK) {
+        (void)hipFree(f->slab);
+        delete f;
+        return rc;
+    }
+    *out = f;
+    return PC_OK;
+}
+
+void pc_frame_destroy(pc_frame* f) {
+    if (!f) return;
+    if (f->ctx) {
+        (void)hipSetDevice(f->ctx->device);
+        (void)hipStreamSynchronize(f->ctx->stream);
+        if (f->ctx->eig_owner == f) f->ctx->eig_owner = nullptr;
+    }
+    if (f->slab) (void)hipFree(f->slab);
+    if (f->d_kps) (void)hipFree(f->d_kps);
+    delete f;
+}
+
+static int set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t row_pitch, int on_device, int channels) {
+    if (!ctx || !f || !src) return fail(PC_E_INVALID, "null argument");
+    if (f->ctx != ctx) return fail(PC_E_INVALID, "frame belongs to another context");
+    const size_t row_bytes = (size_t)f->w * channels;
+    if (row_pitch < row_bytes) return fail(PC_E_INVALID, "row_pitch %zu < %zu", row_pitch, row_bytes);
+    PC_HIP(hipSetDevice(ctx->device));
+    const uint8_t* d_src = src;
+    size_t d_pitch = row_pitch;
+    if (!on_device) {
+        d_pitch = align_up(row_bytes, 16);
+        PC_HIP(ctx->staging.ensure(d_pitch * f->h));
+        // the previous frame's kernels may still read the staging buffer: ordered on the same stream
+        PC_HIP(hipMemcpy2DAsync(ctx->staging.p, d_pitch, src, row_pitch, row_bytes, f->h, hipMemcpyHostToDevice, ctx->stream));
+        d_src = ctx->staging.p;
+    }
+    {
+        ScopedTimer t(ctx, PC_K_GRAY);
+        if (channels == 3) pc::launch_rgb2gray(d_src, d_pitch, f->levels[0], ctx->stream);
+        else pc::launch_copy_gray(d_src, d_pitch, f->levels[0], ctx->stream);
+    }
+    build_pyramid(ctx, f);
+    f->n_kps = -1;
+    f->n_cands = -1;
+    if (ctx->eig_owner == f) ctx->eig_owner = nullptr;
+    if (!on_device) PC_HIP(hipStreamSynchronize(ctx->stream));  // caller may reuse its host buffer
+    return PC_OK;
+}
+
+int pc_frame_set_rgb(pc_context* ctx, pc_frame* f, const uint8_t* rgb, size_t row_pitch, int on_device) {
+    return set_image(ctx, f, rgb, row_pitch, on_device, 3);
+}
+int pc_frame_set_gray(pc_context* ctx, pc_frame* f, const uint8_t* gray, size_t row_pitch, int on_device) {
+    return set_image(ctx, f, gray, row_pitch, on_device, 1);
+}
+
+int pc_frame_num_levels(const pc_frame* f) { return f ? f->nlevels : 0; }
+
+int pc_frame_level_size(const pc_frame* f, int level, int* width, int* height) {
+    if (!f || level < 0 || level >= f->nlevels) return fail(PC_E_INVALID, "bad level");
+    if (width) *width = f->levels[level].w;
+    if (height) *height = f->levels[level].h;
+    return PC_OK;
+}
+
+int pc_frame_download_gray(pc_context* ctx, const pc_frame* f, uint8_t* out) {
+    if (!ctx || !f || !out) return fail(PC_E_INVALID, "null argument");
+    const pc::Level& L = f->levels[0];
+    PC_HIP(hipMemcpy2DAsync(out, L.w, L.img, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    return PC_OK;
+}
+
+int pc_frame_download_level(pc_context* ctx, const pc_frame* f, int level, uint8_t* out) {
+    if (!ctx || !f || !out || level < 0 || level >= f->nlevels) return fail(PC_E_INVALID, "bad argument");
+    const pc::Level& L = f->levels[level];
+    const int win = f->win;
+    const uint8_t* src = L.img - (ptrdiff_t)win * L.pitch - win;
+    PC_HIP(hipMemcpy2DAsync(out, L.w + 2 * win, src, L.pitch, L.w + 2 * win, L.h + 2 * win, hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    return PC_OK;
+}
+
+int pc_frame_download_deriv(pc_context* ctx, const pc_frame* f, int level, int16_t* out) {
+    if (!ctx || !f || !out || level < 0 || level >= f->nlevels) return fail(PC_E_INVALID, "bad argument");
+    const pc::Level& L = f->levels[level];
+    const int win = f->win;
+    const int32_t* src = L.der - (ptrdiff_t)win * L.pitch - win;
+    const size_t row = (size_t)(L.w + 2 * win) * 4;
+    PC_HIP(hipMemcpy2DAsync(out, row, src, (size_t)L.pitch * 4, row, L.h + 2 * win, hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    return PC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int pc_frame_detect(pc_context* ctx, pc_frame* f, const pc_gftt_options* opt) {
+    if (!ctx || !f || !opt) return fail(PC_E_INVALID, "null argument");
+    if (f->ctx != ctx) return fail(PC_E_INVALID, "frame belongs to another context");
+    // CHECKs of gftt.cc:18-19
+    if (!(opt->quality_level > 0 && opt->min_distance >= 0 && opt->max_corners >= 0))
+        return fail(PC_E_INVALID, "GFTT options violate quality_level > 0 && min_distance >= 0 && max_corners >= 0");
+    if (opt->use_harris) return fail(PC_E_INVALID, "use_harris is not implemented on the HIP path");
+    if (opt->block_size != 3 || opt->gradient_size != 3)
+        return fail(PC_E_INVALID, "only block_size == 3 and gradient_size == 3 are implemented on the HIP path");
+    PC_HIP(hipSetDevice(ctx->device));
+    const int w = f->w, h = f->h;
+    pc::GfttGrid g;
+    g.rows = std::max(1, opt->grid_rows);
+    g.cols = std::max(1, opt->grid_cols);
+    if (g.rows * g.cols > pc::kMaxGridCells) return fail(PC_E_INVALID, "grid_rows*grid_cols must be <= %d", pc::kMaxGridCells);
+    g.cell_h = (h + g.rows - 1) / g.rows;
+    g.cell_w = (w + g.cols - 1) / g.cols;
+    const size_t npx = (size_t)w * h;
+    const uint32_t cap = (uint32_t)npx;
+    PC_HIP(ctx->eig.ensure(npx));
+    PC_HIP(ctx->keys_in.ensure(cap));
+    PC_HIP(ctx->keys_out.ensure(cap));
+    PC_HIP(ctx->counters.ensure(1 + pc::kMaxGridCells));
+    PC_HIP(ctx->h_counter.ensure(4));
+    PC_HIP(hipMemsetAsync(ctx->counters.p, 0, (1 + pc::kMaxGridCells) * sizeof(uint32_t), ctx->stream));
+    uint32_t* d_counter = ctx->counters.p;
+    uint32_t* d_cell_max = ctx->counters.p + 1;
+    {
+        ScopedTimer t(ctx, PC_K_MINEIG);
+        pc::launch_min_eig(f->levels[0], ctx->eig.p, g, d_cell_max, ctx->stream);
+    }
+    ctx->eig_owner = f;
+    {
+        ScopedTimer t(ctx, PC_K_NMS);
+        pc::launch_nms_compact(ctx->eig.p, w, h, g, d_cell_max, opt->quality_level, ctx->keys_in.p, cap, d_counter, ctx->stream);
+    }
+    PC_HIP(hipMemcpyAsync(ctx->h_counter.p, d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    const uint32_t n_cand = std::min(ctx->h_counter.p[0], cap);
+    f->n_cands = (int)n_cand;
+    std::vector<float> xy;
+    int n = 0;
+    if (n_cand > 0) {
+        size_t temp_bytes = 0;
+        PC_HIP(pc::sort_keys_desc(nullptr, temp_bytes, ctx->keys_in.p, ctx->keys_out.p, n_cand, ctx->stream));
+        PC_HIP(ctx->sort_temp.ensure(temp_bytes));
+        {
+            ScopedTimer t(ctx, PC_K_SORT);
+            PC_HIP(pc::sort_keys_desc(ctx->sort_temp.p, temp_bytes, ctx->keys_in.p, ctx->keys_out.p, n_cand, ctx->stream));
+        }
+        PC_HIP(ctx->h_keys.ensure(n_cand));
+        PC_HIP(hipMemcpyAsync(ctx->h_keys.p, ctx->keys_out.p, (size_t)n_cand * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        PC_HIP(hipStreamSynchronize(ctx->stream));
+        n = suppress_min_distance(ctx->h_keys.p, n_cand, w, h, opt->min_distance, opt->max_corners, xy);
+    }
+    int rc = ensure_kp_capacity(f, n);
+    if (rc != PC_OK) return rc;
+    if (n > 0) {
+        PC_HIP(ctx->h_kps.ensure((size_t)n * 2));
+        std::memcpy(ctx->h_kps.p, xy.data(), (size_t)n * 2 * sizeof(float));
+        PC_HIP(hipMemcpyAsync(f->d_kps, ctx->h_kps.p, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+        PC_HIP(hipStreamSynchronize(ctx->stream));  // h_kps is reused by the next detect
+    }
+    f->n_kps = n;
+    return PC_OK;
+}
+
+int pc_frame_download_min_eig(pc_context* ctx, const pc_frame* f, float* out) {
+    if (!ctx || !f || !out) return fail(PC_E_INVALID, "null argument");
+    if (ctx->eig_owner != f) return fail(PC_E_STATE, "the min-eig scratch map belongs to another frame (call right after pc_frame_detect)");
+    PC_HIP(hipMemcpyAsync(out, ctx->eig.p, (size_t)f->w * f->h * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    return PC_OK;
+}
+
+int pc_frame_num_candidates(pc_context* ctx, const pc_frame* f, int* out_n) {
+    if (!ctx || !f || !out_n) return fail(PC_E_INVALID, "null argument");
+    if (f->n_cands < 0) return fail(PC_E_STATE, "pc_frame_detect has not run on this frame");
+    *out_n = f->n_cands;
+    return PC_OK;
+}
+
+int pc_frame_num_keypoints(pc_context* ctx, const pc_frame* f, int* out_n) {
+    if (!ctx || !f || !out_n) return fail(PC_E_INVALID, "null argument");
+    if (f->n_kps < 0) return fail(PC_E_STATE, "frame has no keypoints");
+    *out_n = f->n_kps;
+    return PC_OK;
+}
+
+int pc_frame_download_keypoints(pc_context* ctx, const pc_frame* f, float* out_xy, int capacity) {
+    if (!ctx || !f || (!out_xy && capacity > 0)) return fail(PC_E_INVALID, "null argument");
+    if (f->n_kps < 0) return fail(PC_E_STATE, "frame has no keypoints");
+    if (capacity < f->n_kps) return fail(PC_E_CAPACITY, "capacity %d < %d keypoints", capacity, f->n_kps);
+    if (f->n_kps == 0) return PC_OK;
+    PC_HIP(hipMemcpyAsync(out_xy, f->d_kps, (size_t)f->n_kps * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    return PC_OK;
+}
+
+int pc_frame_set_keypoints(pc_context* ctx, pc_frame* f, const float* xy, int n) {
+    if (!ctx || !f || n < 0 || (!xy && n > 0)) return fail(PC_E_INVALID, "bad argument");
+    int rc = ensure_kp_capacity(f, n);
+    if (rc != PC_OK) return rc;
+    if (n > 0) {
+        PC_HIP(hipMemcpyAsync(f->d_kps, xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+        PC_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    f->n_kps = n;
+    return PC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int pc_lk_track(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targets, int n_targets,
+                const pc_flow_options* opt, float* next_xy, uint8_t* status, float* err) {
+    int rc = check_lk_args(ctx, frame1, targets, n_targets, opt);
+    if (rc != PC_OK) return rc;
+    if (!next_xy || !status || !err) return fail(PC_E_INVALID, "null output");
+    PC_HIP(hipSetDevice(ctx->device));
+    rc = run_lk(ctx, frame1, targets, n_targets, opt);
+    if (rc != PC_OK) return rc;
+    const size_t rows = (size_t)frame1->n_kps * n_targets;
+    if (rows > 0) {
+        PC_HIP(hipMemcpyAsync(next_xy, ctx->lk_xy.p, rows * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+        PC_HIP(hipMemcpyAsync(status, ctx->lk_status.p, rows, hipMemcpyDeviceToHost, ctx->stream));
+        PC_HIP(hipMemcpyAsync(err, ctx->lk_err.p, rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    return PC_OK;
+}
+
+int pc_lk_track_filtered(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targets, int n_targets,
+                         const pc_flow_options* opt, uint32_t* src_indices, float* tgt_xy, float* flow_err,
+                         int64_t* row_offset) {
+    int rc = check_lk_args(ctx, frame1, targets, n_targets, opt);
+    if (rc != PC_OK) return rc;
+    if (!row_offset) return fail(PC_E_INVALID, "null row_offset");
+    PC_HIP(hipSetDevice(ctx->device));
+    rc = run_lk(ctx, frame1, targets, n_targets, opt);
+    if (rc != PC_OK) return rc;
+    const int n = frame1->n_kps;
+    const size_t rows = (size_t)n * n_targets;
+    const int nblocks = pc::compact_num_blocks(n);
+    PC_HIP(ctx->lk_cxy.ensure(rows + 1));
+    PC_HIP(ctx->lk_cerr.ensure(rows + 1));
+    PC_HIP(ctx->lk_cidx.ensure(rows + 1));
+    PC_HIP(ctx->lk_block_counts.ensure((size_t)nblocks * n_targets + 1));
+    PC_HIP(ctx->lk_row_offset.ensure(PC_MAX_TARGETS + 1));
+    PC_HIP(ctx->h_row_offset.ensure(PC_MAX_TARGETS + 1));
+    {
+        ScopedTimer t(ctx, PC_K_COMPACT);
+        pc::launch_compact(ctx->lk_xy.p, ctx->lk_status.p, ctx->lk_err.p, n, n_targets, ctx->lk_block_counts.p,
+                           ctx->lk_row_offset.p, ctx->lk_cidx.p, ctx->lk_cxy.p, ctx->lk_cerr.p, ctx->stream);
+    }
+    PC_HIP(hipMemcpyAsync(ctx->h_row_offset.p, ctx->lk_row_offset.p, (size_t)(n_targets + 1) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    for (int t = 0; t <= n_targets; t++) row_offset[t] = (int64_t)ctx->h_row_offset.p[t];
+    const size_t total = (size_t)row_offset[n_targets];
+    if (total > 0) {
+        if (!src_indices || !tgt_xy || !flow_err) return fail(PC_E_INVALID, "null output");
+        PC_HIP(hipMemcpyAsync(src_indices, ctx->lk_cidx.p, total * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        PC_HIP(hipMemcpyAsync(tgt_xy, ctx->lk_cxy.p, total * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+        PC_HIP(hipMemcpyAsync(flow_err, ctx->lk_cerr.p, total * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        PC_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// kernels.hpp -- host-side launchers of the gfx950 kernels (implemented in kernels_*.hip).
+#pragma once
+
+#include "common.hpp"
+
+namespace pc {
+
+// ---- kernels_image.hip ----
+// K1: RGB u8 -> gray u8 written straight into the level-0 plane interior (cvtColor RGB2GRAY).
+void launch_rgb2gray(const uint8_t* rgb, size_t rgb_pitch, const Level& l0, hipStream_t s);
+// gray u8 (arbitrary pitch) -> level-0 interior
+void launch_copy_gray(const uint8_t* gray, size_t gray_pitch, const Level& l0, hipStream_t s);
+// K7: pyrDown 5x5 (src interior -> dst interior)
+void launch_pyrdown(const Level& src, const Level& dst, hipStream_t s);
+// REFLECT_101 border of width `win` around the interior
+void launch_border(const Level& l, int win, hipStream_t s);
+// K6: Scharr derivative plane of the interior (needs the 1-px border to be filled)
+void launch_scharr(const Level& l, hipStream_t s);
+
+// ---- kernels_gftt.hip ----
+struct GfttGrid {
+    int rows, cols;      // grid_rows, grid_cols (>= 1)
+    int cell_w, cell_h;  // ceil(W/cols), ceil(H/rows)
+};
+constexpr int kMaxGridCells = 256;
+// K2: cornerMinEigenVal (block 3, Sobel 3) of the level-0 interior + per-cell max (ordered keys,
+// cell_max must be zeroed first).
+void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, hipStream_t s);
+// K3: per-cell THRESH_TOZERO + 3x3 dilate + strict-interior local maxima -> 64-bit keys
+// (ordered(value) << 32 | y*w+x) appended to `keys` (capacity `cap`), count in *counter.
+void launch_nms_compact(const float* eig, int w, int h, const GfttGrid& g, const uint32_t* cell_max,
+                        double quality_level, unsigned long long* keys, uint32_t cap,
+                        uint32_t* counter, hipStream_t s);
+// K4: descending radix sort of the candidate keys (rocPRIM).  temp may be null to query bytes.
+hipError_t sort_keys_desc(void* temp, size_t& temp_bytes, unsigned long long* keys_in,
+                          unsigned long long* keys_out, uint32_t n, hipStream_t s);
+
+// ---- kernels_lk.hip ----
+struct LKParams {
+    Level src[8];             // frame1 levels
+    const uint8_t* tgt[8][8]; // [target][level] interior origins (same geometry as src)
+    int n_targets;
+    int max_level;            // effective (min over pyramids)
+    int n;                    // number of keypoints
+    const float2* pts;
+    int max_iters;
+    double eps_sq;
+    float min_eig_thr;
+    float2* out_xy;           // [target][n]
+    uint8_t* out_status;      // [target][n]
+    float* out_err;           // [target][n]
+};
+// K8-K10: pyramidal LK, one 16-lane DPP row per (keypoint, target).  Returns false if the window
+// size is unsupported.
+bool launch_lk(const LKParams& p, int win, hipStream_t s);
+
+// Ordered compaction of status==1 rows per target (opticalflow.cc:130-147).
+// block_counts: [n_targets][nblocks] scratch, row_offset: [n_targets+1] int64 (device).
+void launch_compact(const float2* xy, const uint8_t* status, const float* err, int n, int n_targets,
+                    uint32_t* block_counts, long long* row_offset, uint32_t* out_idx, float2* out_xy,
+                    float* out_err, hipStream_t s);
+int compact_num_blocks(int n);
+
+}  // namespace pc

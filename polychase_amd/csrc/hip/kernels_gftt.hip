@@ -1,0 +1,207 @@
+// kernels_gftt.hip -- Shi-Tomasi corner response and candidate extraction on gfx950.
+//
+// Replaces, on the path GoodFeaturesToTrack (reference cpp/feature_detection/gftt.cc:14-192):
+//   K2  cv::cornerMinEigenVal(block 3, Sobel 3)              gftt.cc:35
+//       + per-grid-cell cv::minMaxLoc                         gftt.cc:61-63
+//   K3  per-cell cv::threshold(THRESH_TOZERO)                 gftt.cc:64-65
+//       + cv::dilate 3x3 + strict-interior local maxima       gftt.cc:70-86
+//   K4  std::sort(greaterThanPtr)                             gftt.cc:7-12, :98   (64-bit radix sort)
+// Float order follows oracle/pc_oracle.c exactly (no FMA contraction; fp64 box sums are exact).
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "kernels.hpp"
+
+namespace pc {
+
+// ------------------------------------------------------------------------------------------------
+// K2  min-eigenvalue map.  Tile 64x16 outputs per 256-lane workgroup.
+//   LDS stage 1: gray tile with a 2-px REFLECT_101 halo (68 x 20 bytes, stored as u8).
+//   LDS stage 2: covariance products (Dx^2, DxDy, Dy^2) on the tile + 1-px halo (66 x 18 x 3 floats),
+//                evaluated at the REFLECTED coordinate for positions outside the image (boxFilter's
+//                BORDER_REFLECT_101 applies to the covariance image, not to the gray image).
+//   Stage 3: 3x3 box sums in fp64 (exact), min eigenvalue, per-cell max via LDS then global atomicMax.
+// ------------------------------------------------------------------------------------------------
+constexpr int TW = 64, TH = 16;
+constexpr int GW = TW + 4, GH = TH + 4;   // gray tile
+constexpr int CW = TW + 2, CH = TH + 2;   // covariance tile
+
+__global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict__ img, int pitch, int w, int h,
+                                                      float* __restrict__ eig, GfttGrid g,
+                                                      uint32_t* __restrict__ cell_max, float f1, float f0) {
+    __shared__ uint8_t s_gray[GH][GW];
+    __shared__ float s_cxx[CH][CW + 1];
+    __shared__ float s_cxy[CH][CW + 1];
+    __shared__ float s_cyy[CH][CW + 1];
+    __shared__ uint32_t s_max[4];
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    if (tid < 4) s_max[tid] = 0u;
+
+    // stage 1: gray tile, absolute coords [x0-2, x0+TW+2) x [y0-2, y0+TH+2), reflected into the image
+    for (int i = tid; i < GW * GH; i += 256) {
+        const int ty = i / GW, tx = i - ty * GW;
+        const int ax = reflect101(x0 - 2 + tx, w), ay = reflect101(y0 - 2 + ty, h);
+        s_gray[ty][tx] = img[(size_t)ay * pitch + ax];
+    }
+    __syncthreads();
+
+    // stage 2: Sobel + products at covariance positions [x0-1, x0+TW+1) x [y0-1, y0+TH+1)
+    for (int i = tid; i < CW * CH; i += 256) {
+        const int cy = i / CW, cx = i - cy * CW;
+        // absolute position, reflected into the image, then back to gray-tile coordinates
+        int ax = x0 - 1 + cx, ay = y0 - 1 + cy;
+        float vxx = 0.f, vxy = 0.f, vyy = 0.f;
+        // positions more than one pixel outside the image are never consumed
+        if (ax >= -1 && ax <= w && ay >= -1 && ay <= h) {
+            ax = reflect101(ax, w);
+            ay = reflect101(ay, h);
+            const int tx = ax - (x0 - 2), ty = ay - (y0 - 2);
+            // neighbours of an in-image position: reflect at the image border
+            const int txm = reflect101(ax - 1, w) - (x0 - 2), txp = reflect101(ax + 1, w) - (x0 - 2);
+            const int tym = reflect101(ay - 1, h) - (y0 - 2), typ = reflect101(ay + 1, h) - (y0 - 2);
+            const float g00 = s_gray[tym][txm], g01 = s_gray[tym][tx], g02 = s_gray[tym][txp];
+            const float g10 = s_gray[ty][txm], g11 = s_gray[ty][tx], g12 = s_gray[ty][txp];
+            const float g20 = s_gray[typ][txm], g21 = s_gray[typ][tx], g22 = s_gray[typ][txp];
+            // Dx: row [-1,0,1] then column (S0 + S2)*f1 + S1*f0
+            const float rx0 = g02 - g00, rx1 = g12 - g10, rx2 = g22 - g20;
+            const float dx = (rx0 + rx2) * f1 + rx1 * f0;
+            // Dy: row ((f1*a + f0*b) + f1*c) then column S2 - S0
+            float ry0 = f1 * g00; ry0 += f0 * g01; ry0 += f1 * g02;
+            float ry2 = f1 * g20; ry2 += f0 * g21; ry2 += f1 * g22;
+            const float dy = ry2 - ry0;
+            (void)g11;
+            vxx = dx * dx;
+            vxy = dx * dy;
+            vyy = dy * dy;
+        }
+        s_cxx[cy][cx] = vxx;
+        s_cxy[cy][cx] = vxy;
+        s_cyy[cy][cx] = vyy;
+    }
+    __syncthreads();
+
+    // stage 3: 4 outputs per lane (rows ty, ty+4, ty+8, ty+12 of column tx)
+    const int tx = tid & 63, tyb = tid >> 6;
+    const int x = x0 + tx;
+    const int cell_x0 = x0 / g.cell_w, cell_y0 = y0 / g.cell_h;
+    const bool small_cells = (g.cell_w < TW) || (g.cell_h < TH);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int ty = tyb + 4 * k;
+        const int y = y0 + ty;
+        if (x < w && y < h) {
+            double sxx = 0.0, sxy = 0.0, syy = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    sxx += (double)s_cxx[ty + j][tx + i];
+                    sxy += (double)s_cxy[ty + j][tx + i];
+                    syy += (double)s_cyy[ty + j][tx + i];
+                }
+            const float a = (float)sxx * 0.5f;
+            const float b = (float)sxy;
+            const float c = (float)syy * 0.5f;
+            const float t = a - c;
+            const float e = (a + c) - sqrtf(t * t + b * b);
+            eig[(size_t)y * w + x] = e;
+            const uint32_t key = float_to_ordered(e);
+            const int cx = x / g.cell_w, cy = y / g.cell_h;
+            if (small_cells) {
+                atomicMax(&cell_max[cy * g.cols + cx], key);
+            } else {
+                atomicMax(&s_max[(cy - cell_y0) * 2 + (cx - cell_x0)], key);
+            }
+        }
+    }
+    __syncthreads();
+    if (!small_cells && tid < 4) {
+        const int cx = cell_x0 + (tid & 1), cy = cell_y0 + (tid >> 1);
+        if (cx < g.cols && cy < g.rows && s_max[tid] != 0u) atomicMax(&cell_max[cy * g.cols + cx], s_max[tid]);
+    }
+}
+
+void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, hipStream_t s) {
+    // scale = 1 / (2^(ksize-1) * block_size * 255), folded into the smoothing taps (see oracle)
+    const double scale_d = 1.0 / (4.0 * 3.0 * 255.0);
+    const float f1 = (float)(1.0 * scale_d), f0 = (float)(2.0 * scale_d);
+    dim3 grid((l0.w + TW - 1) / TW, (l0.h + TH - 1) / TH);
+    hipLaunchKernelGGL(min_eig_kernel, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3  threshold (per cell of the NEIGHBOUR) + 3x3 dilate + local-max test + wave-ballot compaction.
+// One lane per pixel of the strict interior; keys = ordered(value) << 32 | (y*w + x).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restrict__ eig, int w, int h, GfttGrid g,
+                                                          const uint32_t* __restrict__ cell_max,
+                                                          double quality_level,
+                                                          unsigned long long* __restrict__ keys, uint32_t cap,
+                                                          uint32_t* __restrict__ counter) {
+    __shared__ float s_thr[kMaxGridCells];
+    const int ncells = g.rows * g.cols;
+    for (int i = threadIdx.x; i < ncells; i += blockDim.x) {
+        // cv::threshold on CV_32F compares with (float)(maxVal * quality_level), maxVal a double
+        const float mx = ordered_to_float(cell_max[i]);
+        s_thr[i] = (float)((double)mx * quality_level);
+    }
+    __syncthreads();
+
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    bool is_cand = false;
+    float val = 0.f;
+    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+        const int cx = x / g.cell_w, cy = y / g.cell_h;
+        // cells of the 3 columns / 3 rows of the neighbourhood
+        const int cxs[3] = {(x - 1) / g.cell_w, cx, (x + 1) / g.cell_w};
+        const int cys[3] = {(y - 1) / g.cell_h, cy, (y + 1) / g.cell_h};
+        const float c = eig[(size_t)y * w + x];
+        val = (c > s_thr[cy * g.cols + cx]) ? c : 0.f;
+        if (val != 0.f) {
+            float m = val;
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const float e = eig[(size_t)(y + j - 1) * w + (x + i - 1)];
+                    const float v = (e > s_thr[cys[j] * g.cols + cxs[i]]) ? e : 0.f;
+                    m = (v > m) ? v : m;
+                }
+            is_cand = (val == m);
+        }
+    }
+    const unsigned long long ballot = __ballot(is_cand);
+    if (ballot == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_in_wave = (uint32_t)__popcll(ballot);
+    uint32_t base = 0;
+    const int leader = __ffsll((long long)ballot) - 1;
+    if (lane == leader) base = atomicAdd(counter, n_in_wave);
+    base = __shfl(base, leader);
+    if (is_cand) {
+        const uint32_t pos = base + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+        if (pos < cap)
+            keys[pos] = ((unsigned long long)float_to_ordered(val) << 32) | (unsigned long long)(uint32_t)(y * w + x);
+    }
+}
+
+void launch_nms_compact(const float* eig, int w, int h, const GfttGrid& g, const uint32_t* cell_max,
+                        double quality_level, unsigned long long* keys, uint32_t cap, uint32_t* counter,
+                        hipStream_t s) {
+    dim3 grid((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(nms_compact_kernel, grid, dim3(256), 0, s, eig, w, h, g, cell_max, quality_level, keys, cap,
+                       counter);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4  descending 64-bit radix sort (value desc, linear index desc).
+// ------------------------------------------------------------------------------------------------
+hipError_t sort_keys_desc(void* temp, size_t& temp_bytes, unsigned long long* keys_in,
+                          unsigned long long* keys_out, uint32_t n, hipStream_t s) {
+    return rocprim::radix_sort_keys_desc(temp, temp_bytes, keys_in, keys_out, (size_t)n, 0u, 64u, s);
+}
+
+}  // namespace pc

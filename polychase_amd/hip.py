@@ -1,0 +1,293 @@
+"""ctypes binding of the C ABI in include/polychase_hip.h (polychase_amd/lib/libpolychase_hip.so).
+
+Thin and literal: one Python method per C entry point.  There is NO fallback: importing works
+without a GPU (so symbol checks can run on CPU), but `Context()` raises when no gfx950 device is
+usable, and `load()` raises when the library has not been built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+PC_MAX_TARGETS = 8
+KERNEL_CLASSES = ["gray", "pyramid", "min_eig", "nms", "sort", "suppress", "lk", "compact"]
+
+# every symbol include/polychase_hip.h declares (tests check they are all exported)
+SYMBOLS = [
+    "pc_gftt_default_options", "pc_flow_default_options", "pc_last_error", "pc_version",
+    "pc_context_create", "pc_context_destroy", "pc_context_synchronize", "pc_context_stream",
+    "pc_context_enable_timing", "pc_context_get_timing", "pc_context_reset_timing",
+    "pc_frame_create", "pc_frame_destroy", "pc_frame_set_rgb", "pc_frame_set_gray",
+    "pc_frame_num_levels", "pc_frame_level_size", "pc_frame_download_gray", "pc_frame_download_level",
+    "pc_frame_download_deriv", "pc_frame_detect", "pc_frame_download_min_eig", "pc_frame_num_candidates",
+    "pc_frame_num_keypoints", "pc_frame_download_keypoints", "pc_frame_set_keypoints",
+    "pc_lk_track", "pc_lk_track_filtered",
+]
+
+
+class GfttOptions(C.Structure):
+    """GFTTOptions (reference cpp/feature_detection/gftt.h:5-21)."""
+    _fields_ = [("quality_level", C.c_double), ("min_distance", C.c_double), ("block_size", C.c_int),
+                ("gradient_size", C.c_int), ("max_corners", C.c_int), ("use_harris", C.c_int),
+                ("harris_k", C.c_double), ("grid_rows", C.c_int), ("grid_cols", C.c_int)]
+
+
+class FlowOptions(C.Structure):
+    """OpticalFlowOptions (reference cpp/opticalflow.h:27-33)."""
+    _fields_ = [("window_size", C.c_int), ("max_level", C.c_int), ("term_max_iters", C.c_int),
+                ("term_epsilon", C.c_double), ("min_eigen_threshold", C.c_double)]
+
+
+class PolychaseHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.hip_library_path()
+    if not os.path.exists(path):
+        raise PolychaseHipError(
+            f"{path} is missing: run `python -m polychase_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the hot path.")
+    # One HIP runtime per process: torch wheels bundle their own libamdhip64.so (SONAME
+    # libamdhip64.so.7, same as /opt/rocm's).  Loading torch FIRST makes our DT_NEEDED entry resolve
+    # to the copy torch already mapped; the other order maps two runtimes and the second one finds
+    # "no HIP GPUs".  Without torch the library uses /opt/rocm/lib via its RUNPATH.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C ABI
+        pass
+    L = C.CDLL(path)
+    vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    L.pc_last_error.restype = C.c_char_p
+    L.pc_version.restype = C.c_char_p
+    L.pc_gftt_default_options.argtypes = [C.POINTER(GfttOptions)]
+    L.pc_flow_default_options.argtypes = [C.POINTER(FlowOptions)]
+    L.pc_context_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.pc_context_destroy.argtypes = [vp]
+    L.pc_context_destroy.restype = None
+    L.pc_context_synchronize.argtypes = [vp]
+    L.pc_context_stream.argtypes = [vp]
+    L.pc_context_stream.restype = vp
+    L.pc_context_enable_timing.argtypes = [vp, C.c_int]
+    L.pc_context_get_timing.argtypes = [vp, C.c_int, ip, C.POINTER(C.c_double)]
+    L.pc_context_reset_timing.argtypes = [vp]
+    L.pc_frame_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.pc_frame_destroy.argtypes = [vp]
+    L.pc_frame_destroy.restype = None
+    L.pc_frame_set_rgb.argtypes = [vp, vp, vp, C.c_size_t, C.c_int]
+    L.pc_frame_set_gray.argtypes = [vp, vp, vp, C.c_size_t, C.c_int]
+    L.pc_frame_num_levels.argtypes = [vp]
+    L.pc_frame_level_size.argtypes = [vp, C.c_int, ip, ip]
+    L.pc_frame_download_gray.argtypes = [vp, vp, vp]
+    L.pc_frame_download_level.argtypes = [vp, vp, C.c_int, vp]
+    L.pc_frame_download_deriv.argtypes = [vp, vp, C.c_int, vp]
+    L.pc_frame_detect.argtypes = [vp, vp, C.POINTER(GfttOptions)]
+    L.pc_frame_download_min_eig.argtypes = [vp, vp, vp]
+    L.pc_frame_num_candidates.argtypes = [vp, vp, ip]
+    L.pc_frame_num_keypoints.argtypes = [vp, vp, ip]
+    L.pc_frame_download_keypoints.argtypes = [vp, vp, vp, C.c_int]
+    L.pc_frame_set_keypoints.argtypes = [vp, vp, vp, C.c_int]
+    L.pc_lk_track.argtypes = [vp, vp, C.POINTER(vp), C.c_int, C.POINTER(FlowOptions), vp, vp, vp]
+    L.pc_lk_track_filtered.argtypes = [vp, vp, C.POINTER(vp), C.c_int, C.POINTER(FlowOptions), vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise PolychaseHipError(f"polychase_hip error {rc}: {load().pc_last_error().decode()}")
+
+
+def gftt_options(**kw) -> GfttOptions:
+    o = GfttOptions()
+    load().pc_gftt_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def flow_options(**kw) -> FlowOptions:
+    o = FlowOptions()
+    load().pc_flow_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _check(load().pc_context_create(device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().pc_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(load().pc_context_synchronize(self._h))
+
+    @property
+    def stream(self) -> int:
+        return load().pc_context_stream(self._h)
+
+    def enable_timing(self, on=True):
+        _check(load().pc_context_enable_timing(self._h, 1 if on else 0))
+
+    def reset_timing(self):
+        _check(load().pc_context_reset_timing(self._h))
+
+    def timing(self) -> dict:
+        out = {}
+        for k, name in enumerate(KERNEL_CLASSES):
+            n, ms = C.c_int(), C.c_double()
+            _check(load().pc_context_get_timing(self._h, k, C.byref(n), C.byref(ms)))
+            out[name] = (n.value, ms.value)
+        return out
+
+
+def _ptr(a):
+    """numpy array (host) or torch tensor (host or device) -> (address, is_device, row_pitch_bytes)."""
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data, 0, a.strides[0]
+    # torch tensor
+    assert a.is_contiguous()
+    return a.data_ptr(), 1 if a.is_cuda else 0, a.stride(0) * a.element_size()
+
+
+class Frame:
+    """Gray image + LK pyramid + keypoints of one video frame, resident in HBM."""
+
+    def __init__(self, ctx: Context, width: int, height: int, window_size: int = 10, max_level: int = 3):
+        self.ctx, self.w, self.h, self.win = ctx, width, height, window_size
+        self._h = C.c_void_p()
+        _check(load().pc_frame_create(ctx._h, width, height, window_size, max_level, C.byref(self._h)))
+
+    def close(self):
+        if self._h and self.ctx._h:
+            load().pc_frame_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_rgb(self, rgb):
+        assert tuple(rgb.shape) == (self.h, self.w, 3), rgb.shape
+        p, dev, pitch = _ptr(rgb)
+        _check(load().pc_frame_set_rgb(self.ctx._h, self._h, p, pitch, dev))
+        self._keep = rgb  # device sources must outlive the async kernels
+
+    def set_gray(self, gray):
+        assert tuple(gray.shape) == (self.h, self.w), gray.shape
+        p, dev, pitch = _ptr(gray)
+        _check(load().pc_frame_set_gray(self.ctx._h, self._h, p, pitch, dev))
+        self._keep = gray
+
+    @property
+    def num_levels(self) -> int:
+        return load().pc_frame_num_levels(self._h)
+
+    def level_size(self, level: int):
+        w, h = C.c_int(), C.c_int()
+        _check(load().pc_frame_level_size(self._h, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def gray(self) -> np.ndarray:
+        out = np.empty((self.h, self.w), np.uint8)
+        _check(load().pc_frame_download_gray(self.ctx._h, self._h, out.ctypes.data))
+        return out
+
+    def level(self, l: int) -> np.ndarray:
+        w, h = self.level_size(l)
+        out = np.empty((h + 2 * self.win, w + 2 * self.win), np.uint8)
+        _check(load().pc_frame_download_level(self.ctx._h, self._h, l, out.ctypes.data))
+        return out
+
+    def deriv(self, l: int) -> np.ndarray:
+        w, h = self.level_size(l)
+        out = np.empty((h + 2 * self.win, w + 2 * self.win, 2), np.int16)
+        _check(load().pc_frame_download_deriv(self.ctx._h, self._h, l, out.ctypes.data))
+        return out
+
+    def detect(self, opt: GfttOptions | None = None):
+        opt = opt or gftt_options()
+        _check(load().pc_frame_detect(self.ctx._h, self._h, C.byref(opt)))
+
+    def min_eig(self) -> np.ndarray:
+        out = np.empty((self.h, self.w), np.float32)
+        _check(load().pc_frame_download_min_eig(self.ctx._h, self._h, out.ctypes.data))
+        return out
+
+    @property
+    def num_candidates(self) -> int:
+        n = C.c_int()
+        _check(load().pc_frame_num_candidates(self.ctx._h, self._h, C.byref(n)))
+        return n.value
+
+    @property
+    def num_keypoints(self) -> int:
+        n = C.c_int()
+        _check(load().pc_frame_num_keypoints(self.ctx._h, self._h, C.byref(n)))
+        return n.value
+
+    def keypoints(self) -> np.ndarray:
+        n = self.num_keypoints
+        out = np.empty((n, 2), np.float32)
+        _check(load().pc_frame_download_keypoints(self.ctx._h, self._h, out.ctypes.data, n))
+        return out
+
+    def set_keypoints(self, xy: np.ndarray):
+        xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+        _check(load().pc_frame_set_keypoints(self.ctx._h, self._h, xy.ctypes.data, len(xy)))
+
+
+def lk_track(ctx: Context, frame1: Frame, targets: list[Frame], opt: FlowOptions | None = None):
+    """Raw LK outputs: next_xy [T,N,2], status [T,N], err [T,N]."""
+    opt = opt or flow_options()
+    n, t = frame1.num_keypoints, len(targets)
+    xy = np.zeros((t, n, 2), np.float32)
+    st = np.zeros((t, n), np.uint8)
+    err = np.zeros((t, n), np.float32)
+    arr = (C.c_void_p * t)(*[f._h for f in targets])
+    _check(load().pc_lk_track(ctx._h, frame1._h, arr, t, C.byref(opt), xy.ctypes.data, st.ctypes.data,
+                              err.ctypes.data))
+    return xy, st, err
+
+
+def lk_track_filtered(ctx: Context, frame1: Frame, targets: list[Frame], opt: FlowOptions | None = None):
+    """status==1 rows per target: list of (src_indices u32 [M], tgt_xy f32 [M,2], err f32 [M])."""
+    opt = opt or flow_options()
+    n, t = frame1.num_keypoints, len(targets)
+    rows = max(1, n * t)
+    idx = np.zeros(rows, np.uint32)
+    xy = np.zeros((rows, 2), np.float32)
+    err = np.zeros(rows, np.float32)
+    off = np.zeros(t + 1, np.int64)
+    arr = (C.c_void_p * t)(*[f._h for f in targets])
+    _check(load().pc_lk_track_filtered(ctx._h, frame1._h, arr, t, C.byref(opt), idx.ctypes.data, xy.ctypes.data,
+                                       err.ctypes.data, off.ctypes.data))
+    out = []
+    for k in range(t):
+        a, b = int(off[k]), int(off[k + 1])
+        out.append((idx[a:b].copy(), xy[a:b].copy(), err[a:b].copy()))
+    return out
