@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- optical-flow frames/s of the MI355X hot path on a synthetic clip.
+
+A "step" = one frame1 of the clip: make the new neighbour frame resident (RGB->gray + LK pyramid),
+detect keypoints (GFTT), track them into its 8 neighbours (+-1,2,4,8) with pyramidal LK, filter
+status==1 and deliver the records to the host -- i.e. one iteration of the outer loop of
+GenerateOpticalFlowDatabase (reference cpp/opticalflow.cc:237-316) without the SQLite insert
+(reported separately).  Frames are resident in HBM before the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c1]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; frames are sharded across ranks
+(contiguous ranges + 8-frame halo, no data-path collective) and the flow records are stitched with
+one RCCL all-gather at the end, inside the timed region.  scaling = "weak".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (width, height, max_level, label)
+    "c1": (640, 480, 3, "C1 640x480 checkerboard-size noise clip"),
+    "c2": (1920, 1080, 3, "C2 1920x1080 300-frame synthetic clip, 3-level pyramidal LK (max_level=3)"),
+    "c3": (3840, 2160, 4, "C3 3840x2160 300-frame clip, 4-level LK (max_level=4) + feature detect"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def level_pixels(w, h, max_level, win=10):
+    s, lw, lh = 0, w, h
+    for _ in range(max_level + 1):
+        s += lw * lh
+        lw, lh = (lw + 1) // 2, (lh + 1) // 2
+        if lw <= win or lh <= win:
+            break
+    return s
+
+
+def cpu_baseline(frames_host, first_id, f1_ids, gopt_kw, fopt_kw):
+    """Times the oracle's reference-shaped CPU path (per-pair gray+pyramid rebuild) on this host."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle  # test infrastructure: used here ONLY as the reported CPU baseline
+
+    so = os.path.join(ROOT, "oracle", "libpc_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "libpc_oracle_native.so"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        so = None
+    cores = os.cpu_count() or 1
+    pair_threads = min(8, cores)
+    feat_threads = max(1, cores // pair_threads)
+    t0 = time.perf_counter()
+    oracle.analyze_clip(frames_host, first_frame=first_id, f1_range=(f1_ids[0], f1_ids[-1] + 1),
+                        gopt=oracle.gftt_options(**gopt_kw), fopt=oracle.flow_options(**fopt_kw),
+                        threads=pair_threads, feature_threads=feat_threads, libpath=so)
+    dt = time.perf_counter() - t0
+    return {"value": len(f1_ids) / dt, "unit": "frames/s", "cores": pair_threads * feat_threads,
+            "kind": "port",
+            "sample": f"{len(f1_ids)} interior frame1 x 8 pairs of the same clip, oracle/pc_oracle.c "
+                      f"(-O3 -march=native), {pair_threads} pair-threads x {feat_threads} feature-threads, "
+                      f"per-pair gray+pyramid rebuild as in opticalflow.cc:298-302; {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="frame1 count of the CPU sample (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from polychase_amd import hip, synth
+    from polychase_amd.pipeline import ClipAnalyzer
+
+    w, h, max_level, label = CONFIGS[args.config]
+    K, W = args.steps, args.warmup
+    n_local = K + W + 16          # every timed frame1 is interior (8 targets)
+    first_id = 1 + rank * (K + W)  # frame ids of this rank's shard (8-frame halo on both sides)
+    clip = synth.NoiseClip(w, h, max(300, world * (K + W) + 16), device=str(dev))
+    frames = {first_id + i: clip.frame_torch(first_id - 1 + i) for i in range(n_local)}
+    torch.cuda.synchronize()
+
+    ctx = hip.Context(local_rank)
+    gopt_kw, fopt_kw = {}, {"max_level": max_level}
+    an = ClipAnalyzer(ctx, w, h, first_id, n_local, lambda fid: frames[fid], hip.gftt_options(**gopt_kw),
+                      hip.flow_options(**fopt_kw))
+
+    def barrier():
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    f1_first = first_id + 8
+    n_kps, n_rows = [], []
+    for i in range(W):
+        an.process(f1_first + i)
+    barrier()
+    ctx.enable_timing(True)
+    ctx.reset_timing()
+    t0 = time.perf_counter()
+    records = []
+    for i in range(K):
+        kps, _, flows = an.process(f1_first + W + i)
+        n_kps.append(len(kps))
+        n_rows.append(sum(len(v[0]) for v in flows.values()))
+        if world > 1:
+            records.append((kps, flows))
+    if world > 1:
+        # stitch the flow database: one RCCL all-gather of the packed records
+        blobs = []
+        for kps, flows in records:
+            blobs.append(kps.view(np.uint8).ravel())
+            for idx, xy, err in flows.values():
+                blobs += [idx.view(np.uint8).ravel(), xy.view(np.uint8).ravel(), err.view(np.uint8).ravel()]
+        local = torch.from_numpy(np.concatenate(blobs)).to(dev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([local.numel()], dtype=torch.int64, device=dev))
+        mx = int(max(int(s.item()) for s in sizes))
+        padded = torch.zeros(mx, dtype=torch.uint8, device=dev)
+        padded[:local.numel()] = local
+        gathered = torch.empty(world * mx, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered, padded)
+    barrier()
+    dt = time.perf_counter() - t0
+    timing = ctx.timing()
+    ctx.enable_timing(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        P = w * h
+        S = level_pixels(w, h, max_level)
+        lk_n, lk_ms = timing["lk"]
+        lk_avg_ms = lk_ms / max(1, lk_n)
+        lk_bytes = (5 + 8) * S  # LK I-side 5S (image S + derivs 4S) + J-side S per target, K_f = 8
+        frame_bytes = 14 * P + (12 + 8) * S
+        achieved = lk_bytes / (lk_avg_ms * 1e-3) / 1e9 if lk_avg_ms > 0 else 0.0
+        fps = world * K / dt
+        out = {
+            "metric": "optical-flow frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 fixed-point + f32 2x2 solve",
+            "data": "synthetic",
+            "config": {"workload": label, "width": w, "height": h, "max_level": max_level,
+                       "window": 10, "pairs_per_frame": 8, "frames_per_gpu": K,
+                       "mean_keypoints": float(np.mean(n_kps)), "mean_flow_rows": float(np.mean(n_rows)),
+                       "parallelism": f"frame-shard x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "lk_kernel<10>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": lk_bytes, "avg_launch_ms": lk_avg_ms,
+                         "launches": lk_n},
+            "path_roofline": {"algorithmic_bytes_per_frame": frame_bytes,
+                              "achieved_GBs": frame_bytes * (K / dt) / 1e9,
+                              "frac": frame_bytes * (K / dt) / 1e9 / HBM_PEAK_GBS},
+            "kernel_ms_per_frame": {k: v[1] / K for k, v in timing.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            n_s = args.cpu_sample or (2 if P > 4_000_000 else 4)
+            f1s = [f1_first + W + i for i in range(n_s)]
+            lo, hi = f1s[0] - 8, f1s[-1] + 8
+            host = [frames[f].cpu().numpy() for f in range(lo, hi + 1)]
+            out["cpu_baseline"] = cpu_baseline(host, lo, f1s, gopt_kw, fopt_kw)
+            out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    an.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
