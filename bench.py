@@ -110,7 +110,7 @@ def main():
     ctx = hip.Context(local_rank)
     gopt_kw, fopt_kw = {}, {"max_level": max_level}
     an = ClipAnalyzer(ctx, w, h, first_id, n_local, lambda fid: frames[fid], hip.gftt_options(**gopt_kw),
-                      hip.flow_options(**fopt_kw))
+                      hip.flow_options(**fopt_kw), max_jobs=3)
 
     def barrier():
         torch.cuda.synchronize()
@@ -120,19 +120,20 @@ def main():
 
     f1_first = first_id + 8
     n_kps, n_rows = [], []
-    for i in range(W):
-        an.process(f1_first + i)
-    barrier()
-    ctx.enable_timing(True)
-    ctx.reset_timing()
-    t0 = time.perf_counter()
     records = []
-    for i in range(K):
-        kps, _, flows = an.process(f1_first + W + i)
+
+    def sink(frame1, kps, detected, flows):
         n_kps.append(len(kps))
         n_rows.append(sum(len(v[0]) for v in flows.values()))
         if world > 1:
             records.append((kps, flows))
+
+    an.run(range(f1_first, f1_first + W), None)
+    barrier()
+    ctx.enable_timing(True)
+    ctx.reset_timing()
+    t0 = time.perf_counter()
+    an.run(range(f1_first + W, f1_first + W + K), sink, copy=(world > 1))
     if world > 1:
         # stitch the flow database: one RCCL all-gather of the packed records
         blobs = []

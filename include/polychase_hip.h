@@ -138,6 +138,47 @@ int pc_lk_track_filtered(pc_context* ctx, const pc_frame* frame1, const pc_frame
                          int n_targets, const pc_flow_options* opt, uint32_t* src_indices,
                          float* tgt_xy, float* flow_err, int64_t* row_offset);
 
+/* ---- analyzer: the pipelined per-clip engine behind GenerateOpticalFlowDatabase ----
+ * (cpp/opticalflow.cc:209-321).  Holds a ring of resident frames (the reference's 17-frame
+ * SequentialWrapper cache, cpp/opticalflow_thread.h:34-79, generalised), builds every frame's gray
+ * image and pyramid ONCE (the reference rebuilds them per pair, opticalflow.cc:298-302), and runs
+ * frame1 jobs asynchronously: submit() enqueues, collect() hands back the records of the oldest
+ * job in pinned host memory.  One analyzer per context; calls are not thread-safe. */
+typedef struct pc_analyzer pc_analyzer;
+
+typedef struct pc_frame_result {
+    int32_t frame1;
+    int32_t n_keypoints;
+    int32_t keypoints_detected;            /* 1: detected by this run (a new `keypoints` row), 0: supplied */
+    const float* keypoints_xy;             /* n_keypoints x 2 (gftt.cc acceptance order) */
+    int32_t n_targets;
+    int32_t targets[PC_MAX_TARGETS];       /* frame ids, in submit order */
+    int64_t row_offset[PC_MAX_TARGETS + 1];/* rows of target t: [row_offset[t], row_offset[t+1]) */
+    const uint32_t* src_indices;           /* src_keypoints_indices, ascending per target */
+    const float* tgt_xy;                   /* tgt_keypoints, rows x 2 */
+    const float* flow_err;                 /* flow_errors */
+} pc_frame_result;
+
+int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_options* gftt,
+                       const pc_flow_options* flow, int ring_frames, int max_jobs, pc_analyzer** out);
+void pc_analyzer_destroy(pc_analyzer* a);
+/* Make `frame_id` resident in ring slot frame_id mod ring_frames (evicting what was there):
+ * RGB->gray + pyramid, and, when will_detect != 0, the dense part of GoodFeaturesToTrack.
+ * Replaces RequestFrame + cvtColor + GeneratePyramid (opticalflow.cc:249-263, :287-302). */
+int pc_analyzer_put_frame(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, size_t row_pitch,
+                          int on_device, int will_detect);
+int pc_analyzer_has_frame(const pc_analyzer* a, int32_t frame_id);
+/* Keypoints already stored in the database for this frame (resume, opticalflow.cc:168-178). */
+int pc_analyzer_set_keypoints(pc_analyzer* a, int32_t frame_id, const float* xy, int n);
+/* Enqueue one iteration of the outer loop (opticalflow.cc:259-309) for frame1 and the given
+ * resident target frames (0..PC_MAX_TARGETS of them; the caller has already dropped pairs whose
+ * flow exists, opticalflow.cc:286).  Fails with PC_E_STATE when max_jobs jobs are in flight. */
+int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, int n_targets);
+int pc_analyzer_pending(const pc_analyzer* a);
+/* Wait for the oldest submitted job.  Pointers stay valid until the job slot is reused, i.e. for
+ * the next max_jobs-1 submits. */
+int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,130 +3,14 @@
 // Host-side orchestration only: HBM plane layout, stream ordering, read-backs, and the two pieces of
 // GoodFeaturesToTrack that are sequential by definition (greedy min-distance suppression,
 // reference cpp/feature_detection/gftt.cc:100-164).  No pixel arithmetic happens on the CPU.
-#include <hip/hip_runtime.h>
+#include "internal.hpp"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "../../../include/polychase_hip.h"
-#include "kernels.hpp"
-
-namespace {
-
-thread_local std::string g_err;
-
-int fail(int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
+namespace pc {
+std::string& last_error() {
+    thread_local std::string e;
+    return e;
 }
-
-#define PC_HIP(expr)                                                                              \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess)                                                                     \
-            return fail(PC_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-
-template <typename T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t cap = 0;  // elements
-    hipError_t ensure(size_t n) {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = n + n / 4 + 64;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-template <typename T>
-struct PinBuf {
-    T* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t n) {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = n + n / 4 + 64;
-        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocDefault);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-struct TimedRange {
-    int cls;
-    hipEvent_t a, b;
-};
-
-}  // namespace
-
-struct pc_context {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    // staging of host-provided frames
-    DevBuf<uint8_t> staging;
-    // GFTT scratch
-    DevBuf<float> eig;
-    DevBuf<unsigned long long> keys_in, keys_out;
-    DevBuf<uint32_t> counters;  // [0] candidate counter, [1..] cell max keys
-    DevBuf<uint8_t> sort_temp;
-    PinBuf<unsigned long long> h_keys;
-    PinBuf<float> h_kps;
-    PinBuf<uint32_t> h_counter;
-    const pc_frame* eig_owner = nullptr;
-    // LK scratch
-    DevBuf<float2> lk_xy, lk_cxy;
-    DevBuf<uint8_t> lk_status;
-    DevBuf<float> lk_err, lk_cerr;
-    DevBuf<uint32_t> lk_cidx, lk_block_counts;
-    DevBuf<long long> lk_row_offset;
-    PinBuf<long long> h_row_offset;
-    // timing
-    bool timing = false;
-    std::vector<TimedRange> ranges;
-    std::vector<hipEvent_t> event_pool;
-    int launches[PC_K_COUNT] = {0};
-    double total_ms[PC_K_COUNT] = {0};
-};
-
-struct pc_frame {
-    pc_context* ctx = nullptr;
-    int w = 0, h = 0, win = 0, max_level = 0, nlevels = 0;
-    pc::Level levels[PC_MAX_LEVELS];
-    uint8_t* slab = nullptr;
-    size_t slab_bytes = 0;
-    float2* d_kps = nullptr;
-    int kp_cap = 0;
-    int n_kps = -1;   // -1: none
-    int n_cands = -1;
-};
+}  // namespace pc
 
 namespace {
 
@@ -324,7 +208,7 @@ void pc_flow_default_options(pc_flow_options* o) {
     o->min_eigen_threshold = 1e-4;
 }
 
-const char* pc_last_error(void) { return g_err.c_str(); }
+const char* pc_last_error(void) { return pc::last_error().c_str(); }
 const char* pc_version(void) { return "polychase_hip 0.1 (gfx950, hand-written HIP)"; }
 
 int pc_context_create(int device_index, pc_context** out) {
@@ -727,6 +611,357 @@ int pc_lk_track_filtered(pc_context* ctx, const pc_frame* frame1, const pc_frame
         PC_HIP(hipMemcpyAsync(flow_err, ctx->lk_cerr.p, total * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         PC_HIP(hipStreamSynchronize(ctx->stream));
     }
+    return PC_OK;
+}
+
+
+// =============================================================================================
+// analyzer: pipelined per-clip engine (see include/polychase_hip.h)
+// =============================================================================================
+}  // extern "C"  (helpers below are C++)
+
+namespace {
+
+enum DetState { DET_NONE = 0, DET_DENSE = 1, DET_SORT = 2, DET_DONE = 3 };
+
+struct Slot {
+    pc_frame* frame = nullptr;
+    int32_t frame_id = 0;
+    bool valid = false;
+    DetState det = DET_NONE;
+    bool supplied = false;  // keypoints came from the caller (database), not from detection
+    DevBuf<unsigned long long> keys_in;
+    DevBuf<uint32_t> counters;  // [0] candidate counter, [1..] per-cell max keys
+    PinBuf<uint32_t> h_counter;
+    PinBuf<unsigned long long> h_keys;
+    PinBuf<float> h_kps;
+    hipEvent_t ev_dense = nullptr, ev_sort = nullptr;
+    uint32_t n_cand = 0;
+};
+
+struct Job {
+    bool active = false;
+    int32_t frame1 = 0;
+    int n_kps = 0;
+    bool detected = false;
+    int n_targets = 0;
+    int32_t targets[PC_MAX_TARGETS];
+    PinBuf<float> h_kps, h_xy, h_err;
+    PinBuf<uint32_t> h_idx;
+    PinBuf<long long> h_row_offset;
+    hipEvent_t done = nullptr;
+};
+
+}  // namespace
+
+struct pc_analyzer {
+    pc_context* ctx = nullptr;
+    int w = 0, h = 0;
+    pc_gftt_options gopt;
+    pc_flow_options fopt;
+    pc::GfttGrid grid;
+    std::vector<Slot> slots;
+    std::vector<Job> jobs;
+    size_t job_head = 0, job_count = 0;  // ring of in-flight jobs
+    std::vector<float> scratch_xy;
+};
+
+namespace {
+
+Slot* find_slot(pc_analyzer* a, int32_t frame_id) {
+    const int n = (int)a->slots.size();
+    Slot& s = a->slots[(size_t)(((frame_id % n) + n) % n)];
+    return (s.valid && s.frame_id == frame_id) ? &s : nullptr;
+}
+
+// dense part of GoodFeaturesToTrack: min-eig map, per-cell max, threshold + NMS -> candidate keys
+int detect_dense(pc_analyzer* a, Slot& s) {
+    pc_context* ctx = a->ctx;
+    const size_t npx = (size_t)a->w * a->h;
+    PC_HIP(ctx->eig.ensure(npx));
+    PC_HIP(s.keys_in.ensure(npx));
+    PC_HIP(s.counters.ensure(1 + pc::kMaxGridCells));
+    PC_HIP(s.h_counter.ensure(4));
+    PC_HIP(hipMemsetAsync(s.counters.p, 0, (1 + pc::kMaxGridCells) * sizeof(uint32_t), ctx->stream));
+    {
+        ScopedTimer t(ctx, PC_K_MINEIG);
+        pc::launch_min_eig(s.frame->levels[0], ctx->eig.p, a->grid, s.counters.p + 1, ctx->stream);
+    }
+    ctx->eig_owner = nullptr;
+    {
+        ScopedTimer t(ctx, PC_K_NMS);
+        pc::launch_nms_compact(ctx->eig.p, a->w, a->h, a->grid, s.counters.p + 1, a->gopt.quality_level, s.keys_in.p,
+                               (uint32_t)npx, s.counters.p, ctx->stream);
+    }
+    PC_HIP(hipMemcpyAsync(s.h_counter.p, s.counters.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipEventRecord(s.ev_dense, ctx->stream));
+    s.det = DET_DENSE;
+    return PC_OK;
+}
+
+// sort the candidates (gftt.cc:98) and start their download
+int detect_sort(pc_analyzer* a, Slot& s) {
+    pc_context* ctx = a->ctx;
+    PC_HIP(hipEventSynchronize(s.ev_dense));
+    s.n_cand = std::min<uint32_t>(s.h_counter.p[0], (uint32_t)((size_t)a->w * a->h));
+    s.frame->n_cands = (int)s.n_cand;
+    if (s.n_cand > 0) {
+        PC_HIP(ctx->keys_out.ensure(s.n_cand));
+        size_t temp_bytes = 0;
+        PC_HIP(pc::sort_keys_desc(nullptr, temp_bytes, s.keys_in.p, ctx->keys_out.p, s.n_cand, ctx->stream));
+        PC_HIP(ctx->sort_temp.ensure(temp_bytes));
+        {
+            ScopedTimer t(ctx, PC_K_SORT);
+            PC_HIP(pc::sort_keys_desc(ctx->sort_temp.p, temp_bytes, s.keys_in.p, ctx->keys_out.p, s.n_cand, ctx->stream));
+        }
+        PC_HIP(s.h_keys.ensure(s.n_cand));
+        PC_HIP(hipMemcpyAsync(s.h_keys.p, ctx->keys_out.p, (size_t)s.n_cand * sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PC_HIP(hipEventRecord(s.ev_sort, ctx->stream));
+    s.det = DET_SORT;
+    return PC_OK;
+}
+
+// greedy min-distance suppression on the host (gftt.cc:100-164) + upload of the accepted corners
+int detect_finish(pc_analyzer* a, Slot& s) {
+    pc_context* ctx = a->ctx;
+    int rc;
+    if (s.det == DET_NONE && (rc = detect_dense(a, s)) != PC_OK) return rc;
+    if (s.det == DET_DENSE && (rc = detect_sort(a, s)) != PC_OK) return rc;
+    PC_HIP(hipEventSynchronize(s.ev_sort));
+    const int n = suppress_min_distance(s.h_keys.p, s.n_cand, a->w, a->h, a->gopt.min_distance, a->gopt.max_corners,
+                                        a->scratch_xy);
+    rc = ensure_kp_capacity(s.frame, n);
+    if (rc != PC_OK) return rc;
+    PC_HIP(s.h_kps.ensure((size_t)std::max(n, 1) * 2));
+    if (n > 0) {
+        std::memcpy(s.h_kps.p, a->scratch_xy.data(), (size_t)n * 2 * sizeof(float));
+        PC_HIP(hipMemcpyAsync(s.frame->d_kps, s.h_kps.p, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    }
+    s.frame->n_kps = n;
+    s.det = DET_DONE;
+    s.supplied = false;
+    return PC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_options* gftt,
+                       const pc_flow_options* flow, int ring_frames, int max_jobs, pc_analyzer** out) {
+    if (!ctx || !gftt || !flow || !out) return fail(PC_E_INVALID, "null argument");
+    *out = nullptr;
+    if (ring_frames < 1 || ring_frames > 4096) return fail(PC_E_INVALID, "ring_frames must be in [1,4096]");
+    if (max_jobs < 1 || max_jobs > 64) return fail(PC_E_INVALID, "max_jobs must be in [1,64]");
+    if (!(gftt->quality_level > 0 && gftt->min_distance >= 0 && gftt->max_corners >= 0))
+        return fail(PC_E_INVALID, "GFTT options violate quality_level > 0 && min_distance >= 0 && max_corners >= 0");
+    if (gftt->use_harris) return fail(PC_E_INVALID, "use_harris is not implemented on the HIP path");
+    if (gftt->block_size != 3 || gftt->gradient_size != 3)
+        return fail(PC_E_INVALID, "only block_size == 3 and gradient_size == 3 are implemented on the HIP path");
+    PC_HIP(hipSetDevice(ctx->device));
+    pc_analyzer* a = new (std::nothrow) pc_analyzer();
+    if (!a) return fail(PC_E_INVALID, "out of host memory");
+    a->ctx = ctx;
+    a->w = width;
+    a->h = height;
+    a->gopt = *gftt;
+    a->fopt = *flow;
+    a->grid.rows = std::max(1, gftt->grid_rows);
+    a->grid.cols = std::max(1, gftt->grid_cols);
+    if (a->grid.rows * a->grid.cols > pc::kMaxGridCells) {
+        delete a;
+        return fail(PC_E_INVALID, "grid_rows*grid_cols must be <= %d", pc::kMaxGridCells);
+    }
+    a->grid.cell_h = (height + a->grid.rows - 1) / a->grid.rows;
+    a->grid.cell_w = (width + a->grid.cols - 1) / a->grid.cols;
+    a->slots.resize((size_t)ring_frames);
+    a->jobs.resize((size_t)max_jobs);
+    int rc = PC_OK;
+    for (auto& s : a->slots) {
+        rc = pc_frame_create(ctx, width, height, flow->window_size, flow->max_level, &s.frame);
+        if (rc != PC_OK) break;
+        if (hipEventCreateWithFlags(&s.ev_dense, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.ev_sort, hipEventDisableTiming) != hipSuccess) {
+            rc = fail(PC_E_HIP, "hipEventCreate failed");
+            break;
+        }
+    }
+    if (rc == PC_OK)
+        for (auto& j : a->jobs)
+            if (hipEventCreateWithFlags(&j.done, hipEventDisableTiming) != hipSuccess) {
+                rc = fail(PC_E_HIP, "hipEventCreate failed");
+                break;
+            }
+    if (rc != PC_OK) {
+        std::string keep = pc::last_error();
+        pc_analyzer_destroy(a);
+        pc::last_error() = keep;
+        return rc;
+    }
+    *out = a;
+    return PC_OK;
+}
+
+void pc_analyzer_destroy(pc_analyzer* a) {
+    if (!a) return;
+    (void)hipSetDevice(a->ctx->device);
+    (void)hipStreamSynchronize(a->ctx->stream);
+    for (auto& s : a->slots) {
+        if (s.frame) pc_frame_destroy(s.frame);
+        s.keys_in.release();
+        s.counters.release();
+        s.h_counter.release();
+        s.h_keys.release();
+        s.h_kps.release();
+        if (s.ev_dense) (void)hipEventDestroy(s.ev_dense);
+        if (s.ev_sort) (void)hipEventDestroy(s.ev_sort);
+    }
+    for (auto& j : a->jobs) {
+        j.h_kps.release();
+        j.h_xy.release();
+        j.h_err.release();
+        j.h_idx.release();
+        j.h_row_offset.release();
+        if (j.done) (void)hipEventDestroy(j.done);
+    }
+    delete a;
+}
+
+int pc_analyzer_put_frame(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, size_t row_pitch, int on_device,
+                          int will_detect) {
+    if (!a || !rgb) return fail(PC_E_INVALID, "null argument");
+    const int n = (int)a->slots.size();
+    Slot& s = a->slots[(size_t)(((frame_id % n) + n) % n)];
+    // a job in flight may still read this slot: everything is ordered on the one stream
+    int rc = pc_frame_set_rgb(a->ctx, s.frame, rgb, row_pitch, on_device);
+    if (rc != PC_OK) {
+        s.valid = false;
+        return rc;
+    }
+    s.frame_id = frame_id;
+    s.valid = true;
+    s.det = DET_NONE;
+    s.supplied = false;
+    if (will_detect) return detect_dense(a, s);
+    return PC_OK;
+}
+
+int pc_analyzer_has_frame(const pc_analyzer* a, int32_t frame_id) {
+    if (!a) return 0;
+    return find_slot(const_cast<pc_analyzer*>(a), frame_id) != nullptr;
+}
+
+int pc_analyzer_set_keypoints(pc_analyzer* a, int32_t frame_id, const float* xy, int n) {
+    if (!a || n < 0 || (!xy && n > 0)) return fail(PC_E_INVALID, "bad argument");
+    Slot* s = find_slot(a, frame_id);
+    if (!s) return fail(PC_E_STATE, "frame %d is not resident", frame_id);
+    int rc = ensure_kp_capacity(s->frame, n);
+    if (rc != PC_OK) return rc;
+    PC_HIP(s->h_kps.ensure((size_t)std::max(n, 1) * 2));
+    if (n > 0) {
+        std::memcpy(s->h_kps.p, xy, (size_t)n * 2 * sizeof(float));
+        PC_HIP(hipMemcpyAsync(s->frame->d_kps, s->h_kps.p, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, a->ctx->stream));
+    }
+    s->frame->n_kps = n;
+    s->det = DET_DONE;
+    s->supplied = true;
+    return PC_OK;
+}
+
+int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, int n_targets) {
+    if (!a || (n_targets > 0 && !targets)) return fail(PC_E_INVALID, "null argument");
+    if (n_targets < 0 || n_targets > PC_MAX_TARGETS) return fail(PC_E_INVALID, "n_targets must be in [0,%d]", PC_MAX_TARGETS);
+    if (a->job_count == a->jobs.size()) return fail(PC_E_STATE, "%zu jobs already in flight: call pc_analyzer_collect", a->job_count);
+    pc_context* ctx = a->ctx;
+    PC_HIP(hipSetDevice(ctx->device));
+    Slot* s1 = find_slot(a, frame1);
+    if (!s1) return fail(PC_E_STATE, "frame1 %d is not resident", frame1);
+    const pc_frame* tg[PC_MAX_TARGETS];
+    for (int t = 0; t < n_targets; t++) {
+        Slot* st = find_slot(a, targets[t]);
+        if (!st) return fail(PC_E_STATE, "target frame %d is not resident", targets[t]);
+        tg[t] = st->frame;
+    }
+    int rc;
+    // (1) keypoints of frame1: host suppression overlaps the previous job's LK on the GPU
+    bool detected = false;
+    if (s1->det != DET_DONE) {
+        if ((rc = detect_finish(a, *s1)) != PC_OK) return rc;
+        detected = true;
+    } else {
+        detected = !s1->supplied;
+    }
+    // (2) look ahead: sort + download the next frame's candidates BEFORE this frame's LK is queued
+    if (Slot* nx = find_slot(a, frame1 + 1))
+        if (nx->det == DET_DENSE && (rc = detect_sort(a, *nx)) != PC_OK) return rc;
+
+    Job& j = a->jobs[(a->job_head + a->job_count) % a->jobs.size()];
+    const int n = s1->frame->n_kps;
+    const size_t rows = (size_t)n * (size_t)std::max(n_targets, 0);
+    PC_HIP(j.h_kps.ensure((size_t)std::max(n, 1) * 2));
+    PC_HIP(j.h_idx.ensure(rows + 1));
+    PC_HIP(j.h_xy.ensure(rows * 2 + 2));
+    PC_HIP(j.h_err.ensure(rows + 1));
+    PC_HIP(j.h_row_offset.ensure(PC_MAX_TARGETS + 1));
+    if (n > 0) std::memcpy(j.h_kps.p, s1->h_kps.p, (size_t)n * 2 * sizeof(float));
+    j.frame1 = frame1;
+    j.n_kps = n;
+    j.detected = detected;
+    j.n_targets = n_targets;
+    for (int t = 0; t < n_targets; t++) j.targets[t] = targets[t];
+    for (int t = 0; t <= PC_MAX_TARGETS; t++) j.h_row_offset.p[t] = 0;
+    // (3) LK + status filter + download
+    if (n_targets > 0) {
+        if (a->fopt.window_size != s1->frame->win) return fail(PC_E_INVALID, "window size mismatch");
+        if ((rc = run_lk(ctx, s1->frame, tg, n_targets, &a->fopt)) != PC_OK) return rc;
+        const int nblocks = pc::compact_num_blocks(n);
+        PC_HIP(ctx->lk_cxy.ensure(rows + 1));
+        PC_HIP(ctx->lk_cerr.ensure(rows + 1));
+        PC_HIP(ctx->lk_cidx.ensure(rows + 1));
+        PC_HIP(ctx->lk_block_counts.ensure((size_t)nblocks * n_targets + 1));
+        PC_HIP(ctx->lk_row_offset.ensure(PC_MAX_TARGETS + 1));
+        {
+            ScopedTimer t(ctx, PC_K_COMPACT);
+            pc::launch_compact(ctx->lk_xy.p, ctx->lk_status.p, ctx->lk_err.p, n, n_targets, ctx->lk_block_counts.p,
+                               ctx->lk_row_offset.p, ctx->lk_cidx.p, ctx->lk_cxy.p, ctx->lk_cerr.p, ctx->stream);
+        }
+        PC_HIP(hipMemcpyAsync(j.h_row_offset.p, ctx->lk_row_offset.p, (size_t)(n_targets + 1) * sizeof(long long),
+                              hipMemcpyDeviceToHost, ctx->stream));
+        if (rows > 0) {
+            // the row count is only known on the device: download the capacity (n * n_targets rows)
+            PC_HIP(hipMemcpyAsync(j.h_idx.p, ctx->lk_cidx.p, rows * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            PC_HIP(hipMemcpyAsync(j.h_xy.p, ctx->lk_cxy.p, rows * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+            PC_HIP(hipMemcpyAsync(j.h_err.p, ctx->lk_cerr.p, rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    PC_HIP(hipEventRecord(j.done, ctx->stream));
+    j.active = true;
+    a->job_count++;
+    return PC_OK;
+}
+
+int pc_analyzer_pending(const pc_analyzer* a) { return a ? (int)a->job_count : 0; }
+
+int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out) {
+    if (!a || !out) return fail(PC_E_INVALID, "null argument");
+    if (a->job_count == 0) return fail(PC_E_STATE, "no job in flight");
+    Job& j = a->jobs[a->job_head];
+    PC_HIP(hipEventSynchronize(j.done));
+    out->frame1 = j.frame1;
+    out->n_keypoints = j.n_kps;
+    out->keypoints_detected = j.detected ? 1 : 0;
+    out->keypoints_xy = j.h_kps.p;
+    out->n_targets = j.n_targets;
+    for (int t = 0; t < PC_MAX_TARGETS; t++) out->targets[t] = t < j.n_targets ? j.targets[t] : 0;
+    for (int t = 0; t <= PC_MAX_TARGETS; t++) out->row_offset[t] = t <= j.n_targets ? (int64_t)j.h_row_offset.p[t] : (int64_t)j.h_row_offset.p[j.n_targets];
+    out->src_indices = j.h_idx.p;
+    out->tgt_xy = j.h_xy.p;
+    out->flow_err = j.h_err.p;
+    j.active = false;
+    a->job_head = (a->job_head + 1) % a->jobs.size();
+    a->job_count--;
     return PC_OK;
 }
 

@@ -1,0 +1,133 @@
+// internal.hpp -- host-side structures shared by api.hip and analyzer.hip (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../../include/polychase_hip.h"
+#include "kernels.hpp"
+
+namespace pc {
+
+std::string& last_error();
+
+inline int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+#define PC_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(PC_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+template <typename T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct TimedRange {
+    int cls;
+    hipEvent_t a, b;
+};
+
+}  // namespace pc
+
+using pc::DevBuf;
+using pc::PinBuf;
+using pc::TimedRange;
+using pc::fail;
+
+struct pc_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // staging of host-provided frames
+    DevBuf<uint8_t> staging;
+    // GFTT scratch
+    DevBuf<float> eig;
+    DevBuf<unsigned long long> keys_in, keys_out;
+    DevBuf<uint32_t> counters;  // [0] candidate counter, [1..] cell max keys
+    DevBuf<uint8_t> sort_temp;
+    PinBuf<unsigned long long> h_keys;
+    PinBuf<float> h_kps;
+    PinBuf<uint32_t> h_counter;
+    const pc_frame* eig_owner = nullptr;
+    // LK scratch
+    DevBuf<float2> lk_xy, lk_cxy;
+    DevBuf<uint8_t> lk_status;
+    DevBuf<float> lk_err, lk_cerr;
+    DevBuf<uint32_t> lk_cidx, lk_block_counts;
+    DevBuf<long long> lk_row_offset;
+    PinBuf<long long> h_row_offset;
+    // timing
+    bool timing = false;
+    std::vector<TimedRange> ranges;
+    std::vector<hipEvent_t> event_pool;
+    int launches[PC_K_COUNT] = {0};
+    double total_ms[PC_K_COUNT] = {0};
+};
+
+struct pc_frame {
+    pc_context* ctx = nullptr;
+    int w = 0, h = 0, win = 0, max_level = 0, nlevels = 0;
+    pc::Level levels[PC_MAX_LEVELS];
+    uint8_t* slab = nullptr;
+    size_t slab_bytes = 0;
+    float2* d_kps = nullptr;
+    int kp_cap = 0;
+    int n_kps = -1;   // -1: none
+    int n_cands = -1;
+};
+

@@ -141,6 +141,8 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restric
                                                           unsigned long long* __restrict__ keys, uint32_t cap,
                                                           uint32_t* __restrict__ counter) {
     __shared__ float s_thr[kMaxGridCells];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base;
     const int ncells = g.rows * g.cols;
     for (int i = threadIdx.x; i < ncells; i += blockDim.x) {
         // cv::threshold on CV_32F compares with (float)(maxVal * quality_level), maxVal a double
@@ -149,49 +151,76 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restric
     }
     __syncthreads();
 
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    bool is_cand = false;
-    float val = 0.f;
-    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
-        const int cx = x / g.cell_w, cy = y / g.cell_h;
-        // cells of the 3 columns / 3 rows of the neighbourhood
-        const int cxs[3] = {(x - 1) / g.cell_w, cx, (x + 1) / g.cell_w};
-        const int cys[3] = {(y - 1) / g.cell_h, cy, (y + 1) / g.cell_h};
-        const float c = eig[(size_t)y * w + x];
-        val = (c > s_thr[cy * g.cols + cx]) ? c : 0.f;
-        if (val != 0.f) {
-            float m = val;
+    // tile 64 x 16: lane = column, 4 rows per lane (ty, ty+4, ty+8, ty+12)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    float vals[4];
+    uint32_t flags = 0;
+    const bool x_in = (x >= 1 && x < w - 1);
+    int cxs[3] = {0, 0, 0};
+    if (x_in) {
+        cxs[0] = (x - 1) / g.cell_w;
+        cxs[1] = x / g.cell_w;
+        cxs[2] = (x + 1) / g.cell_w;
+    }
 #pragma unroll
-            for (int j = 0; j < 3; j++)
+    for (int k = 0; k < 4; k++) {
+        const int y = blockIdx.y * 16 + wave + 4 * k;
+        vals[k] = 0.f;
+        if (x_in && y >= 1 && y < h - 1) {
+            const int cys[3] = {(y - 1) / g.cell_h, y / g.cell_h, (y + 1) / g.cell_h};
+            const float c = eig[(size_t)y * w + x];
+            const float val = (c > s_thr[cys[1] * g.cols + cxs[1]]) ? c : 0.f;
+            if (val != 0.f) {
+                float m = val;
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    const float e = eig[(size_t)(y + j - 1) * w + (x + i - 1)];
-                    const float v = (e > s_thr[cys[j] * g.cols + cxs[i]]) ? e : 0.f;
-                    m = (v > m) ? v : m;
+                for (int j = 0; j < 3; j++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        const float e = eig[(size_t)(y + j - 1) * w + (x + i - 1)];
+                        const float v = (e > s_thr[cys[j] * g.cols + cxs[i]]) ? e : 0.f;
+                        m = (v > m) ? v : m;
+                    }
+                if (val == m) {
+                    flags |= 1u << k;
+                    vals[k] = val;
                 }
-            is_cand = (val == m);
+            }
         }
     }
-    const unsigned long long ballot = __ballot(is_cand);
-    if (ballot == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    const uint32_t n_in_wave = (uint32_t)__popcll(ballot);
-    uint32_t base = 0;
-    const int leader = __ffsll((long long)ballot) - 1;
-    if (lane == leader) base = atomicAdd(counter, n_in_wave);
-    base = __shfl(base, leader);
-    if (is_cand) {
-        const uint32_t pos = base + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-        if (pos < cap)
-            keys[pos] = ((unsigned long long)float_to_ordered(val) << 32) | (unsigned long long)(uint32_t)(y * w + x);
+    // workgroup-aggregated append: one global atomic per 1024-pixel tile
+    const uint32_t cnt = (uint32_t)__popc(flags);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        s_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    if (cnt == 0) return;
+    uint32_t pos = s_base + incl - cnt;
+    for (int wv = 0; wv < wave; wv++) pos += s_wave[wv];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (flags & (1u << k)) {
+            const int y = blockIdx.y * 16 + wave + 4 * k;
+            if (pos < cap)
+                keys[pos] = ((unsigned long long)float_to_ordered(vals[k]) << 32) | (unsigned long long)(uint32_t)(y * w + x);
+            pos++;
+        }
     }
 }
 
 void launch_nms_compact(const float* eig, int w, int h, const GfttGrid& g, const uint32_t* cell_max,
                         double quality_level, unsigned long long* keys, uint32_t cap, uint32_t* counter,
                         hipStream_t s) {
-    dim3 grid((w + 63) / 64, (h + 3) / 4);
+    dim3 grid((w + 63) / 64, (h + 15) / 16);
     hipLaunchKernelGGL(nms_compact_kernel, grid, dim3(256), 0, s, eig, w, h, g, cell_max, quality_level, keys, cap,
                        counter);
 }

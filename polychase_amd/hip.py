@@ -26,6 +26,8 @@ SYMBOLS = [
     "pc_frame_download_deriv", "pc_frame_detect", "pc_frame_download_min_eig", "pc_frame_num_candidates",
     "pc_frame_num_keypoints", "pc_frame_download_keypoints", "pc_frame_set_keypoints",
     "pc_lk_track", "pc_lk_track_filtered",
+    "pc_analyzer_create", "pc_analyzer_destroy", "pc_analyzer_put_frame", "pc_analyzer_has_frame",
+    "pc_analyzer_set_keypoints", "pc_analyzer_submit", "pc_analyzer_pending", "pc_analyzer_collect",
 ]
 
 
@@ -40,6 +42,15 @@ class FlowOptions(C.Structure):
     """OpticalFlowOptions (reference cpp/opticalflow.h:27-33)."""
     _fields_ = [("window_size", C.c_int), ("max_level", C.c_int), ("term_max_iters", C.c_int),
                 ("term_epsilon", C.c_double), ("min_eigen_threshold", C.c_double)]
+
+
+class FrameResult(C.Structure):
+    """pc_frame_result (include/polychase_hip.h)."""
+    _fields_ = [("frame1", C.c_int32), ("n_keypoints", C.c_int32), ("keypoints_detected", C.c_int32),
+                ("keypoints_xy", C.POINTER(C.c_float)), ("n_targets", C.c_int32),
+                ("targets", C.c_int32 * 8), ("row_offset", C.c_int64 * 9),
+                ("src_indices", C.POINTER(C.c_uint32)), ("tgt_xy", C.POINTER(C.c_float)),
+                ("flow_err", C.POINTER(C.c_float))]
 
 
 class PolychaseHipError(RuntimeError):
@@ -99,6 +110,16 @@ def load():
     L.pc_frame_set_keypoints.argtypes = [vp, vp, vp, C.c_int]
     L.pc_lk_track.argtypes = [vp, vp, C.POINTER(vp), C.c_int, C.POINTER(FlowOptions), vp, vp, vp]
     L.pc_lk_track_filtered.argtypes = [vp, vp, C.POINTER(vp), C.c_int, C.POINTER(FlowOptions), vp, vp, vp, vp]
+    L.pc_analyzer_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(GfttOptions), C.POINTER(FlowOptions), C.c_int,
+                                     C.c_int, C.POINTER(vp)]
+    L.pc_analyzer_destroy.argtypes = [vp]
+    L.pc_analyzer_destroy.restype = None
+    L.pc_analyzer_put_frame.argtypes = [vp, C.c_int32, vp, C.c_size_t, C.c_int, C.c_int]
+    L.pc_analyzer_has_frame.argtypes = [vp, C.c_int32]
+    L.pc_analyzer_set_keypoints.argtypes = [vp, C.c_int32, vp, C.c_int]
+    L.pc_analyzer_submit.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.c_int]
+    L.pc_analyzer_pending.argtypes = [vp]
+    L.pc_analyzer_collect.argtypes = [vp, C.POINTER(FrameResult)]
     _lib = L
     return L
 
@@ -291,3 +312,75 @@ def lk_track_filtered(ctx: Context, frame1: Frame, targets: list[Frame], opt: Fl
         a, b = int(off[k]), int(off[k + 1])
         out.append((idx[a:b].copy(), xy[a:b].copy(), err[a:b].copy()))
     return out
+
+
+class Analyzer:
+    """pc_analyzer: pipelined per-clip engine (ring of resident frames + asynchronous frame1 jobs)."""
+
+    def __init__(self, ctx: Context, width: int, height: int, gftt: GfttOptions | None = None,
+                 flow: FlowOptions | None = None, ring_frames: int = 17, max_jobs: int = 3):
+        self.ctx, self.w, self.h = ctx, width, height
+        self.gftt = gftt or gftt_options()
+        self.flow = flow or flow_options()
+        self._h = C.c_void_p()
+        self._keep = {}
+        _check(load().pc_analyzer_create(ctx._h, width, height, C.byref(self.gftt), C.byref(self.flow), ring_frames,
+                                         max_jobs, C.byref(self._h)))
+        self.ring = ring_frames
+
+    def close(self):
+        if self._h and self.ctx._h:
+            load().pc_analyzer_destroy(self._h)
+        self._h = C.c_void_p()
+        self._keep = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def put_frame(self, frame_id: int, rgb, will_detect: bool = True):
+        assert tuple(rgb.shape) == (self.h, self.w, 3), rgb.shape
+        p, dev, pitch = _ptr(rgb)
+        _check(load().pc_analyzer_put_frame(self._h, frame_id, p, pitch, dev, 1 if will_detect else 0))
+        if dev:
+            self._keep[frame_id % self.ring] = rgb  # device sources must outlive the async kernels
+
+    def has_frame(self, frame_id: int) -> bool:
+        return bool(load().pc_analyzer_has_frame(self._h, frame_id))
+
+    def set_keypoints(self, frame_id: int, xy: np.ndarray):
+        xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+        _check(load().pc_analyzer_set_keypoints(self._h, frame_id, xy.ctypes.data, len(xy)))
+
+    def submit(self, frame1: int, targets):
+        t = list(targets)
+        arr = (C.c_int32 * max(1, len(t)))(*t)
+        _check(load().pc_analyzer_submit(self._h, frame1, arr, len(t)))
+
+    @property
+    def pending(self) -> int:
+        return load().pc_analyzer_pending(self._h)
+
+    def collect_raw(self) -> FrameResult:
+        r = FrameResult()
+        _check(load().pc_analyzer_collect(self._h, C.byref(r)))
+        return r
+
+    def collect(self, copy: bool = True):
+        """-> (frame1, keypoints [N,2], detected, {frame2: (src_idx, tgt_xy, err)})"""
+        r = self.collect_raw()
+        n = r.n_keypoints
+        kps = np.ctypeslib.as_array(r.keypoints_xy, shape=(n, 2)) if n else np.zeros((0, 2), np.float32)
+        flows = {}
+        for t in range(r.n_targets):
+            a, b = int(r.row_offset[t]), int(r.row_offset[t + 1])
+            if b > a:
+                idx = np.ctypeslib.as_array(r.src_indices, shape=(b,))[a:b]
+                xy = np.ctypeslib.as_array(r.tgt_xy, shape=(b, 2))[a:b]
+                err = np.ctypeslib.as_array(r.flow_err, shape=(b,))[a:b]
+            else:
+                idx, xy, err = np.zeros(0, np.uint32), np.zeros((0, 2), np.float32), np.zeros(0, np.float32)
+            flows[int(r.targets[t])] = (idx.copy(), xy.copy(), err.copy()) if copy else (idx, xy, err)
+        return r.frame1, (kps.copy() if copy else kps), bool(r.keypoints_detected), flows

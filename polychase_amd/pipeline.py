@@ -3,13 +3,12 @@
 
 For every frame1: make frame1 and its valid +-{1,2,4,8} neighbours resident (gray + pyramid, once per
 frame instead of once per pair), detect keypoints (or take the ones supplied on resume), track into
-all targets in one launch, emit  keypoints(frame1)  and  flow(frame1 -> frame2)  records.
+all targets in one launch, emit  keypoints(frame1)  and  flow(frame1 -> frame2)  records.  Jobs are
+pipelined through pc_analyzer: frame f+1 is submitted before frame f is collected.
 """
 from __future__ import annotations
 
 from typing import Callable, Iterable
-
-import numpy as np
 
 from . import hip
 
@@ -22,50 +21,40 @@ class ClipAnalyzer:
 
     def __init__(self, ctx: hip.Context, width: int, height: int, first_frame: int, num_frames: int,
                  frame_source: Callable[[int], object], gftt: hip.GfttOptions | None = None,
-                 flow: hip.FlowOptions | None = None):
-        self.ctx, self.w, self.h = ctx, width, height
+                 flow: hip.FlowOptions | None = None, max_jobs: int = 3):
         self.first, self.end = first_frame, first_frame + num_frames
         self.source = frame_source
-        self.gftt = gftt or hip.gftt_options()
-        self.flow = flow or hip.flow_options()
-        self.slots = [hip.Frame(ctx, width, height, self.flow.window_size, self.flow.max_level) for _ in range(RING)]
-        self.slot_id = [None] * RING
+        self.an = hip.Analyzer(ctx, width, height, gftt, flow, RING, max_jobs)
+        self.max_jobs = max_jobs
+        self.highest = None  # highest frame id made resident so far
 
     def close(self):
-        for f in self.slots:
-            f.close()
-        self.slots = []
-
-    def _resident(self, frame_id: int) -> hip.Frame:
-        s = frame_id % RING
-        if self.slot_id[s] != frame_id:
-            self.slots[s].set_rgb(self.source(frame_id))
-            self.slot_id[s] = frame_id
-        return self.slots[s]
+        self.an.close()
 
     def targets_of(self, frame1: int) -> list[int]:
         return [frame1 + s for s in IMAGE_SKIPS if self.first <= frame1 + s < self.end]
 
-    def process(self, frame1: int, known_keypoints: np.ndarray | None = None,
-                targets: Iterable[int] | None = None):
-        """Returns (keypoints [N,2], detected: bool, {frame2: (src_idx, tgt_xy, err)})."""
-        f1 = self._resident(frame1)
-        tg_ids = list(self.targets_of(frame1) if targets is None else targets)
-        tg = [self._resident(t) for t in tg_ids]
-        detected = False
-        if known_keypoints is not None and len(known_keypoints) > 0:
-            f1.set_keypoints(known_keypoints)
-        elif self.slot_kps_valid(frame1):
-            pass
-        else:
-            f1.detect(self.gftt)
-            detected = True
-            self._kps_frame = frame1
-        flows = {}
-        if tg:
-            res = hip.lk_track_filtered(self.ctx, f1, tg, self.flow)
-            flows = dict(zip(tg_ids, res))
-        return f1.keypoints(), detected, flows
+    def _ensure_resident(self, upto: int, frame1: int):
+        """Frames are requested once each, in increasing order (like SequentialWrapper)."""
+        lo = max(self.first, frame1 - 8) if self.highest is None else self.highest + 1
+        for fid in range(lo, min(upto, self.end - 1) + 1):
+            self.an.put_frame(fid, self.source(fid), will_detect=True)
+            self.highest = fid
 
-    def slot_kps_valid(self, frame1: int) -> bool:
-        return False
+    def submit(self, frame1: int, targets: Iterable[int] | None = None):
+        self._ensure_resident(frame1 + 8, frame1)
+        tg = list(self.targets_of(frame1) if targets is None else targets)
+        self.an.submit(frame1, tg)
+
+    def run(self, frame_ids: Iterable[int], sink: Callable | None = None, copy: bool = True):
+        """Process frame1 ids in order, keeping the job pipeline full; sink(frame1, kps, detected, flows)."""
+        for f in frame_ids:
+            if self.an.pending == self.max_jobs:
+                r = self.an.collect(copy)
+                if sink:
+                    sink(*r)
+            self.submit(f)
+        while self.an.pending:
+            r = self.an.collect(copy)
+            if sink:
+                sink(*r)

@@ -191,3 +191,82 @@ def test_errors(ctx):
         hip.lk_track(ctx, f, [g])
     f.close()
     g.close()
+
+
+def _compare_clip(kps_o, flows_o, got_kps, got_flows):
+    assert sorted(got_kps) == sorted(kps_o)
+    for f in kps_o:
+        assert np.array_equal(got_kps[f], kps_o[f]), f"keypoints of frame {f}"
+    assert sorted(got_flows) == sorted(flows_o)
+    for key in flows_o:
+        for a, b in zip(got_flows[key], flows_o[key]):
+            assert a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"flow {key}"
+
+
+def test_analyzer_whole_clip_matches_reference_shaped_cpu_path(ctx):
+    """C1-like plumbing case: a whole short clip through the pipelined analyzer equals the
+    reference-shaped CPU path (per-pair rebuild) record for record, byte for byte."""
+    from polychase_amd.pipeline import ClipAnalyzer
+    w, h, n, first = 320, 240, 20, 1
+    clip = synth.NoiseClip(w, h, n)
+    frames = [clip.frame(t) for t in range(n)]
+    kps_o, flows_o = oracle.analyze_clip(frames, first_frame=first, threads=4)
+    got_kps, got_flows = {}, {}
+
+    def sink(f1, kps, detected, flows):
+        assert detected
+        got_kps[f1] = kps
+        for f2, rec in flows.items():
+            got_flows[(f1, f2)] = rec
+
+    an = ClipAnalyzer(ctx, w, h, first, n, lambda fid: frames[fid - first])
+    an.run(range(first, first + n), sink)
+    an.close()
+    assert len(got_flows) == 8 * n - 30   # SURVEY appendix B.1
+    _compare_clip(kps_o, flows_o, got_kps, got_flows)
+
+
+def test_analyzer_checkerboard_c1(ctx):
+    """BASELINE config C1: 640x480x30 translating checkerboard."""
+    from polychase_amd.pipeline import ClipAnalyzer
+    frames = synth.checkerboard_clip(30)
+    kps_o, flows_o = oracle.analyze_clip(frames, first_frame=1, threads=4)
+    got_kps, got_flows = {}, {}
+
+    def sink(f1, kps, detected, flows):
+        got_kps[f1] = kps
+        for f2, rec in flows.items():
+            got_flows[(f1, f2)] = rec
+
+    an = ClipAnalyzer(ctx, 640, 480, 1, 30, lambda fid: frames[fid - 1])
+    an.run(range(1, 31), sink)
+    an.close()
+    _compare_clip(kps_o, flows_o, got_kps, got_flows)
+    # analytic truth: +1 frame => (+1.25, +0.75) px
+    idx, xy, _ = got_flows[(10, 11)]
+    d = xy - got_kps[10][idx]
+    assert np.abs(np.median(d, axis=0) - [1.25, 0.75]).max() < 0.1
+
+
+def test_analyzer_resume_with_supplied_keypoints(ctx):
+    from polychase_amd.pipeline import ClipAnalyzer
+    w, h, n = 320, 240, 12
+    clip = synth.NoiseClip(w, h, n)
+    frames = [clip.frame(t) for t in range(n)]
+    an = ClipAnalyzer(ctx, w, h, 1, n, lambda fid: frames[fid - 1])
+    out = {}
+    an.run([3], lambda f1, kps, det, flows: out.update(a=(kps, det, flows)))
+    kps = out["a"][0]
+    # second pass over the same frame with keypoints "read from the database": not re-detected,
+    # only the requested pair
+    an.an.set_keypoints(3, kps[::-1].copy())
+    an.an.submit(3, [4])
+    f1, kps2, det2, flows2 = an.an.collect()
+    assert not det2 and np.array_equal(kps2, kps[::-1])
+    idx_a, xy_a, err_a = out["a"][2][4]
+    idx_b, xy_b, err_b = flows2[4]
+    # same keypoints in reversed order -> same tracks, reversed
+    m = len(kps) - 1 - idx_b[::-1]
+    assert np.array_equal(m.astype(np.uint32), idx_a)
+    assert np.array_equal(xy_b[::-1], xy_a)
+    an.close()
