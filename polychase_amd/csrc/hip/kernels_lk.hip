@@ -6,11 +6,18 @@
 // structure tensor / mismatch vector accumulated EXACTLY in integers, one rounding to fp32, 2x2
 // solve in fp32 without FMA contraction.
 //
-// Mapping: one 16-lane DPP row per (keypoint, target) pair -> 4 pairs per wavefront, 16 per
-// 256-lane workgroup.  A row owns the WIN x WIN window (pixel p = lane + 16k); window sums are
-// all-reduced inside the row with row_ror DPP adds (no LDS, no cross-row traffic), so every lane of
-// the row holds the same A, b, delta and the convergence branches are row-uniform.  Consecutive rows
-// are the targets of one keypoint, so the I-side gathers of a wave hit the same cache lines.
+// Mapping (v2): one group of GL = 8 lanes per (keypoint, target) pair -> 8 pairs per wavefront,
+// 32 per 256-lane workgroup.  A group owns the WIN x WIN window (pixel p = lane + GL*k).
+//   * Every gather goes through LDS: per pyramid level the group stages (a) the I window as
+//     "byte pairs" P[c] = (I[c], I[c+1]) and the raw Scharr window, (b) a (WIN+7) x (WIN+7..) search
+//     region of the target image J in the same pair format.  One pixel of one LK iteration is then
+//     two aligned ds_read_u16 (rows y, y+1 -> the 4 bilinear taps in one dword) and two
+//     v_dot4_u32_u8 (the 14-bit weights are split w = 128*wh + wl so they fit u8 lanes).  The region
+//     is re-staged only when the window leaves it.
+//   * Window sums are all-reduced inside the group with DPP adds (quad_perm xor1/xor2 +
+//     row_half_mirror): no LDS traffic, no cross-group traffic, so every lane holds the same A, b,
+//     delta and the convergence branches are group-uniform.
+//   * Consecutive groups are the targets of one keypoint: their I-side staging hits the same lines.
 #include "kernels.hpp"
 
 namespace pc {
@@ -21,24 +28,30 @@ template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
 }
-// all-reduce (sum) across the 16 lanes of a DPP row: row_ror 8, 4, 2, 1
-__device__ __forceinline__ int row_allreduce_add(int v) {
-    v += dpp_i32<0x128>(v);
-    v += dpp_i32<0x124>(v);
-    v += dpp_i32<0x122>(v);
-    v += dpp_i32<0x121>(v);
+// all-reduce (sum) across a group of GL lanes (GL = 8 or 16, groups are aligned)
+template <int GL>
+__device__ __forceinline__ int group_allreduce_add(int v) {
+    v += dpp_i32<0xB1>(v);    // quad_perm [1,0,3,2]  (lane ^ 1)
+    v += dpp_i32<0x4E>(v);    // quad_perm [2,3,0,1]  (lane ^ 2)
+    v += dpp_i32<0x141>(v);   // row_half_mirror      (other quad of the 8-lane half)
+    if (GL == 16) v += dpp_i32<0x140>(v);  // row_mirror (other half of the row)
     return v;
 }
 
-// exact float of (hi * 2^16 + lo): both parts fit an int32; fp64 holds the integer exactly, the
-// fp64 -> fp32 conversion rounds once (== (float)(int64) of the oracle).
+// exact float of (hi * 2^16 + lo): each term is exactly representable (|hi| < 2^24, |lo| < 2^24),
+// so the single fp32 add rounds the exact integer once (== (float)(int64) of the oracle).
 __device__ __forceinline__ float exact_sum_to_float(int hi, int lo) {
-    const double d = (double)hi * 65536.0 + (double)lo;
-    return (float)d;
+    return (float)hi * 65536.f + (float)lo;
+}
+template <int GL>
+__device__ __forceinline__ float group_exact_sum(int partial) {
+    return exact_sum_to_float(group_allreduce_add<GL>(partial >> 16), group_allreduce_add<GL>(partial & 0xffff));
 }
 
 struct Weights {
-    int w00, w01, w10, w11;
+    int w00, w01, w10, w11;   // w11 may be -1 (rounding of the other three), never smaller
+    uint32_t lo4, hi4;        // u8 lanes of (w & 127) and (w >> 7), w11 clamped at 0
+    bool neg11;
 };
 __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
     Weights w;
@@ -46,31 +59,93 @@ __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
     w.w01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
     w.w10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
     w.w11 = (1 << W_BITS) - w.w00 - w.w01 - w.w10;
+    w.neg11 = w.w11 < 0;
+    const int c11 = w.neg11 ? 0 : w.w11;
+    w.lo4 = (uint32_t)(w.w00 & 127) | ((uint32_t)(w.w01 & 127) << 8) | ((uint32_t)(w.w10 & 127) << 16) |
+            ((uint32_t)(c11 & 127) << 24);
+    w.hi4 = (uint32_t)(w.w00 >> 7) | ((uint32_t)(w.w01 >> 7) << 8) | ((uint32_t)(w.w10 >> 7) << 16) |
+            ((uint32_t)(c11 >> 7) << 24);
     return w;
 }
+// CV_DESCALE(sum_t tap_t * w_t, W_BITS - 5) of the 4 taps packed in j4 = (p00, p01, p10, p11)
+__device__ __forceinline__ int interp4(uint32_t j4, const Weights& w) {
+    const uint32_t lo = __builtin_amdgcn_udot4(j4, w.lo4, 1u << (W_BITS - 5 - 1), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(j4, w.hi4, 0u, false);
+    uint32_t s = lo + (hi << 7);
+    if (__builtin_expect(w.neg11, 0)) s -= (j4 >> 24);  // w11 == -1
+    return (int)(s >> (W_BITS - 5));
+}
 
-__device__ __forceinline__ int interp_u8(const uint8_t* __restrict__ p, int pitch, const Weights& w) {
-    return PC_DESCALE((int)p[0] * w.w00 + (int)p[1] * w.w01 + (int)p[pitch] * w.w10 + (int)p[pitch + 1] * w.w11,
-                      W_BITS - 5);
+typedef short pc_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(pc_short2, a), __builtin_bit_cast(pc_short2, b), c, false);
 }
 
 template <int WIN>
-__global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
-    constexpr int NPX = WIN * WIN;
-    constexpr int K = (NPX + 15) / 16;
-    const int gid = (int)((blockIdx.x * 256u + threadIdx.x) >> 4);
-    const int l16 = threadIdx.x & 15;
-    if (gid >= p.n * p.n_targets) return;  // whole rows exit together
-    const int feat = gid / p.n_targets;
-    const int tgt = gid - feat * p.n_targets;
+struct LKGeo {
+    static constexpr int MX = 3, MY = 3;                              // search margin of the staged J region
+    static constexpr int RW_DW = (WIN + 1 + 2 * MX + 3 + 3) / 4;      // raw dwords per region row
+    static constexpr int RWB = RW_DW * 4;                             // positions (bytes) per region row
+    static constexpr int RH = WIN + 1 + 2 * MY;                       // region rows
+    static constexpr int PAIR_PITCH = RWB * 2;                        // bytes per row in pair format
+    static constexpr int J_BYTES = RH * PAIR_PITCH;
+    static constexpr int I_BYTES = (WIN + 1) * PAIR_PITCH;
+    static constexpr int D_PITCH = WIN + 1;                           // dwords per Scharr window row
+    static constexpr int D_BYTES = (WIN + 1) * D_PITCH * 4;
+    static constexpr int BUF_BYTES0 = (J_BYTES > I_BYTES + D_BYTES) ? J_BYTES : (I_BYTES + D_BYTES);
+    static constexpr int BUF_DW = ((BUF_BYTES0 + 7) / 8) * 2 + 1;     // 8-B granules, odd dword stride
+};
 
-    // window offsets owned by this lane
-    int off_x[K], off_y[K];
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Stage `nrows` rows of an u8 plane, starting at (rx0, ry0) (rx0 4-aligned relative to the interior
+// origin), as byte pairs: P[r][c] = (A[r][c], A[r][c+1]) for c in [0, RWB).  Addresses are clamped
+// to the padded plane; clamped positions are never consumed by a window that passed the bounds
+// check.
+template <int WIN, int GL>
+__device__ __forceinline__ void stage_pairs(const uint8_t* __restrict__ img, int pitch, int lh, int rx0, int ry0,
+                                            int nrows, uint8_t* buf, int lg) {
+    using G = LKGeo<WIN>;
+    const int total = nrows * G::RW_DW;
+    const int xmax = pitch - kPadX - 4;
+    for (int i = lg; i < total; i += GL) {
+        const int r = i / G::RW_DW, m = i - r * G::RW_DW;
+        const int yy = clampi(ry0 + r, -WIN, lh + WIN - 1);
+        const int xb = rx0 + 4 * m;
+        const uint8_t* rowp = img + (ptrdiff_t)yy * pitch;
+        const uint32_t d0 = *reinterpret_cast<const uint32_t*>(rowp + clampi(xb, -kPadX, xmax));
+        const uint32_t d1 = *reinterpret_cast<const uint32_t*>(rowp + clampi(xb + 4, -kPadX, xmax));
+        // v_perm_b32: byte pool = {d0: indices 0-3, d1: indices 4-7}
+        const uint32_t p0 = __builtin_amdgcn_perm(d1, d0, 0x02010100u);  // (A0,A1),(A1,A2)
+        const uint32_t p1 = __builtin_amdgcn_perm(d1, d0, 0x04030302u);  // (A2,A3),(A3,A4)
+        *reinterpret_cast<uint2*>(buf + r * G::PAIR_PITCH + 8 * m) = make_uint2(p0, p1);
+    }
+}
+
+template <int WIN, int GL>
+__global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
+    using G = LKGeo<WIN>;
+    constexpr int NPX = WIN * WIN;
+    constexpr int K = (NPX + GL - 1) / GL;
+    constexpr int GROUPS = 256 / GL;
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[GROUPS][G::BUF_DW + 1];
+
+    const int grp = threadIdx.x / GL, lg = threadIdx.x % GL;
+    const long long gid = (long long)blockIdx.x * GROUPS + grp;
+    if (gid >= (long long)p.n * p.n_targets) return;  // whole groups exit together
+    const int feat = (int)(gid / p.n_targets);
+    const int tgt = (int)(gid - (long long)feat * p.n_targets);
+    uint8_t* const buf = reinterpret_cast<uint8_t*>(&s_buf[grp][0]);   // 8-B aligned: (BUF_DW+1) is even
+    uint8_t* const dbuf = buf + G::I_BYTES;                            // raw Scharr window (I side only)
+
+    // window offsets owned by this lane: pair-format byte offset and Scharr dword offset
+    int offP[K], offD[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const int q = l16 + 16 * k;
-        off_y[k] = q / WIN;
-        off_x[k] = q - off_y[k] * WIN;
+        const int q = lg + GL * k;
+        const int y = q / WIN, x = q - y * WIN;
+        offP[k] = y * G::PAIR_PITCH + 2 * x;
+        offD[k] = (y * G::D_PITCH + x) * 4;
     }
 
     const float2 pt = p.pts[feat];
@@ -107,29 +182,44 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
             }
             continue;
         }
-        Weights wI = bilinear_weights(px - (float)ipx, py - (float)ipy);
+        const Weights wI = bilinear_weights(px - (float)ipx, py - (float)ipy);
+        // signed 16-bit weight pairs for the derivative taps: (w00, w01) and (w10, w11)
+        const uint32_t wrow0 = (uint32_t)(wI.w00 & 0xffff) | ((uint32_t)wI.w01 << 16);
+        const uint32_t wrow1 = (uint32_t)(wI.w10 & 0xffff) | ((uint32_t)wI.w11 << 16);
 
-        // ---- I side: patch, derivative patch, structure tensor ----
+        // ---- I side: stage the I window (pairs) and the raw Scharr window, then patch + tensor ----
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        {
+            const int rx0 = ipx & ~3;
+            stage_pairs<WIN, GL>(L.img, pitch, L.h, rx0, ipy, WIN + 1, buf, lg);
+            for (int i = lg; i < (WIN + 1) * (WIN + 1); i += GL) {
+                const int r = i / (WIN + 1), c = i - r * (WIN + 1);
+                reinterpret_cast<int32_t*>(dbuf)[i] = L.der[(ptrdiff_t)(ipy + r) * pitch + ipx + c];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         int Ival[K];
         int Dxy[K];  // (int16 ix) | (int16 iy << 16)
         int sA11 = 0, sA12 = 0, sA22 = 0;
         {
-            const uint8_t* __restrict__ Ibase = L.img + (ptrdiff_t)ipy * pitch + ipx;
-            const int32_t* __restrict__ Dbase = L.der + (ptrdiff_t)ipy * pitch + ipx;
+            const uint8_t* ib = buf + 2 * (ipx & 3);
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 Ival[k] = 0;
                 Dxy[k] = 0;
-                if (l16 + 16 * k < NPX) {
-                    const int o = off_y[k] * pitch + off_x[k];
-                    Ival[k] = interp_u8(Ibase + o, pitch, wI);
-                    const int32_t d00 = Dbase[o], d01 = Dbase[o + 1], d10 = Dbase[o + pitch], d11 = Dbase[o + pitch + 1];
-                    const int ix = PC_DESCALE((int)(int16_t)(d00 & 0xffff) * wI.w00 + (int)(int16_t)(d01 & 0xffff) * wI.w01 +
-                                                  (int)(int16_t)(d10 & 0xffff) * wI.w10 + (int)(int16_t)(d11 & 0xffff) * wI.w11,
-                                              W_BITS);
-                    const int iy = PC_DESCALE((d00 >> 16) * wI.w00 + (d01 >> 16) * wI.w01 + (d10 >> 16) * wI.w10 +
-                                                  (d11 >> 16) * wI.w11,
-                                              W_BITS);
+                if (lg + GL * k < NPX) {
+                    const uint16_t* q = reinterpret_cast<const uint16_t*>(ib + offP[k]);
+                    const uint32_t i4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);
+                    Ival[k] = interp4(i4, wI);
+                    const uint32_t* d = reinterpret_cast<const uint32_t*>(dbuf + offD[k]);
+                    const uint32_t d00 = d[0], d01 = d[1], d10 = d[G::D_PITCH], d11 = d[G::D_PITCH + 1];
+                    // (dx00, dx01), (dx10, dx11), (dy00, dy01), (dy10, dy11)
+                    const uint32_t dx0 = __builtin_amdgcn_perm(d01, d00, 0x05040100u);
+                    const uint32_t dx1 = __builtin_amdgcn_perm(d11, d10, 0x05040100u);
+                    const uint32_t dy0 = __builtin_amdgcn_perm(d01, d00, 0x07060302u);
+                    const uint32_t dy1 = __builtin_amdgcn_perm(d11, d10, 0x07060302u);
+                    const int ix = sdot2(dx1, wrow1, sdot2(dx0, wrow0, 1 << (W_BITS - 1))) >> W_BITS;
+                    const int iy = sdot2(dy1, wrow1, sdot2(dy0, wrow0, 1 << (W_BITS - 1))) >> W_BITS;
                     Dxy[k] = (int)((uint32_t)(ix & 0xffff) | ((uint32_t)iy << 16));
                     sA11 += ix * ix;
                     sA12 += ix * iy;
@@ -137,11 +227,10 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
                 }
             }
         }
-        // |ix|,|iy| <= 4080: per-lane partials fit int32 (K * 2^24), the row totals may not for
-        // WIN > 11, so they are reduced as exact (hi, lo) 16-bit halves like the b sums below
-        const float A11 = exact_sum_to_float(row_allreduce_add(sA11 >> 16), row_allreduce_add(sA11 & 0xffff)) * FLT_SCALE;
-        const float A12 = exact_sum_to_float(row_allreduce_add(sA12 >> 16), row_allreduce_add(sA12 & 0xffff)) * FLT_SCALE;
-        const float A22 = exact_sum_to_float(row_allreduce_add(sA22 >> 16), row_allreduce_add(sA22 & 0xffff)) * FLT_SCALE;
+        // |ix|,|iy| <= 4080: per-lane partials fit int32; group totals reduced as exact (hi, lo) halves
+        const float A11 = group_exact_sum<GL>(sA11) * FLT_SCALE;
+        const float A12 = group_exact_sum<GL>(sA12) * FLT_SCALE;
+        const float A22 = group_exact_sum<GL>(sA22) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float tdiff = A11 - A22;
         const float min_eig = (A22 + A11 - sqrtf(tdiff * tdiff + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
@@ -151,32 +240,41 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
         }
         D = 1.f / D;
 
-        // ---- iterations ----
+        // ---- iterations on the staged J region ----
         qx -= half_win;
         qy -= half_win;
         float pdx = 0.f, pdy = 0.f;
+        int rx0 = 0, ry0 = 0;
+        bool staged = false;
         for (int j = 0; j < p.max_iters; j++) {
             const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
             if (iqx < -WIN || iqx >= L.w || iqy < -WIN || iqy >= L.h) {
                 if (level == 0) status = false;
                 break;
             }
+            if (!staged || iqx < rx0 || iqx + WIN > rx0 + G::RWB || iqy < ry0 || iqy + WIN + 1 > ry0 + G::RH) {
+                rx0 = (iqx - G::MX) & ~3;
+                ry0 = iqy - G::MY;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                stage_pairs<WIN, GL>(J, pitch, L.h, rx0, ry0, G::RH, buf, lg);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                staged = true;
+            }
             const Weights wJ = bilinear_weights(qx - (float)iqx, qy - (float)iqy);
-            const uint8_t* __restrict__ Jbase = J + (ptrdiff_t)iqy * pitch + iqx;
-            int sb1 = 0, sb2 = 0;  // per-lane partials: <= 7 * 8160 * 4080 < 2^31
+            const uint8_t* jb = buf + (iqy - ry0) * G::PAIR_PITCH + 2 * (iqx - rx0);
+            int sb1 = 0, sb2 = 0;  // per-lane partials: <= K * 8160 * 4080 < 2^31
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                if (l16 + 16 * k < NPX) {
-                    const int diff = interp_u8(Jbase + off_y[k] * pitch + off_x[k], pitch, wJ) - Ival[k];
+                if (lg + GL * k < NPX) {
+                    const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offP[k]);
+                    const uint32_t j4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);
+                    const int diff = interp4(j4, wJ) - Ival[k];
                     sb1 += diff * (int)(int16_t)(Dxy[k] & 0xffff);
                     sb2 += diff * (Dxy[k] >> 16);
                 }
             }
-            // exact 64-bit row sums via (hi, lo) 16-bit split
-            const int b1lo = row_allreduce_add(sb1 & 0xffff), b1hi = row_allreduce_add(sb1 >> 16);
-            const int b2lo = row_allreduce_add(sb2 & 0xffff), b2hi = row_allreduce_add(sb2 >> 16);
-            const float b1 = exact_sum_to_float(b1hi, b1lo) * FLT_SCALE;
-            const float b2 = exact_sum_to_float(b2hi, b2lo) * FLT_SCALE;
+            const float b1 = group_exact_sum<GL>(sb1) * FLT_SCALE;
+            const float b2 = group_exact_sum<GL>(sb2) * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             qx += dx;
@@ -201,22 +299,32 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
                 status = false;
                 continue;
             }
+            if (!staged || iex < rx0 || iex + WIN > rx0 + G::RWB || iey < ry0 || iey + WIN + 1 > ry0 + G::RH) {
+                rx0 = (iex - G::MX) & ~3;
+                ry0 = iey - G::MY;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                stage_pairs<WIN, GL>(J, pitch, L.h, rx0, ry0, G::RH, buf, lg);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                staged = true;
+            }
             const Weights wE = bilinear_weights(ex - (float)iex, ey - (float)iey);
-            const uint8_t* __restrict__ Jbase = J + (ptrdiff_t)iey * pitch + iex;
+            const uint8_t* jb = buf + (iey - ry0) * G::PAIR_PITCH + 2 * (iex - rx0);
             int se = 0;
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                if (l16 + 16 * k < NPX) {
-                    const int diff = interp_u8(Jbase + off_y[k] * pitch + off_x[k], pitch, wE) - Ival[k];
+                if (lg + GL * k < NPX) {
+                    const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offP[k]);
+                    const uint32_t j4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);
+                    const int diff = interp4(j4, wE) - Ival[k];
                     se += diff < 0 ? -diff : diff;
                 }
             }
-            se = row_allreduce_add(se);  // <= 256 * 8160 < 2^24: exact in fp32 too
+            se = group_allreduce_add<GL>(se);  // <= 256 * 8160 < 2^24: exact in fp32 too
             err = ((float)se * 1.f) / (float)(32 * WIN * WIN);
         }
     }
 
-    if (l16 == 0) {
+    if (lg == 0) {
         const size_t o = (size_t)tgt * p.n + feat;
         p.out_xy[o] = make_float2(nx, ny);
         p.out_status[o] = status ? 1 : 0;
@@ -226,10 +334,12 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
 
 template <int WIN>
 static void launch_lk_t(const LKParams& p, hipStream_t s) {
+    constexpr int GL = 8;
+    constexpr int GROUPS = 256 / GL;
     const long long rows = (long long)p.n * p.n_targets;
-    const unsigned blocks = (unsigned)((rows + 15) / 16);
+    const unsigned blocks = (unsigned)((rows + GROUPS - 1) / GROUPS);
     if (blocks == 0) return;
-    hipLaunchKernelGGL(lk_kernel<WIN>, dim3(blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((lk_kernel<WIN, GL>), dim3(blocks), dim3(256), 0, s, p);
 }
 
 bool launch_lk(const LKParams& p, int win, hipStream_t s) {
