@@ -61,8 +61,54 @@ def build_hip(force: bool = False) -> str:
     return out
 
 
+HOST_DIR = os.path.join(PKG, "csrc", "host")
+PYBIND_DIR = os.path.join(PKG, "csrc", "pybind")
+CORE_DIR = os.path.join(PKG, "core")
+
+
+def core_module_path() -> str:
+    import sysconfig
+
+    return os.path.join(CORE_DIR, "polychase_core" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_core(force: bool = False) -> str:
+    """polychase_amd/core/polychase_core*.so: the reference's pybind11 surface over the C ABI."""
+    import sysconfig
+
+    import pybind11
+
+    os.makedirs(CORE_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = sorted([os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR) if f.endswith(".cc")] +
+                  [os.path.join(PYBIND_DIR, f) for f in os.listdir(PYBIND_DIR) if f.endswith(".cc")])
+    headers = [os.path.join(d, f) for d in (HOST_DIR, PYBIND_DIR) for f in os.listdir(d) if f.endswith(".h")]
+    headers.append(os.path.join(ROOT, "include", "polychase_hip.h"))
+    out = core_module_path()
+    if not force and _newer(out, srcs + headers + [hip_library_path()]):
+        return out
+    inc = ["-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], "-I/opt/conda/include"]
+    flags = ["-std=c++17", "-O2", "-fPIC", "-fvisibility=hidden", "-Wall", "-pthread"]
+    if os.path.exists(os.path.join(PYBIND_DIR, "tracker_bindings.cc")):
+        flags.append("-DPC_WITH_TRACKER")
+    objs = [os.path.join(OBJ_DIR, "core_" + os.path.splitext(os.path.basename(s))[0] + ".o") for s in srcs]
+
+    def compile_one(pair):
+        src, obj = pair
+        if force or not _newer(obj, [src] + headers):
+            _run(["g++", *flags, *inc, "-c", src, "-o", obj])
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(compile_one, zip(srcs, objs)))
+    # $ORIGIN/../lib: libpolychase_hip.so travels in-tree; libsqlite3.so.0 is the system one
+    _run(["g++", "-shared", "-o", out, *objs, "-L" + LIB_DIR, "-lpolychase_hip", "-l:libsqlite3.so.0",
+          "-L/usr/lib/x86_64-linux-gnu", "-Wl,-rpath,$ORIGIN/../lib", "-pthread"])
+    return out
+
+
 def build_all(force: bool = False) -> None:
     build_hip(force)
+    build_core(force)
 
 
 if __name__ == "__main__":

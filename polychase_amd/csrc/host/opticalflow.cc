@@ -1,0 +1,179 @@
+// opticalflow.cc -- driver of the video-analysis path on top of the C ABI (include/polychase_hip.h).
+//
+// Control flow mirrors the reference (cpp/opticalflow.cc:209-321): sequential frame1 loop, progress
+// callback + cancellation (:238-247), missing-frame errors (:251-254, :311-315), keypoints read from
+// the database or detected (:168-178), skips {-8,-4,-2,-1,1,2,4,8} (:76-77), existing pairs skipped
+// (:286), status==1 rows written (:130-151).  What differs is WHERE the work happens: every frame
+// is uploaded and turned into gray + pyramid exactly once (the reference does it per pair,
+// :298-302) and kept in a 17-slot ring on the GPU; frame1 jobs are pipelined through pc_analyzer,
+// and the 8 pairs of a frame run as one LK launch instead of 8 TBB tasks.
+#include "opticalflow.h"
+
+#include <chrono>
+#include <cstdlib>
+#include <deque>
+#include <stdexcept>
+
+#include "../../../include/polychase_hip.h"
+#include "database.h"
+#include "utils.h"
+
+namespace {
+
+constexpr int32_t kImageSkips[8] = {-8, -4, -2, -1, 1, 2, 4, 8};  // cpp/opticalflow.cc:76-77
+constexpr int kRing = 17;      // cpp/opticalflow_thread.h:34-79 (SequentialWrapper<17>)
+constexpr int kMaxJobs = 3;
+
+[[noreturn]] void ThrowHip(const char* what) {
+    throw std::runtime_error(std::string(what) + ": " + pc_last_error());
+}
+
+struct Engine {
+    pc_context* ctx = nullptr;
+    pc_analyzer* an = nullptr;
+    ~Engine() {
+        if (an) pc_analyzer_destroy(an);
+        if (ctx) pc_context_destroy(ctx);
+    }
+};
+
+double Now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
+                                 OpticalFlowProgressCallback callback, const std::string& database_path,
+                                 const GFTTOptions& detector_options, const OpticalFlowOptions& flow_options,
+                                 bool /*write_images: debug PNG dump of the reference (:80-96) is not produced*/,
+                                 OpticalFlowRunStats* stats) {
+    CHECK(frame_accessor);
+    const double t_begin = Now();
+    std::unique_ptr<Database> db;
+    if (!database_path.empty()) db = std::make_unique<Database>(database_path);
+
+    const int32_t from = video_info.first_frame;
+    const int32_t to = video_info.first_frame + static_cast<int32_t>(video_info.num_frames);
+
+    pc_gftt_options gopt;
+    gopt.quality_level = detector_options.quality_level;
+    gopt.min_distance = detector_options.min_distance;
+    gopt.block_size = detector_options.block_size;
+    gopt.gradient_size = detector_options.gradient_size;
+    gopt.max_corners = detector_options.max_corners;
+    gopt.use_harris = detector_options.use_harris ? 1 : 0;
+    gopt.harris_k = detector_options.harris_k;
+    gopt.grid_rows = detector_options.grid_rows;
+    gopt.grid_cols = detector_options.grid_cols;
+    pc_flow_options fopt;
+    fopt.window_size = flow_options.window_size;
+    fopt.max_level = flow_options.max_level;
+    fopt.term_max_iters = flow_options.term_max_iters;
+    fopt.term_epsilon = flow_options.term_epsilon;
+    fopt.min_eigen_threshold = flow_options.min_eigen_threshold;
+
+    Engine eng;
+    int device = 0;
+    if (const char* env = std::getenv("POLYCHASE_DEVICE")) device = std::atoi(env);
+    if (pc_context_create(device, &eng.ctx) != PC_OK) ThrowHip("pc_context_create");
+    if (pc_analyzer_create(eng.ctx, static_cast<int>(video_info.width), static_cast<int>(video_info.height), &gopt,
+                           &fopt, kRing, kMaxJobs, &eng.an) != PC_OK)
+        ThrowHip("pc_analyzer_create");
+
+    OpticalFlowRunStats local_stats;
+    double seconds_db = 0;
+
+    // RequestFrame + shape checks (cpp/opticalflow.cc:189-202)
+    auto fetch = [&](int32_t frame_id) -> std::optional<FrameView> {
+        std::optional<FrameView> f = frame_accessor(frame_id);
+        if (f) {
+            CHECK_EQ(static_cast<uint32_t>(f->rows), video_info.height);
+            CHECK_EQ(static_cast<uint32_t>(f->cols), video_info.width);
+            CHECK_EQ(static_cast<uint32_t>(f->channels), 3u);
+        }
+        return f;
+    };
+
+    auto store = [&](const pc_frame_result& r) {
+        local_stats.frames_processed++;
+        if (!db) return;
+        const double t0 = Now();
+        db->Begin();
+        if (r.keypoints_detected && !db->KeypointsExist(r.frame1)) {
+            db->WriteKeypoints(r.frame1, r.keypoints_xy, static_cast<size_t>(r.n_keypoints));
+            local_stats.keypoint_rows_written++;
+        }
+        for (int t = 0; t < r.n_targets; t++) {
+            const int64_t a = r.row_offset[t], b = r.row_offset[t + 1];
+            db->WriteImagePairFlow(r.frame1, r.targets[t], r.src_indices + a, r.tgt_xy + 2 * a, r.flow_err + a,
+                                   static_cast<size_t>(b - a));
+            local_stats.flow_rows_written++;
+        }
+        db->Commit();
+        seconds_db += Now() - t0;
+    };
+
+    auto collect_one = [&]() {
+        pc_frame_result r;
+        if (pc_analyzer_collect(eng.an, &r) != PC_OK) ThrowHip("pc_analyzer_collect");
+        store(r);
+    };
+    auto drain = [&]() {
+        while (pc_analyzer_pending(eng.an) > 0) collect_one();
+    };
+
+    int32_t highest_put = from - 1;
+    Keypoints known;
+    for (int32_t frame_id1 = from; frame_id1 < to; frame_id1++) {
+        if (callback) {
+            const float progress = static_cast<float>(frame_id1 - from) / static_cast<float>(video_info.num_frames);
+            const bool ok = callback(progress, "Processing frame " + std::to_string(frame_id1));
+            if (!ok) {
+                drain();  // jobs already on the GPU are complete work: keep them
+                callback(1.0f, "Cancelled");
+                return;
+            }
+        }
+        // make frame1 .. frame1+8 resident; every frame is requested exactly once, in increasing order
+        const int32_t upto = std::min(frame_id1 + 8, to - 1);
+        for (int32_t fid = std::max(highest_put + 1, std::max(from, frame_id1 - 8)); fid <= upto; fid++) {
+            std::optional<FrameView> f = fetch(fid);
+            if (!f) {
+                drain();
+                if (fid == frame_id1)
+                    throw std::runtime_error("Rquested frame #" + std::to_string(fid) + " was not provided");
+                throw std::runtime_error(
+                    "Exiting optical flow generation prematurely because some frames were not provided");
+            }
+            const bool will_detect = !(db && db->KeypointsExist(fid));
+            if (pc_analyzer_put_frame(eng.an, fid, f->data, f->row_pitch, f->on_device ? 1 : 0, will_detect ? 1 : 0) !=
+                PC_OK)
+                ThrowHip("pc_analyzer_put_frame");
+            highest_put = fid;
+        }
+        // ReadOrGenerateKeypoints (:168-178)
+        if (db) {
+            known.clear();
+            db->ReadKeypoints(frame_id1, known);
+            if (!known.empty() &&
+                pc_analyzer_set_keypoints(eng.an, frame_id1, known[0].data(), static_cast<int>(known.size())) != PC_OK)
+                ThrowHip("pc_analyzer_set_keypoints");
+        }
+        int32_t targets[PC_MAX_TARGETS];
+        int n_targets = 0;
+        for (int32_t skip : kImageSkips) {
+            const int32_t frame_id2 = frame_id1 + skip;
+            if (frame_id2 < from || frame_id2 >= to) continue;               // :282
+            if (db && db->ImagePairFlowExists(frame_id1, frame_id2)) continue;  // :286
+            targets[n_targets++] = frame_id2;
+        }
+        if (pc_analyzer_pending(eng.an) == kMaxJobs) collect_one();
+        if (pc_analyzer_submit(eng.an, frame_id1, targets, n_targets) != PC_OK) ThrowHip("pc_analyzer_submit");
+    }
+    drain();
+    if (callback) callback(1.0f, "Done");
+    local_stats.seconds_total = Now() - t_begin;
+    local_stats.seconds_db = seconds_db;
+    if (stats) *stats = local_stats;
+}

@@ -1,0 +1,202 @@
+// module.cc -- the `polychase_core` extension module with the reference's Python surface
+// (cpp/polychase_pybind.cc:29-348), backed by the MI355X path.  Blender's addon imports it with
+// `from polychase_core import *` (blender_addon/core.py:16-22) and is meant to run unchanged.
+#include <pybind11/functional.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <deque>
+
+#include "../host/database.h"
+#include "../host/opticalflow.h"
+#include "../host/opticalflow_thread.h"
+#include "np_helpers.h"
+
+#ifdef PC_WITH_TRACKER
+void BindTracker(py::module_& m);  // tracker_bindings.cc
+#endif
+
+namespace {
+
+using U8Array = py::array_t<uint8_t, py::array::c_style>;
+
+// Python frame (numpy H x W x 3 uint8, or a torch CUDA tensor of that shape) -> FrameView.
+// Host arrays are deep-copied under the GIL; device tensors are referenced (the caller keeps the
+// py::object alive, see GenerateOpticalFlowDatabasePy).
+std::optional<FrameView> FrameFromPython(const py::object& obj, std::deque<py::object>& keep_alive) {
+    if (obj.is_none()) return std::nullopt;
+    if (py::hasattr(obj, "is_cuda") && obj.attr("is_cuda").cast<bool>()) {
+        py::object t = obj;
+        if (!t.attr("is_contiguous")().cast<bool>()) t = t.attr("contiguous")();
+        const auto shape = t.attr("shape").cast<std::vector<py::ssize_t>>();
+        if (shape.size() != 3) throw py::value_error("frame must have shape (H, W, 3)");
+        if (t.attr("element_size")().cast<int>() != 1) throw py::value_error("frame must be uint8");
+        FrameView v;
+        v.data = reinterpret_cast<const uint8_t*>(t.attr("data_ptr")().cast<uintptr_t>());
+        v.rows = static_cast<int>(shape[0]);
+        v.cols = static_cast<int>(shape[1]);
+        v.channels = static_cast<int>(shape[2]);
+        v.row_pitch = static_cast<size_t>(shape[1] * shape[2]);
+        v.on_device = true;
+        keep_alive.push_back(t);
+        while (keep_alive.size() > 40) keep_alive.pop_front();
+        return v;
+    }
+    U8Array a = U8Array::ensure(obj);
+    if (!a || a.ndim() != 3) throw py::value_error("frame must be a uint8 array of shape (H, W, 3)");
+    auto buf = std::make_shared<std::vector<uint8_t>>(static_cast<size_t>(a.size()));
+    std::memcpy(buf->data(), a.data(), buf->size());
+    FrameView v;
+    v.data = buf->data();
+    v.rows = static_cast<int>(a.shape(0));
+    v.cols = static_cast<int>(a.shape(1));
+    v.channels = static_cast<int>(a.shape(2));
+    v.row_pitch = static_cast<size_t>(a.shape(1) * a.shape(2));
+    v.owner = buf;
+    return v;
+}
+
+OpticalFlowRunStats GenerateOpticalFlowDatabasePy(const VideoInfo& video_info, py::object frame_accessor,
+                                                  py::object callback, const std::string& database_path,
+                                                  const GFTTOptions& detector_options,
+                                                  const OpticalFlowOptions& flow_options, bool write_images) {
+    std::deque<py::object> keep_alive;
+    FrameAccessorFunction accessor;
+    if (!frame_accessor.is_none())
+        accessor = [&](int32_t frame_id) -> std::optional<FrameView> {
+            py::gil_scoped_acquire gil;
+            return FrameFromPython(frame_accessor(frame_id), keep_alive);
+        };
+    OpticalFlowProgressCallback cb;
+    if (!callback.is_none())
+        cb = [&](float progress, const std::string& msg) -> bool {
+            py::gil_scoped_acquire gil;
+            return callback(progress, msg).cast<bool>();
+        };
+    OpticalFlowRunStats stats;
+    {
+        py::gil_scoped_release release;  // polychase_pybind.cc:332
+        GenerateOpticalFlowDatabase(video_info, accessor, cb, database_path, detector_options, flow_options,
+                                    write_images, &stats);
+    }
+    keep_alive.clear();
+    return stats;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(polychase_core, m) {
+    m.doc() = "polychase_core on MI355X: drop-in for the reference's pybind11 module (video-analysis path)";
+
+    py::class_<Database>(m, "Database")
+        .def(py::init<const std::string&>(), py::arg("path"))
+        .def("open", &Database::Open, py::arg("path"))
+        .def("close", &Database::Close)
+        .def("read_keypoints", [](const Database& db, int32_t id) { return VecToNumpy<2>(db.ReadKeypoints(id)); },
+             py::arg("image_id"))
+        .def("write_keypoints",
+             [](Database& db, int32_t id, const F32Array& kps) { db.WriteKeypoints(id, NumpyToVec<2>(kps)); },
+             py::arg("image_id"), py::arg("keypoints"))
+        .def("read_image_pair_flow",
+             py::overload_cast<int32_t, int32_t>(&Database::ReadImagePairFlow, py::const_), py::arg("image_id_from"),
+             py::arg("image_id_to"))
+        .def("write_image_pair_flow",
+             [](Database& db, int32_t from, int32_t to, const U32Array& idx, const F32Array& tgt, const F32Array& err) {
+                 db.WriteImagePairFlow(from, to, NumpyToVec1<uint32_t>(idx), NumpyToVec<2>(tgt), NumpyToVec1<float>(err));
+             },
+             py::arg("image_id_from"), py::arg("image_id_to"), py::arg("src_kps_indices"), py::arg("tgt_kps"),
+             py::arg("flow_errors"))
+        .def("write_image_pair_flow", py::overload_cast<const ImagePairFlow&>(&Database::WriteImagePairFlow),
+             py::arg("image_pair_flow"))
+        .def("find_optical_flows_from_image",
+             py::overload_cast<int32_t>(&Database::FindOpticalFlowsFromImage, py::const_), py::arg("image_id_from"))
+        .def("find_optical_flows_to_image", py::overload_cast<int32_t>(&Database::FindOpticalFlowsToImage, py::const_),
+             py::arg("image_id_to"))
+        .def("keypoints_exist", &Database::KeypointsExist, py::arg("image_id"))
+        .def("image_pair_flow_exists", &Database::ImagePairFlowExists, py::arg("image_id_from"),
+             py::arg("image_id_to"))
+        .def("get_min_image_id_with_keypoints", &Database::GetMinImageIdWithKeypoints)
+        .def("get_max_image_id_with_keypoints", &Database::GetMaxImageIdWithKeypoints);
+
+    py::class_<ImagePairFlow>(m, "ImagePairFlow")
+        .def(py::init<>())
+        .def_readwrite("image_id_from", &ImagePairFlow::image_id_from)
+        .def_readwrite("image_id_to", &ImagePairFlow::image_id_to)
+        .def_property(
+            "src_kps_indices", [](const ImagePairFlow& f) { return Vec1ToNumpy(f.src_kps_indices); },
+            [](ImagePairFlow& f, const U32Array& a) { f.src_kps_indices = NumpyToVec1<uint32_t>(a); })
+        .def_property(
+            "tgt_kps", [](const ImagePairFlow& f) { return VecToNumpy<2>(f.tgt_kps); },
+            [](ImagePairFlow& f, const F32Array& a) { f.tgt_kps = NumpyToVec<2>(a); })
+        .def_property(
+            "flow_errors", [](const ImagePairFlow& f) { return Vec1ToNumpy(f.flow_errors); },
+            [](ImagePairFlow& f, const F32Array& a) { f.flow_errors = NumpyToVec1<float>(a); });
+
+    py::class_<VideoInfo>(m, "VideoInfo")
+        .def(py::init([](uint32_t width, uint32_t height, uint32_t first_frame, uint32_t num_frames) {
+                 return VideoInfo{width, height, static_cast<int32_t>(first_frame), num_frames};
+             }),
+             py::arg("width"), py::arg("height"), py::arg("first_frame"), py::arg("num_frames"))
+        .def_readwrite("width", &VideoInfo::width)
+        .def_readwrite("height", &VideoInfo::height)
+        .def_readwrite("first_frame", &VideoInfo::first_frame)
+        .def_readwrite("num_frames", &VideoInfo::num_frames);
+
+    // grid_rows / grid_cols are not exposed by the reference either (polychase_pybind.cc:128-136)
+    py::class_<GFTTOptions>(m, "GFTTOptions")
+        .def(py::init<>())
+        .def_readwrite("quality_level", &GFTTOptions::quality_level)
+        .def_readwrite("min_distance", &GFTTOptions::min_distance)
+        .def_readwrite("block_size", &GFTTOptions::block_size)
+        .def_readwrite("gradient_size", &GFTTOptions::gradient_size)
+        .def_readwrite("max_corners", &GFTTOptions::max_corners)
+        .def_readwrite("use_harris", &GFTTOptions::use_harris)
+        .def_readwrite("harris_k", &GFTTOptions::harris_k);
+
+    py::class_<OpticalFlowOptions>(m, "OpticalFlowOptions")
+        .def(py::init<>())
+        .def_readwrite("window_size", &OpticalFlowOptions::window_size)
+        .def_readwrite("max_level", &OpticalFlowOptions::max_level)
+        .def_readwrite("term_max_iters", &OpticalFlowOptions::term_max_iters)
+        .def_readwrite("term_epsilon", &OpticalFlowOptions::term_epsilon)
+        .def_readwrite("min_eigen_threshold", &OpticalFlowOptions::min_eigen_threshold);
+
+    py::class_<OpticalFlowProgress>(m, "OpticalFlowProgress")
+        .def_readonly("progress", &OpticalFlowProgress::progress)
+        .def_readonly("progress_message", &OpticalFlowProgress::progress_message);
+
+    py::class_<OpticalFlowRequest>(m, "OpticalFlowRequest").def_readonly("frame_id", &OpticalFlowRequest::frame_id);
+
+    py::class_<CppException>(m, "CppException").def("what", [](const CppException& e) { return e.message; });
+
+    py::class_<OpticalFlowRunStats>(m, "OpticalFlowRunStats")
+        .def_readonly("frames_processed", &OpticalFlowRunStats::frames_processed)
+        .def_readonly("keypoint_rows_written", &OpticalFlowRunStats::keypoint_rows_written)
+        .def_readonly("flow_rows_written", &OpticalFlowRunStats::flow_rows_written)
+        .def_readonly("seconds_total", &OpticalFlowRunStats::seconds_total)
+        .def_readonly("seconds_db", &OpticalFlowRunStats::seconds_db);
+
+    py::class_<OpticalFlowThread>(m, "OpticalFlowThread")
+        .def(py::init<VideoInfo, std::string, GFTTOptions, OpticalFlowOptions, bool>(), py::arg("video_info"),
+             py::arg("database_path"), py::arg("detector_options") = GFTTOptions{},
+             py::arg("OpticalFlowOptions") = OpticalFlowOptions{},  // sic: polychase_pybind.cc:186
+             py::arg("write_images") = false)
+        .def("request_stop", &OpticalFlowThread::RequestStop)
+        .def("join", &OpticalFlowThread::Join, py::call_guard<py::gil_scoped_release>())
+        .def("try_pop", &OpticalFlowThread::TryPop)
+        .def("empty", &OpticalFlowThread::Empty)
+        .def("provide_frame", [](OpticalFlowThread& t, int32_t frame_id, const U8Array& frame) {
+            if (frame.ndim() != 3) throw py::value_error("frame must be a uint8 array of shape (H, W, 3)");
+            t.ProvideFrame(frame_id, frame.data(), static_cast<int>(frame.shape(0)), static_cast<int>(frame.shape(1)),
+                           static_cast<int>(frame.shape(2)), static_cast<size_t>(frame.shape(1) * frame.shape(2)));
+        });
+
+    m.def("generate_optical_flow_database", &GenerateOpticalFlowDatabasePy, py::arg("video_info"),
+          py::arg("frame_accessor_function"), py::arg("callback"), py::arg("database_path"),
+          py::arg("detector_options") = GFTTOptions{}, py::arg("flow_options") = OpticalFlowOptions{},
+          py::arg("write_images") = false);
+
+#ifdef PC_WITH_TRACKER
+    BindTracker(m);
+#endif
+}

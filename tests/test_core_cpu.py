@@ -1,0 +1,108 @@
+"""CPU: the polychase_core module (reference pybind surface) imports, and its Database is
+byte-compatible with the reference's SQLite format (cpp/database.cc:64-135, :350-400)."""
+import os
+import sqlite3
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def core():
+    from polychase_amd import build
+    build.build_all()
+    import torch  # noqa: F401  (one HIP runtime per process: load torch's first, see polychase_amd/hip.py)
+    sys.path.insert(0, os.path.join(ROOT, "polychase_amd", "core"))
+    import polychase_core
+    return polychase_core
+
+
+ANALYSIS_NAMES = ["Database", "ImagePairFlow", "VideoInfo", "GFTTOptions", "OpticalFlowOptions", "OpticalFlowThread",
+                  "OpticalFlowProgress", "OpticalFlowRequest", "CppException", "generate_optical_flow_database"]
+
+
+def test_exports_reference_names(core):
+    for n in ANALYSIS_NAMES:
+        assert hasattr(core, n), n
+
+
+def test_struct_defaults(core):
+    g = core.GFTTOptions()
+    assert (g.quality_level, g.min_distance, g.block_size, g.gradient_size, g.max_corners, g.use_harris,
+            g.harris_k) == (0.01, 5.0, 3, 3, 0, False, 0.04)
+    assert not hasattr(g, "grid_rows")  # not exposed by the reference either (polychase_pybind.cc:128-136)
+    f = core.OpticalFlowOptions()
+    assert (f.window_size, f.max_level, f.term_max_iters, f.term_epsilon, f.min_eigen_threshold) == (10, 3, 30, 0.01, 1e-4)
+    v = core.VideoInfo(width=640, height=480, first_frame=1, num_frames=30)
+    assert (v.width, v.height, v.first_frame, v.num_frames) == (640, 480, 1, 30)
+
+
+def test_database_schema_and_blobs(core, tmp_path):
+    path = str(tmp_path / "flow.db")
+    db = core.Database(path)
+    kps = np.array([[10, 20], [30.5, 40.25], [7, 8]], np.float32)
+    db.write_keypoints(5, kps)
+    idx = np.array([0, 2], np.uint32)
+    tgt = np.array([[11.5, 21.25], [8, 9]], np.float32)
+    err = np.array([0.5, 1.5], np.float32)
+    db.write_image_pair_flow(5, 6, idx, tgt, err)
+    assert db.keypoints_exist(5) and not db.keypoints_exist(6)
+    assert db.image_pair_flow_exists(5, 6) and not db.image_pair_flow_exists(6, 5)
+    assert np.array_equal(db.read_keypoints(5), kps)
+    assert db.read_keypoints(99).shape == (0, 2)
+    f = db.read_image_pair_flow(5, 6)
+    assert (f.image_id_from, f.image_id_to) == (5, 6)
+    assert np.array_equal(f.src_kps_indices, idx) and np.array_equal(f.tgt_kps, tgt) and np.array_equal(f.flow_errors, err)
+    assert db.find_optical_flows_from_image(5) == [6] and db.find_optical_flows_to_image(6) == [5]
+    assert db.get_min_image_id_with_keypoints() == 5 == db.get_max_image_id_with_keypoints()
+    with pytest.raises(RuntimeError, match="SQLite error"):   # plain INSERT: duplicate key throws (database.cc:357)
+        db.write_keypoints(5, kps)
+    db.close()
+
+    con = sqlite3.connect(path)
+    tables = dict(con.execute("select name, sql from sqlite_master where type='table'").fetchall())
+    norm = lambda s: " ".join(s.split())
+    assert norm(tables["keypoints"]) == norm(
+        "CREATE TABLE keypoints( image_id INTEGER PRIMARY KEY NOT NULL, rows INTEGER NOT NULL, keypoints BLOB NOT NULL )")
+    assert norm(tables["optical_flow"]) == norm(
+        "CREATE TABLE optical_flow( image_id_from INTEGER NOT NULL, image_id_to INTEGER NOT NULL, rows INTEGER NOT NULL, "
+        "src_keypoints_indices BLOB NOT NULL, tgt_keypoints BLOB NOT NULL, flow_errors BLOB NOT NULL, "
+        "PRIMARY KEY(image_id_from, image_id_to), FOREIGN KEY(image_id_from) REFERENCES keypoints(image_id) ON DELETE CASCADE )")
+    rows, blob = con.execute("select rows, keypoints from keypoints where image_id=5").fetchone()
+    assert rows == 3 and blob == kps.tobytes()          # raw little-endian memcpy (database.cc:137-158)
+    r = con.execute("select rows, src_keypoints_indices, tgt_keypoints, flow_errors from optical_flow").fetchone()
+    assert r == (2, idx.tobytes(), tgt.tobytes(), err.tobytes())
+    assert con.execute("pragma journal_mode").fetchone()[0] == "wal"
+    # the reference issues PRAGMA auto_vacuum=1 AFTER journal_mode=WAL has initialised the file
+    # (database.cc:80,:89), where SQLite ignores it; same pragma order here => same on-disk header
+    assert con.execute("pragma auto_vacuum").fetchone()[0] == 0
+    con.close()
+
+
+def test_reads_database_written_with_reference_statements(core, tmp_path):
+    """A DB created by the reference's SQL (python sqlite3 here) is readable by our Database."""
+    path = str(tmp_path / "ref.db")
+    con = sqlite3.connect(path)
+    con.execute("CREATE TABLE IF NOT EXISTS keypoints(image_id INTEGER PRIMARY KEY NOT NULL, rows INTEGER NOT NULL, keypoints BLOB NOT NULL);")
+    con.execute("CREATE TABLE IF NOT EXISTS optical_flow(image_id_from INTEGER NOT NULL, image_id_to INTEGER NOT NULL, rows INTEGER NOT NULL, "
+                "src_keypoints_indices BLOB NOT NULL, tgt_keypoints BLOB NOT NULL, flow_errors BLOB NOT NULL, PRIMARY KEY(image_id_from, image_id_to), "
+                "FOREIGN KEY(image_id_from) REFERENCES keypoints(image_id) ON DELETE CASCADE);")
+    kps = np.arange(10, dtype=np.float32).reshape(5, 2)
+    con.execute("INSERT INTO keypoints(image_id, rows, keypoints) VALUES(?, ?, ?);", (3, 5, kps.tobytes()))
+    con.commit()
+    con.close()
+    db = core.Database(path)
+    assert np.array_equal(db.read_keypoints(3), kps)
+    db.close()
+
+
+def test_no_gpu_means_loud_failure(core, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    vi = core.VideoInfo(64, 48, 1, 2)
+    with pytest.raises(RuntimeError, match="no HIP device|No HIP|HIP"):
+        core.generate_optical_flow_database(vi, lambda fid: np.zeros((48, 64, 3), np.uint8), None, str(tmp_path / "x.db"))

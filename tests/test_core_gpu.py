@@ -1,0 +1,140 @@
+"""GPU: the reference's Python surface (polychase_core) end to end.  BASELINE config C1 (640x480x30
+translating checkerboard) through OpticalFlowThread's request/provide protocol, exactly as
+blender_addon/operators/analysis.py drives it; DB contents compared with the reference-shaped CPU path."""
+import os
+import sqlite3
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import oracle
+from polychase_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def core():
+    import torch  # noqa: F401
+    sys.path.insert(0, os.path.join(ROOT, "polychase_amd", "core"))
+    import polychase_core
+    return polychase_core
+
+
+def _run_thread(core, frames, first, path, stop_after=None, **kw):
+    """The caller loop of analysis.py:242-285. Returns (requested ids, progress messages, errors)."""
+    h, w, _ = frames[0].shape
+    th = core.OpticalFlowThread(core.VideoInfo(w, h, first, len(frames)), path, **kw)
+    requested, progress, errors = [], [], []
+    done = False
+    t0 = time.time()
+    while not done and time.time() - t0 < 120:
+        msg = th.try_pop()
+        if msg is None:
+            time.sleep(0.0005)
+            continue
+        if isinstance(msg, core.OpticalFlowRequest):
+            requested.append(msg.frame_id)
+            th.provide_frame(msg.frame_id, frames[msg.frame_id - first])
+        elif isinstance(msg, core.OpticalFlowProgress):
+            progress.append((msg.progress, msg.progress_message))
+            if stop_after is not None and len(progress) == stop_after:
+                th.request_stop()
+        elif isinstance(msg, core.CppException):
+            errors.append(msg.what())
+        elif msg is True:
+            done = True
+    th.join()
+    assert done
+    return requested, progress, errors
+
+
+def _dump(path):
+    con = sqlite3.connect(path)
+    k = {r[0]: (r[1], r[2]) for r in con.execute("select image_id, rows, keypoints from keypoints")}
+    f = {(r[0], r[1]): r[2:] for r in con.execute(
+        "select image_id_from, image_id_to, rows, src_keypoints_indices, tgt_keypoints, flow_errors from optical_flow")}
+    con.close()
+    return k, f
+
+
+def _expect(frames, first, **kw):
+    kps, flows = oracle.analyze_clip(frames, first_frame=first, threads=4, **kw)
+    k = {f: (len(v), v.tobytes()) for f, v in kps.items()}
+    fl = {key: (len(v[0]), v[0].tobytes(), v[1].tobytes(), v[2].tobytes()) for key, v in flows.items()}
+    return k, fl
+
+
+def test_c1_checkerboard_through_thread_protocol(core, tmp_path):
+    frames = synth.checkerboard_clip(30)
+    path = str(tmp_path / "c1.db")
+    requested, progress, errors = _run_thread(core, frames, 1, path)
+    assert not errors
+    assert requested == list(range(1, 31))            # every frame exactly once, increasing (appendix B.7)
+    assert progress[0] == (0.0, "Processing frame 1") and progress[-1] == (1.0, "Done")
+    assert [m for _, m in progress[:-1]] == [f"Processing frame {i}" for i in range(1, 31)]
+    k, f = _dump(path)
+    ek, ef = _expect(frames, 1)
+    assert k == ek
+    assert f == ef
+    assert len(f) == 8 * 30 - 30
+
+
+def test_cancel_then_resume_gives_identical_database(core, tmp_path):
+    clip = synth.NoiseClip(320, 240, 24)
+    frames = [clip.frame(t) for t in range(24)]
+    full, part = str(tmp_path / "full.db"), str(tmp_path / "part.db")
+    _, _, e = _run_thread(core, frames, 1, full)
+    assert not e
+    _, progress, e = _run_thread(core, frames, 1, part, stop_after=9)
+    assert not e and progress[-1] == (1.0, "Cancelled")
+    k_part, f_part = _dump(part)
+    assert 0 < len(f_part) < 8 * 24 - 30
+    requested, progress, e = _run_thread(core, frames, 1, part)        # resume (opticalflow.cc:168-178, :286)
+    assert not e and progress[-1] == (1.0, "Done")
+    assert _dump(part) == _dump(full)
+    # a third run finds everything present: nothing is recomputed or rewritten
+    _, _, e = _run_thread(core, frames, 1, part)
+    assert not e and _dump(part) == _dump(full)
+
+
+def test_sync_binding_with_options_and_errors(core, tmp_path):
+    clip = synth.NoiseClip(256, 192, 12)
+    frames = [clip.frame(t) for t in range(12)]
+    g = core.GFTTOptions()
+    g.max_corners = 200
+    g.min_distance = 7.0
+    fo = core.OpticalFlowOptions()
+    fo.max_level = 2
+    fo.window_size = 9
+    fo.term_max_iters = 10
+    msgs = []
+    path = str(tmp_path / "sync.db")
+    stats = core.generate_optical_flow_database(core.VideoInfo(256, 192, 5, 12), lambda fid: frames[fid - 5],
+                                                lambda p, m: (msgs.append(m) or True), path, g, fo)
+    assert msgs[-1] == "Done" and stats.frames_processed == 12
+    ek, ef = _expect(frames, 5, gopt=oracle.gftt_options(max_corners=200, min_distance=7.0),
+                     fopt=oracle.flow_options(max_level=2, window_size=9, term_max_iters=10))
+    k, f = _dump(path)
+    assert k == ek and f == ef
+    # missing frame -> runtime error with the reference's message (sic)
+    with pytest.raises(RuntimeError, match="Rquested frame #5 was not provided"):
+        core.generate_optical_flow_database(core.VideoInfo(256, 192, 5, 12), lambda fid: None, None, str(tmp_path / "m.db"))
+    # wrong shape -> CHECK failure (opticalflow.cc:196-198)
+    with pytest.raises(Exception, match="Assertion failed"):
+        core.generate_optical_flow_database(core.VideoInfo(256, 192, 5, 12), lambda fid: frames[0][:100], None,
+                                            str(tmp_path / "s.db"))
+
+
+def test_device_resident_frames_through_the_binding(core, tmp_path):
+    import torch
+    clip = synth.NoiseClip(256, 192, 10)
+    frames = [clip.frame(t) for t in range(10)]
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    a, b = str(tmp_path / "host.db"), str(tmp_path / "dev.db")
+    core.generate_optical_flow_database(core.VideoInfo(256, 192, 1, 10), lambda fid: frames[fid - 1], None, a)
+    core.generate_optical_flow_database(core.VideoInfo(256, 192, 1, 10), lambda fid: dev[fid - 1], None, b)
+    assert _dump(a) == _dump(b)
