@@ -179,6 +179,58 @@ int pc_analyzer_pending(const pc_analyzer* a);
  * the next max_jobs-1 submits. */
 int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out);
 
+/* ---- "Track Sequence" path (cpp/tracker.cc:36-131): batched ray casting + PnP accumulation ---- */
+typedef struct pc_mesh pc_mesh;
+typedef struct pc_pnp_problem pc_pnp_problem;
+
+/* Mesh of AcceleratedMesh (cpp/ray_casting.cc:21-63): vertices n_vertices x 3 f32 row-major,
+ * triangles n_triangles x 3 u32 (host pointers; copied to the GPU). */
+int pc_mesh_create(pc_context* ctx, const float* vertices, int n_vertices, const uint32_t* triangles,
+                   int n_triangles, pc_mesh** out);
+/* masked_triangles bitset (cpp/geometry.h:58-66), n_words >= ceil(n_triangles / 32). */
+int pc_mesh_set_mask(pc_context* ctx, pc_mesh* mesh, const uint32_t* mask_words, int n_words);
+void pc_mesh_destroy(pc_mesh* mesh);
+
+/* Camera of GetRayObjectSpace (cpp/ray_casting.h:53-63): inv = (view * model)^-1. */
+typedef struct pc_ray_camera {
+    float dir_matrix[9]; /* inv.block<3,3>(0,0), row-major */
+    float origin[3];     /* inv.col(3).head<3>() */
+    float fx, fy, cx, cy;
+    float unproject_sign; /* CameraIntrinsics::Unproject: +1 OpenCV convention, -1 OpenGL (types.h:95-98) */
+} pc_ray_camera;
+
+/* RayCast(accel_mesh, scene_transform, pos, check_mask) (cpp/ray_casting.cc:123-133) for n pixel
+ * positions in one launch.  Closest hit, no back-face culling; a masked closest triangle is a miss.
+ * Host in/out: xy n x 2; hit n bytes; pos n x 3 (barycentric point, object space); prim n;
+ * uvt n x 3 = (u, v, t). */
+int pc_raycast_pixels(pc_context* ctx, const pc_mesh* mesh, const pc_ray_camera* cam, const float* xy, int n,
+                      int check_mask, uint8_t* hit, float* pos, uint32_t* prim, float* uvt);
+
+/* PnPProblem (cpp/pnp/pnp_problem.h:11-142): object points X n x 3, image points x n x 2,
+ * optional per-residual weights (NULL = 1). Host pointers; copied to the GPU once per frame. */
+int pc_pnp_problem_create(pc_context* ctx, const float* X, const float* x, const float* weights, int n,
+                          pc_pnp_problem** out);
+void pc_pnp_problem_destroy(pc_pnp_problem* prob);
+
+typedef struct pc_pnp_params {
+    float R[9];               /* rotation matrix of the pose (row-major) */
+    float t[3];
+    float fx, fy, cx, cy, aspect_ratio;
+    int convention_opencv;    /* CameraConvention::OpenCV ? 1 : 0 */
+    int optimize_focal_length, optimize_principal_point;
+    int loss_type;            /* BundleOptions::LossType: 0 TRIVIAL, 1 HUBER, 2 CAUCHY */
+    float loss_scale;
+} pc_pnp_params;
+
+/* LevMarqDenseSolver::BuildNormalEquations (cpp/pnp/lev_marq.h:231-297) without the diagonal
+ * clamp: JtJ lower triangle packed row-major (45), Jtr (9), number of valid residuals. */
+int pc_pnp_normal_equations(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,
+                            float* jtj_lower45, float* jtr9, int* valid);
+/* LevMarqDenseSolver::TotalCost (lev_marq.h:316-356) and the inlier count of SolvePnPIterative
+ * (cpp/pnp/solvers.cc:31-47) in one pass. */
+int pc_pnp_total_cost(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,
+                      float max_inlier_error_sq, float* cost, int* valid, int* inliers);
+
 #ifdef __cplusplus
 }
 #endif

@@ -965,4 +965,212 @@ int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out) {
     return PC_OK;
 }
 
+
+// =============================================================================================
+// tracker path: meshes, batched ray casting, PnP accumulation
+// =============================================================================================
+}  // extern "C"
+
+struct pc_mesh {
+    pc_context* ctx = nullptr;
+    int n_vertices = 0, n_triangles = 0;
+    DevBuf<float> verts;
+    DevBuf<uint32_t> tris, mask;
+    // per-call scratch
+    DevBuf<float2> d_xy;
+    DevBuf<uint8_t> d_hit;
+    DevBuf<float> d_pos, d_uvt;
+    DevBuf<uint32_t> d_prim;
+};
+
+struct pc_pnp_problem {
+    pc_context* ctx = nullptr;
+    int n = 0;
+    bool has_weights = false;
+    DevBuf<float> X, x, w, partials, out;
+    PinBuf<float> h_out;
+};
+
+extern "C" {
+
+int pc_mesh_create(pc_context* ctx, const float* vertices, int n_vertices, const uint32_t* triangles,
+                   int n_triangles, pc_mesh** out) {
+    if (!ctx || !out || n_vertices < 0 || n_triangles < 0 || (n_vertices > 0 && !vertices) ||
+        (n_triangles > 0 && !triangles))
+        return fail(PC_E_INVALID, "bad argument");
+    *out = nullptr;
+    for (int i = 0; i < 3 * n_triangles; i++)
+        if (triangles[i] >= (uint32_t)n_vertices) return fail(PC_E_INVALID, "triangle index %u out of range", triangles[i]);
+    PC_HIP(hipSetDevice(ctx->device));
+    pc_mesh* m = new (std::nothrow) pc_mesh();
+    if (!m) return fail(PC_E_INVALID, "out of host memory");
+    m->ctx = ctx;
+    m->n_vertices = n_vertices;
+    m->n_triangles = n_triangles;
+    const int words = (n_triangles + 31) / 32 + 4;
+    hipError_t e = m->verts.ensure((size_t)std::max(1, n_vertices) * 3);
+    if (e == hipSuccess) e = m->tris.ensure((size_t)std::max(1, n_triangles) * 3);
+    if (e == hipSuccess) e = m->mask.ensure((size_t)words);
+    if (e == hipSuccess && n_vertices) e = hipMemcpyAsync(m->verts.p, vertices, (size_t)n_vertices * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n_triangles) e = hipMemcpyAsync(m->tris.p, triangles, (size_t)n_triangles * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(m->mask.p, 0, (size_t)words * sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        pc_mesh_destroy(m);
+        return fail(PC_E_HIP, "mesh upload failed: %s", hipGetErrorString(e));
+    }
+    *out = m;
+    return PC_OK;
+}
+
+int pc_mesh_set_mask(pc_context* ctx, pc_mesh* mesh, const uint32_t* mask_words, int n_words) {
+    if (!ctx || !mesh || !mask_words) return fail(PC_E_INVALID, "null argument");
+    const int need = (mesh->n_triangles + 31) / 32;
+    if (n_words < need) return fail(PC_E_INVALID, "mask has %d words, %d needed", n_words, need);
+    if (need > 0) {
+        PC_HIP(hipMemcpyAsync(mesh->mask.p, mask_words, (size_t)need * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        PC_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PC_OK;
+}
+
+void pc_mesh_destroy(pc_mesh* m) {
+    if (!m) return;
+    if (m->ctx) {
+        (void)hipSetDevice(m->ctx->device);
+        (void)hipStreamSynchronize(m->ctx->stream);
+    }
+    m->verts.release();
+    m->tris.release();
+    m->mask.release();
+    m->d_xy.release();
+    m->d_hit.release();
+    m->d_pos.release();
+    m->d_uvt.release();
+    m->d_prim.release();
+    delete m;
+}
+
+int pc_raycast_pixels(pc_context* ctx, const pc_mesh* mesh_c, const pc_ray_camera* cam, const float* xy, int n,
+                      int check_mask, uint8_t* hit, float* pos, uint32_t* prim, float* uvt) {
+    if (!ctx || !mesh_c || !cam || n < 0) return fail(PC_E_INVALID, "bad argument");
+    if (n == 0) return PC_OK;
+    if (!xy || !hit || !pos || !prim || !uvt) return fail(PC_E_INVALID, "null buffer");
+    pc_mesh* mesh = const_cast<pc_mesh*>(mesh_c);
+    PC_HIP(hipSetDevice(ctx->device));
+    PC_HIP(mesh->d_xy.ensure((size_t)n));
+    PC_HIP(mesh->d_hit.ensure((size_t)n));
+    PC_HIP(mesh->d_pos.ensure((size_t)n * 3));
+    PC_HIP(mesh->d_uvt.ensure((size_t)n * 3));
+    PC_HIP(mesh->d_prim.ensure((size_t)n));
+    pc::RayCamera rc;
+    std::memcpy(rc.m, cam->dir_matrix, sizeof(rc.m));
+    std::memcpy(rc.origin, cam->origin, sizeof(rc.origin));
+    rc.fx = cam->fx;
+    rc.fy = cam->fy;
+    rc.cx = cam->cx;
+    rc.cy = cam->cy;
+    rc.sign = cam->unproject_sign;
+    PC_HIP(hipMemcpyAsync(mesh->d_xy.p, xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    pc::launch_raycast(mesh->verts.p, mesh->tris.p, mesh->n_triangles, mesh->mask.p, check_mask, rc, mesh->d_xy.p, n,
+                       mesh->d_hit.p, mesh->d_pos.p, mesh->d_prim.p, mesh->d_uvt.p, ctx->stream);
+    PC_HIP(hipMemcpyAsync(hit, mesh->d_hit.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipMemcpyAsync(pos, mesh->d_pos.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipMemcpyAsync(prim, mesh->d_prim.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipMemcpyAsync(uvt, mesh->d_uvt.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    return PC_OK;
+}
+
+int pc_pnp_problem_create(pc_context* ctx, const float* X, const float* x, const float* weights, int n,
+                          pc_pnp_problem** out) {
+    if (!ctx || !out || n < 1 || !X || !x) return fail(PC_E_INVALID, "bad argument");
+    *out = nullptr;
+    PC_HIP(hipSetDevice(ctx->device));
+    pc_pnp_problem* p = new (std::nothrow) pc_pnp_problem();
+    if (!p) return fail(PC_E_INVALID, "out of host memory");
+    p->ctx = ctx;
+    p->n = n;
+    p->has_weights = weights != nullptr;
+    const int nb = pc::pnp_num_blocks(n);
+    hipError_t e = p->X.ensure((size_t)n * 3);
+    if (e == hipSuccess) e = p->x.ensure((size_t)n * 2);
+    if (e == hipSuccess && weights) e = p->w.ensure((size_t)n);
+    if (e == hipSuccess) e = p->partials.ensure((size_t)nb * 56);
+    if (e == hipSuccess) e = p->out.ensure(64);
+    if (e == hipSuccess) e = p->h_out.ensure(64);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->X.p, X, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->x.p, x, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && weights) e = hipMemcpyAsync(p->w.p, weights, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        pc_pnp_problem_destroy(p);
+        return fail(PC_E_HIP, "PnP upload failed: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return PC_OK;
+}
+
+void pc_pnp_problem_destroy(pc_pnp_problem* p) {
+    if (!p) return;
+    if (p->ctx) {
+        (void)hipSetDevice(p->ctx->device);
+        (void)hipStreamSynchronize(p->ctx->stream);
+    }
+    p->X.release();
+    p->x.release();
+    p->w.release();
+    p->partials.release();
+    p->out.release();
+    p->h_out.release();
+    delete p;
+}
+
+static pc::PnPParams to_kernel_params(const pc_pnp_params* q) {
+    pc::PnPParams p;
+    std::memcpy(p.R, q->R, sizeof(p.R));
+    std::memcpy(p.t, q->t, sizeof(p.t));
+    p.fx = q->fx;
+    p.fy = q->fy;
+    p.cx = q->cx;
+    p.cy = q->cy;
+    p.aspect_ratio = q->aspect_ratio;
+    p.convention_opencv = q->convention_opencv;
+    p.optimize_focal = q->optimize_focal_length;
+    p.optimize_pp = q->optimize_principal_point;
+    p.loss_type = q->loss_type;
+    p.loss_scale = q->loss_scale;
+    return p;
+}
+
+int pc_pnp_normal_equations(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,
+                            float* jtj_lower45, float* jtr9, int* valid) {
+    if (!ctx || !prob || !params || !jtj_lower45 || !jtr9) return fail(PC_E_INVALID, "null argument");
+    if (params->loss_type < 0 || params->loss_type > 2) return fail(PC_E_INVALID, "Unknown loss type: %d", params->loss_type);
+    PC_HIP(hipSetDevice(ctx->device));
+    pc::launch_pnp_normal_eq(prob->X.p, prob->x.p, prob->has_weights ? prob->w.p : nullptr, prob->n,
+                             to_kernel_params(params), prob->partials.p, prob->out.p, ctx->stream);
+    PC_HIP(hipMemcpyAsync(prob->h_out.p, prob->out.p, 56 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    std::memcpy(jtj_lower45, prob->h_out.p, 45 * sizeof(float));
+    std::memcpy(jtr9, prob->h_out.p + 45, 9 * sizeof(float));
+    if (valid) *valid = (int)prob->h_out.p[54];
+    return PC_OK;
+}
+
+int pc_pnp_total_cost(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,
+                      float max_inlier_error_sq, float* cost, int* valid, int* inliers) {
+    if (!ctx || !prob || !params || !cost) return fail(PC_E_INVALID, "null argument");
+    if (params->loss_type < 0 || params->loss_type > 2) return fail(PC_E_INVALID, "Unknown loss type: %d", params->loss_type);
+    PC_HIP(hipSetDevice(ctx->device));
+    pc::launch_pnp_cost(prob->X.p, prob->x.p, prob->has_weights ? prob->w.p : nullptr, prob->n, to_kernel_params(params),
+                        max_inlier_error_sq, prob->partials.p, prob->out.p, ctx->stream);
+    PC_HIP(hipMemcpyAsync(prob->h_out.p, prob->out.p, 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    *cost = prob->h_out.p[0];
+    if (valid) *valid = (int)prob->h_out.p[1];
+    if (inliers) *inliers = (int)prob->h_out.p[2];
+    return PC_OK;
+}
+
 }  // extern "C"

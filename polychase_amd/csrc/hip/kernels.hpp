@@ -61,4 +61,32 @@ void launch_compact(const float2* xy, const uint8_t* status, const float* err, i
                     float* out_err, hipStream_t s);
 int compact_num_blocks(int n);
 
+
+// ---- kernels_tracker.hip ----
+struct RayCamera {
+    float m[9];        // 3x3 block of (view * model)^-1, row-major: camera direction -> object space
+    float origin[3];   // translation column of (view * model)^-1
+    float fx, fy, cx, cy;
+    float sign;        // CameraIntrinsics::Unproject: +1 OpenCV, -1 OpenGL (types.h:95-98)
+};
+struct PnPParams {
+    float R[9];
+    float t[3];
+    float fx, fy, cx, cy, aspect_ratio;
+    int convention_opencv;
+    int optimize_focal, optimize_pp;
+    int loss_type;     // 0 trivial, 1 Huber, 2 Cauchy (BundleOptions::LossType)
+    float loss_scale;
+};
+void launch_raycast(const float* verts, const uint32_t* tris, int n_tris, const uint32_t* mask, int check_mask,
+                    const RayCamera& cam, const float2* xy, int n, uint8_t* hit, float* pos, uint32_t* prim,
+                    float* uvt, hipStream_t s);
+int pnp_num_blocks(int n);
+// out56: [0..44] JtJ lower triangle (row-major packed), [45..53] Jtr, [54] valid residual count
+void launch_pnp_normal_eq(const float* X, const float* x, const float* w, int n, const PnPParams& p, float* partials,
+                          float* out56, hipStream_t s);
+// out4: [0] cost, [1] valid residuals, [2] inliers (r^2 < max_err_sq)
+void launch_pnp_cost(const float* X, const float* x, const float* w, int n, const PnPParams& p, float max_err_sq,
+                     float* partials, float* out4, hipStream_t s);
+
 }  // namespace pc

@@ -1,0 +1,37 @@
+// ray_casting.h -- AcceleratedMesh and RayCast of the reference (cpp/ray_casting.h:23-51,
+// cpp/ray_casting.cc) with the Embree scene replaced by a mesh resident on the GPU and a batched
+// closest-hit kernel (pc_raycast_pixels).
+#pragma once
+
+#include <memory>
+#include <optional>
+#include <vector>
+
+#include "types.h"
+
+struct pc_mesh;
+
+class AcceleratedMesh {
+   public:
+    AcceleratedMesh(std::vector<float> vertices, std::vector<uint32_t> triangles, std::vector<uint32_t> masked_triangles);
+    AcceleratedMesh(const AcceleratedMesh&) = delete;
+    AcceleratedMesh& operator=(const AcceleratedMesh&) = delete;
+    ~AcceleratedMesh();
+
+    const Mesh& Inner() const { return mesh_; }
+    Mesh& InnerMut() { return mesh_; }
+
+    // Batched RayCast(accel_mesh, scene_transform, pos, check_mask): hits[i] is empty on a miss.
+    void RayCastPixels(const SceneTransformations& scene_transform, const float* xy, size_t n, bool check_mask,
+                       std::vector<std::optional<RayHit>>& hits) const;
+
+   private:
+    Mesh mesh_;
+    pc_mesh* gpu_ = nullptr;
+    mutable std::vector<uint8_t> hit_;
+    mutable std::vector<float> pos_, uvt_;
+    mutable std::vector<uint32_t> prim_;
+};
+
+std::optional<RayHit> RayCast(const AcceleratedMesh& accel_mesh, const SceneTransformations& scene_transform, Vec2f pos,
+                              bool check_mask);

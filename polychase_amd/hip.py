@@ -28,6 +28,8 @@ SYMBOLS = [
     "pc_lk_track", "pc_lk_track_filtered",
     "pc_analyzer_create", "pc_analyzer_destroy", "pc_analyzer_put_frame", "pc_analyzer_has_frame",
     "pc_analyzer_set_keypoints", "pc_analyzer_submit", "pc_analyzer_pending", "pc_analyzer_collect",
+    "pc_mesh_create", "pc_mesh_set_mask", "pc_mesh_destroy", "pc_raycast_pixels",
+    "pc_pnp_problem_create", "pc_pnp_problem_destroy", "pc_pnp_normal_equations", "pc_pnp_total_cost",
 ]
 
 

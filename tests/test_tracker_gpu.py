@@ -1,0 +1,273 @@
+"""GPU: the "Track Sequence" path (reference cpp/tracker.cc) -- batched ray casting, PnP accumulation
+and the LM loop -- against the float64 numpy oracle (oracle/pnp_oracle.py) and analytic ground truth.
+Tolerances: rotation angle <= 1e-4 rad, translation <= 1e-4 * |t| vs the oracle."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pnp_oracle as po  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+W, H, F = 960.0, 540.0, 1100.0
+
+
+@pytest.fixture(scope="module")
+def core():
+    import torch  # noqa: F401
+    sys.path.insert(0, os.path.join(ROOT, "polychase_amd", "core"))
+    import polychase_core
+    return polychase_core
+
+
+def grid_mesh(n=20, size=4.0):
+    xs = np.linspace(-size / 2, size / 2, n + 1)
+    X, Y = np.meshgrid(xs, xs)
+    Z = 0.3 * np.sin(1.3 * X) * np.cos(1.1 * Y)
+    verts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1).astype(np.float32)
+    tris = []
+    for j in range(n):
+        for i in range(n):
+            a = j * (n + 1) + i
+            tris += [[a, a + 1, a + n + 2], [a, a + n + 2, a + n + 1]]
+    return verts, np.array(tris, np.uint32)
+
+
+def rot(axis, ang):
+    axis = np.asarray(axis, float) / np.linalg.norm(axis)
+    return po.quat_to_R(np.concatenate([[math.cos(ang / 2)], axis * math.sin(ang / 2)]))
+
+
+def true_pose(t):
+    """view (world->camera) of frame t: OpenGL camera 6 units in front of the mesh, orbiting slightly."""
+    R = rot([0.2, 1.0, 0.1], 0.012 * t) @ rot([1, 0, 0], 0.004 * t)
+    return R, np.array([0.03 * t, -0.02 * t, -6.0 + 0.01 * t])
+
+
+def intr(core):
+    return core.CameraIntrinsics(fx=-F, fy=-F, cx=W / 2, cy=H / 2, aspect_ratio=1.0, width=W, height=H,
+                                 convention=core.CameraConvention.OpenGL)
+
+
+def ocam(R, t):
+    return po.Camera(fx=-F, fy=-F, cx=W / 2, cy=H / 2, aspect_ratio=1.0, width=W, height=H, opencv=False,
+                     q=po.R_to_quat(R), t=np.asarray(t, float))
+
+
+def view4(R, t):
+    m = np.eye(4, dtype=np.float32)
+    m[:3, :3], m[:3, 3] = R, t
+    return m
+
+
+def rays_object_space(cam: po.Camera, model, xy):
+    inv = np.linalg.inv(view4(cam.R(), cam.t).astype(np.float64) @ model.astype(np.float64))
+    return inv[:3, 3], cam.unproject(xy) @ inv[:3, :3].T
+
+
+def test_ray_casting_matches_oracle(core):
+    verts, tris = grid_mesh()
+    mesh = core.AcceleratedMesh(verts, tris)
+    model = np.diag([1.5, 1.5, 1.5, 1.0]).astype(np.float32)
+    R, t = true_pose(3)
+    st = core.SceneTransformations(model, view4(R, t), intr(core))
+    rng = np.random.default_rng(0)
+    xy = rng.uniform([0, 0], [W, H], (3000, 2)).astype(np.float32)
+    hits = core._ray_cast_pixels(mesh, st, xy, True)
+    origin, dirs = rays_object_space(ocam(R, t), model, xy)
+    hit, prim, u, v, tt, pos = po.raycast_closest(verts, tris, origin, dirs)
+    got = np.array([h is not None for h in hits])
+    # rays grazing an edge may flip between float32 and float64: allow a handful
+    assert (got != hit).sum() <= 3
+    both = got & hit
+    assert both.sum() > 1000
+    gp = np.array([hits[i].pos for i in np.nonzero(both)[0]])
+    assert np.abs(gp - pos[both]).max() < 2e-4
+    same = np.array([hits[i].primitive_id for i in np.nonzero(both)[0]]) == prim[both]
+    assert same.mean() > 0.995
+    # single-ray API and the mask: a masked closest triangle is a miss (ray_casting.cc:104-106)
+    i0 = int(np.nonzero(both)[0][0])
+    h0 = core.ray_cast(mesh, st, xy[i0], True)
+    assert h0 is not None and h0.primitive_id == hits[i0].primitive_id
+    assert abs(np.linalg.norm(h0.normal) - 1) < 1e-5
+    mesh.inner_mut().mask_triangle(h0.primitive_id)
+    assert mesh.inner().is_triangle_masked(h0.primitive_id)
+    assert core.ray_cast(mesh, st, xy[i0], True) is None
+    assert core.ray_cast(mesh, st, xy[i0], False) is not None
+    mesh.inner_mut().unmask_triangle(h0.primitive_id)
+    assert core.ray_cast(mesh, st, xy[i0], True) is not None
+
+
+def _angle(Ra, Rb):
+    c = (np.trace(Ra.T @ Rb) - 1) / 2
+    return math.acos(max(-1.0, min(1.0, c)))
+
+
+@pytest.mark.parametrize("loss", ["Cauchy", "Huber", "Trivial"])
+def test_pnp_matches_oracle_and_truth(core, loss):
+    rng = np.random.default_rng(1)
+    n = 2000
+    Xw = rng.uniform(-2, 2, (n, 3))
+    R, t = true_pose(5)
+    cam_true = ocam(R, t)
+    x, _ = cam_true.project_world(Xw)
+    x += rng.normal(0, 0.3, x.shape)
+    x[:50] += rng.uniform(-80, 80, (50, 2))          # outliers
+    R0, t0 = true_pose(4)
+    init = core.CameraState(intr(core), core.Pose())
+    p = core.Pose()
+    p.q = po.R_to_quat(R0).astype(np.float32)
+    p.t = t0.astype(np.float32)
+    init.pose = p
+    bo = core.BundleOptions()
+    bo.loss_type = getattr(core.LossType, loss)
+    res = core._solve_pnp_iterative(Xw.astype(np.float32), x.astype(np.float32), init, bo, 12.0, False, False)
+    ocam_res, ostats = po.solve_pnp(Xw.astype(np.float32), x.astype(np.float32), ocam(R0, t0), kind=loss.lower())
+    Rg = po.quat_to_R(np.array(res.camera.pose.q, float))
+    tg = np.array(res.camera.pose.t, float)
+    assert _angle(Rg, ocam_res.R()) <= 1e-4
+    assert np.linalg.norm(tg - ocam_res.t) <= 1e-4 * np.linalg.norm(ocam_res.t)
+    assert abs(res.inlier_ratio - ostats["inlier_ratio"]) <= 2.0 / n
+    assert res.bundle_stats.cost == pytest.approx(ostats["cost"], rel=2e-3)
+    assert res.bundle_stats.initial_cost == pytest.approx(ostats["initial_cost"], rel=1e-3)
+    if loss != "Trivial":   # robust losses recover the true pose despite the outliers
+        assert _angle(Rg, R) < 2e-4 and np.linalg.norm(tg - t) < 2e-3
+
+
+def test_pnp_intrinsics_refinement(core):
+    rng = np.random.default_rng(2)
+    Xw = rng.uniform(-2, 2, (1500, 3))
+    R, t = true_pose(2)
+    x, _ = ocam(R, t).project_world(Xw)
+    k = intr(core)
+    k.fx = k.fy = -F * 0.97          # wrong focal length to start from
+    init = core.CameraState(k, core.Pose())
+    p = core.Pose()
+    p.q, p.t = po.R_to_quat(R).astype(np.float32), t.astype(np.float32)
+    init.pose = p
+    res = core._solve_pnp_iterative(Xw.astype(np.float32), x.astype(np.float32), init, core.BundleOptions(), 12.0, True, False)
+    assert abs(res.camera.intrinsics.fy + F) < 0.5 and abs(res.camera.intrinsics.fx + F) < 0.5
+    with pytest.raises(Exception, match="Assertion failed"):   # CHECK_GE(rows, 3), solvers.cc:55
+        core._solve_pnp_iterative(Xw[:2].astype(np.float32), x[:2].astype(np.float32), init, core.BundleOptions(), 12.0, False, False)
+
+
+def _build_flow_db(core, path, verts, tris, model, n_frames, n_kp=300, noise=0.0, seed=3):
+    """keypoints at random pixels; flow f -> f+s = analytic reprojection of the mesh point under the
+    keypoint (so the true trajectory explains every match exactly when noise == 0)."""
+    rng = np.random.default_rng(seed)
+    db = core.Database(path)
+    wverts = verts.astype(np.float64) * np.diag(model)[:3]
+    kp = {}
+    world = {}
+    for f in range(1, n_frames + 1):
+        R, t = true_pose(f)
+        xy = np.floor(rng.uniform([20, 20], [W - 20, H - 20], (n_kp, 2))).astype(np.float32)
+        origin, dirs = rays_object_space(ocam(R, t), model, xy)
+        hit, _, _, _, _, pos = po.raycast_closest(verts, tris, origin, dirs)
+        kp[f], world[f] = xy, (pos * np.diag(model)[:3], hit)
+        db.write_keypoints(f, xy)
+    for f in range(1, n_frames + 1):
+        pw, hit = world[f]
+        for s in (-8, -4, -2, -1, 1, 2, 4, 8):
+            g = f + s
+            if g < 1 or g > n_frames:
+                continue
+            R, t = true_pose(g)
+            x2, Z = ocam(R, t).project_world(pw)
+            ok = hit & (Z[:, 2] < 0) & (x2[:, 0] > 0) & (x2[:, 0] < W) & (x2[:, 1] > 0) & (x2[:, 1] < H)
+            # keypoints that miss the mesh still produce (wrong) flows, as LK would
+            idx = np.nonzero(ok | ~hit)[0].astype(np.uint32)
+            tgt = np.where(hit[idx, None], x2[idx], kp[f][idx] + 1.0) + rng.normal(0, noise, (len(idx), 2))
+            db.write_image_pair_flow(f, g, idx, tgt.astype(np.float32), np.zeros(len(idx), np.float32))
+    db.close()
+    return kp
+
+
+def _oracle_track(path, core, verts, tris, model, frame_from, frame_to):
+    """tracker.cc:36-192 in numpy float64."""
+    db = core.Database(path)
+    traj = {frame_from: ocam(*true_pose(frame_from))}
+    step = 1 if frame_to > frame_from else -1
+    for f in range(frame_from + step, frame_to + step, step):
+        Xs, xs = [], []
+        for src in db.find_optical_flows_to_image(f):
+            if src not in traj:
+                continue
+            kps = db.read_keypoints(src)
+            fl = db.read_image_pair_flow(src, f)
+            origin, dirs = rays_object_space(traj[src], model, kps[fl.src_kps_indices])
+            hit, _, _, _, _, pos = po.raycast_closest(verts, tris, origin, dirs)
+            Xs.append((pos * np.diag(model)[:3])[hit])
+            xs.append(fl.tgt_kps[hit])
+        init = traj.get(f) or traj.get(f - 1) or traj.get(f + 1)
+        cam, _ = po.solve_pnp(np.concatenate(Xs).astype(np.float32), np.concatenate(xs).astype(np.float32), init,
+                              kind="cauchy", scale=1.0)
+        traj[f] = cam
+    db.close()
+    return traj
+
+
+@pytest.mark.parametrize("direction", ["forward", "backward"])
+def test_track_sequence_on_synthetic_database(core, tmp_path, direction):
+    verts, tris = grid_mesh()
+    model = np.diag([1.5, 1.5, 1.5, 1.0]).astype(np.float32)
+    n_frames = 14
+    path = str(tmp_path / "flow.db")
+    _build_flow_db(core, path, verts, tris, model, n_frames, noise=0.05)
+    a, b = (1, n_frames) if direction == "forward" else (n_frames, 1)
+    R0, t0 = true_pose(a)
+    st = core.SceneTransformations(model, view4(R0, t0), intr(core))
+    mesh = core.AcceleratedMesh(verts, tris)
+    bo = core.BundleOptions()
+    bo.loss_type = core.LossType.Cauchy          # what the addon uses (tracking.py:208-210)
+    got = {}
+
+    def cb(r):
+        got[r.frame] = (po.quat_to_R(np.array(r.pose.q, float)), np.array(r.pose.t, float), r.inlier_ratio)
+        return True
+
+    core.track_sequence(path, a, b, st, mesh, cb, False, False, bo)
+    oracle = _oracle_track(path, core, verts, tris, model, a, b)
+    frames = range(2, n_frames + 1) if direction == "forward" else range(1, n_frames)
+    assert sorted(got) == list(frames)
+    for f in frames:
+        Rg, tg, inl = got[f]
+        Rt, tt = true_pose(f)
+        assert _angle(Rg, oracle[f].R()) <= 1e-4, f                          # vs oracle: stated tolerance
+        assert np.linalg.norm(tg - oracle[f].t) <= 1e-4 * np.linalg.norm(oracle[f].t), f
+        assert _angle(Rg, Rt) < 1e-3 and np.linalg.norm(tg - tt) < 1e-2, f     # vs truth (0.05 px noise)
+        assert inl > 0.9
+
+
+def test_tracker_thread_protocol_and_errors(core, tmp_path):
+    import time
+    verts, tris = grid_mesh()
+    model = np.eye(4, dtype=np.float32)
+    path = str(tmp_path / "flow.db")
+    _build_flow_db(core, path, verts, tris, model, 6, n_kp=120)
+    R0, t0 = true_pose(1)
+    st = core.SceneTransformations(model, view4(R0, t0), intr(core))
+    mesh = core.AcceleratedMesh(verts, tris)
+    th = core.TrackerThread(path, 1, 6, st, mesh, False, False, core.BundleOptions())
+    msgs, t_start = [], time.time()
+    while time.time() - t_start < 60:
+        m = th.try_pop()
+        if m is None:
+            time.sleep(0.001)
+            continue
+        msgs.append(m)
+        if m is True:
+            break
+    th.join()
+    assert [m.frame for m in msgs[:-1]] == [2, 3, 4, 5, 6] and msgs[-1] is True
+    # frames beyond the database: "Could not track to frame" (tracker.cc:162-166)
+    th = core.TrackerThread(path, 6, 9, st, mesh, False, False, core.BundleOptions())
+    th.join()
+    out = []
+    while not th.empty():
+        out.append(th.try_pop())
+    assert isinstance(out[0], core.CppException) and "Not enough features" in out[0].what() and out[-1] is True
