@@ -126,7 +126,7 @@ def main():
         n_kps.append(len(kps))
         n_rows.append(sum(len(v[0]) for v in flows.values()))
         if world > 1:
-            records.append((kps, flows))
+            records.append((frame1, kps, flows))
 
     an.run(range(f1_first, f1_first + W), None)
     barrier()
@@ -135,20 +135,10 @@ def main():
     t0 = time.perf_counter()
     an.run(range(f1_first + W, f1_first + W + K), sink, copy=(world > 1))
     if world > 1:
-        # stitch the flow database: one RCCL all-gather of the packed records
-        blobs = []
-        for kps, flows in records:
-            blobs.append(kps.view(np.uint8).ravel())
-            for idx, xy, err in flows.values():
-                blobs += [idx.view(np.uint8).ravel(), xy.view(np.uint8).ravel(), err.view(np.uint8).ravel()]
-        local = torch.from_numpy(np.concatenate(blobs)).to(dev)
-        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([local.numel()], dtype=torch.int64, device=dev))
-        mx = int(max(int(s.item()) for s in sizes))
-        padded = torch.zeros(mx, dtype=torch.uint8, device=dev)
-        padded[:local.numel()] = local
-        gathered = torch.empty(world * mx, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(gathered, padded)
+        # stitch the flow database: all-gather of the packed records over RCCL
+        from polychase_amd import distributed as D
+        stitched = D.all_gather_records(records, device=dev)
+        assert len(stitched) == world * K
     barrier()
     dt = time.perf_counter() - t0
     timing = ctx.timing()

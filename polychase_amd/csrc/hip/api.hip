@@ -59,59 +59,20 @@ int collect_timing(pc_context* c) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// greedy min-distance suppression, reference gftt.cc:100-164 (and :165-181 when min_distance < 1).
-// keys: sorted (value desc, linear index desc).  Output: accepted corners in acceptance order.
-int suppress_min_distance(const unsigned long long* keys, size_t total, int w, int h, double min_distance,
-                          int max_corners, std::vector<float>& out_xy) {
-    out_xy.clear();
-    size_t ncorners = 0;
-    if (min_distance >= 1) {
-        const int cell_size = (int)std::lrint(min_distance);  // cvRound
-        const int grid_w = (w + cell_size - 1) / cell_size;
-        const int grid_h = (h + cell_size - 1) / cell_size;
-        std::vector<int32_t> head((size_t)grid_w * grid_h, -1);
-        std::vector<int32_t> next;
-        next.reserve(total / 4 + 16);
-        const double min_dist_sq = min_distance * min_distance;
-        for (size_t i = 0; i < total; i++) {
-            const uint32_t idx = (uint32_t)(keys[i] & 0xffffffffull);
-            const int y = (int)(idx / (uint32_t)w);
-            const int x = (int)(idx - (uint32_t)y * (uint32_t)w);
-            const int xc = x / cell_size, yc = y / cell_size;
-            const int x1 = std::max(xc - 1, 0), y1 = std::max(yc - 1, 0);
-            const int x2 = std::min(xc + 1, grid_w - 1), y2 = std::min(yc + 1, grid_h - 1);
-            bool good = true;
-            for (int yy = y1; yy <= y2 && good; yy++)
-                for (int xx = x1; xx <= x2 && good; xx++)
-                    for (int32_t j = head[(size_t)yy * grid_w + xx]; j >= 0; j = next[j]) {
-                        const float dx = (float)x - out_xy[2 * (size_t)j];
-                        const float dy = (float)y - out_xy[2 * (size_t)j + 1];
-                        if ((double)(dx * dx + dy * dy) < min_dist_sq) {
-                            good = false;
-                            break;
-                        }
-                    }
-            if (good) {
-                out_xy.push_back((float)x);
-                out_xy.push_back((float)y);
-                next.push_back(head[(size_t)yc * grid_w + xc]);
-                head[(size_t)yc * grid_w + xc] = (int32_t)ncorners;
-                ncorners++;
-                if (max_corners > 0 && (int)ncorners == max_corners) break;
-            }
+// Offsets (dx, dy) != (0, 0) with dx^2 + dy^2 < min_distance^2: the neighbourhood inside which the
+// reference's greedy loop rejects a candidate (gftt.cc:134-141; its 3x3 cell search with
+// cell = cvRound(min_distance) covers exactly these offsets since |dx| < min_distance <= cell + 0.5).
+std::vector<int2> suppression_offsets(double min_distance) {
+    std::vector<int2> out;
+    const double r2 = min_distance * min_distance;
+    const int R = (int)std::ceil(min_distance);
+    for (int dy = -R; dy <= R; dy++)
+        for (int dx = -R; dx <= R; dx++) {
+            if (dx == 0 && dy == 0) continue;
+            const float fx = (float)dx, fy = (float)dy;
+            if ((double)(fx * fx + fy * fy) < r2) out.push_back(make_int2(dx, dy));
         }
-    } else {
-        for (size_t i = 0; i < total; i++) {
-            const uint32_t idx = (uint32_t)(keys[i] & 0xffffffffull);
-            const int y = (int)(idx / (uint32_t)w);
-            const int x = (int)(idx - (uint32_t)y * (uint32_t)w);
-            out_xy.push_back((float)x);
-            out_xy.push_back((float)y);
-            ncorners++;
-            if (max_corners > 0 && (int)ncorners == max_corners) break;
-        }
-    }
-    return (int)ncorners;
+    return out;
 }
 
 int ensure_kp_capacity(pc_frame* f, int n) {
@@ -133,6 +94,108 @@ void build_pyramid(pc_context* c, pc_frame* f) {
         pc::launch_border(f->levels[l], f->win, c->stream);
         pc::launch_scharr(f->levels[l], c->stream);
     }
+}
+
+constexpr int kCounterCells = 4;  // counters[0..3] = candidates, accepted, stuck, pad; then cell max keys
+
+int validate_gftt(const pc_gftt_options* opt, int w, int h, pc::GfttGrid* g) {
+    // CHECKs of gftt.cc:18-19
+    if (!(opt->quality_level > 0 && opt->min_distance >= 0 && opt->max_corners >= 0))
+        return fail(PC_E_INVALID, "GFTT options violate quality_level > 0 && min_distance >= 0 && max_corners >= 0");
+    if (opt->use_harris) return fail(PC_E_INVALID, "use_harris is not implemented on the HIP path");
+    if (opt->block_size != 3 || opt->gradient_size != 3)
+        return fail(PC_E_INVALID, "only block_size == 3 and gradient_size == 3 are implemented on the HIP path");
+    if (opt->min_distance > 64.0) return fail(PC_E_INVALID, "min_distance > 64 is not supported on the HIP path");
+    g->rows = std::max(1, opt->grid_rows);
+    g->cols = std::max(1, opt->grid_cols);
+    if (g->rows * g->cols > pc::kMaxGridCells) return fail(PC_E_INVALID, "grid_rows*grid_cols must be <= %d", pc::kMaxGridCells);
+    g->cell_h = (h + g->rows - 1) / g->rows;
+    g->cell_w = (w + g->cols - 1) / g->cols;
+    return PC_OK;
+}
+
+// Dense part of GoodFeaturesToTrack, fully on the GPU and asynchronous: min-eig map + per-cell max
+// (gftt.cc:35,:61-63), threshold + NMS -> candidates (gftt.cc:64-86), exact min-distance suppression
+// (gftt.cc:100-164), accepted candidates -> list.  Counts are copied to pinned memory; `ev` fires after.
+int detect_phase_a(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const pc_gftt_options& opt,
+                   DetectScratch& d) {
+    const int w = f->w, h = f->h;
+    const size_t npx = (size_t)w * h;
+    PC_HIP(ctx->eig.ensure(npx));
+    PC_HIP(ctx->cmap.ensure(npx));
+    PC_HIP(ctx->state.ensure(npx));
+    PC_HIP(d.keys_in.ensure(npx));
+    PC_HIP(d.acc_keys.ensure(npx));
+    PC_HIP(d.counters.ensure(kCounterCells + pc::kMaxGridCells));
+    PC_HIP(d.h_counters.ensure(kCounterCells));
+    if (!d.ev) PC_HIP(hipEventCreateWithFlags(&d.ev, hipEventDisableTiming));
+    if (ctx->resident_blocks == 0) {
+        hipDeviceProp_t prop;
+        PC_HIP(hipGetDeviceProperties(&prop, ctx->device));
+        ctx->resident_blocks = std::max(1, prop.multiProcessorCount) * 4;  // 256-lane blocks, tiny kernel
+    }
+    const bool suppress = opt.min_distance >= 1;
+    if (suppress && ctx->sup_min_distance != opt.min_distance) {
+        const std::vector<int2> offs = suppression_offsets(opt.min_distance);
+        PC_HIP(ctx->sup_offsets.ensure(offs.size() + 1));
+        PC_HIP(hipStreamSynchronize(ctx->stream));  // a queued suppression may still read the old table
+        PC_HIP(hipMemcpy(ctx->sup_offsets.p, offs.data(), offs.size() * sizeof(int2), hipMemcpyHostToDevice));
+        ctx->n_sup_offsets = (int)offs.size();
+        ctx->sup_min_distance = opt.min_distance;
+    }
+    PC_HIP(hipMemsetAsync(d.counters.p, 0, (kCounterCells + pc::kMaxGridCells) * sizeof(uint32_t), ctx->stream));
+    uint32_t* cell_max = d.counters.p + kCounterCells;
+    {
+        ScopedTimer t(ctx, PC_K_MINEIG);
+        pc::launch_min_eig(f->levels[0], ctx->eig.p, grid, cell_max, ctx->stream);
+    }
+    ctx->eig_owner = f;
+    {
+        ScopedTimer t(ctx, PC_K_NMS);
+        pc::launch_nms_compact(ctx->eig.p, w, h, grid, cell_max, opt.quality_level, d.keys_in.p, (uint32_t)npx,
+                               d.counters.p, ctx->cmap.p, ctx->state.p, ctx->stream);
+    }
+    {
+        ScopedTimer t(ctx, PC_K_SUPPRESS);
+        if (suppress)
+            pc::launch_suppress(d.keys_in.p, d.counters.p, (uint32_t)npx, w, h, ctx->cmap.p, ctx->state.p,
+                                ctx->sup_offsets.p, ctx->n_sup_offsets, d.counters.p + 2, ctx->resident_blocks,
+                                ctx->stream);
+        pc::launch_collect_accepted(d.keys_in.p, d.counters.p, (uint32_t)npx, ctx->state.p, suppress ? 0 : 1,
+                                    d.acc_keys.p, d.counters.p + 1, ctx->stream);
+    }
+    PC_HIP(hipMemcpyAsync(d.h_counters.p, d.counters.p, kCounterCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipEventRecord(d.ev, ctx->stream));
+    return PC_OK;
+}
+
+// Ordering part: sort the accepted corners (value desc, address desc == acceptance order of the
+// greedy loop, gftt.cc:98,:157), truncate to max_corners (gftt.cc:160-162), write float2 keypoints.
+int detect_phase_b(pc_context* ctx, pc_frame* f, const pc_gftt_options& opt, DetectScratch& d) {
+    PC_HIP(hipEventSynchronize(d.ev));
+    const uint32_t npx = (uint32_t)((size_t)f->w * f->h);
+    const uint32_t n_cand = std::min(d.h_counters.p[0], npx);
+    const uint32_t n_acc = std::min(d.h_counters.p[1], n_cand);
+    if (d.h_counters.p[2] != 0)
+        return fail(PC_E_HIP, "suppression kernel did not converge (%u lanes gave up): grid not resident?", d.h_counters.p[2]);
+    f->n_cands = (int)n_cand;
+    int n = (int)n_acc;
+    if (n > 0) {
+        PC_HIP(ctx->keys_out.ensure(n_acc));
+        size_t temp_bytes = 0;
+        PC_HIP(pc::sort_keys_desc(nullptr, temp_bytes, d.acc_keys.p, ctx->keys_out.p, n_acc, ctx->stream));
+        PC_HIP(ctx->sort_temp.ensure(temp_bytes));
+        {
+            ScopedTimer t(ctx, PC_K_SORT);
+            PC_HIP(pc::sort_keys_desc(ctx->sort_temp.p, temp_bytes, d.acc_keys.p, ctx->keys_out.p, n_acc, ctx->stream));
+        }
+        if (opt.max_corners > 0) n = std::min(n, opt.max_corners);
+        int rc = ensure_kp_capacity(f, n);
+        if (rc != PC_OK) return rc;
+        pc::launch_keys_to_xy(ctx->keys_out.p, n, f->w, f->d_kps, ctx->stream);
+    }
+    f->n_kps = n;
+    return PC_OK;
 }
 
 int check_lk_args(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targets, int n_targets,
@@ -243,12 +306,17 @@ void pc_context_destroy(pc_context* c) {
     c->staging.release();
     c->eig.release();
     c->keys_in.release();
+    c->cmap.release();
+    c->state.release();
+    c->sup_offsets.release();
+    if (c->detect) {
+        c->detect->release();
+        delete c->detect;
+        c->detect = nullptr;
+    }
     c->keys_out.release();
     c->counters.release();
     c->sort_temp.release();
-    c->h_keys.release();
-    c->h_kps.release();
-    c->h_counter.release();
     c->lk_xy.release();
     c->lk_cxy.release();
     c->lk_status.release();
@@ -450,67 +518,14 @@ int pc_frame_download_deriv(pc_context* ctx, const pc_frame* f, int level, int16
 int pc_frame_detect(pc_context* ctx, pc_frame* f, const pc_gftt_options* opt) {
     if (!ctx || !f || !opt) return fail(PC_E_INVALID, "null argument");
     if (f->ctx != ctx) return fail(PC_E_INVALID, "frame belongs to another context");
-    // CHECKs of gftt.cc:18-19
-    if (!(opt->quality_level > 0 && opt->min_distance >= 0 && opt->max_corners >= 0))
-        return fail(PC_E_INVALID, "GFTT options violate quality_level > 0 && min_distance >= 0 && max_corners >= 0");
-    if (opt->use_harris) return fail(PC_E_INVALID, "use_harris is not implemented on the HIP path");
-    if (opt->block_size != 3 || opt->gradient_size != 3)
-        return fail(PC_E_INVALID, "only block_size == 3 and gradient_size == 3 are implemented on the HIP path");
-    PC_HIP(hipSetDevice(ctx->device));
-    const int w = f->w, h = f->h;
     pc::GfttGrid g;
-    g.rows = std::max(1, opt->grid_rows);
-    g.cols = std::max(1, opt->grid_cols);
-    if (g.rows * g.cols > pc::kMaxGridCells) return fail(PC_E_INVALID, "grid_rows*grid_cols must be <= %d", pc::kMaxGridCells);
-    g.cell_h = (h + g.rows - 1) / g.rows;
-    g.cell_w = (w + g.cols - 1) / g.cols;
-    const size_t npx = (size_t)w * h;
-    const uint32_t cap = (uint32_t)npx;
-    PC_HIP(ctx->eig.ensure(npx));
-    PC_HIP(ctx->keys_in.ensure(cap));
-    PC_HIP(ctx->keys_out.ensure(cap));
-    PC_HIP(ctx->counters.ensure(1 + pc::kMaxGridCells));
-    PC_HIP(ctx->h_counter.ensure(4));
-    PC_HIP(hipMemsetAsync(ctx->counters.p, 0, (1 + pc::kMaxGridCells) * sizeof(uint32_t), ctx->stream));
-    uint32_t* d_counter = ctx->counters.p;
-    uint32_t* d_cell_max = ctx->counters.p + 1;
-    {
-        ScopedTimer t(ctx, PC_K_MINEIG);
-        pc::launch_min_eig(f->levels[0], ctx->eig.p, g, d_cell_max, ctx->stream);
-    }
-    ctx->eig_owner = f;
-    {
-        ScopedTimer t(ctx, PC_K_NMS);
-        pc::launch_nms_compact(ctx->eig.p, w, h, g, d_cell_max, opt->quality_level, ctx->keys_in.p, cap, d_counter, ctx->stream);
-    }
-    PC_HIP(hipMemcpyAsync(ctx->h_counter.p, d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    PC_HIP(hipStreamSynchronize(ctx->stream));
-    const uint32_t n_cand = std::min(ctx->h_counter.p[0], cap);
-    f->n_cands = (int)n_cand;
-    std::vector<float> xy;
-    int n = 0;
-    if (n_cand > 0) {
-        size_t temp_bytes = 0;
-        PC_HIP(pc::sort_keys_desc(nullptr, temp_bytes, ctx->keys_in.p, ctx->keys_out.p, n_cand, ctx->stream));
-        PC_HIP(ctx->sort_temp.ensure(temp_bytes));
-        {
-            ScopedTimer t(ctx, PC_K_SORT);
-            PC_HIP(pc::sort_keys_desc(ctx->sort_temp.p, temp_bytes, ctx->keys_in.p, ctx->keys_out.p, n_cand, ctx->stream));
-        }
-        PC_HIP(ctx->h_keys.ensure(n_cand));
-        PC_HIP(hipMemcpyAsync(ctx->h_keys.p, ctx->keys_out.p, (size_t)n_cand * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-        PC_HIP(hipStreamSynchronize(ctx->stream));
-        n = suppress_min_distance(ctx->h_keys.p, n_cand, w, h, opt->min_distance, opt->max_corners, xy);
-    }
-    int rc = ensure_kp_capacity(f, n);
+    int rc = validate_gftt(opt, f->w, f->h, &g);
     if (rc != PC_OK) return rc;
-    if (n > 0) {
-        PC_HIP(ctx->h_kps.ensure((size_t)n * 2));
-        std::memcpy(ctx->h_kps.p, xy.data(), (size_t)n * 2 * sizeof(float));
-        PC_HIP(hipMemcpyAsync(f->d_kps, ctx->h_kps.p, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
-        PC_HIP(hipStreamSynchronize(ctx->stream));  // h_kps is reused by the next detect
-    }
-    f->n_kps = n;
+    PC_HIP(hipSetDevice(ctx->device));
+    if (!ctx->detect) ctx->detect = new DetectScratch();
+    if ((rc = detect_phase_a(ctx, f, g, *opt, *ctx->detect)) != PC_OK) return rc;
+    if ((rc = detect_phase_b(ctx, f, *opt, *ctx->detect)) != PC_OK) return rc;
+    PC_HIP(hipStreamSynchronize(ctx->stream));
     return PC_OK;
 }
 
@@ -622,7 +637,7 @@ int pc_lk_track_filtered(pc_context* ctx, const pc_frame* frame1, const pc_frame
 
 namespace {
 
-enum DetState { DET_NONE = 0, DET_DENSE = 1, DET_SORT = 2, DET_DONE = 3 };
+enum DetState { DET_NONE = 0, DET_DENSE = 1, DET_DONE = 3 };
 
 struct Slot {
     pc_frame* frame = nullptr;
@@ -630,13 +645,7 @@ struct Slot {
     bool valid = false;
     DetState det = DET_NONE;
     bool supplied = false;  // keypoints came from the caller (database), not from detection
-    DevBuf<unsigned long long> keys_in;
-    DevBuf<uint32_t> counters;  // [0] candidate counter, [1..] per-cell max keys
-    PinBuf<uint32_t> h_counter;
-    PinBuf<unsigned long long> h_keys;
-    PinBuf<float> h_kps;
-    hipEvent_t ev_dense = nullptr, ev_sort = nullptr;
-    uint32_t n_cand = 0;
+    DetectScratch scratch;
 };
 
 struct Job {
@@ -663,7 +672,6 @@ struct pc_analyzer {
     std::vector<Slot> slots;
     std::vector<Job> jobs;
     size_t job_head = 0, job_count = 0;  // ring of in-flight jobs
-    std::vector<float> scratch_xy;
 };
 
 namespace {
@@ -674,72 +682,16 @@ Slot* find_slot(pc_analyzer* a, int32_t frame_id) {
     return (s.valid && s.frame_id == frame_id) ? &s : nullptr;
 }
 
-// dense part of GoodFeaturesToTrack: min-eig map, per-cell max, threshold + NMS -> candidate keys
 int detect_dense(pc_analyzer* a, Slot& s) {
-    pc_context* ctx = a->ctx;
-    const size_t npx = (size_t)a->w * a->h;
-    PC_HIP(ctx->eig.ensure(npx));
-    PC_HIP(s.keys_in.ensure(npx));
-    PC_HIP(s.counters.ensure(1 + pc::kMaxGridCells));
-    PC_HIP(s.h_counter.ensure(4));
-    PC_HIP(hipMemsetAsync(s.counters.p, 0, (1 + pc::kMaxGridCells) * sizeof(uint32_t), ctx->stream));
-    {
-        ScopedTimer t(ctx, PC_K_MINEIG);
-        pc::launch_min_eig(s.frame->levels[0], ctx->eig.p, a->grid, s.counters.p + 1, ctx->stream);
-    }
-    ctx->eig_owner = nullptr;
-    {
-        ScopedTimer t(ctx, PC_K_NMS);
-        pc::launch_nms_compact(ctx->eig.p, a->w, a->h, a->grid, s.counters.p + 1, a->gopt.quality_level, s.keys_in.p,
-                               (uint32_t)npx, s.counters.p, ctx->stream);
-    }
-    PC_HIP(hipMemcpyAsync(s.h_counter.p, s.counters.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    PC_HIP(hipEventRecord(s.ev_dense, ctx->stream));
-    s.det = DET_DENSE;
-    return PC_OK;
+    int rc = detect_phase_a(a->ctx, s.frame, a->grid, a->gopt, s.scratch);
+    if (rc == PC_OK) s.det = DET_DENSE;
+    return rc;
 }
 
-// sort the candidates (gftt.cc:98) and start their download
-int detect_sort(pc_analyzer* a, Slot& s) {
-    pc_context* ctx = a->ctx;
-    PC_HIP(hipEventSynchronize(s.ev_dense));
-    s.n_cand = std::min<uint32_t>(s.h_counter.p[0], (uint32_t)((size_t)a->w * a->h));
-    s.frame->n_cands = (int)s.n_cand;
-    if (s.n_cand > 0) {
-        PC_HIP(ctx->keys_out.ensure(s.n_cand));
-        size_t temp_bytes = 0;
-        PC_HIP(pc::sort_keys_desc(nullptr, temp_bytes, s.keys_in.p, ctx->keys_out.p, s.n_cand, ctx->stream));
-        PC_HIP(ctx->sort_temp.ensure(temp_bytes));
-        {
-            ScopedTimer t(ctx, PC_K_SORT);
-            PC_HIP(pc::sort_keys_desc(ctx->sort_temp.p, temp_bytes, s.keys_in.p, ctx->keys_out.p, s.n_cand, ctx->stream));
-        }
-        PC_HIP(s.h_keys.ensure(s.n_cand));
-        PC_HIP(hipMemcpyAsync(s.h_keys.p, ctx->keys_out.p, (size_t)s.n_cand * sizeof(unsigned long long),
-                              hipMemcpyDeviceToHost, ctx->stream));
-    }
-    PC_HIP(hipEventRecord(s.ev_sort, ctx->stream));
-    s.det = DET_SORT;
-    return PC_OK;
-}
-
-// greedy min-distance suppression on the host (gftt.cc:100-164) + upload of the accepted corners
 int detect_finish(pc_analyzer* a, Slot& s) {
-    pc_context* ctx = a->ctx;
     int rc;
     if (s.det == DET_NONE && (rc = detect_dense(a, s)) != PC_OK) return rc;
-    if (s.det == DET_DENSE && (rc = detect_sort(a, s)) != PC_OK) return rc;
-    PC_HIP(hipEventSynchronize(s.ev_sort));
-    const int n = suppress_min_distance(s.h_keys.p, s.n_cand, a->w, a->h, a->gopt.min_distance, a->gopt.max_corners,
-                                        a->scratch_xy);
-    rc = ensure_kp_capacity(s.frame, n);
-    if (rc != PC_OK) return rc;
-    PC_HIP(s.h_kps.ensure((size_t)std::max(n, 1) * 2));
-    if (n > 0) {
-        std::memcpy(s.h_kps.p, a->scratch_xy.data(), (size_t)n * 2 * sizeof(float));
-        PC_HIP(hipMemcpyAsync(s.frame->d_kps, s.h_kps.p, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
-    }
-    s.frame->n_kps = n;
+    if ((rc = detect_phase_b(a->ctx, s.frame, a->gopt, s.scratch)) != PC_OK) return rc;
     s.det = DET_DONE;
     s.supplied = false;
     return PC_OK;
@@ -755,11 +707,11 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
     *out = nullptr;
     if (ring_frames < 1 || ring_frames > 4096) return fail(PC_E_INVALID, "ring_frames must be in [1,4096]");
     if (max_jobs < 1 || max_jobs > 64) return fail(PC_E_INVALID, "max_jobs must be in [1,64]");
-    if (!(gftt->quality_level > 0 && gftt->min_distance >= 0 && gftt->max_corners >= 0))
-        return fail(PC_E_INVALID, "GFTT options violate quality_level > 0 && min_distance >= 0 && max_corners >= 0");
-    if (gftt->use_harris) return fail(PC_E_INVALID, "use_harris is not implemented on the HIP path");
-    if (gftt->block_size != 3 || gftt->gradient_size != 3)
-        return fail(PC_E_INVALID, "only block_size == 3 and gradient_size == 3 are implemented on the HIP path");
+    pc::GfttGrid grid0;
+    {
+        int vrc = validate_gftt(gftt, width, height, &grid0);
+        if (vrc != PC_OK) return vrc;
+    }
     PC_HIP(hipSetDevice(ctx->device));
     pc_analyzer* a = new (std::nothrow) pc_analyzer();
     if (!a) return fail(PC_E_INVALID, "out of host memory");
@@ -768,25 +720,13 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
     a->h = height;
     a->gopt = *gftt;
     a->fopt = *flow;
-    a->grid.rows = std::max(1, gftt->grid_rows);
-    a->grid.cols = std::max(1, gftt->grid_cols);
-    if (a->grid.rows * a->grid.cols > pc::kMaxGridCells) {
-        delete a;
-        return fail(PC_E_INVALID, "grid_rows*grid_cols must be <= %d", pc::kMaxGridCells);
-    }
-    a->grid.cell_h = (height + a->grid.rows - 1) / a->grid.rows;
-    a->grid.cell_w = (width + a->grid.cols - 1) / a->grid.cols;
+    a->grid = grid0;
     a->slots.resize((size_t)ring_frames);
     a->jobs.resize((size_t)max_jobs);
     int rc = PC_OK;
     for (auto& s : a->slots) {
         rc = pc_frame_create(ctx, width, height, flow->window_size, flow->max_level, &s.frame);
         if (rc != PC_OK) break;
-        if (hipEventCreateWithFlags(&s.ev_dense, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.ev_sort, hipEventDisableTiming) != hipSuccess) {
-            rc = fail(PC_E_HIP, "hipEventCreate failed");
-            break;
-        }
     }
     if (rc == PC_OK)
         for (auto& j : a->jobs)
@@ -810,13 +750,7 @@ void pc_analyzer_destroy(pc_analyzer* a) {
     (void)hipStreamSynchronize(a->ctx->stream);
     for (auto& s : a->slots) {
         if (s.frame) pc_frame_destroy(s.frame);
-        s.keys_in.release();
-        s.counters.release();
-        s.h_counter.release();
-        s.h_keys.release();
-        s.h_kps.release();
-        if (s.ev_dense) (void)hipEventDestroy(s.ev_dense);
-        if (s.ev_sort) (void)hipEventDestroy(s.ev_sort);
+        s.scratch.release();
     }
     for (auto& j : a->jobs) {
         j.h_kps.release();
@@ -859,10 +793,10 @@ int pc_analyzer_set_keypoints(pc_analyzer* a, int32_t frame_id, const float* xy,
     if (!s) return fail(PC_E_STATE, "frame %d is not resident", frame_id);
     int rc = ensure_kp_capacity(s->frame, n);
     if (rc != PC_OK) return rc;
-    PC_HIP(s->h_kps.ensure((size_t)std::max(n, 1) * 2));
     if (n > 0) {
-        std::memcpy(s->h_kps.p, xy, (size_t)n * 2 * sizeof(float));
-        PC_HIP(hipMemcpyAsync(s->frame->d_kps, s->h_kps.p, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, a->ctx->stream));
+        // resume path (keypoints from the database): pageable source, so the copy is synchronous
+        PC_HIP(hipMemcpyAsync(s->frame->d_kps, xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, a->ctx->stream));
+        PC_HIP(hipStreamSynchronize(a->ctx->stream));
     }
     s->frame->n_kps = n;
     s->det = DET_DONE;
@@ -885,7 +819,7 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
         tg[t] = st->frame;
     }
     int rc;
-    // (1) keypoints of frame1: host suppression overlaps the previous job's LK on the GPU
+    // (1) keypoints of frame1: the dense phase ran when the frame became resident; order them now
     bool detected = false;
     if (s1->det != DET_DONE) {
         if ((rc = detect_finish(a, *s1)) != PC_OK) return rc;
@@ -893,10 +827,6 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     } else {
         detected = !s1->supplied;
     }
-    // (2) look ahead: sort + download the next frame's candidates BEFORE this frame's LK is queued
-    if (Slot* nx = find_slot(a, frame1 + 1))
-        if (nx->det == DET_DENSE && (rc = detect_sort(a, *nx)) != PC_OK) return rc;
-
     Job& j = a->jobs[(a->job_head + a->job_count) % a->jobs.size()];
     const int n = s1->frame->n_kps;
     const size_t rows = (size_t)n * (size_t)std::max(n_targets, 0);
@@ -905,7 +835,8 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     PC_HIP(j.h_xy.ensure(rows * 2 + 2));
     PC_HIP(j.h_err.ensure(rows + 1));
     PC_HIP(j.h_row_offset.ensure(PC_MAX_TARGETS + 1));
-    if (n > 0) std::memcpy(j.h_kps.p, s1->h_kps.p, (size_t)n * 2 * sizeof(float));
+    if (n > 0)
+        PC_HIP(hipMemcpyAsync(j.h_kps.p, s1->frame->d_kps, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
     j.frame1 = frame1;
     j.n_kps = n;
     j.detected = detected;

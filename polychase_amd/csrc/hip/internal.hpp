@@ -90,6 +90,23 @@ using pc::PinBuf;
 using pc::TimedRange;
 using pc::fail;
 
+// Per-detection buffers that must survive between the dense phase (enqueued when a frame becomes
+// resident) and the ordering phase (run when the frame is used as frame1).
+struct DetectScratch {
+    DevBuf<unsigned long long> keys_in, acc_keys;
+    DevBuf<uint32_t> counters;             // [0] candidates, [1] accepted, [2] stuck lanes, [3] pad, [4..] cell max
+    PinBuf<uint32_t> h_counters;
+    hipEvent_t ev = nullptr;
+    void release() {
+        keys_in.release();
+        acc_keys.release();
+        counters.release();
+        h_counters.release();
+        if (ev) (void)hipEventDestroy(ev);
+        ev = nullptr;
+    }
+};
+
 struct pc_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -98,11 +115,14 @@ struct pc_context {
     // GFTT scratch
     DevBuf<float> eig;
     DevBuf<unsigned long long> keys_in, keys_out;
+    DevBuf<uint32_t> cmap, state;          // dense candidate priority / decision maps (K5)
+    DevBuf<int2> sup_offsets;              // suppression neighbourhood for sup_min_distance
+    double sup_min_distance = -1.0;
+    int n_sup_offsets = 0;
+    int resident_blocks = 0;               // fully resident grid size for the suppression kernel
+    struct DetectScratch* detect = nullptr;  // scratch of the stage-level pc_frame_detect
     DevBuf<uint32_t> counters;  // [0] candidate counter, [1..] cell max keys
     DevBuf<uint8_t> sort_temp;
-    PinBuf<unsigned long long> h_keys;
-    PinBuf<float> h_kps;
-    PinBuf<uint32_t> h_counter;
     const pc_frame* eig_owner = nullptr;
     // LK scratch
     DevBuf<float2> lk_xy, lk_cxy;

@@ -28,9 +28,20 @@ constexpr int kMaxGridCells = 256;
 void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, hipStream_t s);
 // K3: per-cell THRESH_TOZERO + 3x3 dilate + strict-interior local maxima -> 64-bit keys
 // (ordered(value) << 32 | y*w+x) appended to `keys` (capacity `cap`), count in *counter.
+// cmap/state (w*h u32 each, may be null): dense candidate priority map + cleared decision map for K5.
 void launch_nms_compact(const float* eig, int w, int h, const GfttGrid& g, const uint32_t* cell_max,
                         double quality_level, unsigned long long* keys, uint32_t cap,
-                        uint32_t* counter, hipStream_t s);
+                        uint32_t* counter, uint32_t* cmap, uint32_t* state, hipStream_t s);
+// K5: exact greedy min-distance suppression (gftt.cc:100-164) as a parallel fixed point; the grid
+// (resident_blocks x 256) must be fully resident.  *stuck != 0 afterwards means the spin bound hit.
+void launch_suppress(const unsigned long long* keys, const uint32_t* counter, uint32_t cap, int w, int h,
+                     const uint32_t* cmap, uint32_t* state, const int2* offsets, int n_offsets, uint32_t* stuck,
+                     int resident_blocks, hipStream_t s);
+// take_all: min_distance < 1 (gftt.cc:165-181).
+void launch_collect_accepted(const unsigned long long* keys, const uint32_t* counter, uint32_t cap,
+                             const uint32_t* state, int take_all, unsigned long long* out, uint32_t* out_counter,
+                             hipStream_t s);
+void launch_keys_to_xy(const unsigned long long* keys, int n, int w, float2* xy, hipStream_t s);
 // K4: descending radix sort of the candidate keys (rocPRIM).  temp may be null to query bytes.
 hipError_t sort_keys_desc(void* temp, size_t& temp_bytes, unsigned long long* keys_in,
                           unsigned long long* keys_out, uint32_t n, hipStream_t s);

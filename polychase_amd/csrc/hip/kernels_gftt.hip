@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restric
                                                           const uint32_t* __restrict__ cell_max,
                                                           double quality_level,
                                                           unsigned long long* __restrict__ keys, uint32_t cap,
-                                                          uint32_t* __restrict__ counter) {
+                                                          uint32_t* __restrict__ counter,
+                                                          uint32_t* __restrict__ cmap, uint32_t* __restrict__ state) {
     __shared__ float s_thr[kMaxGridCells];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
@@ -188,6 +189,18 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restric
             }
         }
     }
+    // dense priority map for the suppression kernel: ordered(value) at candidates, 0 elsewhere;
+    // every pixel is written, so the maps need no clearing between frames
+    if (cmap && x < w) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int y = blockIdx.y * 16 + wave + 4 * k;
+            if (y < h) {
+                cmap[(size_t)y * w + x] = (flags & (1u << k)) ? float_to_ordered(vals[k]) : 0u;
+                state[(size_t)y * w + x] = 0u;
+            }
+        }
+    }
     // workgroup-aggregated append: one global atomic per 1024-pixel tile
     const uint32_t cnt = (uint32_t)__popc(flags);
     uint32_t incl = cnt;
@@ -219,10 +232,141 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restric
 
 void launch_nms_compact(const float* eig, int w, int h, const GfttGrid& g, const uint32_t* cell_max,
                         double quality_level, unsigned long long* keys, uint32_t cap, uint32_t* counter,
-                        hipStream_t s) {
+                        uint32_t* cmap, uint32_t* state, hipStream_t s) {
     dim3 grid((w + 63) / 64, (h + 15) / 16);
     hipLaunchKernelGGL(nms_compact_kernel, grid, dim3(256), 0, s, eig, w, h, g, cell_max, quality_level, keys, cap,
-                       counter);
+                       counter, cmap, state);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5  exact min-distance suppression on the GPU.
+// The reference's greedy loop (gftt.cc:100-164) accepts a candidate iff no ALREADY ACCEPTED candidate
+// lies within min_distance; processing order = (value desc, address desc).  Equivalently: a
+// candidate is accepted iff every higher-priority candidate within the radius is rejected -- the
+// lexicographically-first maximal independent set of the conflict graph.  Each candidate is owned by
+// one lane of a fully resident grid and re-evaluates until all its higher-priority neighbours are
+// decided; decisions are final and monotone, so asynchronous evaluation reaches exactly the
+// sequential result.  Progress: the highest-priority undecided candidate is always decidable, and a
+// lane round-robins over its candidates (never spins on one), so no cycle of waits can form.
+// States (dense u32 map, agent-scope relaxed atomics: per-XCD L2s are not coherent): 0 undecided,
+// 1 accepted, 2 rejected.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t ST_ACCEPTED = 1u, ST_REJECTED = 2u;
+
+__global__ __launch_bounds__(256) void suppress_kernel(const unsigned long long* __restrict__ keys,
+                                                       const uint32_t* __restrict__ counter, uint32_t cap, int w, int h,
+                                                       const uint32_t* __restrict__ cmap, uint32_t* state,
+                                                       const int2* __restrict__ offsets, int n_offsets,
+                                                       uint32_t* __restrict__ stuck) {
+    const uint32_t n = min(*counter, cap);
+    const uint32_t T = gridDim.x * blockDim.x;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n) return;
+    const uint32_t mine = (n - tid + T - 1) / T;   // candidates tid, tid+T, ...
+    uint32_t remaining = mine;
+    // small per-lane "done" bitmap; lanes rarely own more than one candidate (T ~ 5e5)
+    unsigned long long done_lo = 0ull;
+    for (uint32_t spin = 0; remaining > 0; spin++) {
+        for (uint32_t j = 0; j < mine; j++) {
+            if (j < 64 ? ((done_lo >> j) & 1ull) : false) continue;
+            const unsigned long long key = keys[tid + (size_t)j * T];
+            const uint32_t my_val = (uint32_t)(key >> 32), my_idx = (uint32_t)key;
+            if (j >= 64 && __hip_atomic_load(&state[my_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;
+            const int y = (int)(my_idx / (uint32_t)w), x = (int)(my_idx - (uint32_t)y * (uint32_t)w);
+            bool blocked = false, rejected = false;
+            for (int o = 0; o < n_offsets; o++) {
+                const int nx = x + offsets[o].x, ny = y + offsets[o].y;
+                if (nx < 0 || nx >= w || ny < 0 || ny >= h) continue;
+                const uint32_t nidx = (uint32_t)(ny * w + nx);
+                const uint32_t nval = cmap[nidx];
+                if (nval == 0u) continue;
+                if (!(nval > my_val || (nval == my_val && nidx > my_idx))) continue;  // lower priority
+                const uint32_t st = __hip_atomic_load(&state[nidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (st == ST_ACCEPTED) {
+                    rejected = true;
+                    break;
+                }
+                if (st == 0u) blocked = true;
+            }
+            if (rejected || !blocked) {
+                __hip_atomic_store(&state[my_idx], rejected ? ST_REJECTED : ST_ACCEPTED, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                if (j < 64) done_lo |= 1ull << j;
+                remaining--;
+            }
+        }
+        if (remaining > 0) {
+            if (spin > (1u << 22)) {  // bounded spin: report instead of hanging the GPU
+                atomicAdd(stuck, 1u);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+}
+
+// accepted candidates -> dense list (order irrelevant: sorted afterwards); grid-stride so that the
+// launch does not need the candidate count on the host
+__global__ __launch_bounds__(256) void collect_accepted_kernel(const unsigned long long* __restrict__ keys,
+                                                               const uint32_t* __restrict__ counter, uint32_t cap,
+                                                               const uint32_t* __restrict__ state, int take_all,
+                                                               unsigned long long* __restrict__ out,
+                                                               uint32_t* __restrict__ out_counter) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base;
+    const uint32_t n = min(*counter, cap);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        unsigned long long key = 0ull;
+        bool keep = false;
+        if (i < n) {
+            key = keys[i];
+            keep = take_all || state[(uint32_t)key] == ST_ACCEPTED;
+        }
+        const unsigned long long ballot = __ballot(keep);
+        __syncthreads();  // previous iteration's readers of s_wave / s_base are done
+        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(ballot);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            s_base = total ? atomicAdd(out_counter, total) : 0u;
+        }
+        __syncthreads();
+        if (keep) {
+            uint32_t pos = s_base + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+            for (int wv = 0; wv < wave; wv++) pos += s_wave[wv];
+            out[pos] = key;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void keys_to_xy_kernel(const unsigned long long* __restrict__ keys, int n, int w,
+                                                         float2* __restrict__ xy) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t idx = (uint32_t)keys[i];
+    const uint32_t y = idx / (uint32_t)w;
+    xy[i] = make_float2((float)(idx - y * (uint32_t)w), (float)y);  // Point2f((float)x, (float)y), gftt.cc:157
+}
+
+void launch_suppress(const unsigned long long* keys, const uint32_t* counter, uint32_t cap, int w, int h,
+                     const uint32_t* cmap, uint32_t* state, const int2* offsets, int n_offsets, uint32_t* stuck,
+                     int resident_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(suppress_kernel, dim3(resident_blocks), dim3(256), 0, s, keys, counter, cap, w, h, cmap, state,
+                       offsets, n_offsets, stuck);
+}
+
+void launch_collect_accepted(const unsigned long long* keys, const uint32_t* counter, uint32_t cap,
+                             const uint32_t* state, int take_all, unsigned long long* out, uint32_t* out_counter,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(collect_accepted_kernel, dim3(1024), dim3(256), 0, s, keys, counter, cap, state, take_all, out,
+                       out_counter);
+}
+
+void launch_keys_to_xy(const unsigned long long* keys, int n, int w, float2* xy, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(keys_to_xy_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, w, xy);
 }
 
 // ------------------------------------------------------------------------------------------------

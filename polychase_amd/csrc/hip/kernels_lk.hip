@@ -6,8 +6,10 @@
 // structure tensor / mismatch vector accumulated EXACTLY in integers, one rounding to fp32, 2x2
 // solve in fp32 without FMA contraction.
 //
-// Mapping (v2): one group of GL = 8 lanes per (keypoint, target) pair -> 8 pairs per wavefront,
-// 32 per 256-lane workgroup.  A group owns the WIN x WIN window (pixel p = lane + GL*k).
+// Mapping (v3): one wavefront per keypoint, one group of 8 lanes per target (<= 8 targets).  The
+// I side (window patch, Scharr patch, structure tensor) does not depend on the target: the whole
+// wave stages and evaluates it ONCE per level and hands every group its pixels through LDS.  A
+// group owns the WIN x WIN window of its target (pixel p = lane + 8k).
 //   * Every gather goes through LDS: per pyramid level the group stages (a) the I window as
 //     "byte pairs" P[c] = (I[c], I[c+1]) and the raw Scharr window, (b) a (WIN+7) x (WIN+7..) search
 //     region of the target image J in the same pair format.  One pixel of one LK iteration is then
@@ -17,7 +19,6 @@
 //   * Window sums are all-reduced inside the group with DPP adds (quad_perm xor1/xor2 +
 //     row_half_mirror): no LDS traffic, no cross-group traffic, so every lane holds the same A, b,
 //     delta and the convergence branches are group-uniform.
-//   * Consecutive groups are the targets of one keypoint: their I-side staging hits the same lines.
 #include "kernels.hpp"
 
 namespace pc {
@@ -83,69 +84,108 @@ __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c) {
 
 template <int WIN>
 struct LKGeo {
+    static constexpr int NPX = WIN * WIN;
     static constexpr int MX = 3, MY = 3;                              // search margin of the staged J region
     static constexpr int RW_DW = (WIN + 1 + 2 * MX + 3 + 3) / 4;      // raw dwords per region row
     static constexpr int RWB = RW_DW * 4;                             // positions (bytes) per region row
     static constexpr int RH = WIN + 1 + 2 * MY;                       // region rows
     static constexpr int PAIR_PITCH = RWB * 2;                        // bytes per row in pair format
-    static constexpr int J_BYTES = RH * PAIR_PITCH;
-    static constexpr int I_BYTES = (WIN + 1) * PAIR_PITCH;
+    static constexpr int J_DW = RH * PAIR_PITCH / 4 + 1;              // per-group J region (odd dword stride)
+    static constexpr int I_DW = (WIN + 1) * PAIR_PITCH / 4;           // per-wave I window in pair format
     static constexpr int D_PITCH = WIN + 1;                           // dwords per Scharr window row
-    static constexpr int D_BYTES = (WIN + 1) * D_PITCH * 4;
-    static constexpr int BUF_BYTES0 = (J_BYTES > I_BYTES + D_BYTES) ? J_BYTES : (I_BYTES + D_BYTES);
-    static constexpr int BUF_DW = ((BUF_BYTES0 + 7) / 8) * 2 + 1;     // 8-B granules, odd dword stride
+    static constexpr int D_DW = (WIN + 1) * D_PITCH;                  // per-wave raw Scharr window
+    static constexpr int X_DW = NPX * 2;                              // per-wave exchange: (Ival, Dxy) per pixel
+    static constexpr int WAVE_DW = ((I_DW + D_DW + X_DW + 8 * J_DW + 1) / 2) * 2;  // 8-B aligned
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Stage `nrows` rows of an u8 plane, starting at (rx0, ry0) (rx0 4-aligned relative to the interior
-// origin), as byte pairs: P[r][c] = (A[r][c], A[r][c+1]) for c in [0, RWB).  Addresses are clamped
-// to the padded plane; clamped positions are never consumed by a window that passed the bounds
-// check.
-template <int WIN, int GL>
+// origin), as byte pairs: P[r][c] = (A[r][c], A[r][c+1]) for c in [0, RWB), using NL lanes.
+// CLAMP: addresses are clamped to the padded plane; clamped positions are never consumed by a
+// window that passed the bounds check.
+template <int WIN, int NL, bool CLAMP>
 __device__ __forceinline__ void stage_pairs(const uint8_t* __restrict__ img, int pitch, int lh, int rx0, int ry0,
-                                            int nrows, uint8_t* buf, int lg) {
+                                            int nrows, uint8_t* buf, int l) {
     using G = LKGeo<WIN>;
     const int total = nrows * G::RW_DW;
     const int xmax = pitch - kPadX - 4;
-    for (int i = lg; i < total; i += GL) {
-        const int r = i / G::RW_DW, m = i - r * G::RW_DW;
-        const int yy = clampi(ry0 + r, -WIN, lh + WIN - 1);
-        const int xb = rx0 + 4 * m;
-        const uint8_t* rowp = img + (ptrdiff_t)yy * pitch;
-        const uint32_t d0 = *reinterpret_cast<const uint32_t*>(rowp + clampi(xb, -kPadX, xmax));
-        const uint32_t d1 = *reinterpret_cast<const uint32_t*>(rowp + clampi(xb + 4, -kPadX, xmax));
+    int r = l / G::RW_DW, m = l - r * G::RW_DW;
+    for (int i = l; i < total; i += NL) {
+        int yy = ry0 + r, xb = rx0 + 4 * m, xb1 = xb + 4;
+        if (CLAMP) {
+            yy = clampi(yy, -WIN, lh + WIN - 1);
+            xb = clampi(xb, -kPadX, xmax);
+            xb1 = clampi(xb1, -kPadX, xmax);
+        }
+        const uint8_t* rowp = img + (ptrdiff_t)(yy * pitch);
+        const uint32_t d0 = *reinterpret_cast<const uint32_t*>(rowp + xb);
+        const uint32_t d1 = *reinterpret_cast<const uint32_t*>(rowp + xb1);
         // v_perm_b32: byte pool = {d0: indices 0-3, d1: indices 4-7}
         const uint32_t p0 = __builtin_amdgcn_perm(d1, d0, 0x02010100u);  // (A0,A1),(A1,A2)
         const uint32_t p1 = __builtin_amdgcn_perm(d1, d0, 0x04030302u);  // (A2,A3),(A3,A4)
         *reinterpret_cast<uint2*>(buf + r * G::PAIR_PITCH + 8 * m) = make_uint2(p0, p1);
+        // advance (r, m) by NL elements without a division
+        m += NL % G::RW_DW;
+        r += NL / G::RW_DW;
+        if (m >= G::RW_DW) {
+            m -= G::RW_DW;
+            r++;
+        }
     }
 }
 
-template <int WIN, int GL>
+template <int WIN, int NL>
+__device__ __forceinline__ void stage_pairs_auto(const uint8_t* __restrict__ img, int pitch, int lh, int rx0, int ry0,
+                                                 int nrows, uint8_t* buf, int l) {
+    using G = LKGeo<WIN>;
+    const bool inside = (ry0 >= -WIN) && (ry0 + nrows <= lh + WIN) && (rx0 >= -kPadX) &&
+                        (rx0 + G::RWB + 4 <= pitch - kPadX);
+    if (inside) stage_pairs<WIN, NL, false>(img, pitch, lh, rx0, ry0, nrows, buf, l);
+    else stage_pairs<WIN, NL, true>(img, pitch, lh, rx0, ry0, nrows, buf, l);
+}
+
+// wave-wide exact integer sum -> fp32: DPP inside each 16-lane row, then the 4 row results
+// (lanes 0,16,32,48) through readlane
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v = group_allreduce_add<16>(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ float wave_exact_sum(int partial) {
+    return exact_sum_to_float(wave_sum_i32(partial >> 16), wave_sum_i32(partial & 0xffff));
+}
+
+// One wavefront per keypoint; group g = lane / 8 tracks it into target g (v3).
+template <int WIN>
 __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
     using G = LKGeo<WIN>;
+    constexpr int GL = 8;
     constexpr int NPX = WIN * WIN;
     constexpr int K = (NPX + GL - 1) / GL;
-    constexpr int GROUPS = 256 / GL;
-    __shared__ __attribute__((aligned(16))) uint32_t s_buf[GROUPS][G::BUF_DW + 1];
+    constexpr int KW = (NPX + 63) / 64;  // pixels per lane in the cooperative (wave-wide) I-side pass
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[4][G::WAVE_DW];
 
-    const int grp = threadIdx.x / GL, lg = threadIdx.x % GL;
-    const long long gid = (long long)blockIdx.x * GROUPS + grp;
-    if (gid >= (long long)p.n * p.n_targets) return;  // whole groups exit together
-    const int feat = (int)(gid / p.n_targets);
-    const int tgt = (int)(gid - (long long)feat * p.n_targets);
-    uint8_t* const buf = reinterpret_cast<uint8_t*>(&s_buf[grp][0]);   // 8-B aligned: (BUF_DW+1) is even
-    uint8_t* const dbuf = buf + G::I_BYTES;                            // raw Scharr window (I side only)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 3, lg = lane & 7;
+    const int feat = blockIdx.x * 4 + wave;
+    if (feat >= p.n) return;  // whole waves exit together
+    const bool tgt_active = grp < p.n_targets;
+    const int tgt = tgt_active ? grp : 0;
 
-    // window offsets owned by this lane: pair-format byte offset and Scharr dword offset
-    int offP[K], offD[K];
+    uint32_t* const wbase = &s_buf[wave][0];
+    uint8_t* const ibuf = reinterpret_cast<uint8_t*>(wbase);                       // I window, pair format
+    uint8_t* const dbuf = reinterpret_cast<uint8_t*>(wbase + G::I_DW);             // raw Scharr window
+    uint32_t* const xbuf = wbase + G::I_DW + G::D_DW;                              // (Ival, Dxy) exchange
+    uint8_t* const jbuf = reinterpret_cast<uint8_t*>(wbase + G::I_DW + G::D_DW + G::X_DW + grp * G::J_DW);
+
+    // pair-format byte offsets of the window pixels owned by this lane (p = lg + 8k)
+    int offP[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int q = lg + GL * k;
         const int y = q / WIN, x = q - y * WIN;
         offP[k] = y * G::PAIR_PITCH + 2 * x;
-        offD[k] = (y * G::D_PITCH + x) * 4;
     }
 
     const float2 pt = p.pts[feat];
@@ -172,10 +212,11 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
         nx = qx;
         ny = qy;
 
+        // ---- I side: identical for all targets -> computed once by the whole wave ----
         px -= half_win;
         py -= half_win;
         const int ipx = (int)floorf(px), ipy = (int)floorf(py);
-        if (ipx < -WIN || ipx >= L.w || ipy < -WIN || ipy >= L.h) {
+        if (ipx < -WIN || ipx >= L.w || ipy < -WIN || ipy >= L.h) {   // wave-uniform
             if (level == 0) {
                 status = false;
                 err = 0.f;
@@ -187,31 +228,28 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
         const uint32_t wrow0 = (uint32_t)(wI.w00 & 0xffff) | ((uint32_t)wI.w01 << 16);
         const uint32_t wrow1 = (uint32_t)(wI.w10 & 0xffff) | ((uint32_t)wI.w11 << 16);
 
-        // ---- I side: stage the I window (pairs) and the raw Scharr window, then patch + tensor ----
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        stage_pairs_auto<WIN, 64>(L.img, pitch, L.h, ipx & ~3, ipy, WIN + 1, ibuf, lane);
         {
-            const int rx0 = ipx & ~3;
-            stage_pairs<WIN, GL>(L.img, pitch, L.h, rx0, ipy, WIN + 1, buf, lg);
-            for (int i = lg; i < (WIN + 1) * (WIN + 1); i += GL) {
+            const int32_t* __restrict__ Dbase = L.der + (ptrdiff_t)(ipy * pitch + ipx);
+            for (int i = lane; i < (WIN + 1) * (WIN + 1); i += 64) {
                 const int r = i / (WIN + 1), c = i - r * (WIN + 1);
-                reinterpret_cast<int32_t*>(dbuf)[i] = L.der[(ptrdiff_t)(ipy + r) * pitch + ipx + c];
+                reinterpret_cast<int32_t*>(dbuf)[i] = Dbase[r * pitch + c];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        int Ival[K];
-        int Dxy[K];  // (int16 ix) | (int16 iy << 16)
         int sA11 = 0, sA12 = 0, sA22 = 0;
         {
-            const uint8_t* ib = buf + 2 * (ipx & 3);
+            const uint8_t* ib = ibuf + 2 * (ipx & 3);
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                Ival[k] = 0;
-                Dxy[k] = 0;
-                if (lg + GL * k < NPX) {
-                    const uint16_t* q = reinterpret_cast<const uint16_t*>(ib + offP[k]);
-                    const uint32_t i4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);
-                    Ival[k] = interp4(i4, wI);
-                    const uint32_t* d = reinterpret_cast<const uint32_t*>(dbuf + offD[k]);
+            for (int m = 0; m < KW; m++) {
+                const int q = lane + 64 * m;
+                if (q < NPX) {
+                    const int y = q / WIN, x = q - y * WIN;
+                    const uint16_t* qp = reinterpret_cast<const uint16_t*>(ib + y * G::PAIR_PITCH + 2 * x);
+                    const uint32_t i4 = (uint32_t)qp[0] | ((uint32_t)qp[G::RWB] << 16);
+                    const int ival = interp4(i4, wI);
+                    const uint32_t* d = reinterpret_cast<const uint32_t*>(dbuf) + y * G::D_PITCH + x;
                     const uint32_t d00 = d[0], d01 = d[1], d10 = d[G::D_PITCH], d11 = d[G::D_PITCH + 1];
                     // (dx00, dx01), (dx10, dx11), (dy00, dy01), (dy10, dy11)
                     const uint32_t dx0 = __builtin_amdgcn_perm(d01, d00, 0x05040100u);
@@ -220,25 +258,39 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
                     const uint32_t dy1 = __builtin_amdgcn_perm(d11, d10, 0x07060302u);
                     const int ix = sdot2(dx1, wrow1, sdot2(dx0, wrow0, 1 << (W_BITS - 1))) >> W_BITS;
                     const int iy = sdot2(dy1, wrow1, sdot2(dy0, wrow0, 1 << (W_BITS - 1))) >> W_BITS;
-                    Dxy[k] = (int)((uint32_t)(ix & 0xffff) | ((uint32_t)iy << 16));
+                    xbuf[2 * q] = (uint32_t)ival;
+                    xbuf[2 * q + 1] = (uint32_t)(ix & 0xffff) | ((uint32_t)iy << 16);
                     sA11 += ix * ix;
                     sA12 += ix * iy;
                     sA22 += iy * iy;
                 }
             }
         }
-        // |ix|,|iy| <= 4080: per-lane partials fit int32; group totals reduced as exact (hi, lo) halves
-        const float A11 = group_exact_sum<GL>(sA11) * FLT_SCALE;
-        const float A12 = group_exact_sum<GL>(sA12) * FLT_SCALE;
-        const float A22 = group_exact_sum<GL>(sA22) * FLT_SCALE;
+        // |ix|,|iy| <= 4080: per-lane partials fit int32; totals reduced as exact (hi, lo) halves
+        const float A11 = wave_exact_sum(sA11) * FLT_SCALE;
+        const float A12 = wave_exact_sum(sA12) * FLT_SCALE;
+        const float A22 = wave_exact_sum(sA22) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         const float tdiff = A11 - A22;
         const float min_eig = (A22 + A11 - sqrtf(tdiff * tdiff + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
-        if (min_eig < p.min_eig_thr || D < 1.1920928955078125e-07f /* FLT_EPSILON */) {
+        if (min_eig < p.min_eig_thr || D < 1.1920928955078125e-07f /* FLT_EPSILON */) {   // wave-uniform
             if (level == 0) status = false;
             continue;
         }
         D = 1.f / D;
+        if (!tgt_active) continue;  // idle groups only help with the I side
+
+        // every group picks up the pixels it owns
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        int Ival[K];
+        int Dxy[K];  // (int16 ix) | (int16 iy << 16)
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int q = lg + GL * k;
+            const uint2 v = (q < NPX) ? *reinterpret_cast<const uint2*>(xbuf + 2 * q) : make_uint2(0u, 0u);
+            Ival[k] = (int)v.x;
+            Dxy[k] = (int)v.y;
+        }
 
         // ---- iterations on the staged J region ----
         qx -= half_win;
@@ -256,12 +308,12 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
                 rx0 = (iqx - G::MX) & ~3;
                 ry0 = iqy - G::MY;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                stage_pairs<WIN, GL>(J, pitch, L.h, rx0, ry0, G::RH, buf, lg);
+                stage_pairs_auto<WIN, GL>(J, pitch, L.h, rx0, ry0, G::RH, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 staged = true;
             }
             const Weights wJ = bilinear_weights(qx - (float)iqx, qy - (float)iqy);
-            const uint8_t* jb = buf + (iqy - ry0) * G::PAIR_PITCH + 2 * (iqx - rx0);
+            const uint8_t* jb = jbuf + (iqy - ry0) * G::PAIR_PITCH + 2 * (iqx - rx0);
             int sb1 = 0, sb2 = 0;  // per-lane partials: <= K * 8160 * 4080 < 2^31
 #pragma unroll
             for (int k = 0; k < K; k++) {
@@ -303,12 +355,12 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
                 rx0 = (iex - G::MX) & ~3;
                 ry0 = iey - G::MY;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                stage_pairs<WIN, GL>(J, pitch, L.h, rx0, ry0, G::RH, buf, lg);
+                stage_pairs_auto<WIN, GL>(J, pitch, L.h, rx0, ry0, G::RH, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 staged = true;
             }
             const Weights wE = bilinear_weights(ex - (float)iex, ey - (float)iey);
-            const uint8_t* jb = buf + (iey - ry0) * G::PAIR_PITCH + 2 * (iex - rx0);
+            const uint8_t* jb = jbuf + (iey - ry0) * G::PAIR_PITCH + 2 * (iex - rx0);
             int se = 0;
 #pragma unroll
             for (int k = 0; k < K; k++) {
@@ -324,7 +376,7 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
         }
     }
 
-    if (lg == 0) {
+    if (lg == 0 && tgt_active) {
         const size_t o = (size_t)tgt * p.n + feat;
         p.out_xy[o] = make_float2(nx, ny);
         p.out_status[o] = status ? 1 : 0;
@@ -334,12 +386,9 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
 
 template <int WIN>
 static void launch_lk_t(const LKParams& p, hipStream_t s) {
-    constexpr int GL = 8;
-    constexpr int GROUPS = 256 / GL;
-    const long long rows = (long long)p.n * p.n_targets;
-    const unsigned blocks = (unsigned)((rows + GROUPS - 1) / GROUPS);
+    const unsigned blocks = (unsigned)((p.n + 3) / 4);   // one wavefront per keypoint
     if (blocks == 0) return;
-    hipLaunchKernelGGL((lk_kernel<WIN, GL>), dim3(blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((lk_kernel<WIN>), dim3(blocks), dim3(256), 0, s, p);
 }
 
 bool launch_lk(const LKParams& p, int win, hipStream_t s) {

@@ -1,0 +1,116 @@
+"""Frame sharding + flow-database stitch for multi-GPU analysis.
+
+Detection + LK are independent per frame1 (the only coupling is read-only access to frames within
++-8), so each rank (one process per GPU) owns a contiguous range of frame1 ids and additionally
+ingests an 8-frame halo on each side as targets only.  No collective on the data path.  The flow
+database is stitched once at the end with an all-gather of the packed records
+(torch.distributed: backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in the CPU tests), so every
+rank holds the complete record set (rank 0 writes SQLite; tracking can start anywhere).
+
+Record order and bytes are independent of the number of ranks.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+HALO = 8  # largest |skip| of the reference (cpp/opticalflow.cc:76-77)
+
+
+def shard_range(first_frame: int, num_frames: int, world: int, rank: int) -> tuple[int, int]:
+    """frame1 ids [begin, end) owned by `rank`: first + r*n/R ... (SURVEY 8(e) partitioning)."""
+    begin = first_frame + (num_frames * rank) // world
+    end = first_frame + (num_frames * (rank + 1)) // world
+    return begin, end
+
+
+def resident_range(begin: int, end: int, first_frame: int, num_frames: int) -> tuple[int, int]:
+    """frames a rank must ingest: its shard plus the halo, clipped to the clip."""
+    return max(first_frame, begin - HALO), min(first_frame + num_frames, end + HALO)
+
+
+def pack_records(records) -> tuple[np.ndarray, np.ndarray]:
+    """records: iterable of (frame1, kps [N,2] f32, {frame2: (idx u32 [M], xy f32 [M,2], err f32 [M])}).
+    -> (header int64 [n, 3 + 16], payload uint8)."""
+    hdr, blobs = [], []
+    for frame1, kps, flows in records:
+        row = [int(frame1), len(kps), len(flows)]
+        blobs.append(np.ascontiguousarray(kps, np.float32).view(np.uint8).ravel())
+        items = sorted(flows.items())
+        for f2, (idx, xy, err) in items:
+            row += [int(f2), len(idx)]
+            blobs += [np.ascontiguousarray(idx, np.uint32).view(np.uint8).ravel(),
+                      np.ascontiguousarray(xy, np.float32).view(np.uint8).ravel(),
+                      np.ascontiguousarray(err, np.float32).view(np.uint8).ravel()]
+        row += [0, 0] * (8 - len(items))
+        hdr.append(row)
+    header = np.array(hdr, np.int64).reshape(-1, 19)
+    payload = np.concatenate(blobs) if blobs else np.zeros(0, np.uint8)
+    return header, payload
+
+
+def unpack_records(header: np.ndarray, payload: np.ndarray):
+    out, o = [], 0
+    for row in header:
+        frame1, n_kps, n_t = int(row[0]), int(row[1]), int(row[2])
+        kps = payload[o:o + n_kps * 8].view(np.float32).reshape(n_kps, 2).copy()
+        o += n_kps * 8
+        flows = {}
+        for t in range(n_t):
+            f2, m = int(row[3 + 2 * t]), int(row[4 + 2 * t])
+            idx = payload[o:o + 4 * m].view(np.uint32).copy()
+            o += 4 * m
+            xy = payload[o:o + 8 * m].view(np.float32).reshape(m, 2).copy()
+            o += 8 * m
+            err = payload[o:o + 4 * m].view(np.float32).copy()
+            o += 4 * m
+            flows[f2] = (idx, xy, err)
+        out.append((frame1, kps, flows))
+    assert o == len(payload)
+    return out
+
+
+def all_gather_packed(header: np.ndarray, payload: np.ndarray, device=None, group=None):
+    """All-gather of one rank's packed records. Returns (headers, payloads) lists indexed by rank.
+    Two collectives: sizes (2 x int64 per rank), then the padded byte payloads."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    dev = device if device is not None else torch.device("cpu")
+    local = torch.from_numpy(np.concatenate([header.view(np.uint8).ravel(), payload])).to(dev)
+    sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([header.shape[0], payload.shape[0]], dtype=torch.int64, device=dev), group=group)
+    totals = [int(s[0]) * 19 * 8 + int(s[1]) for s in sizes]
+    mx = max(totals) if totals else 0
+    padded = torch.zeros(max(mx, 1), dtype=torch.uint8, device=dev)
+    padded[:local.numel()] = local
+    gathered = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded, group=group)
+    headers, payloads = [], []
+    for r in range(world):
+        buf = gathered[r].cpu().numpy()
+        nh = int(sizes[r][0]) * 19 * 8
+        headers.append(buf[:nh].view(np.int64).reshape(-1, 19).copy())
+        payloads.append(buf[nh:nh + int(sizes[r][1])].copy())
+    return headers, payloads
+
+
+def all_gather_records(records, device=None, group=None):
+    """-> the records of all ranks, in frame1 order (ranks own increasing frame ranges)."""
+    h, p = pack_records(records)
+    hs, ps = all_gather_packed(h, p, device, group)
+    out = []
+    for hh, pp in zip(hs, ps):
+        out += unpack_records(hh, pp)
+    out.sort(key=lambda r: r[0])
+    return out
+
+
+def write_records(db, records):
+    """Store stitched records through a polychase_core.Database (keypoints row first: FK)."""
+    for frame1, kps, flows in records:
+        if not db.keypoints_exist(frame1):
+            db.write_keypoints(frame1, kps)
+        for f2, (idx, xy, err) in sorted(flows.items()):
+            if not db.image_pair_flow_exists(frame1, f2):
+                db.write_image_pair_flow(frame1, f2, idx, xy, err)

@@ -270,3 +270,29 @@ def test_analyzer_resume_with_supplied_keypoints(ctx):
     assert np.array_equal(m.astype(np.uint32), idx_a)
     assert np.array_equal(xy_b[::-1], xy_a)
     an.close()
+
+
+def test_frame_sharding_is_result_invariant(ctx):
+    """SURVEY 8(e) determinism: records do not depend on the number of ranks.  Two shards (each with
+    its 8-frame halo) processed independently == one pass over the whole clip, byte for byte."""
+    from polychase_amd import distributed as D
+    from polychase_amd.pipeline import ClipAnalyzer
+    w, h, n, first = 320, 240, 26, 3
+    clip = synth.NoiseClip(w, h, n)
+    frames = {first + t: clip.frame(t) for t in range(n)}
+
+    def run(f1_begin, f1_end):
+        out = []
+        an = ClipAnalyzer(ctx, w, h, first, n, lambda fid: frames[fid])
+        an.run(range(f1_begin, f1_end), lambda f1, kps, det, flows: out.append((f1, kps, flows)))
+        an.close()
+        return out
+
+    whole = run(first, first + n)
+    parts = []
+    for r in range(2):
+        b, e = D.shard_range(first, n, 2, r)
+        parts += run(b, e)
+    hw, pw = D.pack_records(whole)
+    hp, pp = D.pack_records(parts)
+    assert np.array_equal(hw, hp) and np.array_equal(pw, pp)
