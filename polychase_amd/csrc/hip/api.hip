@@ -132,7 +132,7 @@ int detect_phase_a(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const
     if (ctx->resident_blocks == 0) {
         hipDeviceProp_t prop;
         PC_HIP(hipGetDeviceProperties(&prop, ctx->device));
-        ctx->resident_blocks = std::max(1, prop.multiProcessorCount) * 4;  // 256-lane blocks, tiny kernel
+        ctx->resident_blocks = std::max(1, prop.multiProcessorCount) * 6;  // 256-lane blocks, 34 VGPRs: 8 fit per CU
     }
     const bool suppress = opt.min_distance >= 1;
     if (suppress && ctx->sup_min_distance != opt.min_distance) {

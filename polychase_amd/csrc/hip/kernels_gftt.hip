@@ -253,6 +253,28 @@ void launch_nms_compact(const float* eig, int w, int h, const GfttGrid& g, const
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t ST_ACCEPTED = 1u, ST_REJECTED = 2u;
 
+// Evaluate one candidate against the current states of its higher-priority neighbours.
+// Returns 0 = still blocked, ST_ACCEPTED or ST_REJECTED.
+__device__ __forceinline__ uint32_t suppress_eval_scan(uint32_t my_val, uint32_t my_idx, int x, int y, int w, int h,
+                                                       const uint32_t* __restrict__ cmap, uint32_t* state,
+                                                       const int2* __restrict__ offsets, int n_offsets) {
+    bool blocked = false;
+    for (int o = 0; o < n_offsets; o++) {
+        const int nx = x + offsets[o].x, ny = y + offsets[o].y;
+        if (nx < 0 || nx >= w || ny < 0 || ny >= h) continue;
+        const uint32_t nidx = (uint32_t)(ny * w + nx);
+        const uint32_t nval = cmap[nidx];
+        if (nval == 0u) continue;
+        if (!(nval > my_val || (nval == my_val && nidx > my_idx))) continue;  // lower priority
+        const uint32_t st = __hip_atomic_load(&state[nidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st == ST_ACCEPTED) return ST_REJECTED;
+        if (st == 0u) blocked = true;
+    }
+    return blocked ? 0u : ST_ACCEPTED;
+}
+
+constexpr int SUP_NB = 12;  // higher-priority neighbours cached in registers by the fast path
+
 __global__ __launch_bounds__(256) void suppress_kernel(const unsigned long long* __restrict__ keys,
                                                        const uint32_t* __restrict__ counter, uint32_t cap, int w, int h,
                                                        const uint32_t* __restrict__ cmap, uint32_t* state,
@@ -262,41 +284,84 @@ __global__ __launch_bounds__(256) void suppress_kernel(const unsigned long long*
     const uint32_t T = gridDim.x * blockDim.x;
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= n) return;
+    if (n <= T) {
+        // fast path (the usual case): one candidate per lane.  Scan the neighbourhood once, remember
+        // the higher-priority candidates, then only poll their states.
+        const unsigned long long key = keys[tid];
+        const uint32_t my_val = (uint32_t)(key >> 32), my_idx = (uint32_t)key;
+        const int y = (int)(my_idx / (uint32_t)w), x = (int)(my_idx - (uint32_t)y * (uint32_t)w);
+        uint32_t nb[SUP_NB];
+        int n_nb = 0;
+        bool overflow = false;
+        for (int o = 0; o < n_offsets; o++) {
+            const int nx = x + offsets[o].x, ny = y + offsets[o].y;
+            if (nx < 0 || nx >= w || ny < 0 || ny >= h) continue;
+            const uint32_t nidx = (uint32_t)(ny * w + nx);
+            const uint32_t nval = cmap[nidx];
+            if (nval == 0u) continue;
+            if (!(nval > my_val || (nval == my_val && nidx > my_idx))) continue;
+            if (n_nb < SUP_NB) {
+#pragma unroll
+                for (int k = 0; k < SUP_NB; k++)
+                    if (k == n_nb) nb[k] = nidx;
+                n_nb++;
+            } else {
+                overflow = true;
+            }
+        }
+        // NOTE on control flow: a lane must publish its decision INSIDE the loop and keep iterating
+        // (idle) until the whole wave is done.  With a per-lane `return` the store would sit in the
+        // loop's exit block, which a wave only executes after ALL its lanes left the loop -- a lane
+        // waiting for a neighbour owned by the same wave would then never see it (SIMT deadlock).
+        bool done = false;
+        for (uint32_t spin = 0;; spin++) {
+            if (!done) {
+                uint32_t decision;
+                if (overflow) {
+                    decision = suppress_eval_scan(my_val, my_idx, x, y, w, h, cmap, state, offsets, n_offsets);
+                } else {
+                    bool blocked = false, rejected = false;
+#pragma unroll
+                    for (int k = 0; k < SUP_NB; k++) {
+                        if (k < n_nb) {
+                            const uint32_t st = __hip_atomic_load(&state[nb[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            rejected |= (st == ST_ACCEPTED);
+                            blocked |= (st == 0u);
+                        }
+                    }
+                    decision = rejected ? ST_REJECTED : (blocked ? 0u : ST_ACCEPTED);
+                }
+                if (decision != 0u) {
+                    __hip_atomic_store(&state[my_idx], decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    done = true;
+                }
+            }
+            if (__all(done)) break;           // wave-uniform exit
+            if (spin > (1u << 20)) {          // bounded spin: report instead of hanging the GPU
+                if (!done) atomicAdd(stuck, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return;
+    }
+    // general path: several candidates per lane, visited round-robin (never spin on one candidate)
     const uint32_t mine = (n - tid + T - 1) / T;   // candidates tid, tid+T, ...
     uint32_t remaining = mine;
-    // small per-lane "done" bitmap; lanes rarely own more than one candidate (T ~ 5e5)
-    unsigned long long done_lo = 0ull;
     for (uint32_t spin = 0; remaining > 0; spin++) {
         for (uint32_t j = 0; j < mine; j++) {
-            if (j < 64 ? ((done_lo >> j) & 1ull) : false) continue;
             const unsigned long long key = keys[tid + (size_t)j * T];
             const uint32_t my_val = (uint32_t)(key >> 32), my_idx = (uint32_t)key;
-            if (j >= 64 && __hip_atomic_load(&state[my_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;
+            if (__hip_atomic_load(&state[my_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;
             const int y = (int)(my_idx / (uint32_t)w), x = (int)(my_idx - (uint32_t)y * (uint32_t)w);
-            bool blocked = false, rejected = false;
-            for (int o = 0; o < n_offsets; o++) {
-                const int nx = x + offsets[o].x, ny = y + offsets[o].y;
-                if (nx < 0 || nx >= w || ny < 0 || ny >= h) continue;
-                const uint32_t nidx = (uint32_t)(ny * w + nx);
-                const uint32_t nval = cmap[nidx];
-                if (nval == 0u) continue;
-                if (!(nval > my_val || (nval == my_val && nidx > my_idx))) continue;  // lower priority
-                const uint32_t st = __hip_atomic_load(&state[nidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (st == ST_ACCEPTED) {
-                    rejected = true;
-                    break;
-                }
-                if (st == 0u) blocked = true;
-            }
-            if (rejected || !blocked) {
-                __hip_atomic_store(&state[my_idx], rejected ? ST_REJECTED : ST_ACCEPTED, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                if (j < 64) done_lo |= 1ull << j;
+            const uint32_t decision = suppress_eval_scan(my_val, my_idx, x, y, w, h, cmap, state, offsets, n_offsets);
+            if (decision != 0u) {
+                __hip_atomic_store(&state[my_idx], decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 remaining--;
             }
         }
         if (remaining > 0) {
-            if (spin > (1u << 22)) {  // bounded spin: report instead of hanging the GPU
+            if (spin > (1u << 20)) {
                 atomicAdd(stuck, 1u);
                 return;
             }

@@ -68,12 +68,15 @@ __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
             ((uint32_t)(c11 >> 7) << 24);
     return w;
 }
-// CV_DESCALE(sum_t tap_t * w_t, W_BITS - 5) of the 4 taps packed in j4 = (p00, p01, p10, p11)
+// CV_DESCALE(sum_t tap_t * w_t, W_BITS - 5) of the 4 taps packed in j4 = (p00, p01, p10, p11).
+// NEG: w11 == -1 (possible when the three rounded weights sum to 2^14 + 1); handled by a separate
+// instantiation selected once per window, not per pixel.
+template <bool NEG>
 __device__ __forceinline__ int interp4(uint32_t j4, const Weights& w) {
     const uint32_t lo = __builtin_amdgcn_udot4(j4, w.lo4, 1u << (W_BITS - 5 - 1), false);
     const uint32_t hi = __builtin_amdgcn_udot4(j4, w.hi4, 0u, false);
     uint32_t s = lo + (hi << 7);
-    if (__builtin_expect(w.neg11, 0)) s -= (j4 >> 24);  // w11 == -1
+    if (NEG) s -= (j4 >> 24);
     return (int)(s >> (W_BITS - 5));
 }
 
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
     for (int k = 0; k < K; k++) {
         const int q = lg + GL * k;
         const int y = q / WIN, x = q - y * WIN;
-        offP[k] = y * G::PAIR_PITCH + 2 * x;
+        offP[k] = (q < NPX) ? y * G::PAIR_PITCH + 2 * x : 0;  // slots past the window read pixel 0 and contribute 0
     }
 
     const float2 pt = p.pts[feat];
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
                     const int y = q / WIN, x = q - y * WIN;
                     const uint16_t* qp = reinterpret_cast<const uint16_t*>(ib + y * G::PAIR_PITCH + 2 * x);
                     const uint32_t i4 = (uint32_t)qp[0] | ((uint32_t)qp[G::RWB] << 16);
-                    const int ival = interp4(i4, wI);
+                    const int ival = wI.neg11 ? interp4<true>(i4, wI) : interp4<false>(i4, wI);
                     const uint32_t* d = reinterpret_cast<const uint32_t*>(dbuf) + y * G::D_PITCH + x;
                     const uint32_t d00 = d[0], d01 = d[1], d10 = d[G::D_PITCH], d11 = d[G::D_PITCH + 1];
                     // (dx00, dx01), (dx10, dx11), (dy00, dy01), (dy10, dy11)
@@ -260,9 +263,9 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
                     const int iy = sdot2(dy1, wrow1, sdot2(dy0, wrow0, 1 << (W_BITS - 1))) >> W_BITS;
                     xbuf[2 * q] = (uint32_t)ival;
                     xbuf[2 * q + 1] = (uint32_t)(ix & 0xffff) | ((uint32_t)iy << 16);
-                    sA11 += ix * ix;
-                    sA12 += ix * iy;
-                    sA22 += iy * iy;
+                    sA11 += __mul24(ix, ix);   // |ix|, |iy| <= 4080
+                    sA12 += __mul24(ix, iy);
+                    sA22 += __mul24(iy, iy);
                 }
             }
         }
@@ -315,14 +318,25 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
             const Weights wJ = bilinear_weights(qx - (float)iqx, qy - (float)iqy);
             const uint8_t* jb = jbuf + (iqy - ry0) * G::PAIR_PITCH + 2 * (iqx - rx0);
             int sb1 = 0, sb2 = 0;  // per-lane partials: <= K * 8160 * 4080 < 2^31
+            // b1 += diff * ix, b2 += diff * iy as two v_dot2_i32_i16 on the packed (ix, iy):
+            // (diff, 0) . (ix, iy) and (0, diff) . (ix, iy).  Slots past the window have Dxy == 0.
+            if (__builtin_expect(!wJ.neg11, 1)) {
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                if (lg + GL * k < NPX) {
+                for (int k = 0; k < K; k++) {
                     const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offP[k]);
                     const uint32_t j4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);
-                    const int diff = interp4(j4, wJ) - Ival[k];
-                    sb1 += diff * (int)(int16_t)(Dxy[k] & 0xffff);
-                    sb2 += diff * (Dxy[k] >> 16);
+                    const uint32_t diff = (uint32_t)(interp4<false>(j4, wJ) - Ival[k]);
+                    sb1 = sdot2(diff & 0xffffu, (uint32_t)Dxy[k], sb1);
+                    sb2 = sdot2(diff << 16, (uint32_t)Dxy[k], sb2);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offP[k]);
+                    const uint32_t j4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);
+                    const uint32_t diff = (uint32_t)(interp4<true>(j4, wJ) - Ival[k]);
+                    sb1 = sdot2(diff & 0xffffu, (uint32_t)Dxy[k], sb1);
+                    sb2 = sdot2(diff << 16, (uint32_t)Dxy[k], sb2);
                 }
             }
             const float b1 = group_exact_sum<GL>(sb1) * FLT_SCALE;
@@ -364,12 +378,12 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
             int se = 0;
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                if (lg + GL * k < NPX) {
-                    const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offP[k]);
-                    const uint32_t j4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);
-                    const int diff = interp4(j4, wE) - Ival[k];
-                    se += diff < 0 ? -diff : diff;
-                }
+                const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offP[k]);
+                const uint32_t j4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);
+                const int val = wE.neg11 ? interp4<true>(j4, wE) : interp4<false>(j4, wE);
+                const int diff = val - Ival[k];
+                const int ad = diff < 0 ? -diff : diff;
+                se += (k < K - 1 || lg + GL * k < NPX) ? ad : 0;
             }
             se = group_allreduce_add<GL>(se);  // <= 256 * 8160 < 2^24: exact in fp32 too
             err = ((float)se * 1.f) / (float)(32 * WIN * WIN);
