@@ -12,8 +12,9 @@
 // group owns the WIN x WIN window of its target (pixel p = lane + 8k).
 //   * Every gather goes through LDS: per pyramid level the group stages (a) the I window as
 //     "byte pairs" P[c] = (I[c], I[c+1]) and the raw Scharr window, (b) a (WIN+7) x (WIN+7..) search
-//     region of the target image J in the same pair format.  One pixel of one LK iteration is then
-//     two aligned ds_read_u16 (rows y, y+1 -> the 4 bilinear taps in one dword) and two
+//     region of the target image J in the same pair format.  A lane owns a window COLUMN, so one
+//     pixel of one LK iteration is ONE aligned ds_read_u16 (the row below; the row above is the
+//     previous pixel's) -> the 4 bilinear taps in one dword, and two
 //     v_dot4_u32_u8 (the 14-bit weights are split w = 128*wh + wl so they fit u8 lanes).  The region
 //     is re-staged only when the window leaves it.
 //   * Window sums are all-reduced inside the group with DPP adds (quad_perm xor1/xor2 +
@@ -182,13 +183,22 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
     uint32_t* const xbuf = wbase + G::I_DW + G::D_DW;                              // (Ival, Dxy) exchange
     uint8_t* const jbuf = reinterpret_cast<uint8_t*>(wbase + G::I_DW + G::D_DW + G::X_DW + grp * G::J_DW);
 
-    // pair-format byte offsets of the window pixels owned by this lane (p = lg + 8k)
-    int offP[K];
+    // Window pixels owned by this lane.  Main part: lane lg < WIN owns COLUMN lg (rows 0..WIN-1), so
+    // the bottom taps of row y are the top taps of row y+1 and one LDS read per pixel suffices.
+    // Extra part (WIN > 8): the remaining (WIN-8) columns are dealt out pixel by pixel.
+    constexpr int KM = WIN;                                            // main slots
+    constexpr int NEXTRA = (WIN > GL) ? (WIN - GL) * WIN : 0;          // pixels outside the first 8 columns
+    constexpr int KE = (NEXTRA + GL - 1) / GL;                         // extra slots per lane
+    static_assert(KM + KE == K || WIN < GL, "slot count");
+    const bool main_valid = lg < WIN;
+    int offE[KE > 0 ? KE : 1], qE[KE > 0 ? KE : 1];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int q = lg + GL * k;
-        const int y = q / WIN, x = q - y * WIN;
-        offP[k] = (q < NPX) ? y * G::PAIR_PITCH + 2 * x : 0;  // slots past the window read pixel 0 and contribute 0
+    for (int e = 0; e < KE; e++) {
+        const int r = lg + GL * e;
+        const int col = GL + r / WIN, row = r - (r / WIN) * WIN;
+        const bool ok = r < NEXTRA;
+        offE[e] = ok ? row * G::PAIR_PITCH + 2 * col : 0;   // slots past the window read pixel 0, contribute 0
+        qE[e] = ok ? row * WIN + col : -1;
     }
 
     const float2 pt = p.pts[feat];
@@ -285,14 +295,19 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
 
         // every group picks up the pixels it owns
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        int Ival[K];
-        int Dxy[K];  // (int16 ix) | (int16 iy << 16)
+        int Ival[KM + KE];
+        int Dxy[KM + KE];  // (int16 ix) | (int16 iy << 16); 0 for slots without a pixel
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            const int q = lg + GL * k;
-            const uint2 v = (q < NPX) ? *reinterpret_cast<const uint2*>(xbuf + 2 * q) : make_uint2(0u, 0u);
+        for (int k = 0; k < KM; k++) {
+            const uint2 v = main_valid ? *reinterpret_cast<const uint2*>(xbuf + 2 * (k * WIN + lg)) : make_uint2(0u, 0u);
             Ival[k] = (int)v.x;
             Dxy[k] = (int)v.y;
+        }
+#pragma unroll
+        for (int e = 0; e < KE; e++) {
+            const uint2 v = (qE[e] >= 0) ? *reinterpret_cast<const uint2*>(xbuf + 2 * qE[e]) : make_uint2(0u, 0u);
+            Ival[KM + e] = (int)v.x;
+            Dxy[KM + e] = (int)v.y;
         }
 
         // ---- iterations on the staged J region ----
@@ -319,26 +334,29 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
             const uint8_t* jb = jbuf + (iqy - ry0) * G::PAIR_PITCH + 2 * (iqx - rx0);
             int sb1 = 0, sb2 = 0;  // per-lane partials: <= K * 8160 * 4080 < 2^31
             // b1 += diff * ix, b2 += diff * iy as two v_dot2_i32_i16 on the packed (ix, iy):
-            // (diff, 0) . (ix, iy) and (0, diff) . (ix, iy).  Slots past the window have Dxy == 0.
-            if (__builtin_expect(!wJ.neg11, 1)) {
-#pragma unroll
-                for (int k = 0; k < K; k++) {
-                    const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offP[k]);
-                    const uint32_t j4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);
-                    const uint32_t diff = (uint32_t)(interp4<false>(j4, wJ) - Ival[k]);
-                    sb1 = sdot2(diff & 0xffffu, (uint32_t)Dxy[k], sb1);
-                    sb2 = sdot2(diff << 16, (uint32_t)Dxy[k], sb2);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < K; k++) {
-                    const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offP[k]);
-                    const uint32_t j4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);
-                    const uint32_t diff = (uint32_t)(interp4<true>(j4, wJ) - Ival[k]);
-                    sb1 = sdot2(diff & 0xffffu, (uint32_t)Dxy[k], sb1);
-                    sb2 = sdot2(diff << 16, (uint32_t)Dxy[k], sb2);
-                }
-            }
+            // (diff, 0) . (ix, iy) and (0, diff) . (ix, iy).  Slots without a pixel have Dxy == 0.
+#define PC_LK_ACCUM(NEGFLAG)                                                                          \
+    {                                                                                                 \
+        const uint8_t* cb = jb + 2 * lg;                                                              \
+        uint32_t top = *reinterpret_cast<const uint16_t*>(cb);                                        \
+        _Pragma("unroll") for (int k = 0; k < KM; k++) {                                              \
+            const uint32_t bot = *reinterpret_cast<const uint16_t*>(cb + (k + 1) * G::PAIR_PITCH);    \
+            const uint32_t j4 = top | (bot << 16);                                                    \
+            top = bot;                                                                                \
+            const uint32_t diff = (uint32_t)(interp4<NEGFLAG>(j4, wJ) - Ival[k]);                     \
+            sb1 = sdot2(diff & 0xffffu, (uint32_t)Dxy[k], sb1);                                       \
+            sb2 = sdot2(diff << 16, (uint32_t)Dxy[k], sb2);                                           \
+        }                                                                                             \
+        _Pragma("unroll") for (int e = 0; e < KE; e++) {                                              \
+            const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offE[e]);                      \
+            const uint32_t j4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);                         \
+            const uint32_t diff = (uint32_t)(interp4<NEGFLAG>(j4, wJ) - Ival[KM + e]);                \
+            sb1 = sdot2(diff & 0xffffu, (uint32_t)Dxy[KM + e], sb1);                                  \
+            sb2 = sdot2(diff << 16, (uint32_t)Dxy[KM + e], sb2);                                      \
+        }                                                                                             \
+    }
+            if (__builtin_expect(!wJ.neg11, 1)) PC_LK_ACCUM(false) else PC_LK_ACCUM(true)
+#undef PC_LK_ACCUM
             const float b1 = group_exact_sum<GL>(sb1) * FLT_SCALE;
             const float b2 = group_exact_sum<GL>(sb2) * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D;
@@ -376,14 +394,26 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
             const Weights wE = bilinear_weights(ex - (float)iex, ey - (float)iey);
             const uint8_t* jb = jbuf + (iey - ry0) * G::PAIR_PITCH + 2 * (iex - rx0);
             int se = 0;
+            {
+                const uint8_t* cb = jb + 2 * lg;
+                uint32_t top = *reinterpret_cast<const uint16_t*>(cb);
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offP[k]);
-                const uint32_t j4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);
-                const int val = wE.neg11 ? interp4<true>(j4, wE) : interp4<false>(j4, wE);
-                const int diff = val - Ival[k];
-                const int ad = diff < 0 ? -diff : diff;
-                se += (k < K - 1 || lg + GL * k < NPX) ? ad : 0;
+                for (int k = 0; k < KM; k++) {
+                    const uint32_t bot = *reinterpret_cast<const uint16_t*>(cb + (k + 1) * G::PAIR_PITCH);
+                    const uint32_t j4 = top | (bot << 16);
+                    top = bot;
+                    const int val = wE.neg11 ? interp4<true>(j4, wE) : interp4<false>(j4, wE);
+                    const int diff = val - Ival[k];
+                    se += main_valid ? (diff < 0 ? -diff : diff) : 0;
+                }
+#pragma unroll
+                for (int e = 0; e < KE; e++) {
+                    const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offE[e]);
+                    const uint32_t j4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);
+                    const int val = wE.neg11 ? interp4<true>(j4, wE) : interp4<false>(j4, wE);
+                    const int diff = val - Ival[KM + e];
+                    se += (qE[e] >= 0) ? (diff < 0 ? -diff : diff) : 0;
+                }
             }
             se = group_allreduce_add<GL>(se);  // <= 256 * 8160 < 2^24: exact in fp32 too
             err = ((float)se * 1.f) / (float)(32 * WIN * WIN);
