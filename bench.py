@@ -130,7 +130,7 @@ def main():
 
     an.run(range(f1_first, f1_first + W), None)
     barrier()
-    ctx.enable_timing(True)
+    ctx.enable_timing(["lk"])   # HIP events around the dominant kernel only (2 records per step)
     ctx.reset_timing()
     t0 = time.perf_counter()
     an.run(range(f1_first + W, f1_first + W + K), sink, copy=(world > 1))
@@ -142,6 +142,18 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     timing = ctx.timing()
+    ctx.enable_timing(False)
+    # per-class kernel breakdown from a short extra pass over the same frames (not part of `value`)
+    an.close()
+    n_extra = min(K, 20)
+    an = ClipAnalyzer(ctx, w, h, first_id, n_local, lambda fid: frames[fid], hip.gftt_options(**gopt_kw),
+                      hip.flow_options(**fopt_kw), max_jobs=3)
+    an.run(range(f1_first, f1_first + 2), None)
+    ctx.synchronize()
+    ctx.enable_timing(True)
+    ctx.reset_timing()
+    an.run(range(f1_first + 2, f1_first + 2 + n_extra), None)
+    breakdown = {k: v[1] / n_extra for k, v in ctx.timing().items()}
     ctx.enable_timing(False)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -173,7 +185,7 @@ def main():
             "path_roofline": {"algorithmic_bytes_per_frame": frame_bytes,
                               "achieved_GBs": frame_bytes * (K / dt) / 1e9,
                               "frac": frame_bytes * (K / dt) / 1e9 / HBM_PEAK_GBS},
-            "kernel_ms_per_frame": {k: v[1] / K for k, v in timing.items()},
+            "kernel_ms_per_frame": breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:
             n_s = args.cpu_sample or (2 if P > 4_000_000 else 4)

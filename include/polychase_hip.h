@@ -74,9 +74,10 @@ void pc_context_destroy(pc_context* ctx);
 int pc_context_synchronize(pc_context* ctx);
 /* hipStream_t the context enqueues on (for callers that time with HIP events / torch streams). */
 void* pc_context_stream(pc_context* ctx);
-/* Timing of the context's kernels with HIP events on the context stream.  While enabled every
- * kernel class accumulates (launches, total ms).  Classes: see PC_K_* below. */
-int pc_context_enable_timing(pc_context* ctx, int enable);
+/* Timing of the context's kernels with HIP events on the context stream.  `class_mask` bit k
+ * enables kernel class PC_K_k (0 = off, 0xff = all); enabled classes accumulate (launches, total ms).
+ * Two event records per timed launch: keep the mask to the class of interest inside timed regions. */
+int pc_context_enable_timing(pc_context* ctx, int class_mask);
 int pc_context_get_timing(pc_context* ctx, int kernel_class, int* launches, double* total_ms);
 int pc_context_reset_timing(pc_context* ctx);
 #define PC_K_GRAY 0

@@ -19,7 +19,7 @@ struct ScopedTimer {
     int cls;
     hipEvent_t a = nullptr, b = nullptr;
     ScopedTimer(pc_context* ctx, int k) : c(ctx), cls(k) {
-        if (!c->timing) return;
+        if (!(c->timing_mask & (1u << k))) return;
         auto get = [&]() {
             hipEvent_t e = nullptr;
             if (!c->event_pool.empty()) {
@@ -35,7 +35,7 @@ struct ScopedTimer {
         (void)hipEventRecord(a, c->stream);
     }
     ~ScopedTimer() {
-        if (!c->timing || !a) return;
+        if (!a) return;
         (void)hipEventRecord(b, c->stream);
         c->ranges.push_back({cls, a, b});
     }
@@ -286,6 +286,7 @@ int pc_context_create(int device_index, pc_context** out) {
     if (!c) return fail(PC_E_INVALID, "out of host memory");
     c->device = device_index;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete c;
         return fail(PC_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -326,6 +327,10 @@ void pc_context_destroy(pc_context* c) {
     c->lk_block_counts.release();
     c->lk_row_offset.release();
     c->h_row_offset.release();
+    if (c->copy_stream) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamDestroy(c->copy_stream);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -333,6 +338,7 @@ void pc_context_destroy(pc_context* c) {
 int pc_context_synchronize(pc_context* c) {
     if (!c) return fail(PC_E_INVALID, "null context");
     PC_HIP(hipStreamSynchronize(c->stream));
+    PC_HIP(hipStreamSynchronize(c->copy_stream));
     return PC_OK;
 }
 
@@ -341,7 +347,7 @@ void* pc_context_stream(pc_context* c) { return c ? (void*)c->stream : nullptr; 
 int pc_context_enable_timing(pc_context* c, int enable) {
     if (!c) return fail(PC_E_INVALID, "null context");
     int rc = collect_timing(c);
-    c->timing = enable != 0;
+    c->timing_mask = (unsigned)enable;
     return rc;
 }
 
@@ -658,7 +664,8 @@ struct Job {
     PinBuf<float> h_kps, h_xy, h_err;
     PinBuf<uint32_t> h_idx;
     PinBuf<long long> h_row_offset;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;      // records of this job are in pinned memory (copy stream)
+    hipEvent_t computed = nullptr;  // LK + compaction finished (main stream)
 };
 
 }  // namespace
@@ -672,6 +679,7 @@ struct pc_analyzer {
     std::vector<Slot> slots;
     std::vector<Job> jobs;
     size_t job_head = 0, job_count = 0;  // ring of in-flight jobs
+    hipEvent_t last_done = nullptr;      // download of the most recently submitted job
 };
 
 namespace {
@@ -730,7 +738,8 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
     }
     if (rc == PC_OK)
         for (auto& j : a->jobs)
-            if (hipEventCreateWithFlags(&j.done, hipEventDisableTiming) != hipSuccess) {
+            if (hipEventCreateWithFlags(&j.done, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&j.computed, hipEventDisableTiming) != hipSuccess) {
                 rc = fail(PC_E_HIP, "hipEventCreate failed");
                 break;
             }
@@ -748,6 +757,7 @@ void pc_analyzer_destroy(pc_analyzer* a) {
     if (!a) return;
     (void)hipSetDevice(a->ctx->device);
     (void)hipStreamSynchronize(a->ctx->stream);
+    (void)hipStreamSynchronize(a->ctx->copy_stream);
     for (auto& s : a->slots) {
         if (s.frame) pc_frame_destroy(s.frame);
         s.scratch.release();
@@ -759,6 +769,7 @@ void pc_analyzer_destroy(pc_analyzer* a) {
         j.h_idx.release();
         j.h_row_offset.release();
         if (j.done) (void)hipEventDestroy(j.done);
+        if (j.computed) (void)hipEventDestroy(j.computed);
     }
     delete a;
 }
@@ -835,15 +846,13 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     PC_HIP(j.h_xy.ensure(rows * 2 + 2));
     PC_HIP(j.h_err.ensure(rows + 1));
     PC_HIP(j.h_row_offset.ensure(PC_MAX_TARGETS + 1));
-    if (n > 0)
-        PC_HIP(hipMemcpyAsync(j.h_kps.p, s1->frame->d_kps, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
     j.frame1 = frame1;
     j.n_kps = n;
     j.detected = detected;
     j.n_targets = n_targets;
     for (int t = 0; t < n_targets; t++) j.targets[t] = targets[t];
     for (int t = 0; t <= PC_MAX_TARGETS; t++) j.h_row_offset.p[t] = 0;
-    // (3) LK + status filter + download
+    // (3) LK + status filter on the main stream
     if (n_targets > 0) {
         if (a->fopt.window_size != s1->frame->win) return fail(PC_E_INVALID, "window size mismatch");
         if ((rc = run_lk(ctx, s1->frame, tg, n_targets, &a->fopt)) != PC_OK) return rc;
@@ -853,21 +862,32 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
         PC_HIP(ctx->lk_cidx.ensure(rows + 1));
         PC_HIP(ctx->lk_block_counts.ensure((size_t)nblocks * n_targets + 1));
         PC_HIP(ctx->lk_row_offset.ensure(PC_MAX_TARGETS + 1));
+        // the previous job's download (copy stream) reads the compacted buffers: let it finish first
+        // (it has had a whole LK launch to do so)
+        if (a->last_done) PC_HIP(hipStreamWaitEvent(ctx->stream, a->last_done, 0));
         {
             ScopedTimer t(ctx, PC_K_COMPACT);
             pc::launch_compact(ctx->lk_xy.p, ctx->lk_status.p, ctx->lk_err.p, n, n_targets, ctx->lk_block_counts.p,
                                ctx->lk_row_offset.p, ctx->lk_cidx.p, ctx->lk_cxy.p, ctx->lk_cerr.p, ctx->stream);
         }
+    }
+    PC_HIP(hipEventRecord(j.computed, ctx->stream));
+    // (4) downloads on the copy stream, overlapping the next frame's kernels
+    PC_HIP(hipStreamWaitEvent(ctx->copy_stream, j.computed, 0));
+    if (n > 0)
+        PC_HIP(hipMemcpyAsync(j.h_kps.p, s1->frame->d_kps, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, ctx->copy_stream));
+    if (n_targets > 0) {
         PC_HIP(hipMemcpyAsync(j.h_row_offset.p, ctx->lk_row_offset.p, (size_t)(n_targets + 1) * sizeof(long long),
-                              hipMemcpyDeviceToHost, ctx->stream));
+                              hipMemcpyDeviceToHost, ctx->copy_stream));
         if (rows > 0) {
             // the row count is only known on the device: download the capacity (n * n_targets rows)
-            PC_HIP(hipMemcpyAsync(j.h_idx.p, ctx->lk_cidx.p, rows * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            PC_HIP(hipMemcpyAsync(j.h_xy.p, ctx->lk_cxy.p, rows * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
-            PC_HIP(hipMemcpyAsync(j.h_err.p, ctx->lk_cerr.p, rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            PC_HIP(hipMemcpyAsync(j.h_idx.p, ctx->lk_cidx.p, rows * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->copy_stream));
+            PC_HIP(hipMemcpyAsync(j.h_xy.p, ctx->lk_cxy.p, rows * sizeof(float2), hipMemcpyDeviceToHost, ctx->copy_stream));
+            PC_HIP(hipMemcpyAsync(j.h_err.p, ctx->lk_cerr.p, rows * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
         }
     }
-    PC_HIP(hipEventRecord(j.done, ctx->stream));
+    PC_HIP(hipEventRecord(j.done, ctx->copy_stream));
+    a->last_done = j.done;
     j.active = true;
     a->job_count++;
     return PC_OK;

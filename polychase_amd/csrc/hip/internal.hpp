@@ -110,6 +110,7 @@ struct DetectScratch {
 struct pc_context {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // result downloads overlap the next frame's kernels
     // staging of host-provided frames
     DevBuf<uint8_t> staging;
     // GFTT scratch
@@ -132,7 +133,7 @@ struct pc_context {
     DevBuf<long long> lk_row_offset;
     PinBuf<long long> h_row_offset;
     // timing
-    bool timing = false;
+    unsigned timing_mask = 0;   // bit k: time kernel class k with HIP events
     std::vector<TimedRange> ranges;
     std::vector<hipEvent_t> event_pool;
     int launches[PC_K_COUNT] = {0};

@@ -135,6 +135,8 @@ void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* ce
 // K3  threshold (per cell of the NEIGHBOUR) + 3x3 dilate + local-max test + wave-ballot compaction.
 // One lane per pixel of the strict interior; keys = ordered(value) << 32 | (y*w + x).
 // ------------------------------------------------------------------------------------------------
+constexpr int NMS_R = 16, NMS_TH = 4 * NMS_R;  // rows per lane, tile height
+
 __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restrict__ eig, int w, int h, GfttGrid g,
                                                           const uint32_t* __restrict__ cell_max,
                                                           double quality_level,
@@ -152,10 +154,10 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restric
     }
     __syncthreads();
 
-    // tile 64 x 16: lane = column, 4 rows per lane (ty, ty+4, ty+8, ty+12)
+    // tile 64 x NMS_TH: lane = column, NMS_R rows per lane (wave, wave+4, ...)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane;
-    float vals[4];
+    float vals[NMS_R];
     uint32_t flags = 0;
     const bool x_in = (x >= 1 && x < w - 1);
     int cxs[3] = {0, 0, 0};
@@ -165,8 +167,8 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restric
         cxs[2] = (x + 1) / g.cell_w;
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int y = blockIdx.y * 16 + wave + 4 * k;
+    for (int k = 0; k < NMS_R; k++) {
+        const int y = blockIdx.y * NMS_TH + wave + 4 * k;
         vals[k] = 0.f;
         if (x_in && y >= 1 && y < h - 1) {
             const int cys[3] = {(y - 1) / g.cell_h, y / g.cell_h, (y + 1) / g.cell_h};
@@ -193,15 +195,15 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restric
     // every pixel is written, so the maps need no clearing between frames
     if (cmap && x < w) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int y = blockIdx.y * 16 + wave + 4 * k;
+        for (int k = 0; k < NMS_R; k++) {
+            const int y = blockIdx.y * NMS_TH + wave + 4 * k;
             if (y < h) {
                 cmap[(size_t)y * w + x] = (flags & (1u << k)) ? float_to_ordered(vals[k]) : 0u;
                 state[(size_t)y * w + x] = 0u;
             }
         }
     }
-    // workgroup-aggregated append: one global atomic per 1024-pixel tile
+    // workgroup-aggregated append: one global atomic per 64 x 64 tile
     const uint32_t cnt = (uint32_t)__popc(flags);
     uint32_t incl = cnt;
 #pragma unroll
@@ -220,9 +222,9 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restric
     uint32_t pos = s_base + incl - cnt;
     for (int wv = 0; wv < wave; wv++) pos += s_wave[wv];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NMS_R; k++) {
         if (flags & (1u << k)) {
-            const int y = blockIdx.y * 16 + wave + 4 * k;
+            const int y = blockIdx.y * NMS_TH + wave + 4 * k;
             if (pos < cap)
                 keys[pos] = ((unsigned long long)float_to_ordered(vals[k]) << 32) | (unsigned long long)(uint32_t)(y * w + x);
             pos++;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restric
 void launch_nms_compact(const float* eig, int w, int h, const GfttGrid& g, const uint32_t* cell_max,
                         double quality_level, unsigned long long* keys, uint32_t cap, uint32_t* counter,
                         uint32_t* cmap, uint32_t* state, hipStream_t s) {
-    dim3 grid((w + 63) / 64, (h + 15) / 16);
+    dim3 grid((w + 63) / 64, (h + NMS_TH - 1) / NMS_TH);
     hipLaunchKernelGGL(nms_compact_kernel, grid, dim3(256), 0, s, eig, w, h, g, cell_max, quality_level, keys, cap,
                        counter, cmap, state);
 }

@@ -170,8 +170,15 @@ class Context:
     def stream(self) -> int:
         return load().pc_context_stream(self._h)
 
-    def enable_timing(self, on=True):
-        _check(load().pc_context_enable_timing(self._h, 1 if on else 0))
+    def enable_timing(self, classes=True):
+        """classes: True = all, False = none, or an iterable of KERNEL_CLASSES names."""
+        if classes is True:
+            mask = 0xFF
+        elif not classes:
+            mask = 0
+        else:
+            mask = sum(1 << KERNEL_CLASSES.index(c) for c in classes)
+        _check(load().pc_context_enable_timing(self._h, mask))
 
     def reset_timing(self):
         _check(load().pc_context_reset_timing(self._h))
