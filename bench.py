@@ -46,8 +46,9 @@ def level_pixels(w, h, max_level, win=10):
     return s
 
 
-def cpu_baseline(frames_host, first_id, f1_ids, gopt_kw, fopt_kw):
-    """Times the oracle's reference-shaped CPU path (per-pair gray+pyramid rebuild) on this host."""
+def cpu_baseline(fetch_host, f1_candidates, gopt_kw, fopt_kw, target_seconds=12.0):
+    """Times the oracle's reference-shaped CPU path (per-pair gray+pyramid rebuild,
+    opticalflow.cc:298-302) on this host: a short probe, then a sample sized for ~target_seconds."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle  # test infrastructure: used here ONLY as the reported CPU baseline
 
@@ -60,15 +61,22 @@ def cpu_baseline(frames_host, first_id, f1_ids, gopt_kw, fopt_kw):
     cores = os.cpu_count() or 1
     pair_threads = min(8, cores)
     feat_threads = max(1, cores // pair_threads)
-    t0 = time.perf_counter()
-    oracle.analyze_clip(frames_host, first_frame=first_id, f1_range=(f1_ids[0], f1_ids[-1] + 1),
-                        gopt=oracle.gftt_options(**gopt_kw), fopt=oracle.flow_options(**fopt_kw),
-                        threads=pair_threads, feature_threads=feat_threads, libpath=so)
-    dt = time.perf_counter() - t0
-    return {"value": len(f1_ids) / dt, "unit": "frames/s", "cores": pair_threads * feat_threads,
-            "kind": "port",
-            "sample": f"{len(f1_ids)} interior frame1 x 8 pairs of the same clip, oracle/pc_oracle.c "
-                      f"(-O3 -march=native), {pair_threads} pair-threads x {feat_threads} feature-threads, "
+
+    def run(f1s):
+        lo, hi = f1s[0] - 8, f1s[-1] + 8
+        host = [fetch_host(f) for f in range(lo, hi + 1)]
+        t0 = time.perf_counter()
+        oracle.analyze_clip(host, first_frame=lo, f1_range=(f1s[0], f1s[-1] + 1), gopt=oracle.gftt_options(**gopt_kw),
+                            fopt=oracle.flow_options(**fopt_kw), threads=pair_threads, feature_threads=feat_threads,
+                            libpath=so)
+        return time.perf_counter() - t0
+
+    probe = run(f1_candidates[:2])
+    n = int(max(2, min(len(f1_candidates), round(target_seconds / max(probe / 2, 1e-3)))))
+    dt = run(f1_candidates[:n])
+    return {"value": n / dt, "unit": "frames/s", "cores": pair_threads * feat_threads, "kind": "port",
+            "sample": f"{n} interior frame1 x 8 pairs of the same clip, oracle/pc_oracle.c (-O3 -march=native), "
+                      f"{pair_threads} pair-threads x {feat_threads} feature-threads (all {cores} host cores), "
                       f"per-pair gray+pyramid rebuild as in opticalflow.cc:298-302; {dt:.1f} s"}
 
 
@@ -79,7 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="frame1 count of the CPU sample (0 = auto)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample")
     args = ap.parse_args()
 
     import torch
@@ -188,11 +196,9 @@ def main():
             "kernel_ms_per_frame": breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:
-            n_s = args.cpu_sample or (2 if P > 4_000_000 else 4)
-            f1s = [f1_first + W + i for i in range(n_s)]
-            lo, hi = f1s[0] - 8, f1s[-1] + 8
-            host = [frames[f].cpu().numpy() for f in range(lo, hi + 1)]
-            out["cpu_baseline"] = cpu_baseline(host, lo, f1s, gopt_kw, fopt_kw)
+            f1s = [f1_first + W + i for i in range(K)]
+            out["cpu_baseline"] = cpu_baseline(lambda f: frames[f].cpu().numpy(), f1s, gopt_kw, fopt_kw,
+                                               target_seconds=args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     an.close()

@@ -271,3 +271,48 @@ def test_tracker_thread_protocol_and_errors(core, tmp_path):
     while not th.empty():
         out.append(th.try_pop())
     assert isinstance(out[0], core.CppException) and "Not enough features" in out[0].what() and out[-1] is True
+
+
+def test_c5_end_to_end_rendered_plane(core, tmp_path):
+    """BASELINE config C5 in miniature: frames RENDERED from a textured mesh under a known camera
+    trajectory -> GFTT + LK on the GPU -> SQLite -> ray casting + PnP on the GPU -> poses vs truth."""
+    import torch
+    import torch.nn.functional as Fn
+    from polychase_amd import synth
+
+    n_frames, sx, sy = 12, 9.0, 5.0
+    tex = torch.from_numpy(synth.noise_canvas(1400, 800, margin=0, sigma=2.5))[None]      # 1,3,800,1400
+    ys, xs = torch.meshgrid(torch.arange(int(H), dtype=torch.float64), torch.arange(int(W), dtype=torch.float64),
+                            indexing="ij")
+    d_cam = torch.stack([(xs - W / 2) / F, (ys - H / 2) / F, -torch.ones_like(xs)], -1)     # Unproject, OpenGL
+    frames = []
+    for f in range(1, n_frames + 1):
+        R, t = true_pose(f)
+        Rt = torch.from_numpy(R.T.copy())
+        o = -(Rt @ torch.from_numpy(t))
+        d = d_cam @ Rt.T
+        s = -o[2] / d[..., 2]
+        P = o + s[..., None] * d                                                        # hit on the plane z = 0
+        grid = torch.stack([P[..., 0] / (sx / 2), P[..., 1] / (sy / 2)], -1)[None].float()
+        img = Fn.grid_sample(tex, grid, mode="bicubic", padding_mode="border", align_corners=True)[0]
+        frames.append(img.clamp(0, 255).round().to(torch.uint8).permute(1, 2, 0).contiguous().numpy())
+    path = str(tmp_path / "c5.db")
+    core.generate_optical_flow_database(core.VideoInfo(int(W), int(H), 1, n_frames), lambda fid: frames[fid - 1], None, path)
+    verts = np.array([[-sx / 2, -sy / 2, 0], [sx / 2, -sy / 2, 0], [sx / 2, sy / 2, 0], [-sx / 2, sy / 2, 0]], np.float32)
+    tris = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    mesh = core.AcceleratedMesh(verts, tris)
+    R1, t1 = true_pose(1)
+    st = core.SceneTransformations(np.eye(4, dtype=np.float32), view4(R1, t1), intr(core))
+    bo = core.BundleOptions()
+    bo.loss_type = core.LossType.Cauchy
+    got = {}
+    core.track_sequence(path, 1, n_frames, st, mesh,
+                        lambda r: got.update({r.frame: (po.quat_to_R(np.array(r.pose.q, float)), np.array(r.pose.t, float),
+                                                        r.inlier_ratio)}) or True, False, False, bo)
+    assert sorted(got) == list(range(2, n_frames + 1))
+    for f, (Rg, tg, inl) in got.items():
+        Rt_, tt = true_pose(f)
+        assert _angle(Rg, Rt_) < 2e-3, (f, _angle(Rg, Rt_))
+        assert np.linalg.norm(tg - tt) < 0.05, (f, np.linalg.norm(tg - tt))
+        assert inl > 0.5    # keypoints on the smeared border outside the textured plane are outliers; the
+                            # addon aborts below 0.25 (blender_addon/operators/tracking.py:286-289)
