@@ -28,6 +28,8 @@ std::optional<FrameView> FrameFromPython(const py::object& obj, std::deque<py::o
     if (py::hasattr(obj, "is_cuda") && obj.attr("is_cuda").cast<bool>()) {
         py::object t = obj;
         if (!t.attr("is_contiguous")().cast<bool>()) t = t.attr("contiguous")();
+        // the analysis runs on its own HIP stream: wait for whatever produced the tensor
+        py::module_::import("torch").attr("cuda").attr("current_stream")(t.attr("device")).attr("synchronize")();
         const auto shape = t.attr("shape").cast<std::vector<py::ssize_t>>();
         if (shape.size() != 3) throw py::value_error("frame must have shape (H, W, 3)");
         if (t.attr("element_size")().cast<int>() != 1) throw py::value_error("frame must be uint8");

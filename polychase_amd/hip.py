@@ -199,6 +199,10 @@ def _ptr(a):
         return a.ctypes.data, 0, a.strides[0]
     # torch tensor
     assert a.is_contiguous()
+    if a.is_cuda:
+        # the library enqueues on its own HIP stream: the tensor must be complete before it is read
+        import torch
+        torch.cuda.current_stream(a.device).synchronize()
     return a.data_ptr(), 1 if a.is_cuda else 0, a.stride(0) * a.element_size()
 
 
