@@ -177,6 +177,12 @@ def main():
         frame_bytes = 14 * P + (12 + 8) * S
         achieved = lk_bytes / (lk_avg_ms * 1e-3) / 1e9 if lk_avg_ms > 0 else 0.0
         fps = world * K / dt
+        traffic = None   # HBM bytes per LK launch from a separate rocprofv3 --pmc pass (cannot be collected in-process)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "lk_hbm_traffic.json")))
+            traffic = tj[args.config]["traffic_bytes"]
+        except Exception:
+            pass
         out = {
             "metric": "optical-flow frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
@@ -187,7 +193,7 @@ def main():
                        "mean_keypoints": float(np.mean(n_kps)), "mean_flow_rows": float(np.mean(n_rows)),
                        "parallelism": f"frame-shard x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "lk_kernel<10>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": lk_bytes, "avg_launch_ms": lk_avg_ms,
                          "launches": lk_n},
             "path_roofline": {"algorithmic_bytes_per_frame": frame_bytes,

@@ -234,6 +234,11 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
     p.max_level = max_level;
     p.n = n;
     p.pts = frame1->d_kps;
+    // visiting order: keypoints binned by image tile (they are stored by corner response)
+    PC_HIP(ctx->lk_perm.ensure((size_t)n));
+    PC_HIP(ctx->lk_hist.ensure((size_t)pc::bin_num_tiles(frame1->w, frame1->h) + 1));
+    pc::launch_spatial_bins(frame1->d_kps, n, frame1->w, frame1->h, ctx->lk_hist.p, ctx->lk_perm.p, ctx->stream);
+    p.perm = ctx->lk_perm.p;
     // TermCriteria clamps of calcOpticalFlowPyrLK
     p.max_iters = std::min(std::max(opt->term_max_iters, 0), 100);
     const double eps = std::min(std::max(opt->term_epsilon, 0.), 10.);
@@ -325,6 +330,8 @@ void pc_context_destroy(pc_context* c) {
     c->lk_cerr.release();
     c->lk_cidx.release();
     c->lk_block_counts.release();
+    c->lk_perm.release();
+    c->lk_hist.release();
     c->lk_row_offset.release();
     c->h_row_offset.release();
     if (c->copy_stream) {

@@ -129,7 +129,7 @@ struct pc_context {
     DevBuf<float2> lk_xy, lk_cxy;
     DevBuf<uint8_t> lk_status;
     DevBuf<float> lk_err, lk_cerr;
-    DevBuf<uint32_t> lk_cidx, lk_block_counts;
+    DevBuf<uint32_t> lk_cidx, lk_block_counts, lk_perm, lk_hist;
     DevBuf<long long> lk_row_offset;
     PinBuf<long long> h_row_offset;
     // timing

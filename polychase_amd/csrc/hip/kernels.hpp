@@ -54,6 +54,8 @@ struct LKParams {
     int max_level;            // effective (min over pyramids)
     int n;                    // number of keypoints
     const float2* pts;
+    const uint32_t* perm;     // visiting order (spatially binned keypoint indices) or null
+    int blocks_per_xcd;       // filled in by launch_lk
     int max_iters;
     double eps_sq;
     float min_eig_thr;
@@ -64,6 +66,9 @@ struct LKParams {
 // K8-K10: pyramidal LK, one 16-lane DPP row per (keypoint, target).  Returns false if the window
 // size is unsupported.
 bool launch_lk(const LKParams& p, int win, hipStream_t s);
+// counting sort of keypoint indices by 64x64 tile -> perm[n]; hist: bin_num_tiles(w, h) words of scratch
+int bin_num_tiles(int w, int h);
+void launch_spatial_bins(const float2* pts, int n, int w, int h, uint32_t* hist, uint32_t* perm, hipStream_t s);
 
 // Ordered compaction of status==1 rows per target (opticalflow.cc:130-147).
 // block_counts: [n_targets][nblocks] scratch, row_offset: [n_targets+1] int64 (device).

@@ -172,8 +172,13 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = lane >> 3, lg = lane & 7;
-    const int feat = blockIdx.x * 4 + wave;
-    if (feat >= p.n) return;  // whole waves exit together
+    // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only).  Keypoints are visited in
+    // spatially binned order (p.perm) and each XCD gets one contiguous eighth of that order, so the
+    // windows a private L2 sees belong to one image region.
+    const int lb = (int)(blockIdx.x & 7u) * p.blocks_per_xcd + (int)(blockIdx.x >> 3);
+    const int slot = lb * 4 + wave;
+    if ((int)(blockIdx.x >> 3) >= p.blocks_per_xcd || slot >= p.n) return;  // whole waves exit together
+    const int feat = p.perm ? (int)p.perm[slot] : slot;
     const bool tgt_active = grp < p.n_targets;
     const int tgt = tgt_active ? grp : 0;
 
@@ -429,10 +434,12 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
 }
 
 template <int WIN>
-static void launch_lk_t(const LKParams& p, hipStream_t s) {
-    const unsigned blocks = (unsigned)((p.n + 3) / 4);   // one wavefront per keypoint
+static void launch_lk_t(const LKParams& p0, hipStream_t s) {
+    LKParams p = p0;
+    const int blocks = (p.n + 3) / 4;   // one wavefront per keypoint, 4 per workgroup
     if (blocks == 0) return;
-    hipLaunchKernelGGL((lk_kernel<WIN>), dim3(blocks), dim3(256), 0, s, p);
+    p.blocks_per_xcd = (blocks + 7) / 8;
+    hipLaunchKernelGGL((lk_kernel<WIN>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(256), 0, s, p);
 }
 
 bool launch_lk(const LKParams& p, int win, hipStream_t s) {
@@ -443,6 +450,66 @@ bool launch_lk(const LKParams& p, int win, hipStream_t s) {
 #undef PC_LK_CASE
         default: return false;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Spatial binning of the keypoints (counting sort by 64x64 tile, raster order of tiles): the order
+// in which LK visits keypoints.  Keypoints are stored by corner response, i.e. randomly in space;
+// visiting them tile by tile keeps the gathers of concurrently running waves inside one image
+// region (L2 hits instead of fabric requests).  Results are written by keypoint index, so the order
+// inside a tile (atomics) does not affect the output.
+// ------------------------------------------------------------------------------------------------
+constexpr int BIN_SHIFT = 6;
+
+__global__ __launch_bounds__(256) void bin_count_kernel(const float2* __restrict__ pts, int n, int tiles_x, int n_tiles,
+                                                        uint32_t* __restrict__ hist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 p = pts[i];
+    const int t = min(n_tiles - 1, max(0, ((int)p.y >> BIN_SHIFT) * tiles_x + ((int)p.x >> BIN_SHIFT)));
+    atomicAdd(&hist[t], 1u);
+}
+
+__global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t* __restrict__ hist, int n_tiles) {
+    __shared__ uint32_t s_sum[1024];
+    const int per = (n_tiles + 1023) / 1024;
+    const int b = threadIdx.x * per, e = min(b + per, n_tiles);
+    uint32_t s = 0;
+    for (int i = b; i < e; i++) s += hist[i];
+    s_sum[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = (threadIdx.x >= (unsigned)d) ? s_sum[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_sum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[threadIdx.x] - s;  // exclusive prefix of this lane's range
+    for (int i = b; i < e; i++) {
+        const uint32_t c = hist[i];
+        hist[i] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(256) void bin_scatter_kernel(const float2* __restrict__ pts, int n, int tiles_x, int n_tiles,
+                                                          uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 p = pts[i];
+    const int t = min(n_tiles - 1, max(0, ((int)p.y >> BIN_SHIFT) * tiles_x + ((int)p.x >> BIN_SHIFT)));
+    perm[atomicAdd(&cursor[t], 1u)] = (uint32_t)i;
+}
+
+int bin_num_tiles(int w, int h) { return ((w + 63) >> BIN_SHIFT) * ((h + 63) >> BIN_SHIFT); }
+
+void launch_spatial_bins(const float2* pts, int n, int w, int h, uint32_t* hist, uint32_t* perm, hipStream_t s) {
+    if (n <= 0) return;
+    const int tiles_x = (w + 63) >> BIN_SHIFT, n_tiles = bin_num_tiles(w, h);
+    (void)hipMemsetAsync(hist, 0, (size_t)n_tiles * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(bin_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, tiles_x, n_tiles, hist);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, hist, n_tiles);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, tiles_x, n_tiles, hist, perm);
 }
 
 // ------------------------------------------------------------------------------------------------
