@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist-path", action="store_true",
+                    help="exercise the device-log + stitch code path with a single rank (testing)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample")
     args = ap.parse_args()
 
@@ -128,29 +130,49 @@ def main():
 
     f1_first = first_id + 8
     n_kps, n_rows = [], []
-    records = []
+    dist_path = world > 1 or args.force_dist_path
 
     def sink(frame1, kps, detected, flows):
         n_kps.append(len(kps))
         n_rows.append(sum(len(v[0]) for v in flows.values()))
-        if world > 1:
-            records.append((frame1, kps, flows))
 
-    an.run(range(f1_first, f1_first + W), None)
+    an.run(range(f1_first, f1_first + W), sink)
+    log = None
+    if dist_path:
+        # device-resident record log: the stitch all-gathers these bytes, no host copy of the payload
+        from polychase_amd import distributed as D
+        max_kp = int(1.5 * max(n_kps + [1024])) + 4096
+        log = torch.empty(D.log_capacity_bytes(K + 2, max_kp), dtype=torch.uint8, device=dev)
+        an.an.set_device_log(log)
+    n_kps.clear()
+    n_rows.clear()
     barrier()
     ctx.enable_timing(["lk"])   # HIP events around the dominant kernel only (2 records per step)
     ctx.reset_timing()
     t0 = time.perf_counter()
-    an.run(range(f1_first + W, f1_first + W + K), sink, copy=(world > 1))
-    if world > 1:
-        # stitch the flow database: all-gather of the packed records over RCCL
-        from polychase_amd import distributed as D
-        stitched = D.all_gather_records(records, device=dev)
-        assert len(stitched) == world * K
+    an.run(range(f1_first + W, f1_first + W + K), sink, copy=False)
+    if dist_path:
+        # stitch the flow database: one size exchange + one RCCL all-gather of the device logs
+        ctx.synchronize()
+        used = an.an.device_log_used
+        if world > 1:
+            gathered, sizes = D.all_gather_device_log(log, used)
+        else:
+            gathered, sizes = log[:used][None], [used]
     barrier()
     dt = time.perf_counter() - t0
     timing = ctx.timing()
     ctx.enable_timing(False)
+    if dist_path:
+        # outside the timed region: every rank's shard must parse and hold exactly K records in frame order
+        an.an.set_device_log(None)
+        for r in range(len(sizes)):
+            recs = D.parse_device_log(gathered[r].cpu().numpy(), sizes[r])
+            exp0 = 1 + r * (K + W) + 8 + W
+            assert [x[0] for x in recs] == list(range(exp0, exp0 + K)), "stitched log is not the expected frame range"
+            if r == rank:
+                assert [len(x[1]) for x in recs] == n_kps and [sum(len(v[0]) for v in x[2].values()) for x in recs] == n_rows
+        del gathered, log
     # per-class kernel breakdown from a short extra pass over the same frames (not part of `value`)
     an.close()
     n_extra = min(K, 20)

@@ -176,6 +176,18 @@ int pc_analyzer_set_keypoints(pc_analyzer* a, int32_t frame_id, const float* xy,
  * flow exists, opticalflow.cc:286).  Fails with PC_E_STATE when max_jobs jobs are in flight. */
 int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, int n_targets);
 int pc_analyzer_pending(const pc_analyzer* a);
+/* Device-resident record log (multi-GPU stitch): when set, every submitted job also appends its
+ * records to `d_log` (device memory owned by the caller, e.g. a torch tensor that is later handed
+ * to an RCCL all-gather) without a host round trip.  Layout per job, all little-endian, 16-B aligned:
+ *   int64 hdr[16] = {PC_LOG_MAGIC, frame1, n_keypoints, n_targets, targets[8], rows_capacity, 0, 0, 0}
+ *   int64 row_offset[16]      (first n_targets+1 valid; written by the GPU)
+ *   float  keypoints[n_keypoints][2]
+ *   uint32 src_indices[rows_capacity]; float tgt_xy[rows_capacity][2]; float flow_err[rows_capacity]
+ * with rows_capacity = n_keypoints * n_targets (rows beyond row_offset[n_targets] are unspecified).
+ * Passing NULL detaches the log.  Appending fails with PC_E_CAPACITY when the buffer is full. */
+#define PC_LOG_MAGIC 0x50434c4f47303031ll /* "PCLOG001" */
+int pc_analyzer_set_device_log(pc_analyzer* a, void* d_log, size_t capacity_bytes);
+int pc_analyzer_device_log_used(const pc_analyzer* a, size_t* bytes);
 /* Wait for the oldest submitted job.  Pointers stay valid until the job slot is reused, i.e. for
  * the next max_jobs-1 submits. */
 int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out);

@@ -687,6 +687,9 @@ struct pc_analyzer {
     std::vector<Job> jobs;
     size_t job_head = 0, job_count = 0;  // ring of in-flight jobs
     hipEvent_t last_done = nullptr;      // download of the most recently submitted job
+    uint8_t* d_log = nullptr;            // optional device-resident record log
+    size_t log_cap = 0, log_used = 0;
+    std::vector<PinBuf<long long>> log_hdr;  // one pinned header per job slot
 };
 
 namespace {
@@ -769,6 +772,7 @@ void pc_analyzer_destroy(pc_analyzer* a) {
         if (s.frame) pc_frame_destroy(s.frame);
         s.scratch.release();
     }
+    for (auto& hdr : a->log_hdr) hdr.release();
     for (auto& j : a->jobs) {
         j.h_kps.release();
         j.h_xy.release();
@@ -878,6 +882,38 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
                                ctx->lk_row_offset.p, ctx->lk_cidx.p, ctx->lk_cxy.p, ctx->lk_cerr.p, ctx->stream);
         }
     }
+    if (a->d_log) {
+        // device log: header from pinned memory, everything else device-to-device, all stream-ordered
+        auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        const size_t o_hdr = a->log_used, o_off = o_hdr + 128, o_kps = o_off + 128;
+        const size_t o_idx = up16(o_kps + (size_t)n * 8), o_xy = up16(o_idx + rows * 4), o_err = up16(o_xy + rows * 8);
+        const size_t end = up16(o_err + rows * 4);
+        if (end > a->log_cap) return fail(PC_E_CAPACITY, "device log full (%zu of %zu bytes)", end, a->log_cap);
+        const size_t slot_i = (a->job_head + a->job_count) % a->jobs.size();
+        if (a->log_hdr.size() != a->jobs.size()) a->log_hdr.resize(a->jobs.size());
+        PC_HIP(a->log_hdr[slot_i].ensure(16));
+        long long* hh = a->log_hdr[slot_i].p;
+        for (int k = 0; k < 16; k++) hh[k] = 0;
+        hh[0] = PC_LOG_MAGIC;
+        hh[1] = frame1;
+        hh[2] = n;
+        hh[3] = n_targets;
+        for (int t = 0; t < n_targets; t++) hh[4 + t] = targets[t];
+        hh[12] = (long long)rows;
+        PC_HIP(hipMemcpyAsync(a->d_log + o_hdr, hh, 128, hipMemcpyHostToDevice, ctx->stream));
+        PC_HIP(hipMemsetAsync(a->d_log + o_off, 0, 128, ctx->stream));
+        if (n_targets > 0)
+            PC_HIP(hipMemcpyAsync(a->d_log + o_off, ctx->lk_row_offset.p, (size_t)(n_targets + 1) * sizeof(long long),
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+        if (n > 0)
+            PC_HIP(hipMemcpyAsync(a->d_log + o_kps, s1->frame->d_kps, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (rows > 0) {
+            PC_HIP(hipMemcpyAsync(a->d_log + o_idx, ctx->lk_cidx.p, rows * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            PC_HIP(hipMemcpyAsync(a->d_log + o_xy, ctx->lk_cxy.p, rows * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            PC_HIP(hipMemcpyAsync(a->d_log + o_err, ctx->lk_cerr.p, rows * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        a->log_used = end;
+    }
     PC_HIP(hipEventRecord(j.computed, ctx->stream));
     // (4) downloads on the copy stream, overlapping the next frame's kernels
     PC_HIP(hipStreamWaitEvent(ctx->copy_stream, j.computed, 0));
@@ -901,6 +937,22 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
 }
 
 int pc_analyzer_pending(const pc_analyzer* a) { return a ? (int)a->job_count : 0; }
+
+int pc_analyzer_set_device_log(pc_analyzer* a, void* d_log, size_t capacity_bytes) {
+    if (!a) return fail(PC_E_INVALID, "null analyzer");
+    if (d_log && (reinterpret_cast<uintptr_t>(d_log) & 15)) return fail(PC_E_INVALID, "device log must be 16-byte aligned");
+    PC_HIP(hipStreamSynchronize(a->ctx->stream));
+    a->d_log = static_cast<uint8_t*>(d_log);
+    a->log_cap = d_log ? capacity_bytes : 0;
+    a->log_used = 0;
+    return PC_OK;
+}
+
+int pc_analyzer_device_log_used(const pc_analyzer* a, size_t* bytes) {
+    if (!a || !bytes) return fail(PC_E_INVALID, "null argument");
+    *bytes = a->log_used;
+    return PC_OK;
+}
 
 int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out) {
     if (!a || !out) return fail(PC_E_INVALID, "null argument");

@@ -114,3 +114,61 @@ def write_records(db, records):
         for f2, (idx, xy, err) in sorted(flows.items()):
             if not db.image_pair_flow_exists(frame1, f2):
                 db.write_image_pair_flow(frame1, f2, idx, xy, err)
+
+
+# ----------------------------------------------------------------------------------------------
+# Device-resident path (bench / production multi-GPU): the analyzer appends every job's records to
+# a device log (pc_analyzer_set_device_log); the stitch is ONE size exchange + ONE all-gather of
+# the raw log bytes over RCCL, with no host copy of the payload.
+# ----------------------------------------------------------------------------------------------
+LOG_MAGIC = 0x50434C4F47303031
+
+
+def log_capacity_bytes(n_frames: int, max_keypoints: int, n_targets: int = 8) -> int:
+    per = 256 + max_keypoints * 8 + max_keypoints * n_targets * 16 + 64
+    return n_frames * per
+
+
+def all_gather_device_log(log, used: int, group=None):
+    """log: uint8 CUDA tensor, first `used` bytes valid.  Returns (gathered [world, max_used] uint8
+    on the same device, sizes list).  Collectives: all_gather of one int64, all_gather_into_tensor."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    dev = log.device
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([used], dtype=torch.int64, device=dev), group=group)
+    sizes = [int(s.item()) for s in sizes]
+    mx = (max(sizes) + 15) // 16 * 16
+    if mx > log.numel():
+        raise RuntimeError("device log smaller than the largest shard")
+    out = torch.empty((world, mx), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out.view(-1), log[:mx], group=group)
+    return out, sizes
+
+
+def parse_device_log(buf: np.ndarray, used: int):
+    """buf: uint8 array of one rank's log.  -> records like pack_records' input."""
+    out, o = [], 0
+    up16 = lambda v: (v + 15) & ~15
+    while o < used:
+        hdr = buf[o:o + 128].view(np.int64)
+        assert int(hdr[0]) == LOG_MAGIC, "corrupt device log"
+        frame1, n, nt, rows = int(hdr[1]), int(hdr[2]), int(hdr[3]), int(hdr[12])
+        off = buf[o + 128:o + 256].view(np.int64)
+        o_kps = o + 256
+        o_idx = up16(o_kps + n * 8)
+        o_xy = up16(o_idx + rows * 4)
+        o_err = up16(o_xy + rows * 8)
+        kps = buf[o_kps:o_kps + n * 8].view(np.float32).reshape(n, 2).copy()
+        idx = buf[o_idx:o_idx + rows * 4].view(np.uint32)
+        xy = buf[o_xy:o_xy + rows * 8].view(np.float32).reshape(rows, 2)
+        err = buf[o_err:o_err + rows * 4].view(np.float32)
+        flows = {}
+        for t in range(nt):
+            a, b = int(off[t]), int(off[t + 1])
+            flows[int(hdr[4 + t])] = (idx[a:b].copy(), xy[a:b].copy(), err[a:b].copy())
+        out.append((frame1, kps, flows))
+        o = up16(o_err + rows * 4)
+    return out

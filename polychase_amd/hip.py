@@ -28,6 +28,7 @@ SYMBOLS = [
     "pc_lk_track", "pc_lk_track_filtered",
     "pc_analyzer_create", "pc_analyzer_destroy", "pc_analyzer_put_frame", "pc_analyzer_has_frame",
     "pc_analyzer_set_keypoints", "pc_analyzer_submit", "pc_analyzer_pending", "pc_analyzer_collect",
+    "pc_analyzer_set_device_log", "pc_analyzer_device_log_used",
     "pc_mesh_create", "pc_mesh_set_mask", "pc_mesh_destroy", "pc_raycast_pixels",
     "pc_pnp_problem_create", "pc_pnp_problem_destroy", "pc_pnp_normal_equations", "pc_pnp_total_cost",
 ]
@@ -122,6 +123,8 @@ def load():
     L.pc_analyzer_submit.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.c_int]
     L.pc_analyzer_pending.argtypes = [vp]
     L.pc_analyzer_collect.argtypes = [vp, C.POINTER(FrameResult)]
+    L.pc_analyzer_set_device_log.argtypes = [vp, vp, C.c_size_t]
+    L.pc_analyzer_device_log_used.argtypes = [vp, C.POINTER(C.c_size_t)]
     _lib = L
     return L
 
@@ -375,6 +378,22 @@ class Analyzer:
     @property
     def pending(self) -> int:
         return load().pc_analyzer_pending(self._h)
+
+    def set_device_log(self, tensor):
+        """tensor: torch uint8 CUDA tensor (or None) that receives the device-resident record log."""
+        if tensor is None:
+            _check(load().pc_analyzer_set_device_log(self._h, None, 0))
+            self._log = None
+            return
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.element_size() == 1
+        _check(load().pc_analyzer_set_device_log(self._h, tensor.data_ptr(), tensor.numel()))
+        self._log = tensor
+
+    @property
+    def device_log_used(self) -> int:
+        n = C.c_size_t()
+        _check(load().pc_analyzer_device_log_used(self._h, C.byref(n)))
+        return n.value
 
     def collect_raw(self) -> FrameResult:
         r = FrameResult()

@@ -296,3 +296,31 @@ def test_frame_sharding_is_result_invariant(ctx):
     hw, pw = D.pack_records(whole)
     hp, pp = D.pack_records(parts)
     assert np.array_equal(hw, hp) and np.array_equal(pw, pp)
+
+
+def test_device_log_matches_host_records(ctx):
+    """The device-resident record log (multi-GPU stitch payload) parses to exactly the host records."""
+    import torch
+    from polychase_amd import distributed as D
+    from polychase_amd.pipeline import ClipAnalyzer
+    w, h, n = 320, 240, 14
+    clip = synth.NoiseClip(w, h, n)
+    frames = [clip.frame(t) for t in range(n)]
+    an = ClipAnalyzer(ctx, w, h, 1, n, lambda fid: frames[fid - 1])
+    log = torch.empty(D.log_capacity_bytes(n, 4000), dtype=torch.uint8, device="cuda")
+    an.an.set_device_log(log)
+    host = []
+    an.run(range(1, n + 1), lambda f1, kps, det, flows: host.append((f1, kps, flows)))
+    ctx.synchronize()
+    used = an.an.device_log_used
+    recs = D.parse_device_log(log.cpu().numpy(), used)
+    an.close()
+    ha, pa = D.pack_records(host)
+    hb, pb = D.pack_records(recs)
+    assert np.array_equal(ha, hb) and np.array_equal(pa, pb)
+    # a log that is too small fails loudly, not silently
+    an = ClipAnalyzer(ctx, w, h, 1, n, lambda fid: frames[fid - 1])
+    an.an.set_device_log(torch.empty(4096, dtype=torch.uint8, device="cuda"))
+    with pytest.raises(hip.PolychaseHipError, match="device log full"):
+        an.run(range(1, 4), None)
+    an.close()
