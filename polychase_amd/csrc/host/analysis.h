@@ -1,0 +1,86 @@
+// analysis.h -- "Analyze Video" on the MI355X path: option structs, frame hand-off type and the
+// entry point GenerateOpticalFlowDatabase.
+//
+// The structs carry the reference's field names and defaults because polychase_core exposes them
+// one to one (cpp/polychase_pybind.cc:119-145): GFTTOptions <- cpp/feature_detection/gftt.h:5-21,
+// OpticalFlowOptions and VideoInfo <- cpp/opticalflow.h:20-33.  cv::Mat is replaced by FrameView.
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <optional>
+#include <string>
+
+// ---- options -----------------------------------------------------------------------------------
+
+// Shi-Tomasi detector with per-grid-cell quality threshold.  On the HIP path block_size and
+// gradient_size must be 3 and use_harris false (what the addon always uses).
+struct GFTTOptions {
+    double quality_level = 0.01;  // keep responses above quality_level * (max response of the grid cell)
+    double min_distance = 5.0;    // greedy suppression radius, pixels
+    int block_size = 3;
+    int gradient_size = 3;
+    int max_corners = 0;          // 0: unlimited
+    bool use_harris = false;
+    double harris_k = 0.04;
+    int grid_rows = 4;            // not exposed to Python by the reference either
+    int grid_cols = 4;
+};
+
+// Pyramidal Lucas-Kanade.  max_level counts pyramid levels ABOVE level 0 (OpenCV semantics).
+struct OpticalFlowOptions {
+    int window_size = 10;
+    int max_level = 3;
+    int term_max_iters = 30;
+    double term_epsilon = 0.01;
+    double min_eigen_threshold = 1e-4;
+};
+
+// The clip: frames first_frame .. first_frame + num_frames - 1, all width x height.
+struct VideoInfo {
+    uint32_t width;
+    uint32_t height;
+    int32_t first_frame;
+    uint32_t num_frames;
+};
+
+// ---- frame hand-off ----------------------------------------------------------------------------
+
+// One RGB frame, rows x cols x 3 uint8.  `data` is host memory, or HIP device memory of the GPU in
+// use when on_device is set (zero-copy ingestion); `owner` keeps it alive while the frame is read.
+struct FrameView {
+    const uint8_t* data = nullptr;
+    int rows = 0;
+    int cols = 0;
+    int channels = 0;
+    size_t row_pitch = 0;  // bytes between rows
+    bool on_device = false;
+    std::shared_ptr<void> owner;
+};
+
+// Returns the frame with the given id, or nothing if it cannot be supplied.
+using FrameAccessorFunction = std::function<std::optional<FrameView>(int32_t frame_id)>;
+// (progress in [0,1], message); returning false cancels the run.
+using OpticalFlowProgressCallback = std::function<bool(float progress, const std::string& progress_message)>;
+
+// What one run did (not in the reference; used by bench / tests).
+struct OpticalFlowRunStats {
+    int frames_processed = 0;
+    int keypoint_rows_written = 0;
+    int flow_rows_written = 0;
+    double seconds_total = 0;
+    double seconds_db = 0;
+};
+
+// ---- entry point -------------------------------------------------------------------------------
+
+// Detects keypoints in every frame and tracks them into the frames at distance 1, 2, 4 and 8 on
+// both sides, storing `keypoints` and `optical_flow` rows in the SQLite file at database_path
+// (created if missing; existing rows are kept and not recomputed, so an interrupted run resumes).
+// An empty database_path produces the records without storing them.  write_images is accepted for
+// signature compatibility; the reference's debug PNG dump is not produced.
+void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
+                                 OpticalFlowProgressCallback callback, const std::string& database_path,
+                                 const GFTTOptions& detector_options = {}, const OpticalFlowOptions& flow_options = {},
+                                 bool write_images = false, OpticalFlowRunStats* stats = nullptr);

@@ -1,4 +1,4 @@
-// opticalflow.cc -- driver of the video-analysis path on top of the C ABI (include/polychase_hip.h).
+// analysis_driver.cc -- driver of the video-analysis path on top of the C ABI (include/polychase_hip.h).
 //
 // Control flow mirrors the reference (cpp/opticalflow.cc:209-321): sequential frame1 loop, progress
 // callback + cancellation (:238-247), missing-frame errors (:251-254, :311-315), keypoints read from
@@ -7,7 +7,7 @@
 // is uploaded and turned into gray + pyramid exactly once (the reference does it per pair,
 // :298-302) and kept in a 17-slot ring on the GPU; frame1 jobs are pipelined through pc_analyzer,
 // and the 8 pairs of a frame run as one LK launch instead of 8 TBB tasks.
-#include "opticalflow.h"
+#include "analysis.h"
 
 #include <chrono>
 #include <cstdlib>
@@ -15,7 +15,7 @@
 #include <stdexcept>
 
 #include "../../../include/polychase_hip.h"
-#include "database.h"
+#include "flow_database.h"
 #include "utils.h"
 
 namespace {

@@ -1,0 +1,256 @@
+// flow_database.cc -- see flow_database.h.  The SQL text (schema, pragmas, the ten statements) is the
+// file format and therefore identical to the reference (cpp/database.cc:76-135, :353-399).
+#include "flow_database.h"
+
+#include <cstring>
+#include <stdexcept>
+#include <utility>
+
+#include "utils.h"
+
+namespace {
+
+// error text of the reference: "SQLite error [file:line]: message" (cpp/database.cc:12-36)
+[[noreturn]] void Fail(int line, const char* msg) {
+    throw std::runtime_error(StrFormat("SQLite error [%s:%d]: %s", __FILE__, line, msg ? msg : "Unknown error"));
+}
+
+int Ok(int rc, int line) {
+    if (rc != SQLITE_OK && rc != SQLITE_ROW && rc != SQLITE_DONE) Fail(line, sqlite3_errstr(rc));
+    return rc;
+}
+#define SQL_OK(expr) Ok((expr), __LINE__)
+
+constexpr const char* kSchema[] = {
+    R"(
+        CREATE TABLE IF NOT EXISTS keypoints(
+            image_id   INTEGER  PRIMARY KEY  NOT NULL,
+            rows       INTEGER               NOT NULL,
+            keypoints  BLOB                  NOT NULL
+        );
+    )",
+    R"(
+        CREATE TABLE IF NOT EXISTS optical_flow(
+            image_id_from           INTEGER  NOT NULL,
+            image_id_to             INTEGER  NOT NULL,
+            rows                    INTEGER  NOT NULL,
+            src_keypoints_indices   BLOB     NOT NULL,
+            tgt_keypoints           BLOB     NOT NULL,
+            flow_errors             BLOB     NOT NULL,
+            PRIMARY KEY(image_id_from, image_id_to),
+            FOREIGN KEY(image_id_from) REFERENCES keypoints(image_id) ON DELETE CASCADE
+        );
+    )",
+};
+
+// same order as the reference's Open(): auto_vacuum comes after journal_mode and is therefore inert
+constexpr const char* kPragmas[] = {
+    "PRAGMA synchronous=OFF", "PRAGMA journal_mode=WAL", "PRAGMA temp_store=MEMORY",
+    "PRAGMA foreign_keys=ON", "PRAGMA auto_vacuum=1",
+};
+
+// indexed by Database::Statement
+constexpr const char* kStatementSql[] = {
+    "SELECT rows, keypoints FROM keypoints WHERE image_id = ?;",
+    "INSERT INTO keypoints(image_id, rows, keypoints) VALUES(?, ?, ?);",
+    "SELECT rows, src_keypoints_indices, tgt_keypoints, flow_errors FROM optical_flow WHERE image_id_from = ? AND "
+    "image_id_to = ?;",
+    "INSERT INTO optical_flow(image_id_from, image_id_to, rows, src_keypoints_indices, tgt_keypoints, "
+    "flow_errors) VALUES(?, ?, ?, ?, ?, ?);",
+    "SELECT image_id_to FROM optical_flow WHERE image_id_from = ?",
+    "SELECT image_id_from FROM optical_flow WHERE image_id_to = ?",
+    "SELECT 1 FROM keypoints WHERE image_id = ?;",
+    "SELECT 1 FROM optical_flow WHERE image_id_from = ? AND image_id_to = ?;",
+    "SELECT MIN(image_id) FROM keypoints;",
+    "SELECT MAX(image_id) FROM keypoints;",
+};
+
+// RAII reset: statements are reused, every exit path (including exceptions) must reset them
+struct Resetter {
+    sqlite3_stmt* s;
+    ~Resetter() { sqlite3_reset(s); }
+};
+
+template <typename T>
+void BlobToVector(sqlite3_stmt* stmt, int col, size_t rows, std::vector<T>& out) {
+    out.assign(rows, T{});
+    const size_t bytes = static_cast<size_t>(sqlite3_column_bytes(stmt, col));
+    CHECK_EQ(out.size() * sizeof(T), bytes);
+    if (bytes) std::memcpy(out.data(), sqlite3_column_blob(stmt, col), bytes);
+}
+
+// a NULL pointer would bind SQL NULL and trip NOT NULL: empty blobs bind a valid dummy address
+void BindBlob(sqlite3_stmt* stmt, int col, const void* data, size_t bytes, int line) {
+    static const char kNothing = 0;
+    Ok(sqlite3_bind_blob(stmt, col, bytes ? data : &kNothing, static_cast<int>(bytes), SQLITE_STATIC), line);
+}
+
+}  // namespace
+
+Database::Database(Database&& other) noexcept : db_(std::exchange(other.db_, nullptr)) {
+    statements_ = other.statements_;
+    other.statements_.fill(nullptr);
+}
+
+Database::~Database() {
+    try {
+        Close();
+    } catch (...) {
+    }
+}
+
+void Database::Exec(const char* sql, int line) const {
+    char* err = nullptr;
+    if (sqlite3_exec(db_, sql, nullptr, nullptr, &err) != SQLITE_OK) {
+        const std::string msg = err ? err : "Unknown error";
+        sqlite3_free(err);
+        Fail(line, msg.c_str());
+    }
+}
+
+void Database::Open(const std::string& path) {
+    Close();
+    // NOMUTEX like the reference: callers serialise access (one writer thread here)
+    SQL_OK(sqlite3_open_v2(path.c_str(), &db_, SQLITE_OPEN_READWRITE | SQLITE_OPEN_CREATE | SQLITE_OPEN_NOMUTEX, nullptr));
+    for (const char* pragma : kPragmas) Exec(pragma, __LINE__);
+    for (const char* table : kSchema) Exec(table, __LINE__);
+    for (int i = 0; i < kNumStatements; i++) SQL_OK(sqlite3_prepare_v2(db_, kStatementSql[i], -1, &statements_[i], nullptr));
+}
+
+void Database::FinalizeAll() {
+    for (sqlite3_stmt*& s : statements_) {
+        if (s) sqlite3_finalize(s);
+        s = nullptr;
+    }
+}
+
+void Database::Close() {
+    if (!db_) return;
+    FinalizeAll();
+    sqlite3_close_v2(db_);
+    db_ = nullptr;
+}
+
+void Database::Begin() { Exec("BEGIN", __LINE__); }
+void Database::Commit() { Exec("COMMIT", __LINE__); }
+
+// ---- generic helpers -------------------------------------------------------------------------
+bool Database::HasRow(Statement s, int32_t key_a, const int32_t* key_b) const {
+    sqlite3_stmt* stmt = Stmt(s);
+    Resetter reset{stmt};
+    SQL_OK(sqlite3_bind_int(stmt, 1, key_a));
+    if (key_b) SQL_OK(sqlite3_bind_int(stmt, 2, *key_b));
+    return SQL_OK(sqlite3_step(stmt)) == SQLITE_ROW;
+}
+
+void Database::CollectIds(Statement s, int32_t key, std::vector<int32_t>& append_to) const {
+    sqlite3_stmt* stmt = Stmt(s);
+    Resetter reset{stmt};
+    SQL_OK(sqlite3_bind_int(stmt, 1, key));
+    while (SQL_OK(sqlite3_step(stmt)) == SQLITE_ROW) append_to.push_back(sqlite3_column_int(stmt, 0));
+}
+
+int32_t Database::ScalarOrInvalid(Statement s) const {
+    sqlite3_stmt* stmt = Stmt(s);
+    Resetter reset{stmt};
+    // MIN()/MAX() over an empty table yield one NULL row, read as 0 -- same as the reference
+    return SQL_OK(sqlite3_step(stmt)) == SQLITE_ROW ? sqlite3_column_int(stmt, 0) : kInvalidId;
+}
+
+// ---- keypoints -------------------------------------------------------------------------------
+bool Database::KeypointsExist(int32_t image_id) const { return HasRow(kKeypointsExist, image_id, nullptr); }
+int32_t Database::GetMinImageIdWithKeypoints() const { return ScalarOrInvalid(kMinImageId); }
+int32_t Database::GetMaxImageIdWithKeypoints() const { return ScalarOrInvalid(kMaxImageId); }
+
+void Database::ReadKeypoints(int32_t image_id, Keypoints& out) const {
+    sqlite3_stmt* stmt = Stmt(kReadKeypoints);
+    Resetter reset{stmt};
+    SQL_OK(sqlite3_bind_int(stmt, 1, image_id));
+    if (SQL_OK(sqlite3_step(stmt)) != SQLITE_ROW) return;
+    const int rows = sqlite3_column_int(stmt, 0);
+    CHECK(rows >= 0);
+    BlobToVector(stmt, 1, static_cast<size_t>(rows), out);
+}
+
+Keypoints Database::ReadKeypoints(int32_t image_id) const {
+    Keypoints k;
+    ReadKeypoints(image_id, k);
+    return k;
+}
+
+void Database::WriteKeypoints(int32_t image_id, const float* xy, size_t rows) {
+    sqlite3_stmt* stmt = Stmt(kWriteKeypoints);
+    Resetter reset{stmt};
+    SQL_OK(sqlite3_bind_int(stmt, 1, image_id));
+    SQL_OK(sqlite3_bind_int(stmt, 2, static_cast<int>(rows)));
+    BindBlob(stmt, 3, xy, rows * sizeof(Keypoint), __LINE__);
+    SQL_OK(sqlite3_step(stmt));  // plain INSERT: a second write of the same image_id throws
+}
+
+void Database::WriteKeypoints(int32_t image_id, const Keypoints& keypoints) {
+    WriteKeypoints(image_id, keypoints.empty() ? nullptr : keypoints.front().data(), keypoints.size());
+}
+
+// ---- optical_flow ----------------------------------------------------------------------------
+bool Database::ImagePairFlowExists(int32_t from, int32_t to) const { return HasRow(kFlowExists, from, &to); }
+
+void Database::ReadImagePairFlow(int32_t from, int32_t to, ImagePairFlow& out) const {
+    sqlite3_stmt* stmt = Stmt(kReadFlow);
+    Resetter reset{stmt};
+    SQL_OK(sqlite3_bind_int(stmt, 1, from));
+    SQL_OK(sqlite3_bind_int(stmt, 2, to));
+    if (SQL_OK(sqlite3_step(stmt)) != SQLITE_ROW) return;
+    const size_t rows = static_cast<size_t>(sqlite3_column_int(stmt, 0));
+    BlobToVector(stmt, 1, rows, out.src_kps_indices);
+    BlobToVector(stmt, 2, rows, out.tgt_kps);
+    BlobToVector(stmt, 3, rows, out.flow_errors);
+    out.image_id_from = from;
+    out.image_id_to = to;
+}
+
+ImagePairFlow Database::ReadImagePairFlow(int32_t from, int32_t to) const {
+    ImagePairFlow f;
+    ReadImagePairFlow(from, to, f);
+    return f;
+}
+
+void Database::WriteImagePairFlow(int32_t from, int32_t to, const uint32_t* idx, const float* tgt_xy, const float* err,
+                                  size_t rows) {
+    sqlite3_stmt* stmt = Stmt(kWriteFlow);
+    Resetter reset{stmt};
+    SQL_OK(sqlite3_bind_int(stmt, 1, from));
+    SQL_OK(sqlite3_bind_int(stmt, 2, to));
+    SQL_OK(sqlite3_bind_int(stmt, 3, static_cast<int>(rows)));
+    BindBlob(stmt, 4, idx, rows * sizeof(uint32_t), __LINE__);
+    BindBlob(stmt, 5, tgt_xy, rows * sizeof(Keypoint), __LINE__);
+    BindBlob(stmt, 6, err, rows * sizeof(float), __LINE__);
+    SQL_OK(sqlite3_step(stmt));
+}
+
+void Database::WriteImagePairFlow(int32_t from, int32_t to, const KeypointsIndices& idx, const Keypoints& tgt,
+                                  const FlowErrors& err) {
+    CHECK_EQ(tgt.size(), idx.size());
+    CHECK_EQ(err.size(), idx.size());
+    WriteImagePairFlow(from, to, idx.data(), tgt.empty() ? nullptr : tgt.front().data(), err.data(), idx.size());
+}
+
+void Database::WriteImagePairFlow(const ImagePairFlow& f) {
+    WriteImagePairFlow(f.image_id_from, f.image_id_to, f.src_kps_indices, f.tgt_kps, f.flow_errors);
+}
+
+void Database::FindOpticalFlowsFromImage(int32_t from, std::vector<int32_t>& append_to) const {
+    CollectIds(kFlowsFrom, from, append_to);
+}
+void Database::FindOpticalFlowsToImage(int32_t to, std::vector<int32_t>& append_to) const {
+    CollectIds(kFlowsTo, to, append_to);
+}
+std::vector<int32_t> Database::FindOpticalFlowsFromImage(int32_t from) const {
+    std::vector<int32_t> ids;
+    CollectIds(kFlowsFrom, from, ids);
+    return ids;
+}
+std::vector<int32_t> Database::FindOpticalFlowsToImage(int32_t to) const {
+    std::vector<int32_t> ids;
+    CollectIds(kFlowsTo, to, ids);
+    return ids;
+}

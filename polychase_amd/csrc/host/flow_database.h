@@ -1,0 +1,99 @@
+// flow_database.h -- the on-disk optical-flow database (SQLite).  File format identical to the
+// reference's (cpp/database.h:36-100, cpp/database.cc:64-135, :350-400): same two tables, same
+// pragmas in the same order, same statements, blobs = raw little-endian arrays -- databases written
+// by either implementation are interchangeable and a cancelled analysis can be resumed by the other.
+// The class keeps the reference's public method names because the Python surface
+// (`polychase_core.Database`, cpp/polychase_pybind.cc:71-109) is built from them.
+#pragma once
+
+#include <sqlite3.h>
+
+#include <array>
+#include <cstdint>
+#include <limits>
+#include <string>
+#include <vector>
+
+static constexpr int32_t kInvalidId = std::numeric_limits<int32_t>::max();
+
+using Keypoint = std::array<float, 2>;  // one (x, y) pair, 8 bytes in the blob
+using Keypoints = std::vector<Keypoint>;
+using KeypointsIndices = std::vector<uint32_t>;
+using FlowErrors = std::vector<float>;
+
+// One row of `optical_flow`: matches of frame image_id_from tracked into image_id_to.
+struct ImagePairFlow {
+    int32_t image_id_from = 0;
+    int32_t image_id_to = 0;
+    KeypointsIndices src_kps_indices;  // ascending indices into the keypoints of image_id_from
+    Keypoints tgt_kps;
+    FlowErrors flow_errors;
+    void Clear() {
+        src_kps_indices.clear();
+        tgt_kps.clear();
+        flow_errors.clear();
+    }
+};
+
+class Database {
+   public:
+    explicit Database(const std::string& path) { Open(path); }
+    Database(Database&& other) noexcept;
+    Database(const Database&) = delete;
+    Database& operator=(const Database&) = delete;
+    ~Database();
+
+    void Open(const std::string& path);
+    void Close();
+
+    // ---- keypoints(image_id PK, rows, keypoints BLOB) ----
+    bool KeypointsExist(int32_t image_id) const;
+    Keypoints ReadKeypoints(int32_t image_id) const;
+    void ReadKeypoints(int32_t image_id, Keypoints& out) const;  // leaves `out` untouched if absent
+    void WriteKeypoints(int32_t image_id, const Keypoints& keypoints);
+    void WriteKeypoints(int32_t image_id, const float* xy, size_t rows);
+    int32_t GetMinImageIdWithKeypoints() const;
+    int32_t GetMaxImageIdWithKeypoints() const;
+
+    // ---- optical_flow(image_id_from, image_id_to, rows, 3 BLOBs) ----
+    bool ImagePairFlowExists(int32_t image_id_from, int32_t image_id_to) const;
+    ImagePairFlow ReadImagePairFlow(int32_t image_id_from, int32_t image_id_to) const;
+    void ReadImagePairFlow(int32_t image_id_from, int32_t image_id_to, ImagePairFlow& out) const;
+    void WriteImagePairFlow(const ImagePairFlow& flow);
+    void WriteImagePairFlow(int32_t image_id_from, int32_t image_id_to, const KeypointsIndices& src_kps_indices,
+                            const Keypoints& tgt_kps, const FlowErrors& flow_errors);
+    void WriteImagePairFlow(int32_t image_id_from, int32_t image_id_to, const uint32_t* idx, const float* tgt_xy,
+                            const float* err, size_t rows);
+    std::vector<int32_t> FindOpticalFlowsFromImage(int32_t image_id_from) const;
+    void FindOpticalFlowsFromImage(int32_t image_id_from, std::vector<int32_t>& append_to) const;
+    std::vector<int32_t> FindOpticalFlowsToImage(int32_t image_id_to) const;
+    void FindOpticalFlowsToImage(int32_t image_id_to, std::vector<int32_t>& append_to) const;
+
+    // Not in the reference: explicit transactions, so one frame's rows go in as one batch.
+    void Begin();
+    void Commit();
+
+   private:
+    enum Statement {
+        kReadKeypoints,
+        kWriteKeypoints,
+        kReadFlow,
+        kWriteFlow,
+        kFlowsFrom,
+        kFlowsTo,
+        kKeypointsExist,
+        kFlowExists,
+        kMinImageId,
+        kMaxImageId,
+        kNumStatements
+    };
+    sqlite3_stmt* Stmt(Statement s) const { return statements_[s]; }
+    void Exec(const char* sql, int line) const;
+    void FinalizeAll();
+    void CollectIds(Statement s, int32_t key, std::vector<int32_t>& append_to) const;
+    bool HasRow(Statement s, int32_t key_a, const int32_t* key_b) const;
+    int32_t ScalarOrInvalid(Statement s) const;
+
+    sqlite3* db_ = nullptr;
+    std::array<sqlite3_stmt*, kNumStatements> statements_{};
+};

@@ -1,0 +1,25 @@
+// track_sequence.h -- "Track Sequence": camera poses frame by frame from the flow database
+// (reference cpp/tracker.h:23-39, cpp/tracker.cc:36-213).
+#pragma once
+
+#include <functional>
+#include <string>
+
+#include "flow_database.h"
+#include "ray_casting.h"
+#include "types.h"
+
+// called after every solved frame; returning false stops the run (tracker.cc:170-184)
+using TrackingCallback = std::function<bool(const FrameTrackingResult&)>;
+
+// Solves frames frame_from+-1 ... frame_to_inclusive in order; camera_traj must hold frame_from.
+void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_traj, int32_t frame_from,
+                           int32_t frame_to_inclusive, const Mat4f& model_matrix, const AcceleratedMesh& accel_mesh,
+                           TrackingCallback callback, bool optimize_focal_length, bool optimize_principal_point,
+                           const BundleOptions& opts);
+
+// Opens the database, seeds the trajectory with scene_transform's view/intrinsics at frame_from.
+void TrackSequence(const std::string& database_path, int32_t frame_from, int32_t frame_to_inclusive,
+                   const SceneTransformations& scene_transform, const AcceleratedMesh& accel_mesh,
+                   TrackingCallback callback, bool optimize_focal_length, bool optimize_principal_point,
+                   BundleOptions opts);

@@ -7,9 +7,9 @@
 
 #include <deque>
 
-#include "../host/database.h"
-#include "../host/opticalflow.h"
-#include "../host/opticalflow_thread.h"
+#include "../host/flow_database.h"
+#include "../host/analysis.h"
+#include "../host/analysis_thread.h"
 #include "np_helpers.h"
 
 #ifdef PC_WITH_TRACKER

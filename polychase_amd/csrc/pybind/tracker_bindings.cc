@@ -6,8 +6,8 @@
 
 #include "../host/pnp.h"
 #include "../host/ray_casting.h"
-#include "../host/tracker.h"
-#include "../host/tracker_thread.h"
+#include "../host/track_sequence.h"
+#include "../host/tracking_thread.h"
 #include "np_helpers.h"
 
 namespace {
