@@ -311,7 +311,6 @@ void pc_context_destroy(pc_context* c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     c->staging.release();
     c->eig.release();
-    c->keys_in.release();
     c->cmap.release();
     c->state.release();
     c->sup_offsets.release();
@@ -321,7 +320,6 @@ void pc_context_destroy(pc_context* c) {
         c->detect = nullptr;
     }
     c->keys_out.release();
-    c->counters.release();
     c->sort_temp.release();
     c->lk_xy.release();
     c->lk_cxy.release();

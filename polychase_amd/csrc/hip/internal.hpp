@@ -115,14 +115,13 @@ struct pc_context {
     DevBuf<uint8_t> staging;
     // GFTT scratch
     DevBuf<float> eig;
-    DevBuf<unsigned long long> keys_in, keys_out;
+    DevBuf<unsigned long long> keys_out;   // sorted accepted keys (consumed in stream order)
     DevBuf<uint32_t> cmap, state;          // dense candidate priority / decision maps (K5)
     DevBuf<int2> sup_offsets;              // suppression neighbourhood for sup_min_distance
     double sup_min_distance = -1.0;
     int n_sup_offsets = 0;
     int resident_blocks = 0;               // fully resident grid size for the suppression kernel
     struct DetectScratch* detect = nullptr;  // scratch of the stage-level pc_frame_detect
-    DevBuf<uint32_t> counters;  // [0] candidate counter, [1..] cell max keys
     DevBuf<uint8_t> sort_temp;
     const pc_frame* eig_owner = nullptr;
     // LK scratch

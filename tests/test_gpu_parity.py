@@ -324,3 +324,32 @@ def test_device_log_matches_host_records(ctx):
     with pytest.raises(hip.PolychaseHipError, match="device log full"):
         an.run(range(1, 4), None)
     an.close()
+
+
+def test_hip_path_against_committed_golden_vectors(ctx):
+    """tests/golden/oracle_small.npz: frozen inputs and expected outputs of every stage."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_small.npz"))
+    frames = G["frames"]
+    h, w, _ = frames[0].shape
+    fr = []
+    for f in frames:
+        x = hip.Frame(ctx, w, h, 10, 2)
+        x.set_rgb(np.ascontiguousarray(f))
+        fr.append(x)
+    assert np.array_equal(fr[0].gray(), G["gray0"])
+    assert fr[0].num_levels == int(G["num_levels"])
+    for l in range(fr[0].num_levels):
+        assert np.array_equal(fr[0].level(l), G[f"level{l}"]) and np.array_equal(fr[0].deriv(l), G[f"deriv{l}"])
+    fr[0].detect()
+    assert np.array_equal(fr[0].min_eig().view(np.uint32), G["min_eig0"].view(np.uint32))
+    assert fr[0].num_candidates == int(G["n_candidates0"])
+    assert np.array_equal(fr[0].keypoints(), G["keypoints0"])
+    xy, st, err = hip.lk_track(ctx, fr[0], fr[1:], hip.flow_options(max_level=2))
+    for k in (1, 2):
+        assert np.array_equal(st[k - 1], G[f"lk_status_{k}"])
+        m = st[k - 1] == 1
+        assert np.array_equal(xy[k - 1][m].view(np.uint32), G[f"lk_xy_{k}"][m].view(np.uint32))
+        assert np.array_equal(err[k - 1][m].view(np.uint32), G[f"lk_err_{k}"][m].view(np.uint32))
+    for x in fr:
+        x.close()
