@@ -10,9 +10,13 @@
 #include "analysis.h"
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <deque>
+#include <exception>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 #include "../../../include/polychase_hip.h"
 #include "flow_database.h"
@@ -22,7 +26,9 @@ namespace {
 
 constexpr int32_t kImageSkips[8] = {-8, -4, -2, -1, 1, 2, 4, 8};  // cpp/opticalflow.cc:76-77
 constexpr int kRing = 17;      // cpp/opticalflow_thread.h:34-79 (SequentialWrapper<17>)
-constexpr int kMaxJobs = 3;
+constexpr int kGpuDepth = 3;                        // frame1 jobs kept in flight on the GPU
+constexpr int kWriteBacklog = 4;                    // collected records waiting for SQLite
+constexpr int kMaxJobs = kGpuDepth + kWriteBacklog + 1;  // pinned result slots: a slot is reused kMaxJobs submits later
 
 [[noreturn]] void ThrowHip(const char* what) {
     throw std::runtime_error(std::string(what) + ": " + pc_last_error());
@@ -40,6 +46,92 @@ struct Engine {
 double Now() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+
+// SQLite inserts on their own thread, overlapping the GPU pipeline.  Records are consumed in
+// submission order straight from the analyzer's pinned buffers (no copy); the backlog bound keeps a
+// buffer from being reused before it is written.  `db_mtx` also serialises the driver's reads
+// (the connection is opened NOMUTEX like the reference's, cpp/database.cc:71-74).
+class RecordWriter {
+   public:
+    RecordWriter(Database* db, std::mutex* db_mtx, OpticalFlowRunStats* stats)
+        : db_(db), db_mtx_(db_mtx), stats_(stats), thread_([this] { Run(); }) {}
+    ~RecordWriter() {
+        {
+            std::lock_guard<std::mutex> lk(mtx_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        if (thread_.joinable()) thread_.join();
+    }
+    // blocks while kWriteBacklog records are already waiting
+    void Enqueue(const pc_frame_result& r) {
+        std::unique_lock<std::mutex> lk(mtx_);
+        cv_.wait(lk, [&] { return static_cast<int>(queue_.size()) < kWriteBacklog || error_; });
+        Rethrow();
+        queue_.push_back(r);
+        cv_.notify_all();
+    }
+    void Flush() {
+        std::unique_lock<std::mutex> lk(mtx_);
+        cv_.wait(lk, [&] { return (queue_.empty() && !busy_) || error_; });
+        Rethrow();
+    }
+    double seconds() const { return seconds_; }
+
+   private:
+    void Rethrow() {
+        if (error_) std::rethrow_exception(error_);
+    }
+    void Run() {
+        for (;;) {
+            pc_frame_result r;
+            {
+                std::unique_lock<std::mutex> lk(mtx_);
+                cv_.wait(lk, [&] { return !queue_.empty() || quit_; });
+                if (queue_.empty()) return;
+                r = queue_.front();
+                busy_ = true;
+            }
+            try {
+                const double t0 = Now();
+                std::lock_guard<std::mutex> dblk(*db_mtx_);
+                db_->Begin();
+                if (r.keypoints_detected && !db_->KeypointsExist(r.frame1)) {
+                    db_->WriteKeypoints(r.frame1, r.keypoints_xy, static_cast<size_t>(r.n_keypoints));
+                    stats_->keypoint_rows_written++;
+                }
+                for (int t = 0; t < r.n_targets; t++) {
+                    const int64_t a = r.row_offset[t], b = r.row_offset[t + 1];
+                    db_->WriteImagePairFlow(r.frame1, r.targets[t], r.src_indices + a, r.tgt_xy + 2 * a, r.flow_err + a,
+                                            static_cast<size_t>(b - a));
+                    stats_->flow_rows_written++;
+                }
+                db_->Commit();
+                seconds_ += Now() - t0;
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(mtx_);
+                error_ = std::current_exception();
+            }
+            {
+                std::lock_guard<std::mutex> lk(mtx_);
+                queue_.pop_front();  // only now may the pinned buffers of this record be reused
+                busy_ = false;
+            }
+            cv_.notify_all();
+        }
+    }
+
+    Database* db_;
+    std::mutex* db_mtx_;
+    OpticalFlowRunStats* stats_;
+    std::mutex mtx_;
+    std::condition_variable cv_;
+    std::deque<pc_frame_result> queue_;
+    bool quit_ = false, busy_ = false;
+    std::exception_ptr error_;
+    double seconds_ = 0;
+    std::thread thread_;
+};
 
 }  // namespace
 
@@ -82,7 +174,9 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
         ThrowHip("pc_analyzer_create");
 
     OpticalFlowRunStats local_stats;
-    double seconds_db = 0;
+    std::mutex db_mtx;
+    std::unique_ptr<RecordWriter> writer;
+    if (db) writer = std::make_unique<RecordWriter>(db.get(), &db_mtx, &local_stats);
 
     // RequestFrame + shape checks (cpp/opticalflow.cc:189-202)
     auto fetch = [&](int32_t frame_id) -> std::optional<FrameView> {
@@ -95,32 +189,20 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
         return f;
     };
 
-    auto store = [&](const pc_frame_result& r) {
-        local_stats.frames_processed++;
-        if (!db) return;
-        const double t0 = Now();
-        db->Begin();
-        if (r.keypoints_detected && !db->KeypointsExist(r.frame1)) {
-            db->WriteKeypoints(r.frame1, r.keypoints_xy, static_cast<size_t>(r.n_keypoints));
-            local_stats.keypoint_rows_written++;
-        }
-        for (int t = 0; t < r.n_targets; t++) {
-            const int64_t a = r.row_offset[t], b = r.row_offset[t + 1];
-            db->WriteImagePairFlow(r.frame1, r.targets[t], r.src_indices + a, r.tgt_xy + 2 * a, r.flow_err + a,
-                                   static_cast<size_t>(b - a));
-            local_stats.flow_rows_written++;
-        }
-        db->Commit();
-        seconds_db += Now() - t0;
-    };
-
     auto collect_one = [&]() {
         pc_frame_result r;
         if (pc_analyzer_collect(eng.an, &r) != PC_OK) ThrowHip("pc_analyzer_collect");
-        store(r);
+        local_stats.frames_processed++;
+        if (writer) writer->Enqueue(r);
     };
     auto drain = [&]() {
         while (pc_analyzer_pending(eng.an) > 0) collect_one();
+        if (writer) writer->Flush();
+    };
+    auto finish_stats = [&]() {
+        local_stats.seconds_total = Now() - t_begin;
+        local_stats.seconds_db = writer ? writer->seconds() : 0.0;
+        if (stats) *stats = local_stats;
     };
 
     int32_t highest_put = from - 1;
@@ -131,6 +213,7 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
             const bool ok = callback(progress, "Processing frame " + std::to_string(frame_id1));
             if (!ok) {
                 drain();  // jobs already on the GPU are complete work: keep them
+                finish_stats();
                 callback(1.0f, "Cancelled");
                 return;
             }
@@ -146,7 +229,11 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
                 throw std::runtime_error(
                     "Exiting optical flow generation prematurely because some frames were not provided");
             }
-            const bool will_detect = !(db && db->KeypointsExist(fid));
+            bool will_detect = true;
+            if (db) {
+                std::lock_guard<std::mutex> lk(db_mtx);
+                will_detect = !db->KeypointsExist(fid);
+            }
             if (pc_analyzer_put_frame(eng.an, fid, f->data, f->row_pitch, f->on_device ? 1 : 0, will_detect ? 1 : 0) !=
                 PC_OK)
                 ThrowHip("pc_analyzer_put_frame");
@@ -155,7 +242,10 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
         // ReadOrGenerateKeypoints (:168-178)
         if (db) {
             known.clear();
-            db->ReadKeypoints(frame_id1, known);
+            {
+                std::lock_guard<std::mutex> lk(db_mtx);
+                db->ReadKeypoints(frame_id1, known);
+            }
             if (!known.empty() &&
                 pc_analyzer_set_keypoints(eng.an, frame_id1, known[0].data(), static_cast<int>(known.size())) != PC_OK)
                 ThrowHip("pc_analyzer_set_keypoints");
@@ -165,15 +255,16 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
         for (int32_t skip : kImageSkips) {
             const int32_t frame_id2 = frame_id1 + skip;
             if (frame_id2 < from || frame_id2 >= to) continue;               // :282
-            if (db && db->ImagePairFlowExists(frame_id1, frame_id2)) continue;  // :286
+            if (db) {
+                std::lock_guard<std::mutex> lk(db_mtx);
+                if (db->ImagePairFlowExists(frame_id1, frame_id2)) continue;  // :286
+            }
             targets[n_targets++] = frame_id2;
         }
-        if (pc_analyzer_pending(eng.an) == kMaxJobs) collect_one();
+        while (pc_analyzer_pending(eng.an) >= kGpuDepth) collect_one();
         if (pc_analyzer_submit(eng.an, frame_id1, targets, n_targets) != PC_OK) ThrowHip("pc_analyzer_submit");
     }
     drain();
+    finish_stats();
     if (callback) callback(1.0f, "Done");
-    local_stats.seconds_total = Now() - t_begin;
-    local_stats.seconds_db = seconds_db;
-    if (stats) *stats = local_stats;
 }
