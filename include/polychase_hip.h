@@ -244,6 +244,52 @@ int pc_pnp_normal_equations(pc_context* ctx, const pc_pnp_problem* prob, const p
 int pc_pnp_total_cost(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,
                       float max_inlier_error_sq, float* cost, int* valid, int* inliers);
 
+/* ---- "Refine Sequence" path (cpp/refiner.cc:199-725, cpp/pnp/lev_marq.h:391-871) ----
+ * The segment's keypoints and flows live on the GPU; per LM iteration the host sends the camera
+ * trajectory and receives the cost or the per-edge normal-equation blocks. */
+typedef struct pc_refine_problem pc_refine_problem;
+
+typedef struct pc_refine_desc {
+    int n_frames;                 /* frames of the segment, index 0 = first frame */
+    int n_edges;                  /* flows (image_id_from -> image_id_to) inside the segment */
+    const int32_t* kp_offset;     /* [n_frames + 1]: keypoints of frame f = kp_xy[kp_offset[f] .. kp_offset[f+1]) */
+    const float* kp_xy;           /* all (bbox-filtered) keypoints, x y */
+    const int32_t* edge_src;      /* [n_edges] frame index of image_id_from */
+    const int32_t* edge_tgt;      /* [n_edges] frame index of image_id_to */
+    const int32_t* edge_offset;   /* [n_edges + 1] into the residual arrays */
+    const uint32_t* res_src_kp;   /* per residual: keypoint index within the source frame */
+    const float* res_tgt_xy;      /* per residual: tracked position in the target frame */
+    const float* edge_weight;     /* [n_edges] GlobalRefinementProblem::EdgeWeight (refiner.cc:596-599) */
+    float model_matrix[16];       /* object -> world, row-major */
+    float model_matrix_inv[16];
+    int block_len;                /* parameters per camera: 6, or 9 when intrinsics are optimised */
+    int optimize_focal_length, optimize_principal_point;
+} pc_refine_desc;
+
+/* one camera of the trajectory, 20 floats */
+typedef struct pc_refine_camera {
+    float R[9];
+    float t[3];
+    float fx, fy, cx, cy, aspect_ratio;
+    float unproject_sign;         /* +1 OpenCV, -1 OpenGL */
+    float reserved[2];
+} pc_refine_camera;
+
+int pc_refine_problem_create(pc_context* ctx, const pc_mesh* mesh, const pc_refine_desc* desc,
+                             pc_refine_problem** out);
+void pc_refine_problem_destroy(pc_refine_problem* prob);
+/* LevMarqSparseSolver::TotalCost (lev_marq.h:773-824) over RefinementProblemBase::Evaluate
+ * (refiner.cc:274-361); updates the per-keypoint triangle cache like the reference does. */
+int pc_refine_total_cost(pc_context* ctx, pc_refine_problem* prob, const pc_refine_camera* cameras,
+                         int loss_type, float loss_scale, double* cost);
+/* LevMarqSparseSolver::BuildNormalEquations (lev_marq.h:653-771) without the scatter: per edge the
+ * lower triangle of the (2B x 2B) block (packed row-major, (2B)(2B+1)/2 doubles) followed by the 2B
+ * gradient entries, normalised by the edge's valid-residual count (returned in edge_valid).
+ * Jacobians are evaluated in fp32 like the reference; the sums are fp64 so that J^T J stays positive
+ * semi-definite to rounding (long weakly-damped chains need it). */
+int pc_refine_normal_equations(pc_context* ctx, pc_refine_problem* prob, const pc_refine_camera* cameras,
+                               int loss_type, float loss_scale, double* edge_blocks, int* edge_valid);
+
 #ifdef __cplusplus
 }
 #endif

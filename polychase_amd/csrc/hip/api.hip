@@ -1181,4 +1181,209 @@ int pc_pnp_total_cost(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_
     return PC_OK;
 }
 
+
+// =============================================================================================
+// refiner path
+// =============================================================================================
+}  // extern "C"
+
+struct pc_refine_problem {
+    pc_context* ctx = nullptr;
+    const pc_mesh* mesh = nullptr;
+    int n_frames = 0, n_edges = 0, block_len = 6, opt_f = 0, opt_pp = 0;
+    size_t n_kp = 0, n_res = 0;
+    DevBuf<int> kp_offset, edge_src, edge_tgt, edge_offset, edge_valid;
+    DevBuf<float2> kp_xy, res_tgt_xy;
+    DevBuf<double2> edge_cost;
+    DevBuf<uint32_t> res_src_kp, prim_cache;
+    DevBuf<float> edge_weight;
+    DevBuf<double> edge_blocks;
+    DevBuf<uint8_t> frame_fixed;
+    DevBuf<pc::RefineCamera> cams;
+    PinBuf<double2> h_edge_cost;
+    std::vector<float> h_edge_weight;
+    float model[16], model_inv[16];
+};
+
+namespace {
+
+pc::RefineProblemView refine_view(const pc_refine_problem* p) {
+    pc::RefineProblemView v;
+    v.n_frames = p->n_frames;
+    v.n_edges = p->n_edges;
+    v.n_tris = p->mesh->n_triangles;
+    v.kp_offset = p->kp_offset.p;
+    v.kp_xy = p->kp_xy.p;
+    v.edge_src = p->edge_src.p;
+    v.edge_tgt = p->edge_tgt.p;
+    v.edge_offset = p->edge_offset.p;
+    v.res_src_kp = p->res_src_kp.p;
+    v.res_tgt_xy = p->res_tgt_xy.p;
+    v.edge_weight = p->edge_weight.p;
+    v.frame_fixed = p->frame_fixed.p;
+    v.prim_cache = p->prim_cache.p;
+    v.verts = p->mesh->verts.p;
+    v.tris = p->mesh->tris.p;
+    v.mask = p->mesh->mask.p;
+    std::memcpy(v.model, p->model, sizeof(v.model));
+    std::memcpy(v.model_inv, p->model_inv, sizeof(v.model_inv));
+    return v;
+}
+
+int upload_cameras(pc_context* ctx, pc_refine_problem* p, const pc_refine_camera* cameras) {
+    std::vector<pc::RefineCamera> h((size_t)p->n_frames);
+    for (int f = 0; f < p->n_frames; f++) {
+        std::memcpy(h[f].R, cameras[f].R, sizeof(h[f].R));
+        std::memcpy(h[f].t, cameras[f].t, sizeof(h[f].t));
+        h[f].fx = cameras[f].fx;
+        h[f].fy = cameras[f].fy;
+        h[f].cx = cameras[f].cx;
+        h[f].cy = cameras[f].cy;
+        h[f].aspect = cameras[f].aspect_ratio;
+        h[f].sign = cameras[f].unproject_sign;
+    }
+    PC_HIP(hipMemcpyAsync(p->cams.p, h.data(), h.size() * sizeof(pc::RefineCamera), hipMemcpyHostToDevice, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));  // `h` is pageable and local
+    return PC_OK;
+}
+
+template <typename T, typename U>
+hipError_t upload(DevBuf<T>& dst, const U* src, size_t n, hipStream_t s) {
+    static_assert(sizeof(T) == sizeof(U) || sizeof(T) == 2 * sizeof(U), "layout");
+    hipError_t e = dst.ensure(n ? n : 1);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(dst.p, src, n * sizeof(T), hipMemcpyHostToDevice, s);
+    return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pc_refine_problem_create(pc_context* ctx, const pc_mesh* mesh, const pc_refine_desc* d, pc_refine_problem** out) {
+    if (!ctx || !mesh || !d || !out) return fail(PC_E_INVALID, "null argument");
+    *out = nullptr;
+    if (d->n_frames < 3) return fail(PC_E_INVALID, "a segment needs more than 2 frames");  // CHECK(traj.Count() > 2)
+    if (d->n_edges < 0 || (d->block_len != 6 && d->block_len != 9)) return fail(PC_E_INVALID, "bad problem description");
+    if (!d->kp_offset || !d->edge_offset || (d->n_edges > 0 && (!d->edge_src || !d->edge_tgt || !d->edge_weight)))
+        return fail(PC_E_INVALID, "null array");
+    const size_t n_kp = (size_t)d->kp_offset[d->n_frames], n_res = (size_t)d->edge_offset[d->n_edges];
+    for (int e = 0; e < d->n_edges; e++) {
+        if (d->edge_src[e] < 0 || d->edge_src[e] >= d->n_frames || d->edge_tgt[e] < 0 || d->edge_tgt[e] >= d->n_frames ||
+            d->edge_src[e] == d->edge_tgt[e])
+            return fail(PC_E_INVALID, "edge %d connects invalid frames", e);
+        const size_t src_kps = (size_t)(d->kp_offset[d->edge_src[e] + 1] - d->kp_offset[d->edge_src[e]]);
+        for (int r = d->edge_offset[e]; r < d->edge_offset[e + 1]; r++)
+            if (d->res_src_kp[r] >= src_kps) return fail(PC_E_INVALID, "edge %d references keypoint %u of %zu", e, d->res_src_kp[r], src_kps);
+    }
+    PC_HIP(hipSetDevice(ctx->device));
+    pc_refine_problem* p = new (std::nothrow) pc_refine_problem();
+    if (!p) return fail(PC_E_INVALID, "out of host memory");
+    p->ctx = ctx;
+    p->mesh = mesh;
+    p->n_frames = d->n_frames;
+    p->n_edges = d->n_edges;
+    p->block_len = d->block_len;
+    p->opt_f = d->optimize_focal_length ? 1 : 0;
+    p->opt_pp = d->optimize_principal_point ? 1 : 0;
+    p->n_kp = n_kp;
+    p->n_res = n_res;
+    std::memcpy(p->model, d->model_matrix, sizeof(p->model));
+    std::memcpy(p->model_inv, d->model_matrix_inv, sizeof(p->model_inv));
+    std::vector<uint8_t> fixed((size_t)d->n_frames, 0);
+    fixed.front() = fixed.back() = 1;  // IsGroundTruth (refiner.cc:268-271)
+    const int B2 = 2 * d->block_len, nacc = B2 * (B2 + 1) / 2 + B2;
+    hipStream_t s = ctx->stream;
+    hipError_t e = upload(p->kp_offset, d->kp_offset, (size_t)d->n_frames + 1, s);
+    if (e == hipSuccess) e = upload(p->kp_xy, d->kp_xy, n_kp, s);
+    if (e == hipSuccess) e = upload(p->edge_src, d->edge_src, (size_t)d->n_edges, s);
+    if (e == hipSuccess) e = upload(p->edge_tgt, d->edge_tgt, (size_t)d->n_edges, s);
+    if (e == hipSuccess) e = upload(p->edge_offset, d->edge_offset, (size_t)d->n_edges + 1, s);
+    if (e == hipSuccess) e = upload(p->res_src_kp, d->res_src_kp, n_res, s);
+    if (e == hipSuccess) e = upload(p->res_tgt_xy, d->res_tgt_xy, n_res, s);
+    if (e == hipSuccess) e = upload(p->edge_weight, d->edge_weight, (size_t)d->n_edges, s);
+    if (e == hipSuccess) e = upload(p->frame_fixed, fixed.data(), fixed.size(), s);
+    if (e == hipSuccess) e = p->prim_cache.ensure(n_kp ? n_kp : 1);
+    if (e == hipSuccess) e = hipMemsetAsync(p->prim_cache.p, 0xff, (n_kp ? n_kp : 1) * sizeof(uint32_t), s);
+    if (e == hipSuccess) e = p->edge_cost.ensure((size_t)std::max(1, d->n_edges));
+    if (e == hipSuccess) e = p->h_edge_cost.ensure((size_t)std::max(1, d->n_edges));
+    if (e == hipSuccess) e = p->edge_valid.ensure((size_t)std::max(1, d->n_edges));
+    if (e == hipSuccess) e = p->edge_blocks.ensure((size_t)std::max(1, d->n_edges) * nacc);
+    if (e == hipSuccess) e = p->cams.ensure((size_t)d->n_frames);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        pc_refine_problem_destroy(p);
+        return fail(PC_E_HIP, "refine problem upload failed: %s", hipGetErrorString(e));
+    }
+    p->h_edge_weight.assign(d->edge_weight, d->edge_weight + d->n_edges);
+    *out = p;
+    return PC_OK;
+}
+
+void pc_refine_problem_destroy(pc_refine_problem* p) {
+    if (!p) return;
+    if (p->ctx) {
+        (void)hipSetDevice(p->ctx->device);
+        (void)hipStreamSynchronize(p->ctx->stream);
+    }
+    p->kp_offset.release();
+    p->edge_src.release();
+    p->edge_tgt.release();
+    p->edge_offset.release();
+    p->edge_valid.release();
+    p->kp_xy.release();
+    p->res_tgt_xy.release();
+    p->edge_cost.release();
+    p->res_src_kp.release();
+    p->prim_cache.release();
+    p->edge_weight.release();
+    p->edge_blocks.release();
+    p->frame_fixed.release();
+    p->cams.release();
+    p->h_edge_cost.release();
+    delete p;
+}
+
+int pc_refine_total_cost(pc_context* ctx, pc_refine_problem* p, const pc_refine_camera* cameras, int loss_type,
+                         float loss_scale, double* cost) {
+    if (!ctx || !p || !cameras || !cost) return fail(PC_E_INVALID, "null argument");
+    if (loss_type < 0 || loss_type > 2) return fail(PC_E_INVALID, "Unknown loss type: %d", loss_type);
+    PC_HIP(hipSetDevice(ctx->device));
+    int rc = upload_cameras(ctx, p, cameras);
+    if (rc != PC_OK) return rc;
+    *cost = 0.0;
+    if (p->n_edges == 0) return PC_OK;
+    pc::launch_refine_cost(refine_view(p), p->cams.p, loss_type, loss_scale, p->edge_cost.p, ctx->stream);
+    PC_HIP(hipMemcpyAsync(p->h_edge_cost.p, p->edge_cost.p, (size_t)p->n_edges * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    // cost = sum_e edge_weight * (edge loss sum / valid)   (lev_marq.h:812-820), fixed edge order
+    double total = 0.0;
+    for (int e = 0; e < p->n_edges; e++) {
+        const float w = p->h_edge_weight[(size_t)e];
+        if (w == 0.0f) continue;
+        double edge_cost = p->h_edge_cost.p[e].x;
+        if (p->h_edge_cost.p[e].y > 0.0) edge_cost /= p->h_edge_cost.p[e].y;
+        total += (double)w * edge_cost;
+    }
+    *cost = total;
+    return PC_OK;
+}
+
+int pc_refine_normal_equations(pc_context* ctx, pc_refine_problem* p, const pc_refine_camera* cameras, int loss_type,
+                               float loss_scale, double* edge_blocks, int* edge_valid) {
+    if (!ctx || !p || !cameras || !edge_blocks) return fail(PC_E_INVALID, "null argument");
+    if (loss_type < 0 || loss_type > 2) return fail(PC_E_INVALID, "Unknown loss type: %d", loss_type);
+    PC_HIP(hipSetDevice(ctx->device));
+    int rc = upload_cameras(ctx, p, cameras);
+    if (rc != PC_OK) return rc;
+    if (p->n_edges == 0) return PC_OK;
+    const int B2 = 2 * p->block_len, nacc = B2 * (B2 + 1) / 2 + B2;
+    pc::launch_refine_normal_eq(refine_view(p), p->cams.p, loss_type, loss_scale, p->block_len, p->opt_f, p->opt_pp,
+                                p->edge_blocks.p, p->edge_valid.p, ctx->stream);
+    PC_HIP(hipMemcpyAsync(edge_blocks, p->edge_blocks.p, (size_t)p->n_edges * nacc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (edge_valid)
+        PC_HIP(hipMemcpyAsync(edge_valid, p->edge_valid.p, (size_t)p->n_edges * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    return PC_OK;
+}
+
 }  // extern "C"

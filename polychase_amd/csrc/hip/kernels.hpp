@@ -105,4 +105,37 @@ void launch_pnp_normal_eq(const float* X, const float* x, const float* w, int n,
 void launch_pnp_cost(const float* X, const float* x, const float* w, int n, const PnPParams& p, float max_err_sq,
                      float* partials, float* out4, hipStream_t s);
 
+
+// ---- kernels_refiner.hip ----
+struct RefineCamera {   // one frame of the trajectory
+    float R[9];
+    float t[3];
+    float fx, fy, cx, cy, aspect;
+    float sign;         // +1 OpenCV convention, -1 OpenGL (Unproject / IsBehind)
+};
+struct RefineProblemView {
+    int n_frames, n_edges, n_tris;
+    const int* kp_offset;          // [n_frames + 1]
+    const float2* kp_xy;           // keypoints of all frames
+    const int* edge_src;           // frame index of image_id_from
+    const int* edge_tgt;
+    const int* edge_offset;        // [n_edges + 1] into the residual arrays
+    const uint32_t* res_src_kp;    // keypoint index within the source frame
+    const float2* res_tgt_xy;
+    const float* edge_weight;
+    const uint8_t* frame_fixed;    // first / last frame of the segment: no Jacobian (refiner.cc:611-612)
+    uint32_t* prim_cache;          // per keypoint: cached triangle or 0xffffffff (refiner.cc:547-559)
+    const float* verts;
+    const uint32_t* tris;
+    const uint32_t* mask;
+    float model[16], model_inv[16];
+};
+// edge_out[e] = {sum of losses over valid residuals, valid count}, accumulated in fp64
+void launch_refine_cost(const RefineProblemView& P, const RefineCamera* cams, int loss_type, float loss_scale,
+                        double2* edge_out, hipStream_t s);
+// edge_blocks[e]: lower triangle of the (2B x 2B) JtJ pair block (row-major packed) followed by the 2B
+// Jtr pair vector (fp32 Jacobians, fp64 sums), normalised by the edge's valid count; edge_valid[e] = that count
+void launch_refine_normal_eq(const RefineProblemView& P, const RefineCamera* cams, int loss_type, float loss_scale,
+                             int block_len, int opt_f, int opt_pp, double* edge_blocks, int* edge_valid, hipStream_t s);
+
 }  // namespace pc

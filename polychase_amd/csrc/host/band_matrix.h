@@ -1,0 +1,69 @@
+// band_matrix.h -- symmetric positive definite band matrix with an in-place Cholesky (fp64: the reference factorises in fp32, which
+// loses the low-frequency modes of long chains).  J^T J of
+// the refiner is block-banded (a frame only shares residuals with frames a few steps away), so this
+// replaces Eigen::SimplicialLLT of the reference (cpp/pnp/lev_marq.h:394-397, :826-842).
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+// lower band stored row by row: row r holds columns r - bw ... r
+class BandMatrix {
+   public:
+    BandMatrix(int n, int half_bandwidth) : n_(n), bw_(half_bandwidth), v_(static_cast<size_t>(n) * (half_bandwidth + 1), 0.0) {}
+    int Size() const { return n_; }
+    double& At(int r, int c) { return v_[static_cast<size_t>(r) * (bw_ + 1) + (c - r + bw_)]; }  // r - bw <= c <= r
+    double At(int r, int c) const { return v_[static_cast<size_t>(r) * (bw_ + 1) + (c - r + bw_)]; }
+    void SetZero() { std::fill(v_.begin(), v_.end(), 0.0); }
+
+    // y = A x with A symmetric (selfadjointView<Lower>)
+    void Multiply(const std::vector<double>& x, std::vector<double>& y) const {
+        y.assign(static_cast<size_t>(n_), 0.0);
+        for (int r = 0; r < n_; r++) {
+            double s = At(r, r) * x[r];
+            for (int c = std::max(0, r - bw_); c < r; c++) {
+                const double a = At(r, c);
+                s += a * x[c];
+                y[c] += a * x[r];
+            }
+            y[r] += s;
+        }
+    }
+    // in-place Cholesky A = L L^T; false if a pivot is not positive
+    bool Factorize() {
+        for (int r = 0; r < n_; r++) {
+            const int c0 = std::max(0, r - bw_);
+            for (int c = c0; c <= r; c++) {
+                double s = At(r, c);
+                for (int k = std::max(c0, c - bw_); k < c; k++) s -= At(r, k) * At(c, k);
+                if (c < r) {
+                    At(r, c) = s / At(c, c);
+                } else {
+                    if (!(s > 0.0) || !std::isfinite(s)) return false;
+                    At(r, r) = std::sqrt(s);
+                }
+            }
+        }
+        return true;
+    }
+    // x = (L L^T)^-1 b
+    void Solve(const std::vector<double>& b, std::vector<double>& x) const {
+        x = b;
+        for (int r = 0; r < n_; r++) {
+            double s = x[r];
+            for (int c = std::max(0, r - bw_); c < r; c++) s -= At(r, c) * x[c];
+            x[r] = s / At(r, r);
+        }
+        for (int r = n_ - 1; r >= 0; r--) {
+            const double xr = x[r] / At(r, r);
+            x[r] = xr;
+            for (int c = std::max(0, r - bw_); c < r; c++) x[c] -= At(r, c) * xr;
+        }
+    }
+
+   private:
+    int n_, bw_;
+    std::vector<double> v_;
+};
+

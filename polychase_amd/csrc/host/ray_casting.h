@@ -20,6 +20,7 @@ class AcceleratedMesh {
 
     const Mesh& Inner() const { return mesh_; }
     Mesh& InnerMut() { return mesh_; }
+    pc_mesh* Gpu() const { return gpu_; }
 
     // Batched RayCast(accel_mesh, scene_transform, pos, check_mask): hits[i] is empty on a miss.
     void RayCastPixels(const SceneTransformations& scene_transform, const float* xy, size_t n, bool check_mask,

@@ -4,8 +4,10 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include "../host/band_matrix.h"
 #include "../host/pnp.h"
 #include "../host/ray_casting.h"
+#include "../host/refining_thread.h"
 #include "../host/track_sequence.h"
 #include "../host/tracking_thread.h"
 #include "np_helpers.h"
@@ -29,11 +31,6 @@ struct PinUpdate {  // cpp/pin_mode.h (out of scope: only the type is kept impor
     Vec2f pos;
 };
 enum class TransformationType { Camera, Model };
-struct RefineTrajectoryUpdate {
-    float progress = 0;
-    std::string message;
-    BundleStats stats;
-};
 
 [[noreturn]] void NotInThisBuild(const char* what) {
     throw std::runtime_error(std::string(what) +
@@ -236,10 +233,18 @@ void BindTracker(py::module_& m) {
         .def_readwrite("message", &RefineTrajectoryUpdate::message)
         .def_readwrite("stats", &RefineTrajectoryUpdate::stats);
 
-    struct RefinerThreadStub {};
-    py::class_<RefinerThreadStub>(m, "RefinerThread").def(py::init([](py::args, py::kwargs) -> RefinerThreadStub {
-        NotInThisBuild("RefinerThread (refine sequence)");
-    }));
+    py::class_<RefinerThread>(m, "RefinerThread")
+        .def(py::init([](std::string database_path, std::shared_ptr<CameraTrajectory> traj, const F32Array& model_matrix,
+                         std::shared_ptr<const AcceleratedMesh> mesh, bool opt_f, bool opt_pp, BundleOptions bundle_opts) {
+                 return std::make_unique<RefinerThread>(std::move(database_path), std::move(traj), NumpyToMat4(model_matrix),
+                                                        std::move(mesh), opt_f, opt_pp, bundle_opts);
+             }),
+             py::arg("database_path"), py::arg("camera_trajectory"), py::arg("model_matrix"), py::arg("mesh"),
+             py::arg("optimize_focal_length"), py::arg("optimize_principal_point"), py::arg("bundle_opts"))
+        .def("request_stop", &RefinerThread::RequestStop)
+        .def("join", &RefinerThread::Join, py::call_guard<py::gil_scoped_release>())
+        .def("try_pop", &RefinerThread::TryPop)
+        .def("empty", &RefinerThread::Empty);
 
     m.def(
         "ray_cast",
@@ -249,7 +254,23 @@ void BindTracker(py::module_& m) {
         py::arg("accel_mesh"), py::arg("scene_transform"), py::arg("pos"), py::arg("check_mask"));
 
     m.def("find_transformation", [](py::args, py::kwargs) { NotInThisBuild("find_transformation (pin mode)"); });
-    m.def("refine_trajectory", [](py::args, py::kwargs) { NotInThisBuild("refine_trajectory"); });
+    m.def(
+        "refine_trajectory",
+        [](const std::string& database_path, CameraTrajectory& traj, const F32Array& model_matrix, const AcceleratedMesh& mesh,
+           bool opt_f, bool opt_pp, py::object callback, BundleOptions bundle_opts) {
+            RefineTrajectoryCallback cb;
+            if (!callback.is_none())
+                cb = [&](RefineTrajectoryUpdate u) {
+                    py::gil_scoped_acquire gil;
+                    return callback(std::move(u)).cast<bool>();
+                };
+            const Mat4f model = NumpyToMat4(model_matrix);
+            py::gil_scoped_release release;  // polychase_pybind.cc:347
+            RefineTrajectory(database_path, traj, model, mesh, opt_f, opt_pp, cb, bundle_opts);
+        },
+        py::arg("database_path"), py::arg("camera_trajectory"), py::arg("model_matrix"), py::arg("mesh"),
+        py::arg("optimize_focal_length"), py::arg("optimize_principal_point"), py::arg("callback"),
+        py::arg("bundle_opts") = BundleOptions());
 
     m.def(
         "track_sequence",
@@ -268,6 +289,46 @@ void BindTracker(py::module_& m) {
         py::arg("database_path"), py::arg("frame_from"), py::arg("frame_to_inclusive"), py::arg("scene_transform"),
         py::arg("accel_mesh"), py::arg("callback"), py::arg("optimize_focal_length") = false,
         py::arg("optimize_principal_point") = false, py::arg("bundle_opts") = BundleOptions());
+
+    // Not in the reference's module: the refiner's cost and normal equations at a trajectory, and the banded
+    // Cholesky solve it uses (tests).
+    m.def(
+        "_refinement_system",
+        [](const std::string& database_path, const CameraTrajectory& traj, const F32Array& model_matrix,
+           const AcceleratedMesh& mesh, bool opt_f, bool opt_pp, BundleOptions bundle_opts) {
+            const RefinementSystem sys = EvaluateRefinementSystem(database_path, traj, NumpyToMat4(model_matrix), mesh, opt_f,
+                                                                  opt_pp, bundle_opts);
+            py::array_t<float> JtJ({sys.num_params, sys.num_params});
+            std::memcpy(JtJ.mutable_data(), sys.JtJ.data(), sys.JtJ.size() * sizeof(float));
+            py::array_t<float> Jtr(sys.num_params);
+            std::memcpy(Jtr.mutable_data(), sys.Jtr.data(), sys.Jtr.size() * sizeof(float));
+            py::dict d;
+            d["cost"] = sys.cost;
+            d["JtJ"] = JtJ;
+            d["Jtr"] = Jtr;
+            d["block_length"] = sys.block_length;
+            d["num_edges"] = sys.num_edges;
+            d["num_residuals"] = sys.num_residuals;
+            d["num_keypoints"] = sys.num_keypoints;
+            return d;
+        },
+        py::arg("database_path"), py::arg("camera_trajectory"), py::arg("model_matrix"), py::arg("mesh"),
+        py::arg("optimize_focal_length"), py::arg("optimize_principal_point"), py::arg("bundle_opts") = BundleOptions());
+    m.def(
+        "_banded_llt_solve",
+        [](const F32Array& A, int half_bandwidth, const F32Array& b) -> py::object {
+            const int n = static_cast<int>(A.shape(0));
+            BandMatrix M(n, half_bandwidth);
+            for (int r = 0; r < n; r++)
+                for (int c = std::max(0, r - half_bandwidth); c <= r; c++) M.At(r, c) = A.at(r, c);
+            if (!M.Factorize()) return py::none();
+            std::vector<double> rhs(b.data(), b.data() + n), x;
+            M.Solve(rhs, x);
+            py::array_t<double> out(n);
+            std::memcpy(out.mutable_data(), x.data(), n * sizeof(double));
+            return out;
+        },
+        py::arg("A"), py::arg("half_bandwidth"), py::arg("b"));
 
     // Not in the reference's module: direct access to SolvePnPIterative (cpp/pnp/solvers.h:22-29) and to the
     // batched ray cast, for tests and benchmarks.
