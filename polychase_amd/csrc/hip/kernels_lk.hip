@@ -52,7 +52,7 @@ __device__ __forceinline__ float group_exact_sum(int partial) {
 
 struct Weights {
     int w00, w01, w10, w11;   // w11 may be -1 (rounding of the other three), never smaller
-    uint32_t lo4, hi4;        // u8 lanes of (w & 127) and (w >> 7), w11 clamped at 0
+    uint32_t r0, r1;          // signed 16-bit pairs (w00, w01) and (w10, w11) for v_dot2_i32_i16
     bool neg11;
 };
 __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
@@ -62,28 +62,51 @@ __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
     w.w10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
     w.w11 = (1 << W_BITS) - w.w00 - w.w01 - w.w10;
     w.neg11 = w.w11 < 0;
-    const int c11 = w.neg11 ? 0 : w.w11;
-    w.lo4 = (uint32_t)(w.w00 & 127) | ((uint32_t)(w.w01 & 127) << 8) | ((uint32_t)(w.w10 & 127) << 16) |
-            ((uint32_t)(c11 & 127) << 24);
-    w.hi4 = (uint32_t)(w.w00 >> 7) | ((uint32_t)(w.w01 >> 7) << 8) | ((uint32_t)(w.w10 >> 7) << 16) |
-            ((uint32_t)(c11 >> 7) << 24);
+    w.r0 = (uint32_t)w.w00 | ((uint32_t)w.w01 << 16);             // 0 <= w00, w01, w10 <= 2^14
+    w.r1 = (uint32_t)w.w10 | ((uint32_t)w.w11 << 16);             // w11 == -1 -> 0xffff in the high half
     return w;
-}
-// CV_DESCALE(sum_t tap_t * w_t, W_BITS - 5) of the 4 taps packed in j4 = (p00, p01, p10, p11).
-// NEG: w11 == -1 (possible when the three rounded weights sum to 2^14 + 1); handled by a separate
-// instantiation selected once per window, not per pixel.
-template <bool NEG>
-__device__ __forceinline__ int interp4(uint32_t j4, const Weights& w) {
-    const uint32_t lo = __builtin_amdgcn_udot4(j4, w.lo4, 1u << (W_BITS - 5 - 1), false);
-    const uint32_t hi = __builtin_amdgcn_udot4(j4, w.hi4, 0u, false);
-    uint32_t s = lo + (hi << 7);
-    if (NEG) s -= (j4 >> 24);
-    return (int)(s >> (W_BITS - 5));
 }
 
 typedef short pc_short2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(pc_short2, a), __builtin_bit_cast(pc_short2, b), c, false);
+}
+
+// (A[c], A[c+1]) read as one u16 -> the same two values as 16-bit lanes of a dword
+__device__ __forceinline__ uint32_t widen_pair(uint32_t pair) { return __builtin_amdgcn_perm(0u, pair, 0x0c010c00u); }
+// CV_DESCALE(sum_t tap_t * w_t, W_BITS - 5) of the taps (p00, p01) = top, (p10, p11) = bot: two
+// v_dot2_i32_i16 with the signed weights (so w11 == -1 needs no special case); the sum is >= 1.
+__device__ __forceinline__ int interp_pairs(uint32_t top, uint32_t bot, const Weights& w) {
+    return sdot2(bot, w.r1, sdot2(top, w.r0, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+}
+// interp_pairs(top, bot, w) - ival with the subtraction folded into the accumulator:
+// bias = 2^(W_BITS-6) - ival * 2^(W_BITS-5), and floor((S - 512 i) / 512) == floor(S / 512) - i.
+// The first dot product asks for the clamping form: nothing here can saturate (|S| < 2^23), but that
+// form is the three-address VOP3P encoding, which leaves `bias` intact without a copy (the
+// two-address v_dot2c the compiler otherwise picks needs a v_mov per pixel).
+__device__ __forceinline__ int interp_diff(uint32_t top, uint32_t bot, const Weights& w, int bias) {
+    const int t = __builtin_amdgcn_sdot2(__builtin_bit_cast(pc_short2, top), __builtin_bit_cast(pc_short2, w.r0), bias, true);
+    return sdot2(bot, w.r1, t) >> (W_BITS - 5);
+}
+__device__ __forceinline__ int ival_bias(int ival) { return (1 << (W_BITS - 5 - 1)) - (ival << (W_BITS - 5)); }
+// acc + (int16)a * (int16)b.lo / b.hi in one instruction (v_mad_i32_i16, op_sel picks the half)
+__device__ __forceinline__ int mad16_lo(int a, uint32_t b, int acc) {
+    int d;
+    asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ int mad16_hi(int a, uint32_t b, int acc) {
+    int d;
+    asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[0,1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+    return d;
+}
+// Sum over an 8-lane group of per-lane partials with |partial| < 2^29, as ONE rounding of the exact
+// integer: quad sums stay below 2^31, the two quads are added exactly in fp64.
+__device__ __forceinline__ float group8_exact_sum_small(int partial) {
+    int v = partial + dpp_i32<0xB1>(partial);
+    v += dpp_i32<0x4E>(v);
+    const int other = dpp_i32<0x141>(v);
+    return (float)((double)v + (double)other);
 }
 
 template <int WIN>
@@ -139,13 +162,41 @@ __device__ __forceinline__ void stage_pairs(const uint8_t* __restrict__ img, int
     }
 }
 
+// The same staging for a region that lies inside the padded plane, with the (row, dword) walk done
+// on running pointers: no multiplication and no clamping per item.
+template <int WIN, int NL>
+__device__ __forceinline__ void stage_pairs_inside(const uint8_t* __restrict__ img, int pitch, int rx0, int ry0, int nrows,
+                                                   uint8_t* buf, int l) {
+    using G = LKGeo<WIN>;
+    constexpr int DR = NL / G::RW_DW, DM = NL % G::RW_DW;   // one trip advances DR rows and DM dwords
+    const int total = nrows * G::RW_DW;
+    int r = l / G::RW_DW, m = l - r * G::RW_DW;
+    const uint8_t* src = img + (ptrdiff_t)((ry0 + r) * pitch) + (rx0 + 4 * m);
+    uint8_t* dst = buf + r * G::PAIR_PITCH + 8 * m;
+    const int src_step = DR * pitch + 4 * DM, src_wrap = pitch - 4 * G::RW_DW;
+    constexpr int dst_step = DR * G::PAIR_PITCH + 8 * DM, dst_wrap = G::PAIR_PITCH - 8 * G::RW_DW;
+#pragma unroll 1
+    for (int i = l; i < total; i += NL) {
+        const uint32_t d0 = *reinterpret_cast<const uint32_t*>(src);
+        const uint32_t d1 = *reinterpret_cast<const uint32_t*>(src + 4);
+        const uint32_t p0 = __builtin_amdgcn_perm(d1, d0, 0x02010100u);  // (A0,A1),(A1,A2)
+        const uint32_t p1 = __builtin_amdgcn_perm(d1, d0, 0x04030302u);  // (A2,A3),(A3,A4)
+        *reinterpret_cast<uint2*>(dst) = make_uint2(p0, p1);
+        m += DM;
+        const bool wrap = m >= G::RW_DW;
+        m -= wrap ? G::RW_DW : 0;
+        src += src_step + (wrap ? src_wrap : 0);
+        dst += dst_step + (wrap ? dst_wrap : 0);
+    }
+}
+
 template <int WIN, int NL>
 __device__ __forceinline__ void stage_pairs_auto(const uint8_t* __restrict__ img, int pitch, int lh, int rx0, int ry0,
                                                  int nrows, uint8_t* buf, int l) {
     using G = LKGeo<WIN>;
     const bool inside = (ry0 >= -WIN) && (ry0 + nrows <= lh + WIN) && (rx0 >= -kPadX) &&
                         (rx0 + G::RWB + 4 <= pitch - kPadX);
-    if (inside) stage_pairs<WIN, NL, false>(img, pitch, lh, rx0, ry0, nrows, buf, l);
+    if (inside) stage_pairs_inside<WIN, NL>(img, pitch, rx0, ry0, nrows, buf, l);
     else stage_pairs<WIN, NL, true>(img, pitch, lh, rx0, ry0, nrows, buf, l);
 }
 
@@ -243,8 +294,7 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
         }
         const Weights wI = bilinear_weights(px - (float)ipx, py - (float)ipy);
         // signed 16-bit weight pairs for the derivative taps: (w00, w01) and (w10, w11)
-        const uint32_t wrow0 = (uint32_t)(wI.w00 & 0xffff) | ((uint32_t)wI.w01 << 16);
-        const uint32_t wrow1 = (uint32_t)(wI.w10 & 0xffff) | ((uint32_t)wI.w11 << 16);
+        const uint32_t wrow0 = wI.r0, wrow1 = wI.r1;
 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         stage_pairs_auto<WIN, 64>(L.img, pitch, L.h, ipx & ~3, ipy, WIN + 1, ibuf, lane);
@@ -265,8 +315,7 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
                 if (q < NPX) {
                     const int y = q / WIN, x = q - y * WIN;
                     const uint16_t* qp = reinterpret_cast<const uint16_t*>(ib + y * G::PAIR_PITCH + 2 * x);
-                    const uint32_t i4 = (uint32_t)qp[0] | ((uint32_t)qp[G::RWB] << 16);
-                    const int ival = wI.neg11 ? interp4<true>(i4, wI) : interp4<false>(i4, wI);
+                    const int ival = interp_pairs(widen_pair(qp[0]), widen_pair(qp[G::RWB]), wI);
                     const uint32_t* d = reinterpret_cast<const uint32_t*>(dbuf) + y * G::D_PITCH + x;
                     const uint32_t d00 = d[0], d01 = d[1], d10 = d[G::D_PITCH], d11 = d[G::D_PITCH + 1];
                     // (dx00, dx01), (dx10, dx11), (dy00, dy01), (dy10, dy11)
@@ -300,18 +349,18 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
 
         // every group picks up the pixels it owns
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        int Ival[KM + KE];
+        int Ival[KM + KE];  // ival_bias(I patch value): the accumulator init of interp_diff
         int Dxy[KM + KE];  // (int16 ix) | (int16 iy << 16); 0 for slots without a pixel
 #pragma unroll
         for (int k = 0; k < KM; k++) {
             const uint2 v = main_valid ? *reinterpret_cast<const uint2*>(xbuf + 2 * (k * WIN + lg)) : make_uint2(0u, 0u);
-            Ival[k] = (int)v.x;
+            Ival[k] = ival_bias((int)v.x);
             Dxy[k] = (int)v.y;
         }
 #pragma unroll
         for (int e = 0; e < KE; e++) {
             const uint2 v = (qE[e] >= 0) ? *reinterpret_cast<const uint2*>(xbuf + 2 * qE[e]) : make_uint2(0u, 0u);
-            Ival[KM + e] = (int)v.x;
+            Ival[KM + e] = ival_bias((int)v.x);
             Dxy[KM + e] = (int)v.y;
         }
 
@@ -337,33 +386,36 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
             }
             const Weights wJ = bilinear_weights(qx - (float)iqx, qy - (float)iqy);
             const uint8_t* jb = jbuf + (iqy - ry0) * G::PAIR_PITCH + 2 * (iqx - rx0);
-            int sb1 = 0, sb2 = 0;  // per-lane partials: <= K * 8160 * 4080 < 2^31
-            // b1 += diff * ix, b2 += diff * iy as two v_dot2_i32_i16 on the packed (ix, iy):
-            // (diff, 0) . (ix, iy) and (0, diff) . (ix, iy).  Slots without a pixel have Dxy == 0.
-#define PC_LK_ACCUM(NEGFLAG)                                                                          \
-    {                                                                                                 \
-        const uint8_t* cb = jb + 2 * lg;                                                              \
-        uint32_t top = *reinterpret_cast<const uint16_t*>(cb);                                        \
-        _Pragma("unroll") for (int k = 0; k < KM; k++) {                                              \
-            const uint32_t bot = *reinterpret_cast<const uint16_t*>(cb + (k + 1) * G::PAIR_PITCH);    \
-            const uint32_t j4 = top | (bot << 16);                                                    \
-            top = bot;                                                                                \
-            const uint32_t diff = (uint32_t)(interp4<NEGFLAG>(j4, wJ) - Ival[k]);                     \
-            sb1 = sdot2(diff & 0xffffu, (uint32_t)Dxy[k], sb1);                                       \
-            sb2 = sdot2(diff << 16, (uint32_t)Dxy[k], sb2);                                           \
-        }                                                                                             \
-        _Pragma("unroll") for (int e = 0; e < KE; e++) {                                              \
-            const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offE[e]);                      \
-            const uint32_t j4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);                         \
-            const uint32_t diff = (uint32_t)(interp4<NEGFLAG>(j4, wJ) - Ival[KM + e]);                \
-            sb1 = sdot2(diff & 0xffffu, (uint32_t)Dxy[KM + e], sb1);                                  \
-            sb2 = sdot2(diff << 16, (uint32_t)Dxy[KM + e], sb2);                                      \
-        }                                                                                             \
-    }
-            if (__builtin_expect(!wJ.neg11, 1)) PC_LK_ACCUM(false) else PC_LK_ACCUM(true)
-#undef PC_LK_ACCUM
-            const float b1 = group_exact_sum<GL>(sb1) * FLT_SCALE;
-            const float b2 = group_exact_sum<GL>(sb2) * FLT_SCALE;
+            int sb1 = 0, sb2 = 0;  // per-lane partials: <= K * 8160 * 4080
+            // b1 += diff * ix, b2 += diff * iy: |diff| <= 8160 fits int16, (ix, iy) are the halves of Dxy
+            // (slots without a pixel have Dxy == 0)
+            {
+                const uint8_t* cb = jb + 2 * lg;
+                uint32_t top = widen_pair(*reinterpret_cast<const uint16_t*>(cb));
+#pragma unroll
+                for (int k = 0; k < KM; k++) {
+                    const uint32_t bot = widen_pair(*reinterpret_cast<const uint16_t*>(cb + (k + 1) * G::PAIR_PITCH));
+                    const int diff = interp_diff(top, bot, wJ, Ival[k]);
+                    top = bot;
+                    sb1 = mad16_lo(diff, (uint32_t)Dxy[k], sb1);
+                    sb2 = mad16_hi(diff, (uint32_t)Dxy[k], sb2);
+                }
+#pragma unroll
+                for (int e = 0; e < KE; e++) {
+                    const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offE[e]);
+                    const int diff = interp_diff(widen_pair(q[0]), widen_pair(q[G::RWB]), wJ, Ival[KM + e]);
+                    sb1 = mad16_lo(diff, (uint32_t)Dxy[KM + e], sb1);
+                    sb2 = mad16_hi(diff, (uint32_t)Dxy[KM + e], sb2);
+                }
+            }
+            float b1, b2;
+            if constexpr ((long long)K * 8160 * 4080 < (1ll << 29)) {
+                b1 = group8_exact_sum_small(sb1) * FLT_SCALE;
+                b2 = group8_exact_sum_small(sb2) * FLT_SCALE;
+            } else {
+                b1 = group_exact_sum<GL>(sb1) * FLT_SCALE;
+                b2 = group_exact_sum<GL>(sb2) * FLT_SCALE;
+            }
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             qx += dx;
@@ -401,22 +453,18 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
             int se = 0;
             {
                 const uint8_t* cb = jb + 2 * lg;
-                uint32_t top = *reinterpret_cast<const uint16_t*>(cb);
+                uint32_t top = widen_pair(*reinterpret_cast<const uint16_t*>(cb));
 #pragma unroll
                 for (int k = 0; k < KM; k++) {
-                    const uint32_t bot = *reinterpret_cast<const uint16_t*>(cb + (k + 1) * G::PAIR_PITCH);
-                    const uint32_t j4 = top | (bot << 16);
+                    const uint32_t bot = widen_pair(*reinterpret_cast<const uint16_t*>(cb + (k + 1) * G::PAIR_PITCH));
+                    const int diff = interp_diff(top, bot, wE, Ival[k]);
                     top = bot;
-                    const int val = wE.neg11 ? interp4<true>(j4, wE) : interp4<false>(j4, wE);
-                    const int diff = val - Ival[k];
                     se += main_valid ? (diff < 0 ? -diff : diff) : 0;
                 }
 #pragma unroll
                 for (int e = 0; e < KE; e++) {
                     const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offE[e]);
-                    const uint32_t j4 = (uint32_t)q[0] | ((uint32_t)q[G::RWB] << 16);
-                    const int val = wE.neg11 ? interp4<true>(j4, wE) : interp4<false>(j4, wE);
-                    const int diff = val - Ival[KM + e];
+                    const int diff = interp_diff(widen_pair(q[0]), widen_pair(q[G::RWB]), wE, Ival[KM + e]);
                     se += (qE[e] >= 0) ? (diff < 0 ? -diff : diff) : 0;
                 }
             }
