@@ -16,6 +16,7 @@ one RCCL all-gather at the end, inside the timed region.  scaling = "weak".
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -84,7 +85,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=20)   # > 17 + 2 ring slots: every slot has been used once
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist-path", action="store_true",
@@ -149,6 +150,10 @@ def main():
     barrier()
     ctx.enable_timing(["lk"])   # HIP events around the dominant kernel only (2 records per step)
     ctx.reset_timing()
+    # the Python driver loop must not stall the GPU pipeline: a generation-2 collection pauses this process for
+    # 50-90 ms (the C++ driver of polychase_core has no such pauses)
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     an.run(range(f1_first + W, f1_first + W + K), sink, copy=False)
     if dist_path:
@@ -161,6 +166,7 @@ def main():
             gathered, sizes = log[:used][None], [used]
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     timing = ctx.timing()
     ctx.enable_timing(False)
     if dist_path:

@@ -18,7 +18,8 @@ struct ScopedTimer {
     pc_context* c;
     int cls;
     hipEvent_t a = nullptr, b = nullptr;
-    ScopedTimer(pc_context* ctx, int k) : c(ctx), cls(k) {
+    hipStream_t s = nullptr;
+    ScopedTimer(pc_context* ctx, int k, hipStream_t on = nullptr) : c(ctx), cls(k), s(on ? on : ctx->work) {
         if (!(c->timing_mask & (1u << k))) return;
         auto get = [&]() {
             hipEvent_t e = nullptr;
@@ -32,17 +33,18 @@ struct ScopedTimer {
         };
         a = get();
         b = get();
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, s);
     }
     ~ScopedTimer() {
         if (!a) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, s);
         c->ranges.push_back({cls, a, b});
     }
 };
 
 int collect_timing(pc_context* c) {
     if (c->ranges.empty()) return PC_OK;
+    PC_HIP(hipStreamSynchronize(c->prep_stream));
     PC_HIP(hipStreamSynchronize(c->stream));
     for (auto& r : c->ranges) {
         float ms = 0.f;
@@ -80,7 +82,7 @@ int ensure_kp_capacity(pc_frame* f, int n) {
     if (f->d_kps) (void)hipFree(f->d_kps);
     f->d_kps = nullptr;
     f->kp_cap = 0;
-    const int want = n + n / 4 + 1024;
+    const int want = n + n / 2 + 1024;
     PC_HIP(hipMalloc(reinterpret_cast<void**>(&f->d_kps), (size_t)want * sizeof(float2)));
     f->kp_cap = want;
     return PC_OK;
@@ -90,9 +92,9 @@ int ensure_kp_capacity(pc_frame* f, int n) {
 void build_pyramid(pc_context* c, pc_frame* f) {
     ScopedTimer t(c, PC_K_PYRAMID);
     for (int l = 0; l < f->nlevels; l++) {
-        if (l > 0) pc::launch_pyrdown(f->levels[l - 1], f->levels[l], c->stream);
-        pc::launch_border(f->levels[l], f->win, c->stream);
-        pc::launch_scharr(f->levels[l], c->stream);
+        if (l > 0) pc::launch_pyrdown(f->levels[l - 1], f->levels[l], c->work);
+        pc::launch_border(f->levels[l], f->win, c->work);
+        pc::launch_scharr(f->levels[l], c->work);
     }
 }
 
@@ -138,34 +140,34 @@ int detect_phase_a(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const
     if (suppress && ctx->sup_min_distance != opt.min_distance) {
         const std::vector<int2> offs = suppression_offsets(opt.min_distance);
         PC_HIP(ctx->sup_offsets.ensure(offs.size() + 1));
-        PC_HIP(hipStreamSynchronize(ctx->stream));  // a queued suppression may still read the old table
+        PC_HIP(hipStreamSynchronize(ctx->work));  // a queued suppression may still read the old table
         PC_HIP(hipMemcpy(ctx->sup_offsets.p, offs.data(), offs.size() * sizeof(int2), hipMemcpyHostToDevice));
         ctx->n_sup_offsets = (int)offs.size();
         ctx->sup_min_distance = opt.min_distance;
     }
-    PC_HIP(hipMemsetAsync(d.counters.p, 0, (kCounterCells + pc::kMaxGridCells) * sizeof(uint32_t), ctx->stream));
+    PC_HIP(hipMemsetAsync(d.counters.p, 0, (kCounterCells + pc::kMaxGridCells) * sizeof(uint32_t), ctx->work));
     uint32_t* cell_max = d.counters.p + kCounterCells;
     {
         ScopedTimer t(ctx, PC_K_MINEIG);
-        pc::launch_min_eig(f->levels[0], ctx->eig.p, grid, cell_max, ctx->stream);
+        pc::launch_min_eig(f->levels[0], ctx->eig.p, grid, cell_max, ctx->work);
     }
     ctx->eig_owner = f;
     {
         ScopedTimer t(ctx, PC_K_NMS);
         pc::launch_nms_compact(ctx->eig.p, w, h, grid, cell_max, opt.quality_level, d.keys_in.p, (uint32_t)npx,
-                               d.counters.p, ctx->cmap.p, ctx->state.p, ctx->stream);
+                               d.counters.p, ctx->cmap.p, ctx->state.p, ctx->work);
     }
     {
         ScopedTimer t(ctx, PC_K_SUPPRESS);
         if (suppress)
             pc::launch_suppress(d.keys_in.p, d.counters.p, (uint32_t)npx, w, h, ctx->cmap.p, ctx->state.p,
                                 ctx->sup_offsets.p, ctx->n_sup_offsets, d.counters.p + 2, ctx->resident_blocks,
-                                ctx->stream);
+                                ctx->work);
         pc::launch_collect_accepted(d.keys_in.p, d.counters.p, (uint32_t)npx, ctx->state.p, suppress ? 0 : 1,
-                                    d.acc_keys.p, d.counters.p + 1, ctx->stream);
+                                    d.acc_keys.p, d.counters.p + 1, ctx->work);
     }
-    PC_HIP(hipMemcpyAsync(d.h_counters.p, d.counters.p, kCounterCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    PC_HIP(hipEventRecord(d.ev, ctx->stream));
+    PC_HIP(hipMemcpyAsync(d.h_counters.p, d.counters.p, kCounterCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
+    PC_HIP(hipEventRecord(d.ev, ctx->work));
     return PC_OK;
 }
 
@@ -183,18 +185,57 @@ int detect_phase_b(pc_context* ctx, pc_frame* f, const pc_gftt_options& opt, Det
     if (n > 0) {
         PC_HIP(ctx->keys_out.ensure(n_acc));
         size_t temp_bytes = 0;
-        PC_HIP(pc::sort_keys_desc(nullptr, temp_bytes, d.acc_keys.p, ctx->keys_out.p, n_acc, ctx->stream));
+        PC_HIP(pc::sort_keys_desc(nullptr, temp_bytes, d.acc_keys.p, ctx->keys_out.p, n_acc, ctx->work));
         PC_HIP(ctx->sort_temp.ensure(temp_bytes));
         {
             ScopedTimer t(ctx, PC_K_SORT);
-            PC_HIP(pc::sort_keys_desc(ctx->sort_temp.p, temp_bytes, d.acc_keys.p, ctx->keys_out.p, n_acc, ctx->stream));
+            PC_HIP(pc::sort_keys_desc(ctx->sort_temp.p, temp_bytes, d.acc_keys.p, ctx->keys_out.p, n_acc, ctx->work));
         }
         if (opt.max_corners > 0) n = std::min(n, opt.max_corners);
         int rc = ensure_kp_capacity(f, n);
         if (rc != PC_OK) return rc;
-        pc::launch_keys_to_xy(ctx->keys_out.p, n, f->w, f->d_kps, ctx->stream);
+        pc::launch_keys_to_xy(ctx->keys_out.p, n, f->w, f->d_kps, ctx->work);
     }
     f->n_kps = n;
+    f->perm_valid = false;
+    return PC_OK;
+}
+
+// Stage-level entry points share scratch buffers with work the analyzer queued on prep_stream:
+// order `stream` after it.
+int join_prep(pc_context* ctx) {
+    if (!ctx->prep_dirty) return PC_OK;
+    PC_HIP(hipEventRecord(ctx->prep_fence, ctx->prep_stream));
+    PC_HIP(hipStreamWaitEvent(ctx->stream, ctx->prep_fence, 0));
+    ctx->prep_dirty = false;
+    return PC_OK;
+}
+
+struct PrepScope {   // image / detection helpers enqueue on prep_stream while one of these is alive
+    pc_context* c;
+    explicit PrepScope(pc_context* ctx) : c(ctx) {
+        c->work = c->prep_stream;
+        c->prep_dirty = true;
+    }
+    ~PrepScope() { c->work = c->stream; }
+};
+
+// LK visiting order of the frame's keypoints (counting sort by 64x64 tile) on the current work stream
+int order_keypoints_spatially(pc_context* ctx, pc_frame* f, DevBuf<uint32_t>& hist) {
+    const int n = f->n_kps;
+    f->perm_valid = false;
+    if (n <= 0) return PC_OK;
+    if (f->perm_cap < n) {
+        const int cap = std::max(n + n / 2, 1024);
+        if (f->d_perm) PC_HIP(hipFree(f->d_perm));
+        f->d_perm = nullptr;
+        f->perm_cap = 0;
+        PC_HIP(hipMalloc(&f->d_perm, (size_t)cap * sizeof(uint32_t)));
+        f->perm_cap = cap;
+    }
+    PC_HIP(hist.ensure((size_t)pc::bin_num_tiles(f->w, f->h) + 1));
+    pc::launch_spatial_bins(f->d_kps, n, f->w, f->h, hist.p, f->d_perm, ctx->work);
+    f->perm_valid = true;
     return PC_OK;
 }
 
@@ -234,11 +275,16 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
     p.max_level = max_level;
     p.n = n;
     p.pts = frame1->d_kps;
-    // visiting order: keypoints binned by image tile (they are stored by corner response)
-    PC_HIP(ctx->lk_perm.ensure((size_t)n));
-    PC_HIP(ctx->lk_hist.ensure((size_t)pc::bin_num_tiles(frame1->w, frame1->h) + 1));
-    pc::launch_spatial_bins(frame1->d_kps, n, frame1->w, frame1->h, ctx->lk_hist.p, ctx->lk_perm.p, ctx->stream);
-    p.perm = ctx->lk_perm.p;
+    // visiting order: keypoints binned by image tile (they are stored by corner response); the analyzer
+    // prepares it together with the keypoints, the stage-level calls compute it here
+    if (frame1->perm_valid) {
+        p.perm = frame1->d_perm;
+    } else {
+        PC_HIP(ctx->lk_perm.ensure((size_t)n));
+        PC_HIP(ctx->lk_hist.ensure((size_t)pc::bin_num_tiles(frame1->w, frame1->h) + 1));
+        pc::launch_spatial_bins(frame1->d_kps, n, frame1->w, frame1->h, ctx->lk_hist.p, ctx->lk_perm.p, ctx->stream);
+        p.perm = ctx->lk_perm.p;
+    }
     // TermCriteria clamps of calcOpticalFlowPyrLK
     p.max_iters = std::min(std::max(opt->term_max_iters, 0), 100);
     const double eps = std::min(std::max(opt->term_epsilon, 0.), 10.);
@@ -247,7 +293,7 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
     p.out_xy = ctx->lk_xy.p;
     p.out_status = ctx->lk_status.p;
     p.out_err = ctx->lk_err.p;
-    ScopedTimer tm(ctx, PC_K_LK);
+    ScopedTimer tm(ctx, PC_K_LK, ctx->stream);
     if (!pc::launch_lk(p, frame1->win, ctx->stream)) return fail(PC_E_INVALID, "unsupported window size %d", frame1->win);
     return PC_OK;
 }
@@ -292,6 +338,9 @@ int pc_context_create(int device_index, pc_context** out) {
     c->device = device_index;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->prep_fence, hipEventDisableTiming);
+    c->work = c->stream;
     if (e != hipSuccess) {
         delete c;
         return fail(PC_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -303,6 +352,7 @@ int pc_context_create(int device_index, pc_context** out) {
 void pc_context_destroy(pc_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& r : c->ranges) {
         (void)hipEventDestroy(r.a);
@@ -330,20 +380,25 @@ void pc_context_destroy(pc_context* c) {
     c->lk_block_counts.release();
     c->lk_perm.release();
     c->lk_hist.release();
+    c->prep_hist.release();
     c->lk_row_offset.release();
     c->h_row_offset.release();
     if (c->copy_stream) {
         (void)hipStreamSynchronize(c->copy_stream);
         (void)hipStreamDestroy(c->copy_stream);
     }
+    if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
+    if (c->prep_fence) (void)hipEventDestroy(c->prep_fence);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 int pc_context_synchronize(pc_context* c) {
     if (!c) return fail(PC_E_INVALID, "null context");
+    PC_HIP(hipStreamSynchronize(c->prep_stream));
     PC_HIP(hipStreamSynchronize(c->stream));
     PC_HIP(hipStreamSynchronize(c->copy_stream));
+    c->prep_dirty = false;
     return PC_OK;
 }
 
@@ -444,11 +499,13 @@ void pc_frame_destroy(pc_frame* f) {
     if (!f) return;
     if (f->ctx) {
         (void)hipSetDevice(f->ctx->device);
+        (void)hipStreamSynchronize(f->ctx->prep_stream);
         (void)hipStreamSynchronize(f->ctx->stream);
         if (f->ctx->eig_owner == f) f->ctx->eig_owner = nullptr;
     }
     if (f->slab) (void)hipFree(f->slab);
     if (f->d_kps) (void)hipFree(f->d_kps);
+    if (f->d_perm) (void)hipFree(f->d_perm);
     delete f;
 }
 
@@ -458,25 +515,30 @@ static int set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t ro
     const size_t row_bytes = (size_t)f->w * channels;
     if (row_pitch < row_bytes) return fail(PC_E_INVALID, "row_pitch %zu < %zu", row_pitch, row_bytes);
     PC_HIP(hipSetDevice(ctx->device));
+    if (ctx->work == ctx->stream) {
+        int jrc = join_prep(ctx);
+        if (jrc != PC_OK) return jrc;
+    }
     const uint8_t* d_src = src;
     size_t d_pitch = row_pitch;
     if (!on_device) {
         d_pitch = align_up(row_bytes, 16);
         PC_HIP(ctx->staging.ensure(d_pitch * f->h));
         // the previous frame's kernels may still read the staging buffer: ordered on the same stream
-        PC_HIP(hipMemcpy2DAsync(ctx->staging.p, d_pitch, src, row_pitch, row_bytes, f->h, hipMemcpyHostToDevice, ctx->stream));
+        PC_HIP(hipMemcpy2DAsync(ctx->staging.p, d_pitch, src, row_pitch, row_bytes, f->h, hipMemcpyHostToDevice, ctx->work));
         d_src = ctx->staging.p;
     }
     {
         ScopedTimer t(ctx, PC_K_GRAY);
-        if (channels == 3) pc::launch_rgb2gray(d_src, d_pitch, f->levels[0], ctx->stream);
-        else pc::launch_copy_gray(d_src, d_pitch, f->levels[0], ctx->stream);
+        if (channels == 3) pc::launch_rgb2gray(d_src, d_pitch, f->levels[0], ctx->work);
+        else pc::launch_copy_gray(d_src, d_pitch, f->levels[0], ctx->work);
     }
     build_pyramid(ctx, f);
     f->n_kps = -1;
     f->n_cands = -1;
+    f->perm_valid = false;
     if (ctx->eig_owner == f) ctx->eig_owner = nullptr;
-    if (!on_device) PC_HIP(hipStreamSynchronize(ctx->stream));  // caller may reuse its host buffer
+    if (!on_device) PC_HIP(hipStreamSynchronize(ctx->work));  // caller may reuse its host buffer
     return PC_OK;
 }
 
@@ -498,6 +560,7 @@ int pc_frame_level_size(const pc_frame* f, int level, int* width, int* height) {
 
 int pc_frame_download_gray(pc_context* ctx, const pc_frame* f, uint8_t* out) {
     if (!ctx || !f || !out) return fail(PC_E_INVALID, "null argument");
+    if (int jrc = join_prep(ctx)) return jrc;
     const pc::Level& L = f->levels[0];
     PC_HIP(hipMemcpy2DAsync(out, L.w, L.img, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
     PC_HIP(hipStreamSynchronize(ctx->stream));
@@ -506,6 +569,7 @@ int pc_frame_download_gray(pc_context* ctx, const pc_frame* f, uint8_t* out) {
 
 int pc_frame_download_level(pc_context* ctx, const pc_frame* f, int level, uint8_t* out) {
     if (!ctx || !f || !out || level < 0 || level >= f->nlevels) return fail(PC_E_INVALID, "bad argument");
+    if (int jrc = join_prep(ctx)) return jrc;
     const pc::Level& L = f->levels[level];
     const int win = f->win;
     const uint8_t* src = L.img - (ptrdiff_t)win * L.pitch - win;
@@ -516,6 +580,7 @@ int pc_frame_download_level(pc_context* ctx, const pc_frame* f, int level, uint8
 
 int pc_frame_download_deriv(pc_context* ctx, const pc_frame* f, int level, int16_t* out) {
     if (!ctx || !f || !out || level < 0 || level >= f->nlevels) return fail(PC_E_INVALID, "bad argument");
+    if (int jrc = join_prep(ctx)) return jrc;
     const pc::Level& L = f->levels[level];
     const int win = f->win;
     const int32_t* src = L.der - (ptrdiff_t)win * L.pitch - win;
@@ -533,6 +598,7 @@ int pc_frame_detect(pc_context* ctx, pc_frame* f, const pc_gftt_options* opt) {
     int rc = validate_gftt(opt, f->w, f->h, &g);
     if (rc != PC_OK) return rc;
     PC_HIP(hipSetDevice(ctx->device));
+    if (int jrc = join_prep(ctx)) return jrc;
     if (!ctx->detect) ctx->detect = new DetectScratch();
     if ((rc = detect_phase_a(ctx, f, g, *opt, *ctx->detect)) != PC_OK) return rc;
     if ((rc = detect_phase_b(ctx, f, *opt, *ctx->detect)) != PC_OK) return rc;
@@ -542,6 +608,7 @@ int pc_frame_detect(pc_context* ctx, pc_frame* f, const pc_gftt_options* opt) {
 
 int pc_frame_download_min_eig(pc_context* ctx, const pc_frame* f, float* out) {
     if (!ctx || !f || !out) return fail(PC_E_INVALID, "null argument");
+    if (int jrc = join_prep(ctx)) return jrc;
     if (ctx->eig_owner != f) return fail(PC_E_STATE, "the min-eig scratch map belongs to another frame (call right after pc_frame_detect)");
     PC_HIP(hipMemcpyAsync(out, ctx->eig.p, (size_t)f->w * f->h * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PC_HIP(hipStreamSynchronize(ctx->stream));
@@ -564,6 +631,7 @@ int pc_frame_num_keypoints(pc_context* ctx, const pc_frame* f, int* out_n) {
 
 int pc_frame_download_keypoints(pc_context* ctx, const pc_frame* f, float* out_xy, int capacity) {
     if (!ctx || !f || (!out_xy && capacity > 0)) return fail(PC_E_INVALID, "null argument");
+    if (int jrc = join_prep(ctx)) return jrc;
     if (f->n_kps < 0) return fail(PC_E_STATE, "frame has no keypoints");
     if (capacity < f->n_kps) return fail(PC_E_CAPACITY, "capacity %d < %d keypoints", capacity, f->n_kps);
     if (f->n_kps == 0) return PC_OK;
@@ -574,6 +642,7 @@ int pc_frame_download_keypoints(pc_context* ctx, const pc_frame* f, float* out_x
 
 int pc_frame_set_keypoints(pc_context* ctx, pc_frame* f, const float* xy, int n) {
     if (!ctx || !f || n < 0 || (!xy && n > 0)) return fail(PC_E_INVALID, "bad argument");
+    if (int jrc = join_prep(ctx)) return jrc;
     int rc = ensure_kp_capacity(f, n);
     if (rc != PC_OK) return rc;
     if (n > 0) {
@@ -581,6 +650,7 @@ int pc_frame_set_keypoints(pc_context* ctx, pc_frame* f, const float* xy, int n)
         PC_HIP(hipStreamSynchronize(ctx->stream));
     }
     f->n_kps = n;
+    f->perm_valid = false;
     return PC_OK;
 }
 
@@ -591,6 +661,7 @@ int pc_lk_track(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* 
     if (rc != PC_OK) return rc;
     if (!next_xy || !status || !err) return fail(PC_E_INVALID, "null output");
     PC_HIP(hipSetDevice(ctx->device));
+    if (int jrc = join_prep(ctx)) return jrc;
     rc = run_lk(ctx, frame1, targets, n_targets, opt);
     if (rc != PC_OK) return rc;
     const size_t rows = (size_t)frame1->n_kps * n_targets;
@@ -610,6 +681,7 @@ int pc_lk_track_filtered(pc_context* ctx, const pc_frame* frame1, const pc_frame
     if (rc != PC_OK) return rc;
     if (!row_offset) return fail(PC_E_INVALID, "null row_offset");
     PC_HIP(hipSetDevice(ctx->device));
+    if (int jrc = join_prep(ctx)) return jrc;
     rc = run_lk(ctx, frame1, targets, n_targets, opt);
     if (rc != PC_OK) return rc;
     const int n = frame1->n_kps;
@@ -657,6 +729,9 @@ struct Slot {
     DetState det = DET_NONE;
     bool supplied = false;  // keypoints came from the caller (database), not from detection
     DetectScratch scratch;
+    hipEvent_t last_read = nullptr;  // `computed` event of the latest job whose LK reads this slot
+    hipEvent_t img_ready = nullptr;  // gray + pyramid of the resident frame are complete (prep stream)
+    hipEvent_t kps_ready = nullptr;  // keypoints + visiting order are complete (prep stream)
 };
 
 struct Job {
@@ -698,6 +773,7 @@ Slot* find_slot(pc_analyzer* a, int32_t frame_id) {
     return (s.valid && s.frame_id == frame_id) ? &s : nullptr;
 }
 
+// All three run on the prep stream (the callers hold a PrepScope).
 int detect_dense(pc_analyzer* a, Slot& s) {
     int rc = detect_phase_a(a->ctx, s.frame, a->grid, a->gopt, s.scratch);
     if (rc == PC_OK) s.det = DET_DENSE;
@@ -708,9 +784,21 @@ int detect_finish(pc_analyzer* a, Slot& s) {
     int rc;
     if (s.det == DET_NONE && (rc = detect_dense(a, s)) != PC_OK) return rc;
     if ((rc = detect_phase_b(a->ctx, s.frame, a->gopt, s.scratch)) != PC_OK) return rc;
+    if ((rc = order_keypoints_spatially(a->ctx, s.frame, a->ctx->prep_hist)) != PC_OK) return rc;
+    PC_HIP(hipEventRecord(s.kps_ready, a->ctx->prep_stream));
     s.det = DET_DONE;
     s.supplied = false;
     return PC_OK;
+}
+
+// Ordering phase of the frame that will most likely be the next frame1, if its dense phase has
+// already delivered its counters: keeps sort + binning off the LK stream's critical path.
+int preorder_if_ready(pc_analyzer* a, int32_t frame_id) {
+    Slot* s = find_slot(a, frame_id);
+    if (!s || s->det != DET_DENSE || !s->scratch.ev) return PC_OK;
+    if (hipEventQuery(s->scratch.ev) != hipSuccess) return PC_OK;
+    PrepScope prep(a->ctx);
+    return detect_finish(a, *s);
 }
 
 }  // namespace
@@ -737,12 +825,27 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
     a->gopt = *gftt;
     a->fopt = *flow;
     a->grid = grid0;
-    a->slots.resize((size_t)ring_frames);
+    // two extra slots: a frame can be overwritten (prep stream) while the LK launches that read its
+    // predecessors in the ring are still running, without the two streams waiting on each other
+    a->slots.resize((size_t)ring_frames + 2);
     a->jobs.resize((size_t)max_jobs);
     int rc = PC_OK;
     for (auto& s : a->slots) {
         rc = pc_frame_create(ctx, width, height, flow->window_size, flow->max_level, &s.frame);
         if (rc != PC_OK) break;
+        // room for a typical frame's keypoints up front: growing later frees device memory, which synchronises
+        const int kp0 = std::max(16384, (width * height) / 32);
+        if ((rc = ensure_kp_capacity(s.frame, kp0)) != PC_OK) break;
+        if (hipMalloc(reinterpret_cast<void**>(&s.frame->d_perm), (size_t)kp0 * sizeof(uint32_t)) != hipSuccess) {
+            rc = fail(PC_E_HIP, "hipMalloc failed");
+            break;
+        }
+        s.frame->perm_cap = kp0;
+        if (hipEventCreateWithFlags(&s.img_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.kps_ready, hipEventDisableTiming) != hipSuccess) {
+            rc = fail(PC_E_HIP, "hipEventCreate failed");
+            break;
+        }
     }
     if (rc == PC_OK)
         for (auto& j : a->jobs)
@@ -764,10 +867,13 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
 void pc_analyzer_destroy(pc_analyzer* a) {
     if (!a) return;
     (void)hipSetDevice(a->ctx->device);
+    (void)hipStreamSynchronize(a->ctx->prep_stream);
     (void)hipStreamSynchronize(a->ctx->stream);
     (void)hipStreamSynchronize(a->ctx->copy_stream);
     for (auto& s : a->slots) {
         if (s.frame) pc_frame_destroy(s.frame);
+        if (s.img_ready) (void)hipEventDestroy(s.img_ready);
+        if (s.kps_ready) (void)hipEventDestroy(s.kps_ready);
         s.scratch.release();
     }
     for (auto& hdr : a->log_hdr) hdr.release();
@@ -788,12 +894,17 @@ int pc_analyzer_put_frame(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, 
     if (!a || !rgb) return fail(PC_E_INVALID, "null argument");
     const int n = (int)a->slots.size();
     Slot& s = a->slots[(size_t)(((frame_id % n) + n) % n)];
-    // a job in flight may still read this slot: everything is ordered on the one stream
+    PC_HIP(hipSetDevice(a->ctx->device));
+    PrepScope prep(a->ctx);
+    // an LK launch in flight may still read the frame this slot holds
+    if (s.last_read) PC_HIP(hipStreamWaitEvent(a->ctx->prep_stream, s.last_read, 0));
+    s.last_read = nullptr;
     int rc = pc_frame_set_rgb(a->ctx, s.frame, rgb, row_pitch, on_device);
     if (rc != PC_OK) {
         s.valid = false;
         return rc;
     }
+    PC_HIP(hipEventRecord(s.img_ready, a->ctx->prep_stream));
     s.frame_id = frame_id;
     s.valid = true;
     s.det = DET_NONE;
@@ -815,10 +926,15 @@ int pc_analyzer_set_keypoints(pc_analyzer* a, int32_t frame_id, const float* xy,
     if (rc != PC_OK) return rc;
     if (n > 0) {
         // resume path (keypoints from the database): pageable source, so the copy is synchronous
-        PC_HIP(hipMemcpyAsync(s->frame->d_kps, xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, a->ctx->stream));
-        PC_HIP(hipStreamSynchronize(a->ctx->stream));
+        PC_HIP(hipMemcpyAsync(s->frame->d_kps, xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, a->ctx->prep_stream));
+        PC_HIP(hipStreamSynchronize(a->ctx->prep_stream));
     }
     s->frame->n_kps = n;
+    {
+        PrepScope prep(a->ctx);
+        if ((rc = order_keypoints_spatially(a->ctx, s->frame, a->ctx->prep_hist)) != PC_OK) return rc;
+        PC_HIP(hipEventRecord(s->kps_ready, a->ctx->prep_stream));
+    }
     s->det = DET_DONE;
     s->supplied = true;
     return PC_OK;
@@ -842,12 +958,18 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     // (1) keypoints of frame1: the dense phase ran when the frame became resident; order them now
     bool detected = false;
     if (s1->det != DET_DONE) {
+        PrepScope prep(a->ctx);
         if ((rc = detect_finish(a, *s1)) != PC_OK) return rc;
         detected = true;
     } else {
         detected = !s1->supplied;
     }
     Job& j = a->jobs[(a->job_head + a->job_count) % a->jobs.size()];
+    // (2) the LK launch needs this frame's keypoints and the pyramids of the frames it reads -- not the
+    // detection of frames that were made resident for later
+    PC_HIP(hipStreamWaitEvent(ctx->stream, s1->kps_ready, 0));
+    PC_HIP(hipStreamWaitEvent(ctx->stream, s1->img_ready, 0));
+    for (int t = 0; t < n_targets; t++) PC_HIP(hipStreamWaitEvent(ctx->stream, find_slot(a, targets[t])->img_ready, 0));
     const int n = s1->frame->n_kps;
     const size_t rows = (size_t)n * (size_t)std::max(n_targets, 0);
     PC_HIP(j.h_kps.ensure((size_t)std::max(n, 1) * 2));
@@ -875,7 +997,7 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
         // (it has had a whole LK launch to do so)
         if (a->last_done) PC_HIP(hipStreamWaitEvent(ctx->stream, a->last_done, 0));
         {
-            ScopedTimer t(ctx, PC_K_COMPACT);
+            ScopedTimer t(ctx, PC_K_COMPACT, ctx->stream);
             pc::launch_compact(ctx->lk_xy.p, ctx->lk_status.p, ctx->lk_err.p, n, n_targets, ctx->lk_block_counts.p,
                                ctx->lk_row_offset.p, ctx->lk_cidx.p, ctx->lk_cxy.p, ctx->lk_cerr.p, ctx->stream);
         }
@@ -913,6 +1035,8 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
         a->log_used = end;
     }
     PC_HIP(hipEventRecord(j.computed, ctx->stream));
+    s1->last_read = j.computed;
+    for (int t = 0; t < n_targets; t++) find_slot(a, targets[t])->last_read = j.computed;
     // (4) downloads on the copy stream, overlapping the next frame's kernels
     PC_HIP(hipStreamWaitEvent(ctx->copy_stream, j.computed, 0));
     if (n > 0)
@@ -931,7 +1055,8 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     a->last_done = j.done;
     j.active = true;
     a->job_count++;
-    return PC_OK;
+    // (5) while this LK launch runs: order the keypoints of the next frame1
+    return preorder_if_ready(a, frame1 + 1);
 }
 
 int pc_analyzer_pending(const pc_analyzer* a) { return a ? (int)a->job_count : 0; }
@@ -939,6 +1064,7 @@ int pc_analyzer_pending(const pc_analyzer* a) { return a ? (int)a->job_count : 0
 int pc_analyzer_set_device_log(pc_analyzer* a, void* d_log, size_t capacity_bytes) {
     if (!a) return fail(PC_E_INVALID, "null analyzer");
     if (d_log && (reinterpret_cast<uintptr_t>(d_log) & 15)) return fail(PC_E_INVALID, "device log must be 16-byte aligned");
+    PC_HIP(hipStreamSynchronize(a->ctx->prep_stream));
     PC_HIP(hipStreamSynchronize(a->ctx->stream));
     a->d_log = static_cast<uint8_t*>(d_log);
     a->log_cap = d_log ? capacity_bytes : 0;

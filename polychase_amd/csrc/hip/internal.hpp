@@ -45,7 +45,7 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        size_t want = n + n / 4 + 64;
+        size_t want = n + n / 2 + 64;   // generous: a reallocation synchronises the device
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
         if (e == hipSuccess) cap = want;
         return e;
@@ -66,7 +66,7 @@ struct PinBuf {
         if (p) (void)hipHostFree(p);
         p = nullptr;
         cap = 0;
-        size_t want = n + n / 4 + 64;
+        size_t want = n + n / 2 + 64;   // pinned allocations take tens of milliseconds
         hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocDefault);
         if (e == hipSuccess) cap = want;
         return e;
@@ -111,6 +111,13 @@ struct pc_context {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // result downloads overlap the next frame's kernels
+    // pc_analyzer runs frame preparation (gray, pyramid, detection, keypoint ordering) on its own
+    // stream so that it overlaps the LK launch of the previous frame1 on `stream`.  `work` is the stream
+    // the image / detection helpers enqueue on: `stream` by default, `prep_stream` inside the analyzer.
+    hipStream_t prep_stream = nullptr;
+    hipStream_t work = nullptr;
+    hipEvent_t prep_fence = nullptr;     // orders `stream` after everything queued on prep_stream so far
+    bool prep_dirty = false;
     // staging of host-provided frames
     DevBuf<uint8_t> staging;
     // GFTT scratch
@@ -128,7 +135,7 @@ struct pc_context {
     DevBuf<float2> lk_xy, lk_cxy;
     DevBuf<uint8_t> lk_status;
     DevBuf<float> lk_err, lk_cerr;
-    DevBuf<uint32_t> lk_cidx, lk_block_counts, lk_perm, lk_hist;
+    DevBuf<uint32_t> lk_cidx, lk_block_counts, lk_perm, lk_hist, prep_hist;
     DevBuf<long long> lk_row_offset;
     PinBuf<long long> h_row_offset;
     // timing
@@ -149,5 +156,8 @@ struct pc_frame {
     int kp_cap = 0;
     int n_kps = -1;   // -1: none
     int n_cands = -1;
+    uint32_t* d_perm = nullptr;   // LK visiting order of d_kps (spatial bins), valid iff perm_valid
+    int perm_cap = 0;
+    bool perm_valid = false;
 };
 
