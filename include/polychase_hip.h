@@ -102,6 +102,11 @@ void pc_frame_destroy(pc_frame* f);
  * on_device != 0: rgb is a device pointer; otherwise host memory (copied to the GPU first).
  * Clears the frame's keypoints. */
 int pc_frame_set_rgb(pc_context* ctx, pc_frame* f, const uint8_t* rgb, size_t row_pitch, int on_device);
+/* Same, from the float32 image Blender hands out: H rows of W*channels floats (channels = 3 or 4,
+ * alpha ignored), row_pitch BYTES apart.  Replaces the addon's numpy conversion
+ * `(image_data * 255).astype(np.uint8)` (blender_addon/operators/analysis.py:221-233) followed by
+ * cvtColor: the same fp32 multiply and truncating cast, on the GPU. */
+int pc_frame_set_rgb_f32(pc_context* ctx, pc_frame* f, const float* rgb, size_t row_pitch, int channels, int on_device);
 /* Same, from an 8-bit gray image (tests / callers that already hold gray). */
 int pc_frame_set_gray(pc_context* ctx, pc_frame* f, const uint8_t* gray, size_t row_pitch, int on_device);
 
@@ -168,6 +173,9 @@ void pc_analyzer_destroy(pc_analyzer* a);
  * Replaces RequestFrame + cvtColor + GeneratePyramid (opticalflow.cc:249-263, :287-302). */
 int pc_analyzer_put_frame(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, size_t row_pitch,
                           int on_device, int will_detect);
+/* pc_analyzer_put_frame for a float32 frame (see pc_frame_set_rgb_f32). */
+int pc_analyzer_put_frame_f32(pc_analyzer* a, int32_t frame_id, const float* rgb, size_t row_pitch, int channels,
+                              int on_device, int will_detect);
 int pc_analyzer_has_frame(const pc_analyzer* a, int32_t frame_id);
 /* Keypoints already stored in the database for this frame (resume, opticalflow.cc:168-178). */
 int pc_analyzer_set_keypoints(pc_analyzer* a, int32_t frame_id, const float* xy, int n);

@@ -509,10 +509,14 @@ void pc_frame_destroy(pc_frame* f) {
     delete f;
 }
 
-static int set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t row_pitch, int on_device, int channels) {
+// channels: 1 / 3 = u8 gray / RGB; elem_size 4 = float32 RGB(A) with `channels` floats per pixel
+static int set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t row_pitch, int on_device, int channels,
+                     int elem_size = 1) {
     if (!ctx || !f || !src) return fail(PC_E_INVALID, "null argument");
     if (f->ctx != ctx) return fail(PC_E_INVALID, "frame belongs to another context");
-    const size_t row_bytes = (size_t)f->w * channels;
+    if (elem_size == 4 && channels != 3 && channels != 4) return fail(PC_E_INVALID, "float frames need 3 or 4 channels, got %d", channels);
+    if (elem_size == 4 && ((reinterpret_cast<uintptr_t>(src) | row_pitch) & 3)) return fail(PC_E_INVALID, "float frame is not 4-byte aligned");
+    const size_t row_bytes = (size_t)f->w * channels * elem_size;
     if (row_pitch < row_bytes) return fail(PC_E_INVALID, "row_pitch %zu < %zu", row_pitch, row_bytes);
     PC_HIP(hipSetDevice(ctx->device));
     if (ctx->work == ctx->stream) {
@@ -530,7 +534,8 @@ static int set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t ro
     }
     {
         ScopedTimer t(ctx, PC_K_GRAY);
-        if (channels == 3) pc::launch_rgb2gray(d_src, d_pitch, f->levels[0], ctx->work);
+        if (elem_size == 4) pc::launch_rgbf32_to_gray(reinterpret_cast<const float*>(d_src), d_pitch, channels, f->levels[0], ctx->work);
+        else if (channels == 3) pc::launch_rgb2gray(d_src, d_pitch, f->levels[0], ctx->work);
         else pc::launch_copy_gray(d_src, d_pitch, f->levels[0], ctx->work);
     }
     build_pyramid(ctx, f);
@@ -544,6 +549,9 @@ static int set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t ro
 
 int pc_frame_set_rgb(pc_context* ctx, pc_frame* f, const uint8_t* rgb, size_t row_pitch, int on_device) {
     return set_image(ctx, f, rgb, row_pitch, on_device, 3);
+}
+int pc_frame_set_rgb_f32(pc_context* ctx, pc_frame* f, const float* rgb, size_t row_pitch, int channels, int on_device) {
+    return set_image(ctx, f, reinterpret_cast<const uint8_t*>(rgb), row_pitch, on_device, channels, 4);
 }
 int pc_frame_set_gray(pc_context* ctx, pc_frame* f, const uint8_t* gray, size_t row_pitch, int on_device) {
     return set_image(ctx, f, gray, row_pitch, on_device, 1);
@@ -889,8 +897,8 @@ void pc_analyzer_destroy(pc_analyzer* a) {
     delete a;
 }
 
-int pc_analyzer_put_frame(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, size_t row_pitch, int on_device,
-                          int will_detect) {
+static int analyzer_put(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, size_t row_pitch, int on_device,
+                        int will_detect, int channels, int elem_size) {
     if (!a || !rgb) return fail(PC_E_INVALID, "null argument");
     const int n = (int)a->slots.size();
     Slot& s = a->slots[(size_t)(((frame_id % n) + n) % n)];
@@ -899,7 +907,7 @@ int pc_analyzer_put_frame(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, 
     // an LK launch in flight may still read the frame this slot holds
     if (s.last_read) PC_HIP(hipStreamWaitEvent(a->ctx->prep_stream, s.last_read, 0));
     s.last_read = nullptr;
-    int rc = pc_frame_set_rgb(a->ctx, s.frame, rgb, row_pitch, on_device);
+    int rc = set_image(a->ctx, s.frame, rgb, row_pitch, on_device, channels, elem_size);
     if (rc != PC_OK) {
         s.valid = false;
         return rc;
@@ -911,6 +919,16 @@ int pc_analyzer_put_frame(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, 
     s.supplied = false;
     if (will_detect) return detect_dense(a, s);
     return PC_OK;
+}
+
+int pc_analyzer_put_frame(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, size_t row_pitch, int on_device,
+                          int will_detect) {
+    return analyzer_put(a, frame_id, rgb, row_pitch, on_device, will_detect, 3, 1);
+}
+
+int pc_analyzer_put_frame_f32(pc_analyzer* a, int32_t frame_id, const float* rgb, size_t row_pitch, int channels,
+                              int on_device, int will_detect) {
+    return analyzer_put(a, frame_id, reinterpret_cast<const uint8_t*>(rgb), row_pitch, on_device, will_detect, channels, 4);
 }
 
 int pc_analyzer_has_frame(const pc_analyzer* a, int32_t frame_id) {

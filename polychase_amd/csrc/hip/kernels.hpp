@@ -8,6 +8,8 @@ namespace pc {
 // ---- kernels_image.hip ----
 // K1: RGB u8 -> gray u8 written straight into the level-0 plane interior (cvtColor RGB2GRAY).
 void launch_rgb2gray(const uint8_t* rgb, size_t rgb_pitch, const Level& l0, hipStream_t s);
+// float32 RGB / RGBA (numpy `(x * 255).astype(uint8)` semantics) -> gray u8 in the level-0 interior
+void launch_rgbf32_to_gray(const float* rgb, size_t rgb_pitch, int channels, const Level& l0, hipStream_t s);
 // gray u8 (arbitrary pitch) -> level-0 interior
 void launch_copy_gray(const uint8_t* gray, size_t gray_pitch, const Level& l0, hipStream_t s);
 // K7: pyrDown 5x5 (src interior -> dst interior)

@@ -56,6 +56,33 @@ void launch_rgb2gray(const uint8_t* rgb, size_t rgb_pitch, const Level& l0, hipS
     }
 }
 
+// Float frames as Blender hands them out (H x W x C float32, C = 3 or 4, values nominally in [0,1]):
+// the addon converts them with numpy `(image * 255).astype(np.uint8)` before provide_frame
+// (blender_addon/operators/analysis.py:221-233), i.e. an fp32 multiply and a truncating cast whose
+// out-of-range behaviour is "low 8 bits of the int32".  Same arithmetic here, fused with RGB2GRAY.
+__device__ __forceinline__ uint32_t float_channel_to_u8(float v) {
+    const float s = v * 255.0f;
+    // C-style float -> int32 (truncate; NaN / out of int32 range -> INT_MIN like cvttss2si), then the low byte
+    const int i = (s >= -2147483648.0f && s < 2147483648.0f) ? (int)s : (int)0x80000000;
+    return (uint32_t)i & 0xffu;
+}
+
+__global__ __launch_bounds__(256) void rgbf32_to_gray_kernel(const float* __restrict__ src, size_t src_pitch, int channels,
+                                                             uint8_t* __restrict__ dst, int dst_pitch, int w, int h) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    const float* p = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(src) + (size_t)y * src_pitch) +
+                     (size_t)x * channels;
+    dst[(size_t)y * dst_pitch + x] =
+        (uint8_t)gray_of(float_channel_to_u8(p[0]), float_channel_to_u8(p[1]), float_channel_to_u8(p[2]));
+}
+
+void launch_rgbf32_to_gray(const float* rgb, size_t rgb_pitch, int channels, const Level& l0, hipStream_t s) {
+    dim3 grid((l0.w + 255) / 256, l0.h);
+    hipLaunchKernelGGL(rgbf32_to_gray_kernel, grid, dim3(256), 0, s, rgb, rgb_pitch, channels, l0.img, l0.pitch, l0.w, l0.h);
+}
+
 __global__ __launch_bounds__(256) void copy_gray_kernel(const uint8_t* __restrict__ src, size_t src_pitch,
                                                         uint8_t* __restrict__ dst, int dst_pitch, int w, int h) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;

@@ -54,6 +54,8 @@ struct FrameView {
     int rows = 0;
     int cols = 0;
     int channels = 0;
+    int elem_size = 1;     // 1: uint8 (channels == 3); 4: float32 as Blender hands frames out (channels 3 or 4),
+                           // converted on the GPU like the addon's `(image * 255).astype(np.uint8)`
     size_t row_pitch = 0;  // bytes between rows
     bool on_device = false;
     std::shared_ptr<void> owner;

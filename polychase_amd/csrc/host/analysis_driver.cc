@@ -184,7 +184,8 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
         if (f) {
             CHECK_EQ(static_cast<uint32_t>(f->rows), video_info.height);
             CHECK_EQ(static_cast<uint32_t>(f->cols), video_info.width);
-            CHECK_EQ(static_cast<uint32_t>(f->channels), 3u);
+            if (f->elem_size == 4) CHECK(f->channels == 3 || f->channels == 4);
+            else CHECK_EQ(static_cast<uint32_t>(f->channels), 3u);
         }
         return f;
     };
@@ -234,9 +235,12 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
                 std::lock_guard<std::mutex> lk(db_mtx);
                 will_detect = !db->KeypointsExist(fid);
             }
-            if (pc_analyzer_put_frame(eng.an, fid, f->data, f->row_pitch, f->on_device ? 1 : 0, will_detect ? 1 : 0) !=
-                PC_OK)
-                ThrowHip("pc_analyzer_put_frame");
+            const int put_rc =
+                f->elem_size == 4
+                    ? pc_analyzer_put_frame_f32(eng.an, fid, reinterpret_cast<const float*>(f->data), f->row_pitch, f->channels,
+                                                f->on_device ? 1 : 0, will_detect ? 1 : 0)
+                    : pc_analyzer_put_frame(eng.an, fid, f->data, f->row_pitch, f->on_device ? 1 : 0, will_detect ? 1 : 0);
+            if (put_rc != PC_OK) ThrowHip("pc_analyzer_put_frame");
             highest_put = fid;
         }
         // ReadOrGenerateKeypoints (:168-178)

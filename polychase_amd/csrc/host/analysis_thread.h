@@ -57,8 +57,9 @@ class OpticalFlowThread : public Worker<OpticalFlowThreadMessage> {
     }
 
     // Deep copy on entry (cpp/opticalflow_thread.h:120-132): the caller's buffer is free on return.
-    void ProvideFrame(int32_t frame_id, const uint8_t* data, int rows, int cols, int channels, size_t row_pitch) {
-        const size_t row_bytes = static_cast<size_t>(cols) * channels;
+    void ProvideFrame(int32_t frame_id, const uint8_t* data, int rows, int cols, int channels, size_t row_pitch,
+                      int elem_size = 1) {
+        const size_t row_bytes = static_cast<size_t>(cols) * channels * elem_size;
         auto pixels = std::make_shared<std::vector<uint8_t>>(static_cast<size_t>(rows) * row_bytes);
         for (int y = 0; y < rows; y++) std::copy_n(data + y * row_pitch, row_bytes, pixels->data() + y * row_bytes);
         FrameView view;
@@ -66,6 +67,7 @@ class OpticalFlowThread : public Worker<OpticalFlowThreadMessage> {
         view.rows = rows;
         view.cols = cols;
         view.channels = channels;
+        view.elem_size = elem_size;
         view.row_pitch = row_bytes;
         view.owner = std::move(pixels);
         {

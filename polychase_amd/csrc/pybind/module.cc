@@ -32,16 +32,34 @@ std::optional<FrameView> FrameFromPython(const py::object& obj, std::deque<py::o
         py::module_::import("torch").attr("cuda").attr("current_stream")(t.attr("device")).attr("synchronize")();
         const auto shape = t.attr("shape").cast<std::vector<py::ssize_t>>();
         if (shape.size() != 3) throw py::value_error("frame must have shape (H, W, 3)");
-        if (t.attr("element_size")().cast<int>() != 1) throw py::value_error("frame must be uint8");
+        const std::string dtype = py::str(t.attr("dtype")).cast<std::string>();
+        if (dtype != "torch.uint8" && dtype != "torch.float32") throw py::value_error("frame must be uint8 or float32");
         FrameView v;
+        v.elem_size = dtype == "torch.float32" ? 4 : 1;
         v.data = reinterpret_cast<const uint8_t*>(t.attr("data_ptr")().cast<uintptr_t>());
         v.rows = static_cast<int>(shape[0]);
         v.cols = static_cast<int>(shape[1]);
         v.channels = static_cast<int>(shape[2]);
-        v.row_pitch = static_cast<size_t>(shape[1] * shape[2]);
+        v.row_pitch = static_cast<size_t>(shape[1] * shape[2]) * v.elem_size;
         v.on_device = true;
         keep_alive.push_back(t);
         while (keep_alive.size() > 40) keep_alive.pop_front();
+        return v;
+    }
+    if (py::isinstance<py::array>(obj) && py::array(obj).dtype().is(py::dtype::of<float>())) {
+        // Blender's float pixels: converted on the GPU (no numpy `(x * 255).astype(uint8)` pass on the host)
+        F32Array fa = F32Array::ensure(obj);
+        if (!fa || fa.ndim() != 3) throw py::value_error("float frame must have shape (H, W, 3|4)");
+        auto buf = std::make_shared<std::vector<float>>(static_cast<size_t>(fa.size()));
+        std::memcpy(buf->data(), fa.data(), buf->size() * sizeof(float));
+        FrameView v;
+        v.data = reinterpret_cast<const uint8_t*>(buf->data());
+        v.rows = static_cast<int>(fa.shape(0));
+        v.cols = static_cast<int>(fa.shape(1));
+        v.channels = static_cast<int>(fa.shape(2));
+        v.elem_size = 4;
+        v.row_pitch = static_cast<size_t>(fa.shape(1) * fa.shape(2)) * sizeof(float);
+        v.owner = buf;
         return v;
     }
     U8Array a = U8Array::ensure(obj);
@@ -187,10 +205,19 @@ PYBIND11_MODULE(polychase_core, m) {
         .def("join", &OpticalFlowThread::Join, py::call_guard<py::gil_scoped_release>())
         .def("try_pop", &OpticalFlowThread::TryPop)
         .def("empty", &OpticalFlowThread::Empty)
-        .def("provide_frame", [](OpticalFlowThread& t, int32_t frame_id, const U8Array& frame) {
-            if (frame.ndim() != 3) throw py::value_error("frame must be a uint8 array of shape (H, W, 3)");
-            t.ProvideFrame(frame_id, frame.data(), static_cast<int>(frame.shape(0)), static_cast<int>(frame.shape(1)),
-                           static_cast<int>(frame.shape(2)), static_cast<size_t>(frame.shape(1) * frame.shape(2)));
+        .def("provide_frame", [](OpticalFlowThread& t, int32_t frame_id, const py::array& frame) {
+            if (frame.ndim() != 3) throw py::value_error("frame must be an array of shape (H, W, 3)");
+            if (frame.dtype().is(py::dtype::of<float>())) {   // Blender's float pixels, (H, W, 3|4)
+                const F32Array f = F32Array::ensure(frame);
+                t.ProvideFrame(frame_id, reinterpret_cast<const uint8_t*>(f.data()), static_cast<int>(f.shape(0)),
+                               static_cast<int>(f.shape(1)), static_cast<int>(f.shape(2)),
+                               static_cast<size_t>(f.shape(1) * f.shape(2)) * sizeof(float), 4);
+                return;
+            }
+            const U8Array u = U8Array::ensure(frame);
+            if (!u) throw py::value_error("frame must be a uint8 (H, W, 3) or float32 (H, W, 3|4) array");
+            t.ProvideFrame(frame_id, u.data(), static_cast<int>(u.shape(0)), static_cast<int>(u.shape(1)),
+                           static_cast<int>(u.shape(2)), static_cast<size_t>(u.shape(1) * u.shape(2)));
         });
 
     m.def("generate_optical_flow_database", &GenerateOpticalFlowDatabasePy, py::arg("video_info"),

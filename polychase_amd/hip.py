@@ -21,12 +21,13 @@ SYMBOLS = [
     "pc_gftt_default_options", "pc_flow_default_options", "pc_last_error", "pc_version",
     "pc_context_create", "pc_context_destroy", "pc_context_synchronize", "pc_context_stream",
     "pc_context_enable_timing", "pc_context_get_timing", "pc_context_reset_timing",
-    "pc_frame_create", "pc_frame_destroy", "pc_frame_set_rgb", "pc_frame_set_gray",
+    "pc_frame_create", "pc_frame_destroy", "pc_frame_set_rgb", "pc_frame_set_rgb_f32", "pc_frame_set_gray",
     "pc_frame_num_levels", "pc_frame_level_size", "pc_frame_download_gray", "pc_frame_download_level",
     "pc_frame_download_deriv", "pc_frame_detect", "pc_frame_download_min_eig", "pc_frame_num_candidates",
     "pc_frame_num_keypoints", "pc_frame_download_keypoints", "pc_frame_set_keypoints",
     "pc_lk_track", "pc_lk_track_filtered",
-    "pc_analyzer_create", "pc_analyzer_destroy", "pc_analyzer_put_frame", "pc_analyzer_has_frame",
+    "pc_analyzer_create", "pc_analyzer_destroy", "pc_analyzer_put_frame", "pc_analyzer_put_frame_f32",
+    "pc_analyzer_has_frame",
     "pc_analyzer_set_keypoints", "pc_analyzer_submit", "pc_analyzer_pending", "pc_analyzer_collect",
     "pc_analyzer_set_device_log", "pc_analyzer_device_log_used",
     "pc_mesh_create", "pc_mesh_set_mask", "pc_mesh_destroy", "pc_raycast_pixels",
@@ -101,6 +102,7 @@ def load():
     L.pc_frame_destroy.restype = None
     L.pc_frame_set_rgb.argtypes = [vp, vp, vp, C.c_size_t, C.c_int]
     L.pc_frame_set_gray.argtypes = [vp, vp, vp, C.c_size_t, C.c_int]
+    L.pc_frame_set_rgb_f32.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_int]
     L.pc_frame_num_levels.argtypes = [vp]
     L.pc_frame_level_size.argtypes = [vp, C.c_int, ip, ip]
     L.pc_frame_download_gray.argtypes = [vp, vp, vp]
@@ -119,6 +121,7 @@ def load():
     L.pc_analyzer_destroy.argtypes = [vp]
     L.pc_analyzer_destroy.restype = None
     L.pc_analyzer_put_frame.argtypes = [vp, C.c_int32, vp, C.c_size_t, C.c_int, C.c_int]
+    L.pc_analyzer_put_frame_f32.argtypes = [vp, C.c_int32, vp, C.c_size_t, C.c_int, C.c_int, C.c_int]
     L.pc_analyzer_has_frame.argtypes = [vp, C.c_int32]
     L.pc_analyzer_set_keypoints.argtypes = [vp, C.c_int32, vp, C.c_int]
     L.pc_analyzer_submit.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.c_int]
@@ -210,6 +213,10 @@ def _ptr(a):
     return a.data_ptr(), 1 if a.is_cuda else 0, a.stride(0) * a.element_size()
 
 
+def _is_float32(a) -> bool:
+    return str(a.dtype) in ("float32", "torch.float32")
+
+
 class Frame:
     """Gray image + LK pyramid + keypoints of one video frame, resident in HBM."""
 
@@ -230,9 +237,14 @@ class Frame:
             pass
 
     def set_rgb(self, rgb):
-        assert tuple(rgb.shape) == (self.h, self.w, 3), rgb.shape
+        """uint8 (H, W, 3), or float32 (H, W, 3|4) as Blender hands frames out (converted on the GPU)."""
         p, dev, pitch = _ptr(rgb)
-        _check(load().pc_frame_set_rgb(self.ctx._h, self._h, p, pitch, dev))
+        if _is_float32(rgb):
+            assert tuple(rgb.shape[:2]) == (self.h, self.w) and len(rgb.shape) == 3, rgb.shape
+            _check(load().pc_frame_set_rgb_f32(self.ctx._h, self._h, p, pitch, int(rgb.shape[2]), dev))
+        else:
+            assert tuple(rgb.shape) == (self.h, self.w, 3), rgb.shape
+            _check(load().pc_frame_set_rgb(self.ctx._h, self._h, p, pitch, dev))
         self._keep = rgb  # device sources must outlive the async kernels
 
     def set_gray(self, gray):
@@ -358,9 +370,14 @@ class Analyzer:
             pass
 
     def put_frame(self, frame_id: int, rgb, will_detect: bool = True):
-        assert tuple(rgb.shape) == (self.h, self.w, 3), rgb.shape
         p, dev, pitch = _ptr(rgb)
-        _check(load().pc_analyzer_put_frame(self._h, frame_id, p, pitch, dev, 1 if will_detect else 0))
+        if _is_float32(rgb):
+            assert tuple(rgb.shape[:2]) == (self.h, self.w) and len(rgb.shape) == 3, rgb.shape
+            _check(load().pc_analyzer_put_frame_f32(self._h, frame_id, p, pitch, int(rgb.shape[2]), dev,
+                                                    1 if will_detect else 0))
+        else:
+            assert tuple(rgb.shape) == (self.h, self.w, 3), rgb.shape
+            _check(load().pc_analyzer_put_frame(self._h, frame_id, p, pitch, dev, 1 if will_detect else 0))
         if dev:
             self._keep[frame_id % self.ring] = rgb  # device sources must outlive the async kernels
 

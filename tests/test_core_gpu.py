@@ -138,3 +138,22 @@ def test_device_resident_frames_through_the_binding(core, tmp_path):
     core.generate_optical_flow_database(core.VideoInfo(256, 192, 1, 10), lambda fid: frames[fid - 1], None, a)
     core.generate_optical_flow_database(core.VideoInfo(256, 192, 1, 10), lambda fid: dev[fid - 1], None, b)
     assert _dump(a) == _dump(b)
+
+
+def test_float_frames_through_thread_and_sync_binding(core, tmp_path):
+    """provide_frame / the frame accessor accept Blender's float32 (H, W, 4) pixels directly: same database as
+    when the addon converts them with `(image_data[:, :, :3] * 255).astype(np.uint8)` first."""
+    rng = np.random.default_rng(3)
+    clip = synth.NoiseClip(256, 192, 12)
+    u8 = [clip.frame(t) for t in range(12)]
+    f32 = []
+    for f in u8:
+        x = (f.astype(np.float32) + rng.uniform(0.05, 0.95, f.shape).astype(np.float32)) / np.float32(255.0)
+        f32.append(np.ascontiguousarray(np.concatenate([x, np.ones(f.shape[:2] + (1,), np.float32)], axis=2)))
+        assert np.array_equal((f32[-1][:, :, :3] * 255).astype(np.uint8), f)
+    a, b, c = (str(tmp_path / n) for n in ("u8.db", "f32_thread.db", "f32_sync.db"))
+    core.generate_optical_flow_database(core.VideoInfo(256, 192, 1, 12), lambda fid: u8[fid - 1], None, a)
+    requested, _, errors = _run_thread(core, f32, 1, b)
+    assert not errors and requested == list(range(1, 13))
+    core.generate_optical_flow_database(core.VideoInfo(256, 192, 1, 12), lambda fid: f32[fid - 1], None, c)
+    assert _dump(a) == _dump(b) == _dump(c)

@@ -54,6 +54,37 @@ def test_device_resident_rgb(ctx):
     f.close()
 
 
+def _blender_floats(rgb_u8, channels, rng):
+    """float32 pixels whose addon-side conversion `(x * 255).astype(np.uint8)` (analysis.py:232) gives rgb_u8 back"""
+    x = (rgb_u8.astype(np.float32) + rng.uniform(0.05, 0.95, rgb_u8.shape).astype(np.float32)) / np.float32(255.0)
+    if channels == 4:
+        x = np.concatenate([x, rng.uniform(0, 1, rgb_u8.shape[:2] + (1,)).astype(np.float32)], axis=2)
+    return np.ascontiguousarray(x)
+
+
+@pytest.mark.parametrize("channels,on_device", [(3, False), (4, False), (4, True)])
+def test_float_frames_convert_like_the_addon(ctx, channels, on_device):
+    """Frame ingestion: Blender's float pixels go to the GPU as they are; the addon's numpy pass
+    `(image_data * 255).astype(np.uint8)` (+ dropping alpha) happens in the RGB->gray kernel."""
+    import torch
+    rng = np.random.default_rng(7)
+    w, h = 333, 211
+    x = _blender_floats(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), channels, rng)
+    x[0, 0, :3] = [1.0, 0.0, 0.999999]            # exactly white / black / just below white
+    x[0, 1, :3] = [1.5, -0.1, 2.0]                # out of range: numpy keeps the low byte of the int32
+    want_u8 = (x[:, :, :3] * 255).astype(np.uint8)
+    assert want_u8[0, 0].tolist() == [255, 0, 254] and want_u8[0, 1].tolist() == [126, 231, 254]
+    f = hip.Frame(ctx, w, h, 10, 3)
+    f.set_rgb(torch.from_numpy(x).cuda() if on_device else x)
+    assert np.array_equal(f.gray(), oracle.rgb2gray(want_u8))
+    p = oracle.Pyramid(oracle.rgb2gray(want_u8), 10, 3)
+    for l in range(p.num_levels):
+        assert np.array_equal(f.level(l), p.image(l)) and np.array_equal(f.deriv(l), p.deriv(l))
+    with pytest.raises(hip.PolychaseHipError):
+        f.set_rgb(np.zeros((h, w, 2), np.float32))
+    f.close()
+
+
 @pytest.mark.parametrize("w,h,kind", [(640, 480, "checker"), (640, 360, "noise"), (333, 211, "noise"),
                                       (1920, 1080, "noise")])
 def test_gftt_bit_exact(ctx, w, h, kind):
