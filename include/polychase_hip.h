@@ -226,6 +226,10 @@ typedef struct pc_ray_camera {
  * uvt n x 3 = (u, v, t). */
 int pc_raycast_pixels(pc_context* ctx, const pc_mesh* mesh, const pc_ray_camera* cam, const float* xy, int n,
                       int check_mask, uint8_t* hit, float* pos, uint32_t* prim, float* uvt);
+/* The same result by an exhaustive sweep over every triangle instead of the hierarchy pc_mesh_create
+ * builds (Embree's BVH in the reference, ray_casting.cc:23-63): the validation path of that hierarchy. */
+int pc_raycast_pixels_sweep(pc_context* ctx, const pc_mesh* mesh, const pc_ray_camera* cam, const float* xy, int n,
+                            int check_mask, uint8_t* hit, float* pos, uint32_t* prim, float* uvt);
 
 /* PnPProblem (cpp/pnp/pnp_problem.h:11-142): object points X n x 3, image points x n x 2,
  * optional per-residual weights (NULL = 1). Host pointers; copied to the GPU once per frame. */

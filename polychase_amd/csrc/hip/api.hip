@@ -1128,6 +1128,18 @@ struct pc_mesh {
     int n_vertices = 0, n_triangles = 0;
     DevBuf<float> verts;
     DevBuf<uint32_t> tris, mask;
+    // LBVH (bvh.hpp): n_triangles - 1 internal nodes + the sorted leaf order
+    DevBuf<pc::BvhNode> bvh_nodes;
+    DevBuf<uint32_t> bvh_leaf_tri;
+    pc::BvhView bvh() const {
+        pc::BvhView v;
+        v.nodes = bvh_nodes.p;
+        v.leaf_tri = bvh_leaf_tri.p;
+        v.verts = verts.p;
+        v.tris = tris.p;
+        v.n_tris = n_triangles;
+        return v;
+    }
     // per-call scratch
     DevBuf<float2> d_xy;
     DevBuf<uint8_t> d_hit;
@@ -1166,6 +1178,56 @@ int pc_mesh_create(pc_context* ctx, const float* vertices, int n_vertices, const
     if (e == hipSuccess && n_vertices) e = hipMemcpyAsync(m->verts.p, vertices, (size_t)n_vertices * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && n_triangles) e = hipMemcpyAsync(m->tris.p, triangles, (size_t)n_triangles * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(m->mask.p, 0, (size_t)words * sizeof(uint32_t), ctx->stream);
+    // acceleration structure (rtcCommitScene in the reference, ray_casting.cc:23-63): LBVH built on the GPU
+    if (e == hipSuccess && n_triangles > 0) {
+        const size_t n = (size_t)n_triangles;
+        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        for (int v = 0; v < n_vertices; v++)
+            for (int k = 0; k < 3; k++) {
+                const float x = vertices[3 * (size_t)v + k];
+                if (v == 0 || x < lo[k]) lo[k] = x;
+                if (v == 0 || x > hi[k]) hi[k] = x;
+            }
+        const float extent = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+        const float pad = 1e-5f * extent + 1e-30f;
+        DevBuf<unsigned long long> keys_in, keys_out;
+        DevBuf<float> box_lo, box_hi;
+        DevBuf<int> links;      // parent (2n-1) | visits (n) | left (n) | right (n)
+        DevBuf<uint32_t> bounds;
+        DevBuf<uint8_t> sort_temp;
+        const size_t temp_bytes = pc::bvh_sort_temp_bytes(n_triangles);
+        e = m->bvh_nodes.ensure(n);
+        if (e == hipSuccess) e = m->bvh_leaf_tri.ensure(n);
+        if (e == hipSuccess) e = keys_in.ensure(n);
+        if (e == hipSuccess) e = keys_out.ensure(n);
+        if (e == hipSuccess) e = box_lo.ensure(3 * (2 * n));
+        if (e == hipSuccess) e = box_hi.ensure(3 * (2 * n));
+        if (e == hipSuccess) e = links.ensure(5 * n + 8);
+        if (e == hipSuccess) e = bounds.ensure(8);
+        if (e == hipSuccess) e = sort_temp.ensure(temp_bytes + 16);
+        if (e == hipSuccess) {
+            pc::BvhBuildScratch sc;
+            sc.keys_in = keys_in.p;
+            sc.keys_out = keys_out.p;
+            sc.box_lo = box_lo.p;
+            sc.box_hi = box_hi.p;
+            sc.parent = links.p;
+            sc.visits = links.p + 2 * n;
+            sc.left = links.p + 3 * n;
+            sc.right = links.p + 4 * n;
+            sc.bounds = bounds.p;
+            e = pc::bvh_build(m->verts.p, m->tris.p, n_triangles, pad, sc, sort_temp.p, temp_bytes, m->bvh_nodes.p,
+                              m->bvh_leaf_tri.p, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        keys_in.release();
+        keys_out.release();
+        box_lo.release();
+        box_hi.release();
+        links.release();
+        bounds.release();
+        sort_temp.release();
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         pc_mesh_destroy(m);
@@ -1195,6 +1257,8 @@ void pc_mesh_destroy(pc_mesh* m) {
     m->verts.release();
     m->tris.release();
     m->mask.release();
+    m->bvh_nodes.release();
+    m->bvh_leaf_tri.release();
     m->d_xy.release();
     m->d_hit.release();
     m->d_pos.release();
@@ -1203,8 +1267,8 @@ void pc_mesh_destroy(pc_mesh* m) {
     delete m;
 }
 
-int pc_raycast_pixels(pc_context* ctx, const pc_mesh* mesh_c, const pc_ray_camera* cam, const float* xy, int n,
-                      int check_mask, uint8_t* hit, float* pos, uint32_t* prim, float* uvt) {
+static int raycast_pixels(pc_context* ctx, const pc_mesh* mesh_c, const pc_ray_camera* cam, const float* xy, int n,
+                          int check_mask, uint8_t* hit, float* pos, uint32_t* prim, float* uvt, bool sweep) {
     if (!ctx || !mesh_c || !cam || n < 0) return fail(PC_E_INVALID, "bad argument");
     if (n == 0) return PC_OK;
     if (!xy || !hit || !pos || !prim || !uvt) return fail(PC_E_INVALID, "null buffer");
@@ -1224,14 +1288,28 @@ int pc_raycast_pixels(pc_context* ctx, const pc_mesh* mesh_c, const pc_ray_camer
     rc.cy = cam->cy;
     rc.sign = cam->unproject_sign;
     PC_HIP(hipMemcpyAsync(mesh->d_xy.p, xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
-    pc::launch_raycast(mesh->verts.p, mesh->tris.p, mesh->n_triangles, mesh->mask.p, check_mask, rc, mesh->d_xy.p, n,
-                       mesh->d_hit.p, mesh->d_pos.p, mesh->d_prim.p, mesh->d_uvt.p, ctx->stream);
+    if (sweep)
+        pc::launch_raycast_sweep(mesh->verts.p, mesh->tris.p, mesh->n_triangles, mesh->mask.p, check_mask, rc, mesh->d_xy.p, n,
+                                 mesh->d_hit.p, mesh->d_pos.p, mesh->d_prim.p, mesh->d_uvt.p, ctx->stream);
+    else
+        pc::launch_raycast(mesh->bvh(), mesh->mask.p, check_mask, rc, mesh->d_xy.p, n, mesh->d_hit.p, mesh->d_pos.p,
+                           mesh->d_prim.p, mesh->d_uvt.p, ctx->stream);
     PC_HIP(hipMemcpyAsync(hit, mesh->d_hit.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     PC_HIP(hipMemcpyAsync(pos, mesh->d_pos.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PC_HIP(hipMemcpyAsync(prim, mesh->d_prim.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     PC_HIP(hipMemcpyAsync(uvt, mesh->d_uvt.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PC_HIP(hipStreamSynchronize(ctx->stream));
     return PC_OK;
+}
+
+int pc_raycast_pixels(pc_context* ctx, const pc_mesh* mesh, const pc_ray_camera* cam, const float* xy, int n, int check_mask,
+                      uint8_t* hit, float* pos, uint32_t* prim, float* uvt) {
+    return raycast_pixels(ctx, mesh, cam, xy, n, check_mask, hit, pos, prim, uvt, false);
+}
+
+int pc_raycast_pixels_sweep(pc_context* ctx, const pc_mesh* mesh, const pc_ray_camera* cam, const float* xy, int n,
+                            int check_mask, uint8_t* hit, float* pos, uint32_t* prim, float* uvt) {
+    return raycast_pixels(ctx, mesh, cam, xy, n, check_mask, hit, pos, prim, uvt, true);
 }
 
 int pc_pnp_problem_create(pc_context* ctx, const float* X, const float* x, const float* weights, int n,
@@ -1369,6 +1447,7 @@ pc::RefineProblemView refine_view(const pc_refine_problem* p) {
     v.verts = p->mesh->verts.p;
     v.tris = p->mesh->tris.p;
     v.mask = p->mesh->mask.p;
+    v.bvh = p->mesh->bvh();
     std::memcpy(v.model, p->model, sizeof(v.model));
     std::memcpy(v.model_inv, p->model_inv, sizeof(v.model_inv));
     return v;

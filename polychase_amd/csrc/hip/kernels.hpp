@@ -1,6 +1,7 @@
 // kernels.hpp -- host-side launchers of the gfx950 kernels (implemented in kernels_*.hip).
 #pragma once
 
+#include "bvh.hpp"
 #include "common.hpp"
 
 namespace pc {
@@ -96,9 +97,13 @@ struct PnPParams {
     int loss_type;     // 0 trivial, 1 Huber, 2 Cauchy (BundleOptions::LossType)
     float loss_scale;
 };
-void launch_raycast(const float* verts, const uint32_t* tris, int n_tris, const uint32_t* mask, int check_mask,
-                    const RayCamera& cam, const float2* xy, int n, uint8_t* hit, float* pos, uint32_t* prim,
-                    float* uvt, hipStream_t s);
+// closest hit per pixel through the mesh's LBVH
+void launch_raycast(const BvhView& bvh, const uint32_t* mask, int check_mask, const RayCamera& cam, const float2* xy, int n,
+                    uint8_t* hit, float* pos, uint32_t* prim, float* uvt, hipStream_t s);
+// the same by an exhaustive sweep over all triangles (validation of the hierarchy)
+void launch_raycast_sweep(const float* verts, const uint32_t* tris, int n_tris, const uint32_t* mask, int check_mask,
+                          const RayCamera& cam, const float2* xy, int n, uint8_t* hit, float* pos, uint32_t* prim,
+                          float* uvt, hipStream_t s);
 int pnp_num_blocks(int n);
 // out56: [0..44] JtJ lower triangle (row-major packed), [45..53] Jtr, [54] valid residual count
 void launch_pnp_normal_eq(const float* X, const float* x, const float* w, int n, const PnPParams& p, float* partials,
@@ -130,6 +135,7 @@ struct RefineProblemView {
     const float* verts;
     const uint32_t* tris;
     const uint32_t* mask;
+    BvhView bvh;                   // closest-hit ray casts when the cached triangle is missed
     float model[16], model_inv[16];
 };
 // edge_out[e] = {sum of losses over valid residuals, valid count}, accumulated in fp64

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void refine_cost_kernel(RefineProblemView P, c
                                                           int loss_type, float loss_scale,
                                                           double2* __restrict__ edge_out) {
     __shared__ double s_part[4][2];
+    __shared__ int s_stack[kBvhStack][256];   // per-lane traversal stacks
     const int e = blockIdx.x;
     const int src = P.edge_src[e], tgt = P.edge_tgt[e];
     const RefineCamera cs = cams[src], ct = cams[tgt];
@@ -105,23 +106,13 @@ __global__ __launch_bounds__(256) void refine_cost_kernel(RefineProblemView P, c
             found = ray_triangle(o_obj, d_obj, load_vertex(P.verts, a), load_vertex(P.verts, b), load_vertex(P.verts, c), &p_obj) >= 0.f;
         }
         if (!found) {  // closest hit over the whole mesh, masked closest triangle = miss (:333-345)
-            float best_t = __builtin_inff();
-            int best = -1;
-            float3 best_p = p_obj;
-            for (int k = 0; k < P.n_tris; k++) {
-                float3 h;
-                const float t = ray_triangle(o_obj, d_obj, load_vertex(P.verts, P.tris[3 * k]), load_vertex(P.verts, P.tris[3 * k + 1]),
-                                             load_vertex(P.verts, P.tris[3 * k + 2]), &h);
-                if (t >= 0.f && t < best_t) {
-                    best_t = t;
-                    best = k;
-                    best_p = h;
-                }
-            }
+            float bt, bu, bv;
+            const int best = bvh_closest_hit(P.bvh, o_obj.x, o_obj.y, o_obj.z, d_obj.x, d_obj.y, d_obj.z, &s_stack[0][threadIdx.x], 256,
+                                             &bt, &bu, &bv);
             if (best >= 0 && !((P.mask[best >> 5] >> (best & 31)) & 1u)) {
                 // Embree reports the barycentric point; identical to o + t d up to rounding
                 found = true;
-                p_obj = best_p;
+                p_obj = add3(o_obj, scale3(d_obj, bt));
                 P.prim_cache[kp] = (uint32_t)best;
             } else {
                 P.prim_cache[kp] = 0xffffffffu;

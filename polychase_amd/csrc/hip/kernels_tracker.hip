@@ -1,11 +1,13 @@
 // kernels_tracker.hip -- GPU kernels of the "Track Sequence" path (reference cpp/tracker.cc):
 //   K12  closest-hit ray casting of source keypoints onto the mesh   (tracker.cc:64-78; Embree
-//        rtcIntersect1 in the reference, cpp/ray_casting.cc:65-121).  Brute force over triangles
-//        staged through LDS; the per-triangle test is the reference's own Moeller-Trumbore
-//        (cpp/ray_casting.h:125-179).
+//        rtcIntersect1 in the reference, cpp/ray_casting.cc:65-121).  One lane per ray walking the
+//        LBVH of bvh.hpp with a per-lane stack in LDS; the per-triangle test is the reference's own
+//        Moeller-Trumbore (cpp/ray_casting.h:125-179).  The exhaustive sweep over all triangles
+//        (staged through LDS) is kept as the validation path of the hierarchy.
 //   K11  PnP residual / Jacobian / normal equations / cost          (cpp/pnp/pnp_problem.h:52-99,
 //        cpp/pnp/lev_marq.h:231-356), deterministic two-stage reduction.
 // fp32 throughout like the reference (Float = float, cpp/eigen_typedefs.h).
+#include "bvh.hpp"
 #include "kernels.hpp"
 
 namespace pc {
@@ -15,7 +17,7 @@ namespace pc {
 // ------------------------------------------------------------------------------------------------
 constexpr int RC_TILE = 256;
 
-__global__ __launch_bounds__(256) void raycast_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ tris,
+__global__ __launch_bounds__(256) void raycast_sweep_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ tris,
                                                       int n_tris, const uint32_t* __restrict__ mask, int check_mask,
                                                       RayCamera cam, const float2* __restrict__ xy, int n,
                                                       uint8_t* __restrict__ hit, float* __restrict__ pos,
@@ -99,12 +101,58 @@ __global__ __launch_bounds__(256) void raycast_kernel(const float* __restrict__ 
     }
 }
 
-void launch_raycast(const float* verts, const uint32_t* tris, int n_tris, const uint32_t* mask, int check_mask,
-                    const RayCamera& cam, const float2* xy, int n, uint8_t* hit, float* pos, uint32_t* prim,
-                    float* uvt, hipStream_t s) {
+void launch_raycast_sweep(const float* verts, const uint32_t* tris, int n_tris, const uint32_t* mask, int check_mask,
+                          const RayCamera& cam, const float2* xy, int n, uint8_t* hit, float* pos, uint32_t* prim,
+                          float* uvt, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(raycast_kernel, dim3((n + 255) / 256), dim3(256), 0, s, verts, tris, n_tris, mask, check_mask,
+    hipLaunchKernelGGL(raycast_sweep_kernel, dim3((n + 255) / 256), dim3(256), 0, s, verts, tris, n_tris, mask, check_mask,
                        cam, xy, n, hit, pos, prim, uvt);
+}
+
+constexpr int RC_BLOCK = 128;
+
+__global__ __launch_bounds__(RC_BLOCK) void raycast_bvh_kernel(BvhView B, const uint32_t* __restrict__ mask, int check_mask,
+                                                               RayCamera cam, const float2* __restrict__ xy, int n,
+                                                               uint8_t* __restrict__ hit, float* __restrict__ pos,
+                                                               uint32_t* __restrict__ prim, float* __restrict__ uvt) {
+    __shared__ int s_stack[kBvhStack][RC_BLOCK];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // CameraIntrinsics::Unproject (cpp/pnp/types.h:95-98) then rotate into object space
+    const float2 p = xy[i];
+    const float ux = cam.sign * ((p.x - cam.cx) / cam.fx), uy = cam.sign * ((p.y - cam.cy) / cam.fy), uz = cam.sign;
+    const float dx = cam.m[0] * ux + cam.m[1] * uy + cam.m[2] * uz;
+    const float dy = cam.m[3] * ux + cam.m[4] * uy + cam.m[5] * uz;
+    const float dz = cam.m[6] * ux + cam.m[7] * uy + cam.m[8] * uz;
+    float best_t, best_u, best_v;
+    const int best = bvh_closest_hit(B, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, &s_stack[0][threadIdx.x], RC_BLOCK,
+                                     &best_t, &best_u, &best_v);
+    bool ok = best >= 0;
+    // a masked closest triangle is a miss, not a pass-through (ray_casting.cc:104-106)
+    if (ok && check_mask && ((mask[best >> 5] >> (best & 31)) & 1u)) ok = false;
+    hit[i] = ok ? 1 : 0;
+    if (ok) {
+        const uint32_t a = B.tris[3 * best], b = B.tris[3 * best + 1], c = B.tris[3 * best + 2];
+        const float w0 = 1.0f - best_u - best_v;
+#pragma unroll
+        for (int k = 0; k < 3; k++)  // Triangle::Barycentric (geometry.h:17-19)
+            pos[3 * i + k] = w0 * B.verts[3 * a + k] + best_u * B.verts[3 * b + k] + best_v * B.verts[3 * c + k];
+        prim[i] = (uint32_t)best;
+        uvt[3 * i] = best_u;
+        uvt[3 * i + 1] = best_v;
+        uvt[3 * i + 2] = best_t;
+    } else {
+        pos[3 * i] = pos[3 * i + 1] = pos[3 * i + 2] = 0.f;
+        prim[i] = 0xffffffffu;
+        uvt[3 * i] = uvt[3 * i + 1] = uvt[3 * i + 2] = 0.f;
+    }
+}
+
+void launch_raycast(const BvhView& bvh, const uint32_t* mask, int check_mask, const RayCamera& cam, const float2* xy, int n,
+                    uint8_t* hit, float* pos, uint32_t* prim, float* uvt, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(raycast_bvh_kernel, dim3((n + RC_BLOCK - 1) / RC_BLOCK), dim3(RC_BLOCK), 0, s, bvh, mask, check_mask, cam, xy,
+                       n, hit, pos, prim, uvt);
 }
 
 // ------------------------------------------------------------------------------------------------

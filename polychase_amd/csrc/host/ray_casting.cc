@@ -16,7 +16,7 @@ AcceleratedMesh::AcceleratedMesh(std::vector<float> vertices, std::vector<uint32
 AcceleratedMesh::~AcceleratedMesh() { pc_mesh_destroy(gpu_); }
 
 void AcceleratedMesh::RayCastPixels(const SceneTransformations& st, const float* xy, size_t n, bool check_mask,
-                                    std::vector<std::optional<RayHit>>& hits) const {
+                                    std::vector<std::optional<RayHit>>& hits, bool exhaustive) const {
     hits.assign(n, std::nullopt);
     if (n == 0) return;
     pc_context* ctx = SharedGpuContext();
@@ -41,8 +41,8 @@ void AcceleratedMesh::RayCastPixels(const SceneTransformations& st, const float*
     pos_.resize(3 * n);
     uvt_.resize(3 * n);
     prim_.resize(n);
-    if (pc_raycast_pixels(ctx, gpu_, &cam, xy, static_cast<int>(n), check_mask ? 1 : 0, hit_.data(), pos_.data(),
-                          prim_.data(), uvt_.data()) != PC_OK)
+    if ((exhaustive ? pc_raycast_pixels_sweep : pc_raycast_pixels)(ctx, gpu_, &cam, xy, static_cast<int>(n), check_mask ? 1 : 0,
+                                                                   hit_.data(), pos_.data(), prim_.data(), uvt_.data()) != PC_OK)
         throw std::runtime_error(std::string("pc_raycast_pixels: ") + pc_last_error());
     for (size_t i = 0; i < n; i++) {
         if (!hit_[i]) continue;

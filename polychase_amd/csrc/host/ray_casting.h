@@ -1,6 +1,6 @@
 // ray_casting.h -- AcceleratedMesh and RayCast of the reference (cpp/ray_casting.h:23-51,
-// cpp/ray_casting.cc) with the Embree scene replaced by a mesh resident on the GPU and a batched
-// closest-hit kernel (pc_raycast_pixels).
+// cpp/ray_casting.cc) with the Embree scene replaced by a mesh resident on the GPU, an LBVH built on the
+// GPU at construction, and a batched closest-hit kernel (pc_raycast_pixels).
 #pragma once
 
 #include <memory>
@@ -23,8 +23,9 @@ class AcceleratedMesh {
     pc_mesh* Gpu() const { return gpu_; }
 
     // Batched RayCast(accel_mesh, scene_transform, pos, check_mask): hits[i] is empty on a miss.
+    // exhaustive: sweep over every triangle instead of walking the hierarchy (validation only)
     void RayCastPixels(const SceneTransformations& scene_transform, const float* xy, size_t n, bool check_mask,
-                       std::vector<std::optional<RayHit>>& hits) const;
+                       std::vector<std::optional<RayHit>>& hits, bool exhaustive = false) const;
 
    private:
     Mesh mesh_;

@@ -356,13 +356,14 @@ void BindTracker(py::module_& m) {
 
     m.def(
         "_ray_cast_pixels",
-        [](const AcceleratedMesh& mesh, const SceneTransformations& st, const F32Array& xy, bool check_mask) {
+        [](const AcceleratedMesh& mesh, const SceneTransformations& st, const F32Array& xy, bool check_mask, bool exhaustive) {
             if (xy.ndim() != 2 || xy.shape(1) != 2) throw py::value_error("expected (N,2) pixel positions");
             std::vector<std::optional<RayHit>> hits;
-            mesh.RayCastPixels(st, xy.data(), static_cast<size_t>(xy.shape(0)), check_mask, hits);
+            mesh.RayCastPixels(st, xy.data(), static_cast<size_t>(xy.shape(0)), check_mask, hits, exhaustive);
             return hits;
         },
-        py::arg("accel_mesh"), py::arg("scene_transform"), py::arg("xy"), py::arg("check_mask"));
+        py::arg("accel_mesh"), py::arg("scene_transform"), py::arg("xy"), py::arg("check_mask"),
+        py::arg("exhaustive") = false);   // exhaustive: sweep over all triangles instead of the BVH (validation)
 
     // 9x9 lower Cholesky solve used by the LM step (known-answer test of
     // cpp/examples/levmarq_ill_conditioned_float32_issue.cpp)

@@ -316,3 +316,48 @@ def test_c5_end_to_end_rendered_plane(core, tmp_path):
         assert np.linalg.norm(tg - tt) < 0.05, (f, np.linalg.norm(tg - tt))
         assert inl > 0.5    # keypoints on the smeared border outside the textured plane are outliers; the
                             # addon aborts below 0.25 (blender_addon/operators/tracking.py:286-289)
+
+
+def _random_soup(n_tris, rng):
+    """triangle soup with wildly different sizes, duplicates and degenerate (zero-area) triangles"""
+    c = rng.uniform(-2, 2, (n_tris, 1, 3))
+    size = 10 ** rng.uniform(-2.5, -0.3, (n_tris, 1, 1))
+    verts = (c + rng.normal(0, 1, (n_tris, 3, 3)) * size).reshape(-1, 3).astype(np.float32)
+    tris = np.arange(3 * n_tris, dtype=np.uint32).reshape(-1, 3)
+    tris[5] = tris[4]                        # duplicate triangle: equal t, lowest index must win
+    verts[tris[7]] = verts[tris[7][0]]       # degenerate
+    return verts, tris
+
+
+@pytest.mark.parametrize("kind,n_tris", [("grid", 2 * 150 * 150), ("soup", 30000), ("one", 1), ("two", 2)])
+def test_bvh_ray_casting_equals_exhaustive_sweep(core, kind, n_tris):
+    """The LBVH (Embree's role, ray_casting.cc:23-121) must return exactly what a sweep over every triangle
+    returns: same hit flags, triangles, barycentrics and distances, bit for bit."""
+    rng = np.random.default_rng(5)
+    if kind == "grid":
+        verts, tris = grid_mesh(150)
+    else:
+        verts, tris = _random_soup(max(n_tris, 8), rng)
+        tris = tris[:n_tris] if kind in ("one", "two") else tris
+    mesh = core.AcceleratedMesh(verts, tris)
+    for t in range(0, len(tris), 7):
+        mesh.inner_mut().mask_triangle(t)
+    model = np.diag([1.5, 1.2, 1.3, 1.0]).astype(np.float32)
+    for frame, opencv in ((3, False), (40, False)):
+        R, t = true_pose(frame)
+        st = core.SceneTransformations(model, view4(R, t), intr(core))
+        xy = rng.uniform([-50, -50], [W + 50, H + 50], (60000, 2)).astype(np.float32)
+        xy[:64] = np.floor(xy[:64])                     # integer pixels, like detected keypoints
+        for check_mask in (False, True):
+            a = core._ray_cast_pixels(mesh, st, xy, check_mask)
+            b = core._ray_cast_pixels(mesh, st, xy, check_mask, exhaustive=True)
+            hit_a = np.array([h is not None for h in a])
+            hit_b = np.array([h is not None for h in b])
+            assert np.array_equal(hit_a, hit_b)
+            if kind in ("grid", "soup") and frame == 3:
+                assert 0.05 < hit_a.mean() <= 1.0
+            for ha, hb in zip(a, b):
+                if ha is None:
+                    continue
+                assert ha.primitive_id == hb.primitive_id and ha.t == hb.t
+                assert np.array_equal(ha.barycentric_coordinate, hb.barycentric_coordinate) and np.array_equal(ha.pos, hb.pos)
