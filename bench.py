@@ -220,7 +220,7 @@ def main():
                        "window": 10, "pairs_per_frame": 8, "frames_per_gpu": K,
                        "mean_keypoints": float(np.mean(n_kps)), "mean_flow_rows": float(np.mean(n_rows)),
                        "parallelism": f"frame-shard x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "lk_kernel<10>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "lk2_kernel<10>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": lk_bytes, "avg_launch_ms": lk_avg_ms,
                          "launches": lk_n},

@@ -69,6 +69,8 @@ struct LKParams {
 // K8-K10: pyramidal LK, one 16-lane DPP row per (keypoint, target).  Returns false if the window
 // size is unsupported.
 bool launch_lk(const LKParams& p, int win, hipStream_t s);
+// the same with two keypoints per wavefront (kernels_lk2.hip); window sizes 4..11
+bool launch_lk2(const LKParams& p, int win, hipStream_t s);
 // counting sort of keypoint indices by 64x64 tile -> perm[n]; hist: bin_num_tiles(w, h) words of scratch
 int bin_num_tiles(int w, int h);
 void launch_spatial_bins(const float2* pts, int n, int w, int h, uint32_t* hist, uint32_t* perm, hipStream_t s);
