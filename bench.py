@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)   # > 17 + 2 ring slots: every slot has been used once
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true",
+                    help="skip the extra per-class timing pass (profilers: only warm-up + timed launches remain)")
     ap.add_argument("--force-dist-path", action="store_true",
                     help="exercise the device-log + stitch code path with a single rank (testing)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample")
@@ -181,16 +183,19 @@ def main():
         del gathered, log
     # per-class kernel breakdown from a short extra pass over the same frames (not part of `value`)
     an.close()
-    n_extra = min(K, 20)
-    an = ClipAnalyzer(ctx, w, h, first_id, n_local, lambda fid: frames[fid], hip.gftt_options(**gopt_kw),
-                      hip.flow_options(**fopt_kw), max_jobs=3)
-    an.run(range(f1_first, f1_first + 2), None)
-    ctx.synchronize()
-    ctx.enable_timing(True)
-    ctx.reset_timing()
-    an.run(range(f1_first + 2, f1_first + 2 + n_extra), None)
-    breakdown = {k: v[1] / n_extra for k, v in ctx.timing().items()}
-    ctx.enable_timing(False)
+    breakdown = None
+    if not args.no_breakdown:
+        n_extra = min(K, 20)
+        an = ClipAnalyzer(ctx, w, h, first_id, n_local, lambda fid: frames[fid], hip.gftt_options(**gopt_kw),
+                          hip.flow_options(**fopt_kw), max_jobs=3)
+        an.run(range(f1_first, f1_first + 2), None)
+        ctx.synchronize()
+        ctx.enable_timing(True)
+        ctx.reset_timing()
+        an.run(range(f1_first + 2, f1_first + 2 + n_extra), None)
+        breakdown = {k: v[1] / n_extra for k, v in ctx.timing().items()}
+        ctx.enable_timing(False)
+        an.close()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -235,7 +240,6 @@ def main():
                                                target_seconds=args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    an.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
