@@ -182,6 +182,37 @@ def test_lk_bit_exact_odd_size_and_windows(ctx):
     _lk_case(ctx, 333, 211, 5, [7], max_level=4, win=13)
 
 
+@pytest.mark.parametrize("win,n_targets", [(3, 2), (4, 1), (5, 3), (6, 8), (8, 5), (9, 7), (11, 4), (12, 2), (16, 3)])
+def test_lk_every_window_size_and_target_count(ctx, win, n_targets):
+    """Windows 4..11 run the two-keypoints-per-wavefront kernel (chains + remainder columns differ per size),
+    the others the one-keypoint kernel; target counts below 8 leave groups idle."""
+    ts = [11, 12, 14, 18, 9, 8, 6, 2][:n_targets]
+    _lk_case(ctx, 320, 200, 10, ts, max_level=2, win=win)
+
+
+def test_lk_odd_keypoint_count_and_tiny_sets(ctx):
+    """An odd number of keypoints leaves the last wavefront's second half without a keypoint; 1 and 2 keypoints."""
+    w, h = 320, 200
+    clip, frames = _noise_frames(w, h, [4, 6, 7])
+    grays = [oracle.rgb2gray(fr) for fr in frames]
+    fr = [hip.Frame(ctx, w, h) for _ in frames]
+    for f, im in zip(fr, frames):
+        f.set_rgb(im)
+    rng = np.random.default_rng(4)
+    for n in (1, 2, 3, 77, 1001):
+        pts = np.floor(rng.uniform([12, 12], [w - 12, h - 12], (n, 2))).astype(np.float32)
+        fr[0].set_keypoints(pts)
+        xy, st, err = hip.lk_track(ctx, fr[0], fr[1:])
+        for k in range(2):
+            oxy, ost, oerr = oracle.lk(oracle.Pyramid(grays[0]), oracle.Pyramid(grays[1 + k]), pts)
+            assert np.array_equal(st[k], ost)
+            m = ost == 1
+            assert np.array_equal(xy[k][m].view(np.uint32), oxy[m].view(np.uint32))
+            assert np.array_equal(err[k][m].view(np.uint32), oerr[m].view(np.uint32))
+    for f in fr:
+        f.close()
+
+
 def test_lk_bit_exact_1080p(ctx):
     _lk_case(ctx, 1920, 1080, 15, [16, 23], n=30)
 
