@@ -107,6 +107,13 @@ int pc_frame_set_rgb(pc_context* ctx, pc_frame* f, const uint8_t* rgb, size_t ro
  * `(image_data * 255).astype(np.uint8)` (blender_addon/operators/analysis.py:221-233) followed by
  * cvtColor: the same fp32 multiply and truncating cast, on the GPU. */
 int pc_frame_set_rgb_f32(pc_context* ctx, pc_frame* f, const float* rgb, size_t row_pitch, int channels, int on_device);
+/* Page-locked host memory that the GPU reads directly (hipHostMalloc): a frame copied into such a buffer
+ * can be handed to pc_frame_set_rgb* / pc_analyzer_put_frame* with on_device = 1 -- the gray kernel then
+ * pulls the pixels over PCIe itself, asynchronously, instead of a blocking pageable copy into a staging
+ * buffer.  The buffer must stay untouched until the frame has been converted (for the analyzer: until 4
+ * more frames have been put).  Replaces the cv::Mat clone of opticalflow_thread.h:120-132. */
+int pc_host_buffer_alloc(size_t bytes, void** out);
+void pc_host_buffer_free(void* buffer);
 /* Same, from an 8-bit gray image (tests / callers that already hold gray). */
 int pc_frame_set_gray(pc_context* ctx, pc_frame* f, const uint8_t* gray, size_t row_pitch, int on_device);
 

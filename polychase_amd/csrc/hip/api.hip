@@ -547,6 +547,16 @@ static int set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t ro
     return PC_OK;
 }
 
+int pc_host_buffer_alloc(size_t bytes, void** out) {
+    if (!out) return fail(PC_E_INVALID, "null out");
+    *out = nullptr;
+    PC_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return PC_OK;
+}
+void pc_host_buffer_free(void* buffer) {
+    if (buffer) (void)hipHostFree(buffer);
+}
+
 int pc_frame_set_rgb(pc_context* ctx, pc_frame* f, const uint8_t* rgb, size_t row_pitch, int on_device) {
     return set_image(ctx, f, rgb, row_pitch, on_device, 3);
 }

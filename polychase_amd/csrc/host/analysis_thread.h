@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "analysis.h"
+#include "frame_pool.h"
 #include "worker.h"
 
 struct OpticalFlowProgress {
@@ -56,19 +57,22 @@ class OpticalFlowThread : public Worker<OpticalFlowThreadMessage> {
         frame_cv_.notify_all();
     }
 
-    // Deep copy on entry (cpp/opticalflow_thread.h:120-132): the caller's buffer is free on return.
+    // Deep copy on entry (cpp/opticalflow_thread.h:120-132): the caller's buffer is free on return.  The copy
+    // lands in pinned memory, which the GPU reads directly (frame_pool.h).
     void ProvideFrame(int32_t frame_id, const uint8_t* data, int rows, int cols, int channels, size_t row_pitch,
                       int elem_size = 1) {
         const size_t row_bytes = static_cast<size_t>(cols) * channels * elem_size;
-        auto pixels = std::make_shared<std::vector<uint8_t>>(static_cast<size_t>(rows) * row_bytes);
-        for (int y = 0; y < rows; y++) std::copy_n(data + y * row_pitch, row_bytes, pixels->data() + y * row_bytes);
+        std::shared_ptr<void> pixels = AcquirePinnedFrameBuffer(static_cast<size_t>(rows) * row_bytes);
+        uint8_t* dst = static_cast<uint8_t*>(pixels.get());
+        for (int y = 0; y < rows; y++) std::copy_n(data + y * row_pitch, row_bytes, dst + y * row_bytes);
         FrameView view;
-        view.data = pixels->data();
+        view.data = dst;
         view.rows = rows;
         view.cols = cols;
         view.channels = channels;
         view.elem_size = elem_size;
         view.row_pitch = row_bytes;
+        view.on_device = true;   // device-accessible (pinned) host memory
         view.owner = std::move(pixels);
         {
             std::lock_guard<std::mutex> lk(frame_mtx_);

@@ -9,6 +9,7 @@
 
 #include "../host/flow_database.h"
 #include "../host/analysis.h"
+#include "../host/frame_pool.h"
 #include "../host/analysis_thread.h"
 #include "np_helpers.h"
 
@@ -50,10 +51,11 @@ std::optional<FrameView> FrameFromPython(const py::object& obj, std::deque<py::o
         // Blender's float pixels: converted on the GPU (no numpy `(x * 255).astype(uint8)` pass on the host)
         F32Array fa = F32Array::ensure(obj);
         if (!fa || fa.ndim() != 3) throw py::value_error("float frame must have shape (H, W, 3|4)");
-        auto buf = std::make_shared<std::vector<float>>(static_cast<size_t>(fa.size()));
-        std::memcpy(buf->data(), fa.data(), buf->size() * sizeof(float));
+        std::shared_ptr<void> buf = AcquirePinnedFrameBuffer(static_cast<size_t>(fa.size()) * sizeof(float));
+        std::memcpy(buf.get(), fa.data(), static_cast<size_t>(fa.size()) * sizeof(float));
         FrameView v;
-        v.data = reinterpret_cast<const uint8_t*>(buf->data());
+        v.on_device = true;   // pinned host memory, read by the GPU directly (frame_pool.h)
+        v.data = static_cast<const uint8_t*>(buf.get());
         v.rows = static_cast<int>(fa.shape(0));
         v.cols = static_cast<int>(fa.shape(1));
         v.channels = static_cast<int>(fa.shape(2));
@@ -64,10 +66,11 @@ std::optional<FrameView> FrameFromPython(const py::object& obj, std::deque<py::o
     }
     U8Array a = U8Array::ensure(obj);
     if (!a || a.ndim() != 3) throw py::value_error("frame must be a uint8 array of shape (H, W, 3)");
-    auto buf = std::make_shared<std::vector<uint8_t>>(static_cast<size_t>(a.size()));
-    std::memcpy(buf->data(), a.data(), buf->size());
+    std::shared_ptr<void> buf = AcquirePinnedFrameBuffer(static_cast<size_t>(a.size()));
+    std::memcpy(buf.get(), a.data(), static_cast<size_t>(a.size()));
     FrameView v;
-    v.data = buf->data();
+    v.on_device = true;   // pinned host memory, read by the GPU directly (frame_pool.h)
+    v.data = static_cast<const uint8_t*>(buf.get());
     v.rows = static_cast<int>(a.shape(0));
     v.cols = static_cast<int>(a.shape(1));
     v.channels = static_cast<int>(a.shape(2));

@@ -22,6 +22,7 @@ SYMBOLS = [
     "pc_context_create", "pc_context_destroy", "pc_context_synchronize", "pc_context_stream",
     "pc_context_enable_timing", "pc_context_get_timing", "pc_context_reset_timing",
     "pc_frame_create", "pc_frame_destroy", "pc_frame_set_rgb", "pc_frame_set_rgb_f32", "pc_frame_set_gray",
+    "pc_host_buffer_alloc", "pc_host_buffer_free",
     "pc_frame_num_levels", "pc_frame_level_size", "pc_frame_download_gray", "pc_frame_download_level",
     "pc_frame_download_deriv", "pc_frame_detect", "pc_frame_download_min_eig", "pc_frame_num_candidates",
     "pc_frame_num_keypoints", "pc_frame_download_keypoints", "pc_frame_set_keypoints",
