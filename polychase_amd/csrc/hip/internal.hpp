@@ -3,6 +3,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -36,6 +39,12 @@ inline int fail(int code, const char* fmt, ...) {
             return fail(PC_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// POLYCHASE_TRACE_ALLOC=1: report every (re)allocation of a scratch buffer (each one stalls the pipeline)
+inline bool trace_allocations() {
+    static const bool on = getenv("POLYCHASE_TRACE_ALLOC") != nullptr;
+    return on;
+}
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -46,6 +55,7 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
         size_t want = n + n / 2 + 64;   // generous: a reallocation synchronises the device
+        if (trace_allocations()) fprintf(stderr, "[polychase_hip] device buffer %zu -> %zu bytes\n", cap * sizeof(T), want * sizeof(T));
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
         if (e == hipSuccess) cap = want;
         return e;
@@ -67,6 +77,7 @@ struct PinBuf {
         p = nullptr;
         cap = 0;
         size_t want = n + n / 2 + 64;   // pinned allocations take tens of milliseconds
+        if (trace_allocations()) fprintf(stderr, "[polychase_hip] pinned buffer %zu -> %zu bytes\n", cap * sizeof(T), want * sizeof(T));
         hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocDefault);
         if (e == hipSuccess) cap = want;
         return e;
