@@ -139,6 +139,12 @@ def main():
         n_kps.append(len(kps))
         n_rows.append(sum(len(v[0]) for v in flows.values()))
 
+    # the Python driver loop must not stall the GPU pipeline: a generation-2 collection pauses this process for
+    # 50-90 ms (the C++ driver of polychase_core has no such pauses).  Collected BEFORE the warm-up so that nothing
+    # slow sits between the warm-up and the timed region: an idle GPU drops its clocks and the first launches
+    # after the barrier would run at a fraction of their speed.
+    gc.collect()
+    gc.disable()
     an.run(range(f1_first, f1_first + W), sink)
     log = None
     if dist_path:
@@ -152,10 +158,6 @@ def main():
     barrier()
     ctx.enable_timing(["lk"])   # HIP events around the dominant kernel only (2 records per step)
     ctx.reset_timing()
-    # the Python driver loop must not stall the GPU pipeline: a generation-2 collection pauses this process for
-    # 50-90 ms (the C++ driver of polychase_core has no such pauses)
-    gc.collect()
-    gc.disable()
     t0 = time.perf_counter()
     an.run(range(f1_first + W, f1_first + W + K), sink, copy=False)
     if dist_path:

@@ -3,6 +3,9 @@
 // Host-side orchestration only: HBM plane layout, stream ordering, read-backs, and the two pieces of
 // GoodFeaturesToTrack that are sequential by definition (greedy min-distance suppression,
 // reference cpp/feature_detection/gftt.cc:100-164).  No pixel arithmetic happens on the CPU.
+#include <chrono>
+#include <ratio>
+
 #include "internal.hpp"
 
 namespace pc {
@@ -207,6 +210,8 @@ int join_prep(pc_context* ctx) {
     if (!ctx->prep_dirty) return PC_OK;
     PC_HIP(hipEventRecord(ctx->prep_fence, ctx->prep_stream));
     PC_HIP(hipStreamWaitEvent(ctx->stream, ctx->prep_fence, 0));
+    PC_HIP(hipEventRecord(ctx->prep_fence, ctx->copy_stream));
+    PC_HIP(hipStreamWaitEvent(ctx->stream, ctx->prep_fence, 0));
     ctx->prep_dirty = false;
     return PC_OK;
 }
@@ -255,12 +260,12 @@ int check_lk_args(pc_context* ctx, const pc_frame* frame1, const pc_frame* const
 }
 
 int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targets, int n_targets,
-           const pc_flow_options* opt) {
+           const pc_flow_options* opt, int set = 0) {
     const int n = frame1->n_kps;
     const size_t rows = (size_t)n * n_targets;
-    PC_HIP(ctx->lk_xy.ensure(rows + 1));
-    PC_HIP(ctx->lk_status.ensure(rows + 1));
-    PC_HIP(ctx->lk_err.ensure(rows + 1));
+    PC_HIP(ctx->lk_xy[set].ensure(rows + 1));
+    PC_HIP(ctx->lk_status[set].ensure(rows + 1));
+    PC_HIP(ctx->lk_err[set].ensure(rows + 1));
     if (n == 0) return PC_OK;
     pc::LKParams p;
     std::memset(&p, 0, sizeof(p));
@@ -290,9 +295,9 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
     const double eps = std::min(std::max(opt->term_epsilon, 0.), 10.);
     p.eps_sq = eps * eps;
     p.min_eig_thr = (float)opt->min_eigen_threshold;
-    p.out_xy = ctx->lk_xy.p;
-    p.out_status = ctx->lk_status.p;
-    p.out_err = ctx->lk_err.p;
+    p.out_xy = ctx->lk_xy[set].p;
+    p.out_status = ctx->lk_status[set].p;
+    p.out_err = ctx->lk_err[set].p;
     ScopedTimer tm(ctx, PC_K_LK, ctx->stream);
     if (!pc::launch_lk(p, frame1->win, ctx->stream)) return fail(PC_E_INVALID, "unsupported window size %d", frame1->win);
     return PC_OK;
@@ -371,10 +376,13 @@ void pc_context_destroy(pc_context* c) {
     }
     c->keys_out.release();
     c->sort_temp.release();
-    c->lk_xy.release();
+    c->lk_xy[0].release();
+    c->lk_xy[1].release();
     c->lk_cxy.release();
-    c->lk_status.release();
-    c->lk_err.release();
+    c->lk_status[0].release();
+    c->lk_status[1].release();
+    c->lk_err[0].release();
+    c->lk_err[1].release();
     c->lk_cerr.release();
     c->lk_cidx.release();
     c->lk_block_counts.release();
@@ -383,6 +391,7 @@ void pc_context_destroy(pc_context* c) {
     c->prep_hist.release();
     c->lk_row_offset.release();
     c->h_row_offset.release();
+    c->lk_pack.release();
     if (c->copy_stream) {
         (void)hipStreamSynchronize(c->copy_stream);
         (void)hipStreamDestroy(c->copy_stream);
@@ -501,6 +510,7 @@ void pc_frame_destroy(pc_frame* f) {
         (void)hipSetDevice(f->ctx->device);
         (void)hipStreamSynchronize(f->ctx->prep_stream);
         (void)hipStreamSynchronize(f->ctx->stream);
+        (void)hipStreamSynchronize(f->ctx->copy_stream);
         if (f->ctx->eig_owner == f) f->ctx->eig_owner = nullptr;
     }
     if (f->slab) (void)hipFree(f->slab);
@@ -684,9 +694,9 @@ int pc_lk_track(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* 
     if (rc != PC_OK) return rc;
     const size_t rows = (size_t)frame1->n_kps * n_targets;
     if (rows > 0) {
-        PC_HIP(hipMemcpyAsync(next_xy, ctx->lk_xy.p, rows * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
-        PC_HIP(hipMemcpyAsync(status, ctx->lk_status.p, rows, hipMemcpyDeviceToHost, ctx->stream));
-        PC_HIP(hipMemcpyAsync(err, ctx->lk_err.p, rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        PC_HIP(hipMemcpyAsync(next_xy, ctx->lk_xy[0].p, rows * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+        PC_HIP(hipMemcpyAsync(status, ctx->lk_status[0].p, rows, hipMemcpyDeviceToHost, ctx->stream));
+        PC_HIP(hipMemcpyAsync(err, ctx->lk_err[0].p, rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     }
     PC_HIP(hipStreamSynchronize(ctx->stream));
     return PC_OK;
@@ -713,7 +723,7 @@ int pc_lk_track_filtered(pc_context* ctx, const pc_frame* frame1, const pc_frame
     PC_HIP(ctx->h_row_offset.ensure(PC_MAX_TARGETS + 1));
     {
         ScopedTimer t(ctx, PC_K_COMPACT);
-        pc::launch_compact(ctx->lk_xy.p, ctx->lk_status.p, ctx->lk_err.p, n, n_targets, ctx->lk_block_counts.p,
+        pc::launch_compact(ctx->lk_xy[0].p, ctx->lk_status[0].p, ctx->lk_err[0].p, n, n_targets, ctx->lk_block_counts.p,
                            ctx->lk_row_offset.p, ctx->lk_cidx.p, ctx->lk_cxy.p, ctx->lk_cerr.p, ctx->stream);
     }
     PC_HIP(hipMemcpyAsync(ctx->h_row_offset.p, ctx->lk_row_offset.p, (size_t)(n_targets + 1) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -759,11 +769,11 @@ struct Job {
     bool detected = false;
     int n_targets = 0;
     int32_t targets[PC_MAX_TARGETS];
-    PinBuf<float> h_kps, h_xy, h_err;
-    PinBuf<uint32_t> h_idx;
-    PinBuf<long long> h_row_offset;
+    PinBuf<uint8_t> h_pack;   // the job's records, same layout as pc_context::lk_pack
+    size_t o_kps = 0, o_idx = 0, o_xy = 0, o_err = 0, pack_bytes = 0;
     hipEvent_t done = nullptr;      // records of this job are in pinned memory (copy stream)
-    hipEvent_t computed = nullptr;  // LK + compaction finished (main stream)
+    hipEvent_t computed = nullptr;  // compaction (+ device-log copies) finished (copy stream)
+    hipEvent_t lk_done = nullptr;   // the LK launch finished (main stream)
 };
 
 }  // namespace
@@ -778,6 +788,8 @@ struct pc_analyzer {
     std::vector<Job> jobs;
     size_t job_head = 0, job_count = 0;  // ring of in-flight jobs
     hipEvent_t last_done = nullptr;      // download of the most recently submitted job
+    uint64_t submitted = 0;              // jobs submitted so far: job k writes LK output set k & 1
+    hipEvent_t set_free[2] = {nullptr, nullptr};  // `computed` of the last job that used each LK output set
     uint8_t* d_log = nullptr;            // optional device-resident record log
     size_t log_cap = 0, log_used = 0;
     std::vector<PinBuf<long long>> log_hdr;  // one pinned header per job slot
@@ -868,10 +880,30 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
     if (rc == PC_OK)
         for (auto& j : a->jobs)
             if (hipEventCreateWithFlags(&j.done, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&j.computed, hipEventDisableTiming) != hipSuccess) {
+                hipEventCreateWithFlags(&j.computed, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&j.lk_done, hipEventDisableTiming) != hipSuccess) {
                 rc = fail(PC_E_HIP, "hipEventCreate failed");
                 break;
             }
+    if (rc == PC_OK) {
+        // Warm the runtime's copy engines: it picks a free SDMA engine per copy and creates an engine's queue the first
+        // time it is used (5-8 ms inside some hipMemcpyAsync, observed twice or three times in the first few dozen
+        // frames).  A burst of overlapping downloads makes it create them now.
+        const size_t chunk = (size_t)4 << 20, burst = 12;
+        Job& j0 = a->jobs[0];
+        if (ctx->lk_pack.ensure(chunk) != hipSuccess || j0.h_pack.ensure(chunk * burst) != hipSuccess) {
+            rc = fail(PC_E_HIP, "allocation failed");
+        } else {
+            hipStream_t streams[3] = {ctx->copy_stream, ctx->prep_stream, ctx->stream};
+            for (int round = 0; round < 3 && rc == PC_OK; round++) {
+                for (size_t k = 0; k < burst; k++)
+                    if (hipMemcpyAsync(j0.h_pack.p + k * chunk, ctx->lk_pack.p, chunk, hipMemcpyDeviceToHost, streams[k % 3]) !=
+                        hipSuccess)
+                        rc = fail(PC_E_HIP, "copy engine warm-up failed");
+                for (hipStream_t st : streams) (void)hipStreamSynchronize(st);
+            }
+        }
+    }
     if (rc != PC_OK) {
         std::string keep = pc::last_error();
         pc_analyzer_destroy(a);
@@ -896,13 +928,10 @@ void pc_analyzer_destroy(pc_analyzer* a) {
     }
     for (auto& hdr : a->log_hdr) hdr.release();
     for (auto& j : a->jobs) {
-        j.h_kps.release();
-        j.h_xy.release();
-        j.h_err.release();
-        j.h_idx.release();
-        j.h_row_offset.release();
+        j.h_pack.release();
         if (j.done) (void)hipEventDestroy(j.done);
         if (j.computed) (void)hipEventDestroy(j.computed);
+        if (j.lk_done) (void)hipEventDestroy(j.lk_done);
     }
     delete a;
 }
@@ -968,6 +997,19 @@ int pc_analyzer_set_keypoints(pc_analyzer* a, int32_t frame_id, const float* xy,
     return PC_OK;
 }
 
+namespace {
+struct SlowSection {   // POLYCHASE_TRACE_ALLOC: report host-side sections of a call that take more than 2 ms
+    const char* name;
+    std::chrono::steady_clock::time_point t0;
+    explicit SlowSection(const char* n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    ~SlowSection() {
+        if (!pc::trace_allocations()) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > 2.0) fprintf(stderr, "[polychase_hip] slow host section %s: %.2f ms\n", name, ms);
+    }
+};
+}  // namespace
+
 int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, int n_targets) {
     if (!a || (n_targets > 0 && !targets)) return fail(PC_E_INVALID, "null argument");
     if (n_targets < 0 || n_targets > PC_MAX_TARGETS) return fail(PC_E_INVALID, "n_targets must be in [0,%d]", PC_MAX_TARGETS);
@@ -986,6 +1028,7 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     // (1) keypoints of frame1: the dense phase ran when the frame became resident; order them now
     bool detected = false;
     if (s1->det != DET_DONE) {
+        SlowSection ss("submit/detect_finish");
         PrepScope prep(a->ctx);
         if ((rc = detect_finish(a, *s1)) != PC_OK) return rc;
         detected = true;
@@ -995,47 +1038,64 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     Job& j = a->jobs[(a->job_head + a->job_count) % a->jobs.size()];
     // (2) the LK launch needs this frame's keypoints and the pyramids of the frames it reads -- not the
     // detection of frames that were made resident for later
-    PC_HIP(hipStreamWaitEvent(ctx->stream, s1->kps_ready, 0));
-    PC_HIP(hipStreamWaitEvent(ctx->stream, s1->img_ready, 0));
-    for (int t = 0; t < n_targets; t++) PC_HIP(hipStreamWaitEvent(ctx->stream, find_slot(a, targets[t])->img_ready, 0));
+    {
+        SlowSection ss("submit/waits");
+        PC_HIP(hipStreamWaitEvent(ctx->stream, s1->kps_ready, 0));
+        PC_HIP(hipStreamWaitEvent(ctx->stream, s1->img_ready, 0));
+        for (int t = 0; t < n_targets; t++) PC_HIP(hipStreamWaitEvent(ctx->stream, find_slot(a, targets[t])->img_ready, 0));
+    }
     const int n = s1->frame->n_kps;
     const size_t rows = (size_t)n * (size_t)std::max(n_targets, 0);
-    PC_HIP(j.h_kps.ensure((size_t)std::max(n, 1) * 2));
-    PC_HIP(j.h_idx.ensure(rows + 1));
-    PC_HIP(j.h_xy.ensure(rows * 2 + 2));
-    PC_HIP(j.h_err.ensure(rows + 1));
-    PC_HIP(j.h_row_offset.ensure(PC_MAX_TARGETS + 1));
+    // packed record layout (= a device-log record without its 128-byte header)
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    j.o_kps = 128;
+    j.o_idx = up16(j.o_kps + (size_t)n * 8);
+    j.o_xy = up16(j.o_idx + rows * 4);
+    j.o_err = up16(j.o_xy + rows * 8);
+    j.pack_bytes = up16(j.o_err + rows * 4);
+    {
+        SlowSection ss("submit/ensure pack");
+        PC_HIP(j.h_pack.ensure(j.pack_bytes));
+        PC_HIP(ctx->lk_pack.ensure(j.pack_bytes));
+    }
     j.frame1 = frame1;
     j.n_kps = n;
     j.detected = detected;
     j.n_targets = n_targets;
     for (int t = 0; t < n_targets; t++) j.targets[t] = targets[t];
-    for (int t = 0; t <= PC_MAX_TARGETS; t++) j.h_row_offset.p[t] = 0;
-    // (3) LK + status filter on the main stream
+    // (3) LK on the main stream, into output set `set`; its compaction (status filter), the device-log copies and the
+    // downloads on the copy stream, so that the next LK launch starts right behind this one
+    const int set = (int)(a->submitted & 1);
+    hipStream_t post = ctx->copy_stream;
+    ctx->prep_dirty = true;   // stage-level calls must order themselves behind the side streams
     if (n_targets > 0) {
         if (a->fopt.window_size != s1->frame->win) return fail(PC_E_INVALID, "window size mismatch");
-        if ((rc = run_lk(ctx, s1->frame, tg, n_targets, &a->fopt)) != PC_OK) return rc;
-        const int nblocks = pc::compact_num_blocks(n);
-        PC_HIP(ctx->lk_cxy.ensure(rows + 1));
-        PC_HIP(ctx->lk_cerr.ensure(rows + 1));
-        PC_HIP(ctx->lk_cidx.ensure(rows + 1));
-        PC_HIP(ctx->lk_block_counts.ensure((size_t)nblocks * n_targets + 1));
-        PC_HIP(ctx->lk_row_offset.ensure(PC_MAX_TARGETS + 1));
-        // the previous job's download (copy stream) reads the compacted buffers: let it finish first
-        // (it has had a whole LK launch to do so)
-        if (a->last_done) PC_HIP(hipStreamWaitEvent(ctx->stream, a->last_done, 0));
-        {
-            ScopedTimer t(ctx, PC_K_COMPACT, ctx->stream);
-            pc::launch_compact(ctx->lk_xy.p, ctx->lk_status.p, ctx->lk_err.p, n, n_targets, ctx->lk_block_counts.p,
-                               ctx->lk_row_offset.p, ctx->lk_cidx.p, ctx->lk_cxy.p, ctx->lk_cerr.p, ctx->stream);
-        }
+        // the compaction of the job two submits ago read this output set
+        SlowSection ss("submit/run_lk");
+        if (a->set_free[set]) PC_HIP(hipStreamWaitEvent(ctx->stream, a->set_free[set], 0));
+        if ((rc = run_lk(ctx, s1->frame, tg, n_targets, &a->fopt, set)) != PC_OK) return rc;
     }
+    SlowSection ss_post("submit/post-stream enqueue");
+    PC_HIP(hipEventRecord(j.lk_done, ctx->stream));
+    s1->last_read = j.lk_done;
+    for (int t = 0; t < n_targets; t++) find_slot(a, targets[t])->last_read = j.lk_done;
+    PC_HIP(hipStreamWaitEvent(post, j.lk_done, 0));
+    uint8_t* const pack = ctx->lk_pack.p;
+    long long* const p_ro = reinterpret_cast<long long*>(pack);
+    PC_HIP(hipMemsetAsync(pack, 0, 128, post));
+    if (n_targets > 0) {
+        const int nblocks = pc::compact_num_blocks(n);
+        PC_HIP(ctx->lk_block_counts.ensure((size_t)nblocks * n_targets + 1));
+        // the previous job's download reads the pack: it precedes this compaction on the same stream
+        ScopedTimer t(ctx, PC_K_COMPACT, post);
+        pc::launch_compact(ctx->lk_xy[set].p, ctx->lk_status[set].p, ctx->lk_err[set].p, n, n_targets, ctx->lk_block_counts.p, p_ro,
+                           reinterpret_cast<uint32_t*>(pack + j.o_idx), reinterpret_cast<float2*>(pack + j.o_xy),
+                           reinterpret_cast<float*>(pack + j.o_err), post);
+    }
+    pc::launch_copy_keypoints(s1->frame->d_kps, reinterpret_cast<float2*>(pack + j.o_kps), n, post);
     if (a->d_log) {
-        // device log: header from pinned memory, everything else device-to-device, all stream-ordered
-        auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
-        const size_t o_hdr = a->log_used, o_off = o_hdr + 128, o_kps = o_off + 128;
-        const size_t o_idx = up16(o_kps + (size_t)n * 8), o_xy = up16(o_idx + rows * 4), o_err = up16(o_xy + rows * 8);
-        const size_t end = up16(o_err + rows * 4);
+        // device log: header from pinned memory, the record itself is the pack (one device-to-device copy)
+        const size_t o_hdr = a->log_used, end = o_hdr + 128 + j.pack_bytes;
         if (end > a->log_cap) return fail(PC_E_CAPACITY, "device log full (%zu of %zu bytes)", end, a->log_cap);
         const size_t slot_i = (a->job_head + a->job_count) % a->jobs.size();
         if (a->log_hdr.size() != a->jobs.size()) a->log_hdr.resize(a->jobs.size());
@@ -1048,42 +1108,23 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
         hh[3] = n_targets;
         for (int t = 0; t < n_targets; t++) hh[4 + t] = targets[t];
         hh[12] = (long long)rows;
-        PC_HIP(hipMemcpyAsync(a->d_log + o_hdr, hh, 128, hipMemcpyHostToDevice, ctx->stream));
-        PC_HIP(hipMemsetAsync(a->d_log + o_off, 0, 128, ctx->stream));
-        if (n_targets > 0)
-            PC_HIP(hipMemcpyAsync(a->d_log + o_off, ctx->lk_row_offset.p, (size_t)(n_targets + 1) * sizeof(long long),
-                                  hipMemcpyDeviceToDevice, ctx->stream));
-        if (n > 0)
-            PC_HIP(hipMemcpyAsync(a->d_log + o_kps, s1->frame->d_kps, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        if (rows > 0) {
-            PC_HIP(hipMemcpyAsync(a->d_log + o_idx, ctx->lk_cidx.p, rows * 4, hipMemcpyDeviceToDevice, ctx->stream));
-            PC_HIP(hipMemcpyAsync(a->d_log + o_xy, ctx->lk_cxy.p, rows * 8, hipMemcpyDeviceToDevice, ctx->stream));
-            PC_HIP(hipMemcpyAsync(a->d_log + o_err, ctx->lk_cerr.p, rows * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        }
+        PC_HIP(hipMemcpyAsync(a->d_log + o_hdr, hh, 128, hipMemcpyHostToDevice, post));
+        PC_HIP(hipMemcpyAsync(a->d_log + o_hdr + 128, pack, j.pack_bytes, hipMemcpyDeviceToDevice, post));
         a->log_used = end;
     }
-    PC_HIP(hipEventRecord(j.computed, ctx->stream));
-    s1->last_read = j.computed;
-    for (int t = 0; t < n_targets; t++) find_slot(a, targets[t])->last_read = j.computed;
-    // (4) downloads on the copy stream, overlapping the next frame's kernels
-    PC_HIP(hipStreamWaitEvent(ctx->copy_stream, j.computed, 0));
-    if (n > 0)
-        PC_HIP(hipMemcpyAsync(j.h_kps.p, s1->frame->d_kps, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, ctx->copy_stream));
-    if (n_targets > 0) {
-        PC_HIP(hipMemcpyAsync(j.h_row_offset.p, ctx->lk_row_offset.p, (size_t)(n_targets + 1) * sizeof(long long),
-                              hipMemcpyDeviceToHost, ctx->copy_stream));
-        if (rows > 0) {
-            // the row count is only known on the device: download the capacity (n * n_targets rows)
-            PC_HIP(hipMemcpyAsync(j.h_idx.p, ctx->lk_cidx.p, rows * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->copy_stream));
-            PC_HIP(hipMemcpyAsync(j.h_xy.p, ctx->lk_cxy.p, rows * sizeof(float2), hipMemcpyDeviceToHost, ctx->copy_stream));
-            PC_HIP(hipMemcpyAsync(j.h_err.p, ctx->lk_cerr.p, rows * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
-        }
-    }
+    PC_HIP(hipEventRecord(j.computed, post));
+    a->set_free[set] = j.computed;
+    a->submitted++;
+    // (4) download, behind the compaction on the same stream: ONE copy with fixed endpoints (the context's pack ->
+    // the job's pinned pack).  The runtime stalls the host for 5-8 ms the first time it sees a buffer as a copy
+    // source, so per-frame buffers must not appear here.
+    PC_HIP(hipMemcpyAsync(j.h_pack.p, pack, j.pack_bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
     PC_HIP(hipEventRecord(j.done, ctx->copy_stream));
     a->last_done = j.done;
     j.active = true;
     a->job_count++;
     // (5) while this LK launch runs: order the keypoints of the next frame1
+    SlowSection ss("submit/preorder");
     return preorder_if_ready(a, frame1 + 1);
 }
 
@@ -1111,16 +1152,21 @@ int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out) {
     if (a->job_count == 0) return fail(PC_E_STATE, "no job in flight");
     Job& j = a->jobs[a->job_head];
     PC_HIP(hipEventSynchronize(j.done));
+    // let the runtime retire the finished commands of the other streams now, a few at a time: left alone it does
+    // so in one batch of several milliseconds every couple of hundred frames, inside some later launch
+    (void)hipStreamQuery(a->ctx->stream);
+    (void)hipStreamQuery(a->ctx->prep_stream);
     out->frame1 = j.frame1;
     out->n_keypoints = j.n_kps;
     out->keypoints_detected = j.detected ? 1 : 0;
-    out->keypoints_xy = j.h_kps.p;
+    out->keypoints_xy = reinterpret_cast<const float*>(j.h_pack.p + j.o_kps);
     out->n_targets = j.n_targets;
     for (int t = 0; t < PC_MAX_TARGETS; t++) out->targets[t] = t < j.n_targets ? j.targets[t] : 0;
-    for (int t = 0; t <= PC_MAX_TARGETS; t++) out->row_offset[t] = t <= j.n_targets ? (int64_t)j.h_row_offset.p[t] : (int64_t)j.h_row_offset.p[j.n_targets];
-    out->src_indices = j.h_idx.p;
-    out->tgt_xy = j.h_xy.p;
-    out->flow_err = j.h_err.p;
+    const long long* h_ro = reinterpret_cast<const long long*>(j.h_pack.p);
+    for (int t = 0; t <= PC_MAX_TARGETS; t++) out->row_offset[t] = (int64_t)h_ro[std::min(t, j.n_targets)];
+    out->src_indices = reinterpret_cast<const uint32_t*>(j.h_pack.p + j.o_idx);
+    out->tgt_xy = reinterpret_cast<const float*>(j.h_pack.p + j.o_xy);
+    out->flow_err = reinterpret_cast<const float*>(j.h_pack.p + j.o_err);
     j.active = false;
     a->job_head = (a->job_head + 1) % a->jobs.size();
     a->job_count--;

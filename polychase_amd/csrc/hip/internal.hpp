@@ -121,7 +121,10 @@ struct DetectScratch {
 struct pc_context {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;   // result downloads overlap the next frame's kernels
+    // compaction, device-log copies and result downloads of job f run beside the LK launch of job f+1.  (No
+    // further stream: HIP multiplexes streams onto 4 hardware queues, and a stream that shares a queue with the
+    // prep stream waits behind its kernels.)
+    hipStream_t copy_stream = nullptr;
     // pc_analyzer runs frame preparation (gray, pyramid, detection, keypoint ordering) on its own
     // stream so that it overlaps the LK launch of the previous frame1 on `stream`.  `work` is the stream
     // the image / detection helpers enqueue on: `stream` by default, `prep_stream` inside the analyzer.
@@ -143,11 +146,15 @@ struct pc_context {
     DevBuf<uint8_t> sort_temp;
     const pc_frame* eig_owner = nullptr;
     // LK scratch
-    DevBuf<float2> lk_xy, lk_cxy;
-    DevBuf<uint8_t> lk_status;
-    DevBuf<float> lk_err, lk_cerr;
+    // raw LK outputs: two sets, so that the analyzer can launch LK(f+1) while LK(f)'s are being compacted
+    DevBuf<float2> lk_xy[2], lk_cxy;
+    DevBuf<uint8_t> lk_status[2];
+    DevBuf<float> lk_err[2], lk_cerr;
     DevBuf<uint32_t> lk_cidx, lk_block_counts, lk_perm, lk_hist, prep_hist;
     DevBuf<long long> lk_row_offset;
+    // the analyzer's compacted records of one job, packed like a device-log record without its header:
+    // row offsets (128 B) | keypoints | src indices | tgt xy | errors, every part 16-byte aligned
+    DevBuf<uint8_t> lk_pack;
     PinBuf<long long> h_row_offset;
     // timing
     unsigned timing_mask = 0;   // bit k: time kernel class k with HIP events

@@ -81,6 +81,8 @@ void launch_compact(const float2* xy, const uint8_t* status, const float* err, i
                     uint32_t* block_counts, long long* row_offset, uint32_t* out_idx, float2* out_xy,
                     float* out_err, hipStream_t s);
 int compact_num_blocks(int n);
+// keypoints -> packed record buffer (both 16-byte aligned)
+void launch_copy_keypoints(const float2* src, float2* dst, int n, hipStream_t s);
 
 
 // ---- kernels_tracker.hip ----

@@ -20,6 +20,7 @@
 //   * Window sums are all-reduced inside the group with DPP adds (quad_perm xor1/xor2 +
 //     row_half_mirror): no LDS traffic, no cross-group traffic, so every lane holds the same A, b,
 //     delta and the convergence branches are group-uniform.
+#include <algorithm>
 #include <cstdlib>
 
 #include "lk_common.hpp"
@@ -456,6 +457,18 @@ __global__ __launch_bounds__(1024) void compact_scatter_kernel(const float2* __r
         out_xy[pos] = xy[src];
         out_err[pos] = err[src];
     }
+}
+
+// keypoints of frame1 -> the job's packed record buffer (device to device, 16 bytes per lane)
+__global__ __launch_bounds__(256) void copy_keypoints_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // one pair of keypoints
+    if (2 * i + 1 < n) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    else if (2 * i < n) dst[2 * i] = src[2 * i];
+}
+void launch_copy_keypoints(const float2* src, float2* dst, int n, hipStream_t s) {
+    if (n <= 0) return;
+    const int pairs = (n + 1) / 2;
+    hipLaunchKernelGGL(copy_keypoints_kernel, dim3((pairs + 255) / 256), dim3(256), 0, s, src, dst, n);
 }
 
 void launch_compact(const float2* xy, const uint8_t* status, const float* err, int n, int n_targets,

@@ -32,6 +32,7 @@ an.run(range(19, 19 + K), None, copy=False)
 ctx.synchronize()
 dt = time.perf_counter() - t0
 print(f"{K / dt:.1f} fps, {dt / K * 1e3:.3f} ms/step")
+print("  first calls:", " ".join(f"{n[0]}{f}:{ms * 1e3:.2f}" for n, f, ms, _ in log[:24]))
 for name in ("put", "submit", "collect"):
     v = np.array([x[2] for x in log if x[0] == name]) * 1e3
     print(f"  {name:8s} mean {v.mean():.4f} ms  p50 {np.percentile(v, 50):.4f}  p99 {np.percentile(v, 99):.4f}  max {v.max():.4f}")
