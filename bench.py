@@ -75,10 +75,16 @@ def cpu_baseline(fetch_host, f1_candidates, gopt_kw, fopt_kw, target_seconds=12.
     probe = run(f1_candidates[:2])
     n = int(max(2, min(len(f1_candidates), round(target_seconds / max(probe / 2, 1e-3)))))
     dt = run(f1_candidates[:n])
-    return {"value": n / dt, "unit": "frames/s", "cores": pair_threads * feat_threads, "kind": "port",
-            "sample": f"{n} interior frame1 x 8 pairs of the same clip, oracle/pc_oracle.c (-O3 -march=native), "
-                      f"{pair_threads} pair-threads x {feat_threads} feature-threads (all {cores} host cores), "
-                      f"per-pair gray+pyramid rebuild as in opticalflow.cc:298-302; {dt:.1f} s"}
+    out = {"value": n / dt, "unit": "frames/s", "cores": pair_threads * feat_threads, "kind": "port",
+           "sample": f"{n} interior frame1 x 8 pairs of the same clip, oracle/pc_oracle.c (-O3 -march=native), "
+                     f"{pair_threads} pair-threads x {feat_threads} feature-threads (all {cores} host cores), "
+                     f"per-pair gray+pyramid rebuild as in opticalflow.cc:298-302; {dt:.1f} s"}
+    # the reference's own threading: TBB capped at 4 threads over the pairs (opticalflow.cc:271), features serial
+    pair_threads, feat_threads = min(4, cores), 1
+    dt4 = run(f1_candidates[:1])
+    out["reference_threading"] = {"value": 1 / dt4, "unit": "frames/s", "cores": pair_threads,
+                                  "sample": f"1 interior frame1 x 8 pairs, 4 pair-threads x 1 feature-thread; {dt4:.1f} s"}
+    return out
 
 
 def main():
