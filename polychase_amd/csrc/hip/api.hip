@@ -763,7 +763,6 @@ struct Slot {
 };
 
 struct Job {
-    bool active = false;
     int32_t frame1 = 0;
     int n_kps = 0;
     bool detected = false;
@@ -787,7 +786,6 @@ struct pc_analyzer {
     std::vector<Slot> slots;
     std::vector<Job> jobs;
     size_t job_head = 0, job_count = 0;  // ring of in-flight jobs
-    hipEvent_t last_done = nullptr;      // download of the most recently submitted job
     uint64_t submitted = 0;              // jobs submitted so far: job k writes LK output set k & 1
     hipEvent_t set_free[2] = {nullptr, nullptr};  // `computed` of the last job that used each LK output set
     uint8_t* d_log = nullptr;            // optional device-resident record log
@@ -1120,8 +1118,6 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     // source, so per-frame buffers must not appear here.
     PC_HIP(hipMemcpyAsync(j.h_pack.p, pack, j.pack_bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
     PC_HIP(hipEventRecord(j.done, ctx->copy_stream));
-    a->last_done = j.done;
-    j.active = true;
     a->job_count++;
     // (5) while this LK launch runs: order the keypoints of the next frame1
     SlowSection ss("submit/preorder");
@@ -1167,7 +1163,6 @@ int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out) {
     out->src_indices = reinterpret_cast<const uint32_t*>(j.h_pack.p + j.o_idx);
     out->tgt_xy = reinterpret_cast<const float*>(j.h_pack.p + j.o_xy);
     out->flow_err = reinterpret_cast<const float*>(j.h_pack.p + j.o_err);
-    j.active = false;
     a->job_head = (a->job_head + 1) % a->jobs.size();
     a->job_count--;
     return PC_OK;

@@ -16,6 +16,13 @@
 
 namespace pc {
 
+#ifndef PC_LK2_DXY_LDS
+// 1: the (ix, iy) gradients stay in LDS and are re-read every iteration: 128 instead of 137 VGPRs, 4 waves/SIMD, and
+// the launch alone is 2 % faster -- but four such waves fill a SIMD's register file, the preparation kernels of the
+// other stream no longer fit beside them, and the frame rate DROPS 15 % (1413 vs 1665 fps at C2).  Kept at 0.
+#define PC_LK2_DXY_LDS 0
+#endif
+
 template <int WIN>
 struct LK2Geo {
     using G = LKGeo<WIN>;
@@ -29,7 +36,8 @@ struct LK2Geo {
     static constexpr int HALF_I_DW = G::I_DW + G::D_DW + G::X_DW;   // I-side buffers of one keypoint
     static constexpr int J_ALL_DW = 16 * G::J_DW;
     static constexpr int RAW_DW = J_ALL_DW > 2 * HALF_I_DW ? J_ALL_DW : 2 * HALF_I_DW;
-    static constexpr int WAVE_DW = ((RAW_DW + 1) / 2) * 2;
+    static constexpr int DXY_DW = PC_LK2_DXY_LDS ? 2 * G::NPX : 0;   // gradients of both keypoints, kept for the whole level
+    static constexpr int WAVE_DW = ((RAW_DW + DXY_DW + 1) / 2) * 2;
 };
 
 // every lane gets the sum over its 32-lane half: DPP inside the 16-lane rows, then the other row
@@ -83,6 +91,7 @@ __global__ __launch_bounds__(128) void lk2_kernel(const LKParams p) {
     uint8_t* const dbuf = reinterpret_cast<uint8_t*>(wbase + half * G2::HALF_I_DW + G::I_DW);       // raw Scharr window
     uint32_t* const xbuf = wbase + half * G2::HALF_I_DW + G::I_DW + G::D_DW;                        // (Ival, Dxy) exchange
     uint8_t* const jbuf = reinterpret_cast<uint8_t*>(wbase + (half * 8 + grp) * G::J_DW);           // aliases the above
+    uint32_t* const gbuf = wbase + G2::RAW_DW + half * NPX;                                         // (ix, iy) per pixel, not aliased
 
     // window pixels of the remaining columns, dealt out pixel by pixel
     int offE[KE > 0 ? KE : 1], qE[KE > 0 ? KE : 1];
@@ -162,6 +171,7 @@ __global__ __launch_bounds__(128) void lk2_kernel(const LKParams p) {
                     const int iy = sdot2(dy1, wrow1, sdot2(dy0, wrow0, 1 << (W_BITS - 1))) >> W_BITS;
                     xbuf[2 * q] = (uint32_t)ival;
                     xbuf[2 * q + 1] = (uint32_t)(ix & 0xffff) | ((uint32_t)iy << 16);
+                    if (PC_LK2_DXY_LDS) gbuf[q] = (uint32_t)(ix & 0xffff) | ((uint32_t)iy << 16);
                     sA11 += __mul24(ix, ix);   // |ix|, |iy| <= 4080
                     sA12 += __mul24(ix, iy);
                     sA22 += __mul24(iy, iy);
@@ -186,11 +196,11 @@ __global__ __launch_bounds__(128) void lk2_kernel(const LKParams p) {
         // every group picks up the pixels it owns
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         int Ival[K];  // ival_bias(I patch value): the accumulator init of interp_diff
-        int Dxy[K];   // (int16 ix) | (int16 iy << 16); 0 for slots without a pixel
+        int Dxy[PC_LK2_DXY_LDS ? 1 : K];   // (int16 ix) | (int16 iy << 16); 0 for slots without a pixel
 #pragma unroll
         for (int k = 0; k < K; k++) {
             Ival[k] = 0;
-            Dxy[k] = 0;
+            if (!PC_LK2_DXY_LDS) Dxy[k] = 0;
         }
         if (lvl_ok) {
 #pragma unroll
@@ -199,13 +209,13 @@ __global__ __launch_bounds__(128) void lk2_kernel(const LKParams p) {
                 for (int r = 0; r < WIN; r++) {
                     const uint2 v = *reinterpret_cast<const uint2*>(xbuf + 2 * (r * WIN + lg + GL * c));
                     Ival[c * WIN + r] = ival_bias((int)v.x);
-                    Dxy[c * WIN + r] = (int)v.y;
+                    if (!PC_LK2_DXY_LDS) Dxy[c * WIN + r] = (int)v.y;
                 }
 #pragma unroll
             for (int e = 0; e < KE; e++) {
                 const uint2 v = (qE[e] >= 0) ? *reinterpret_cast<const uint2*>(xbuf + 2 * qE[e]) : make_uint2(0u, 0u);
                 Ival[KM + e] = ival_bias((int)v.x);
-                Dxy[KM + e] = (int)v.y;
+                if (!PC_LK2_DXY_LDS) Dxy[KM + e] = (int)v.y;
             }
         }
         // the J regions alias the I-side buffers of BOTH halves: no group may stage before every group has read
@@ -244,16 +254,19 @@ __global__ __launch_bounds__(128) void lk2_kernel(const LKParams p) {
                     const uint32_t bot = widen_pair(*reinterpret_cast<const uint16_t*>(cb + (r + 1) * G::PAIR_PITCH));
                     const int diff = interp_diff(top, bot, wJ, Ival[c * WIN + r]);
                     top = bot;
-                    sb1 = mad16_lo(diff, (uint32_t)Dxy[c * WIN + r], sb1);
-                    sb2 = mad16_hi(diff, (uint32_t)Dxy[c * WIN + r], sb2);
+                    const uint32_t g = PC_LK2_DXY_LDS ? gbuf[r * WIN + lg + GL * c] : (uint32_t)Dxy[PC_LK2_DXY_LDS ? 0 : c * WIN + r];
+                    sb1 = mad16_lo(diff, g, sb1);
+                    sb2 = mad16_hi(diff, g, sb2);
                 }
             }
 #pragma unroll
             for (int e = 0; e < KE; e++) {
                 const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offE[e]);
                 const int diff = interp_diff(widen_pair(q[0]), widen_pair(q[G::RWB]), wJ, Ival[KM + e]);
-                sb1 = mad16_lo(diff, (uint32_t)Dxy[KM + e], sb1);
-                sb2 = mad16_hi(diff, (uint32_t)Dxy[KM + e], sb2);
+                // slots past the window (qE < 0) read pixel 0's gradient: their diff must not count
+                const uint32_t g = PC_LK2_DXY_LDS ? (qE[e] >= 0 ? gbuf[qE[e]] : 0u) : (uint32_t)Dxy[PC_LK2_DXY_LDS ? 0 : KM + e];
+                sb1 = mad16_lo(diff, g, sb1);
+                sb2 = mad16_hi(diff, g, sb2);
             }
             const float b1 = group4_exact_sum<K>(sb1) * FLT_SCALE;
             const float b2 = group4_exact_sum<K>(sb2) * FLT_SCALE;
