@@ -16,6 +16,9 @@
 
 namespace pc {
 
+#ifndef PC_LK2_WAVES
+#define PC_LK2_WAVES 1   // wavefronts per workgroup
+#endif
 #ifndef PC_LK2_DXY_LDS
 // 1: the (ix, iy) gradients stay in LDS and are re-read every iteration: 128 instead of 137 VGPRs, 4 waves/SIMD, and
 // the launch alone is 2 % faster -- but four such waves fill a SIMD's register file, the preparation kernels of the
@@ -66,18 +69,18 @@ __device__ __forceinline__ float group4_exact_sum(int partial) {
 }
 
 template <int WIN>
-__global__ __launch_bounds__(128) void lk2_kernel(const LKParams p) {
+__global__ __launch_bounds__(64 * PC_LK2_WAVES) void lk2_kernel(const LKParams p) {
     using G = LKGeo<WIN>;
     using G2 = LK2Geo<WIN>;
     constexpr int GL = G2::GL, NPX = WIN * WIN, NCH = G2::NCH, KM = G2::KM, KE = G2::KE, K = G2::K;
     constexpr int KW = (NPX + 31) / 32;   // pixels per lane in the half-wave I-side pass
-    __shared__ __attribute__((aligned(16))) uint32_t s_buf[2][G2::WAVE_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[PC_LK2_WAVES][G2::WAVE_DW];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, l32 = lane & 31, grp = (lane >> 2) & 7, lg = lane & 3;
     // Workgroup b runs on XCD b % 8; each XCD takes one contiguous eighth of the (spatially binned) keypoint order
     const int lb = (int)(blockIdx.x & 7u) * p.blocks_per_xcd + (int)(blockIdx.x >> 3);
-    const int first = (lb * 2 + wave) * 2;            // first of this wave's two keypoint slots
+    const int first = (lb * PC_LK2_WAVES + wave) * 2;  // first of this wave's two keypoint slots
     if ((int)(blockIdx.x >> 3) >= p.blocks_per_xcd || first >= p.n) return;   // whole waves exit together
     const int slot = first + half;
     const bool kp_valid = slot < p.n;                 // n odd: the last wave's second half idles
@@ -340,10 +343,11 @@ __global__ __launch_bounds__(128) void lk2_kernel(const LKParams p) {
 template <int WIN>
 static void launch_lk2_t(const LKParams& p0, hipStream_t s) {
     LKParams p = p0;
-    const int blocks = (p.n + 3) / 4;   // two keypoints per wavefront, two wavefronts per workgroup
+    const int per_block = 2 * PC_LK2_WAVES;   // two keypoints per wavefront
+    const int blocks = (p.n + per_block - 1) / per_block;
     if (blocks == 0) return;
     p.blocks_per_xcd = (blocks + 7) / 8;
-    hipLaunchKernelGGL((lk2_kernel<WIN>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(128), 0, s, p);
+    hipLaunchKernelGGL((lk2_kernel<WIN>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(64 * PC_LK2_WAVES), 0, s, p);
 }
 
 bool launch_lk2(const LKParams& p, int win, hipStream_t s) {
