@@ -310,6 +310,33 @@ def test_analyzer_checkerboard_c1(ctx):
     assert np.abs(np.median(d, axis=0) - [1.25, 0.75]).max() < 0.1
 
 
+def test_analyzer_degenerate_clips(ctx):
+    """Ragged inputs through the pipelined engine: a one-frame clip (no targets at all), a two-frame clip, flat frames
+    (no keypoints, so empty flow records) between textured ones."""
+    from polychase_amd.pipeline import ClipAnalyzer
+    w, h = 192, 128
+    clip, tex = _noise_frames(w, h, [3, 4, 5, 6], 12)
+    flat = np.full((h, w, 3), 90, np.uint8)
+    for frames in ([tex[0]], [tex[0], tex[1]], [tex[0], flat, tex[1], flat, flat, tex[2], tex[3]]):
+        n = len(frames)
+        kps_o, flows_o = oracle.analyze_clip(frames, first_frame=1, threads=2)
+        got_kps, got_flows = {}, {}
+
+        def sink(f1, kps, detected, flows):
+            got_kps[f1] = kps
+            for f2, rec in flows.items():
+                got_flows[(f1, f2)] = rec
+
+        an = ClipAnalyzer(ctx, w, h, 1, n, lambda fid: frames[fid - 1])
+        an.run(range(1, n + 1), sink)
+        an.close()
+        assert sorted(got_kps) == list(range(1, n + 1))
+        _compare_clip(kps_o, flows_o, got_kps, got_flows)
+        if n == 7:
+            assert len(got_kps[2]) == 0 and len(got_kps[4]) == 0 and len(got_kps[1]) > 0
+            assert all(len(got_flows[(2, f2)][0]) == 0 for f2 in (1, 3, 4, 6))
+
+
 def test_analyzer_resume_with_supplied_keypoints(ctx):
     from polychase_amd.pipeline import ClipAnalyzer
     w, h, n = 320, 240, 12
