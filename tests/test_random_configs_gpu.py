@@ -89,3 +89,45 @@ def test_random_configuration(ctx, seed):
         assert np.array_equal(err[k][m].view(np.uint32), oerr[m].view(np.uint32)), f"{case}: errors of target {k}"
     for f in [f1] + frames:
         f.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_clip_through_the_analyzer(ctx, seed):
+    """Whole clips through the pipelined engine (three streams, ring of resident frames, pre-ordering) with random
+    length, first frame id, options and job depth: every record equals the reference-shaped CPU path."""
+    from polychase_amd.pipeline import ClipAnalyzer
+    rng = np.random.default_rng(5000 + seed)
+    w, h = int(rng.integers(48, 200)), int(rng.integers(48, 160))
+    n, first = int(rng.integers(1, 27)), int(rng.integers(-3, 40))
+    kind = ["noise", "blocks", "smooth"][seed % 3]
+    win, max_level = int(rng.integers(4, 14)), int(rng.integers(0, 4))
+    gk = dict(quality_level=float(rng.choice([0.01, 0.05])), min_distance=float(rng.choice([0.0, 3.0, 5.0])),
+              max_corners=int(rng.choice([0, 40])), grid_rows=int(rng.integers(1, 5)), grid_cols=int(rng.integers(1, 5)))
+    fk = dict(window_size=win, max_level=max_level, term_max_iters=int(rng.choice([5, 30])))
+    base = _image(rng, w + 64, h + 64, kind)
+    frames = []
+    for t in range(n):                                  # a drifting crop of one texture, plus noise
+        ox, oy = 32 + int(round(1.3 * t)) % 30, 32 - int(round(0.7 * t)) % 30
+        fr = base[oy:oy + h, ox:ox + w].astype(np.int16) + rng.integers(-3, 4, (h, w, 3), dtype=np.int16)
+        frames.append(np.ascontiguousarray(np.clip(fr, 0, 255).astype(np.uint8)))
+    kps_o, flows_o = oracle.analyze_clip(frames, first_frame=first, gopt=oracle.gftt_options(**gk), fopt=oracle.flow_options(**fk),
+                                         threads=2)
+    got_kps, got_flows = {}, {}
+
+    def sink(f1, kps, detected, flows):
+        got_kps[f1] = kps
+        for f2, rec in flows.items():
+            got_flows[(f1, f2)] = rec
+
+    an = ClipAnalyzer(ctx, w, h, first, n, lambda fid: frames[fid - first], hip.gftt_options(**gk), hip.flow_options(**fk),
+                      max_jobs=int(rng.integers(1, 5)))
+    an.run(range(first, first + n), sink)
+    an.close()
+    case = f"seed {seed}: {w}x{h} {kind} n {n} first {first} win {win} L {max_level} {gk} {fk}"
+    assert sorted(got_kps) == sorted(kps_o), case
+    for f in kps_o:
+        assert np.array_equal(got_kps[f], kps_o[f]), f"{case}: keypoints of frame {f}"
+    assert sorted(got_flows) == sorted(flows_o), case
+    for key in flows_o:
+        for a, b in zip(got_flows[key], flows_o[key]):
+            assert a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"{case}: flow {key}"
