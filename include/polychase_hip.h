@@ -156,7 +156,10 @@ int pc_lk_track_filtered(pc_context* ctx, const pc_frame* frame1, const pc_frame
  * SequentialWrapper cache, cpp/opticalflow_thread.h:34-79, generalised), builds every frame's gray
  * image and pyramid ONCE (the reference rebuilds them per pair, opticalflow.cc:298-302), and runs
  * frame1 jobs asynchronously: submit() enqueues, collect() hands back the records of the oldest
- * job in pinned host memory.  One analyzer per context; calls are not thread-safe. */
+ * job in pinned host memory.  Internally three HIP streams: frame preparation (gray, pyramid,
+ * detection, keypoint ordering), the LK launches, and compaction + record download; per-slot events
+ * carry the dependencies, so preparation and downloads run beside the LK launch of another frame.
+ * One analyzer per context; calls are not thread-safe. */
 typedef struct pc_analyzer pc_analyzer;
 
 typedef struct pc_frame_result {
@@ -175,7 +178,8 @@ typedef struct pc_frame_result {
 int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_options* gftt,
                        const pc_flow_options* flow, int ring_frames, int max_jobs, pc_analyzer** out);
 void pc_analyzer_destroy(pc_analyzer* a);
-/* Make `frame_id` resident in ring slot frame_id mod ring_frames (evicting what was there):
+/* Make `frame_id` resident (evicting the frame ring_frames + 2 ids back: the ring holds two slots more than
+ * asked for, so that a put never waits for LK launches that still read older frames):
  * RGB->gray + pyramid, and, when will_detect != 0, the dense part of GoodFeaturesToTrack.
  * Replaces RequestFrame + cvtColor + GeneratePyramid (opticalflow.cc:249-263, :287-302). */
 int pc_analyzer_put_frame(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, size_t row_pitch,
