@@ -1,0 +1,422 @@
+// api_analyzer.hip -- pc_analyzer: the pipelined per-clip engine behind GenerateOpticalFlowDatabase
+// (reference cpp/opticalflow.cc:209-321).  See include/polychase_hip.h for the contract and DESIGN.md section 3
+// for the stream / event structure.
+#include "api_internal.hpp"
+
+using namespace pc_api;
+
+// =============================================================================================
+// analyzer: pipelined per-clip engine (see include/polychase_hip.h)
+// =============================================================================================
+
+namespace {
+
+enum DetState { DET_NONE = 0, DET_DENSE = 1, DET_DONE = 3 };
+
+struct Slot {
+    pc_frame* frame = nullptr;
+    int32_t frame_id = 0;
+    bool valid = false;
+    DetState det = DET_NONE;
+    bool supplied = false;  // keypoints came from the caller (database), not from detection
+    DetectScratch scratch;
+    hipEvent_t last_read = nullptr;  // `computed` event of the latest job whose LK reads this slot
+    hipEvent_t img_ready = nullptr;  // gray + pyramid of the resident frame are complete (prep stream)
+    hipEvent_t kps_ready = nullptr;  // keypoints + visiting order are complete (prep stream)
+};
+
+struct Job {
+    int32_t frame1 = 0;
+    int n_kps = 0;
+    bool detected = false;
+    int n_targets = 0;
+    int32_t targets[PC_MAX_TARGETS];
+    PinBuf<uint8_t> h_pack;   // the job's records, same layout as pc_context::lk_pack
+    size_t o_kps = 0, o_idx = 0, o_xy = 0, o_err = 0, pack_bytes = 0;
+    hipEvent_t done = nullptr;      // records of this job are in pinned memory (copy stream)
+    hipEvent_t computed = nullptr;  // compaction (+ device-log copies) finished (copy stream)
+    hipEvent_t lk_done = nullptr;   // the LK launch finished (main stream)
+};
+
+}  // namespace
+
+struct pc_analyzer {
+    pc_context* ctx = nullptr;
+    int w = 0, h = 0;
+    pc_gftt_options gopt;
+    pc_flow_options fopt;
+    pc::GfttGrid grid;
+    std::vector<Slot> slots;
+    std::vector<Job> jobs;
+    size_t job_head = 0, job_count = 0;  // ring of in-flight jobs
+    uint64_t submitted = 0;              // jobs submitted so far: job k writes LK output set k & 1
+    hipEvent_t set_free[2] = {nullptr, nullptr};  // `computed` of the last job that used each LK output set
+    uint8_t* d_log = nullptr;            // optional device-resident record log
+    size_t log_cap = 0, log_used = 0;
+    std::vector<PinBuf<long long>> log_hdr;  // one pinned header per job slot
+};
+
+namespace {
+
+Slot* find_slot(pc_analyzer* a, int32_t frame_id) {
+    const int n = (int)a->slots.size();
+    Slot& s = a->slots[(size_t)(((frame_id % n) + n) % n)];
+    return (s.valid && s.frame_id == frame_id) ? &s : nullptr;
+}
+
+// All three run on the prep stream (the callers hold a PrepScope).
+int detect_dense(pc_analyzer* a, Slot& s) {
+    int rc = detect_phase_a(a->ctx, s.frame, a->grid, a->gopt, s.scratch);
+    if (rc == PC_OK) s.det = DET_DENSE;
+    return rc;
+}
+
+int detect_finish(pc_analyzer* a, Slot& s) {
+    int rc;
+    if (s.det == DET_NONE && (rc = detect_dense(a, s)) != PC_OK) return rc;
+    if ((rc = detect_phase_b(a->ctx, s.frame, a->gopt, s.scratch)) != PC_OK) return rc;
+    if ((rc = order_keypoints_spatially(a->ctx, s.frame, a->ctx->prep_hist)) != PC_OK) return rc;
+    PC_HIP(hipEventRecord(s.kps_ready, a->ctx->prep_stream));
+    s.det = DET_DONE;
+    s.supplied = false;
+    return PC_OK;
+}
+
+// Ordering phase of the frame that will most likely be the next frame1, if its dense phase has
+// already delivered its counters: keeps sort + binning off the LK stream's critical path.
+int preorder_if_ready(pc_analyzer* a, int32_t frame_id) {
+    Slot* s = find_slot(a, frame_id);
+    if (!s || s->det != DET_DENSE || !s->scratch.ev) return PC_OK;
+    if (hipEventQuery(s->scratch.ev) != hipSuccess) return PC_OK;
+    PrepScope prep(a->ctx);
+    return detect_finish(a, *s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_options* gftt,
+                       const pc_flow_options* flow, int ring_frames, int max_jobs, pc_analyzer** out) {
+    if (!ctx || !gftt || !flow || !out) return fail(PC_E_INVALID, "null argument");
+    *out = nullptr;
+    if (ring_frames < 1 || ring_frames > 4096) return fail(PC_E_INVALID, "ring_frames must be in [1,4096]");
+    if (max_jobs < 1 || max_jobs > 64) return fail(PC_E_INVALID, "max_jobs must be in [1,64]");
+    pc::GfttGrid grid0;
+    {
+        int vrc = validate_gftt(gftt, width, height, &grid0);
+        if (vrc != PC_OK) return vrc;
+    }
+    PC_HIP(hipSetDevice(ctx->device));
+    pc_analyzer* a = new (std::nothrow) pc_analyzer();
+    if (!a) return fail(PC_E_INVALID, "out of host memory");
+    a->ctx = ctx;
+    a->w = width;
+    a->h = height;
+    a->gopt = *gftt;
+    a->fopt = *flow;
+    a->grid = grid0;
+    // two extra slots: a frame can be overwritten (prep stream) while the LK launches that read its
+    // predecessors in the ring are still running, without the two streams waiting on each other
+    a->slots.resize((size_t)ring_frames + 2);
+    a->jobs.resize((size_t)max_jobs);
+    int rc = PC_OK;
+    for (auto& s : a->slots) {
+        rc = pc_frame_create(ctx, width, height, flow->window_size, flow->max_level, &s.frame);
+        if (rc != PC_OK) break;
+        // room for a typical frame's keypoints up front: growing later frees device memory, which synchronises
+        const int kp0 = std::max(16384, (width * height) / 32);
+        if ((rc = ensure_kp_capacity(s.frame, kp0)) != PC_OK) break;
+        if (hipMalloc(reinterpret_cast<void**>(&s.frame->d_perm), (size_t)kp0 * sizeof(uint32_t)) != hipSuccess) {
+            rc = fail(PC_E_HIP, "hipMalloc failed");
+            break;
+        }
+        s.frame->perm_cap = kp0;
+        if (hipEventCreateWithFlags(&s.img_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.kps_ready, hipEventDisableTiming) != hipSuccess) {
+            rc = fail(PC_E_HIP, "hipEventCreate failed");
+            break;
+        }
+    }
+    if (rc == PC_OK)
+        for (auto& j : a->jobs)
+            if (hipEventCreateWithFlags(&j.done, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&j.computed, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&j.lk_done, hipEventDisableTiming) != hipSuccess) {
+                rc = fail(PC_E_HIP, "hipEventCreate failed");
+                break;
+            }
+    if (rc == PC_OK) {
+        // Warm the runtime's copy engines: it picks a free SDMA engine per copy and creates an engine's queue the first
+        // time it is used (5-8 ms inside some hipMemcpyAsync, observed twice or three times in the first few dozen
+        // frames).  A burst of overlapping downloads makes it create them now.
+        const size_t chunk = (size_t)4 << 20, burst = 12;
+        Job& j0 = a->jobs[0];
+        if (ctx->lk_pack.ensure(chunk) != hipSuccess || j0.h_pack.ensure(chunk * burst) != hipSuccess) {
+            rc = fail(PC_E_HIP, "allocation failed");
+        } else {
+            hipStream_t streams[3] = {ctx->copy_stream, ctx->prep_stream, ctx->stream};
+            for (int round = 0; round < 3 && rc == PC_OK; round++) {
+                for (size_t k = 0; k < burst; k++)
+                    if (hipMemcpyAsync(j0.h_pack.p + k * chunk, ctx->lk_pack.p, chunk, hipMemcpyDeviceToHost, streams[k % 3]) !=
+                        hipSuccess)
+                        rc = fail(PC_E_HIP, "copy engine warm-up failed");
+                for (hipStream_t st : streams) (void)hipStreamSynchronize(st);
+            }
+        }
+    }
+    if (rc != PC_OK) {
+        std::string keep = pc::last_error();
+        pc_analyzer_destroy(a);
+        pc::last_error() = keep;
+        return rc;
+    }
+    *out = a;
+    return PC_OK;
+}
+
+void pc_analyzer_destroy(pc_analyzer* a) {
+    if (!a) return;
+    (void)hipSetDevice(a->ctx->device);
+    (void)hipStreamSynchronize(a->ctx->prep_stream);
+    (void)hipStreamSynchronize(a->ctx->stream);
+    (void)hipStreamSynchronize(a->ctx->copy_stream);
+    for (auto& s : a->slots) {
+        if (s.frame) pc_frame_destroy(s.frame);
+        if (s.img_ready) (void)hipEventDestroy(s.img_ready);
+        if (s.kps_ready) (void)hipEventDestroy(s.kps_ready);
+        s.scratch.release();
+    }
+    for (auto& hdr : a->log_hdr) hdr.release();
+    for (auto& j : a->jobs) {
+        j.h_pack.release();
+        if (j.done) (void)hipEventDestroy(j.done);
+        if (j.computed) (void)hipEventDestroy(j.computed);
+        if (j.lk_done) (void)hipEventDestroy(j.lk_done);
+    }
+    delete a;
+}
+
+static int analyzer_put(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, size_t row_pitch, int on_device,
+                        int will_detect, int channels, int elem_size) {
+    if (!a || !rgb) return fail(PC_E_INVALID, "null argument");
+    const int n = (int)a->slots.size();
+    Slot& s = a->slots[(size_t)(((frame_id % n) + n) % n)];
+    PC_HIP(hipSetDevice(a->ctx->device));
+    PrepScope prep(a->ctx);
+    // an LK launch in flight may still read the frame this slot holds
+    if (s.last_read) PC_HIP(hipStreamWaitEvent(a->ctx->prep_stream, s.last_read, 0));
+    s.last_read = nullptr;
+    int rc = set_image(a->ctx, s.frame, rgb, row_pitch, on_device, channels, elem_size);
+    if (rc != PC_OK) {
+        s.valid = false;
+        return rc;
+    }
+    PC_HIP(hipEventRecord(s.img_ready, a->ctx->prep_stream));
+    s.frame_id = frame_id;
+    s.valid = true;
+    s.det = DET_NONE;
+    s.supplied = false;
+    if (will_detect) return detect_dense(a, s);
+    return PC_OK;
+}
+
+int pc_analyzer_put_frame(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, size_t row_pitch, int on_device,
+                          int will_detect) {
+    return analyzer_put(a, frame_id, rgb, row_pitch, on_device, will_detect, 3, 1);
+}
+
+int pc_analyzer_put_frame_f32(pc_analyzer* a, int32_t frame_id, const float* rgb, size_t row_pitch, int channels,
+                              int on_device, int will_detect) {
+    return analyzer_put(a, frame_id, reinterpret_cast<const uint8_t*>(rgb), row_pitch, on_device, will_detect, channels, 4);
+}
+
+int pc_analyzer_has_frame(const pc_analyzer* a, int32_t frame_id) {
+    if (!a) return 0;
+    return find_slot(const_cast<pc_analyzer*>(a), frame_id) != nullptr;
+}
+
+int pc_analyzer_set_keypoints(pc_analyzer* a, int32_t frame_id, const float* xy, int n) {
+    if (!a || n < 0 || (!xy && n > 0)) return fail(PC_E_INVALID, "bad argument");
+    Slot* s = find_slot(a, frame_id);
+    if (!s) return fail(PC_E_STATE, "frame %d is not resident", frame_id);
+    int rc = ensure_kp_capacity(s->frame, n);
+    if (rc != PC_OK) return rc;
+    if (n > 0) {
+        // resume path (keypoints from the database): pageable source, so the copy is synchronous
+        PC_HIP(hipMemcpyAsync(s->frame->d_kps, xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, a->ctx->prep_stream));
+        PC_HIP(hipStreamSynchronize(a->ctx->prep_stream));
+    }
+    s->frame->n_kps = n;
+    {
+        PrepScope prep(a->ctx);
+        if ((rc = order_keypoints_spatially(a->ctx, s->frame, a->ctx->prep_hist)) != PC_OK) return rc;
+        PC_HIP(hipEventRecord(s->kps_ready, a->ctx->prep_stream));
+    }
+    s->det = DET_DONE;
+    s->supplied = true;
+    return PC_OK;
+}
+
+
+int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, int n_targets) {
+    if (!a || (n_targets > 0 && !targets)) return fail(PC_E_INVALID, "null argument");
+    if (n_targets < 0 || n_targets > PC_MAX_TARGETS) return fail(PC_E_INVALID, "n_targets must be in [0,%d]", PC_MAX_TARGETS);
+    if (a->job_count == a->jobs.size()) return fail(PC_E_STATE, "%zu jobs already in flight: call pc_analyzer_collect", a->job_count);
+    pc_context* ctx = a->ctx;
+    PC_HIP(hipSetDevice(ctx->device));
+    Slot* s1 = find_slot(a, frame1);
+    if (!s1) return fail(PC_E_STATE, "frame1 %d is not resident", frame1);
+    const pc_frame* tg[PC_MAX_TARGETS];
+    for (int t = 0; t < n_targets; t++) {
+        Slot* st = find_slot(a, targets[t]);
+        if (!st) return fail(PC_E_STATE, "target frame %d is not resident", targets[t]);
+        tg[t] = st->frame;
+    }
+    int rc;
+    // (1) keypoints of frame1: the dense phase ran when the frame became resident; order them now
+    bool detected = false;
+    if (s1->det != DET_DONE) {
+        SlowSection ss("submit/detect_finish");
+        PrepScope prep(a->ctx);
+        if ((rc = detect_finish(a, *s1)) != PC_OK) return rc;
+        detected = true;
+    } else {
+        detected = !s1->supplied;
+    }
+    Job& j = a->jobs[(a->job_head + a->job_count) % a->jobs.size()];
+    // (2) the LK launch needs this frame's keypoints and the pyramids of the frames it reads -- not the
+    // detection of frames that were made resident for later
+    {
+        SlowSection ss("submit/waits");
+        PC_HIP(hipStreamWaitEvent(ctx->stream, s1->kps_ready, 0));
+        PC_HIP(hipStreamWaitEvent(ctx->stream, s1->img_ready, 0));
+        for (int t = 0; t < n_targets; t++) PC_HIP(hipStreamWaitEvent(ctx->stream, find_slot(a, targets[t])->img_ready, 0));
+    }
+    const int n = s1->frame->n_kps;
+    const size_t rows = (size_t)n * (size_t)std::max(n_targets, 0);
+    // packed record layout (= a device-log record without its 128-byte header)
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    j.o_kps = 128;
+    j.o_idx = up16(j.o_kps + (size_t)n * 8);
+    j.o_xy = up16(j.o_idx + rows * 4);
+    j.o_err = up16(j.o_xy + rows * 8);
+    j.pack_bytes = up16(j.o_err + rows * 4);
+    {
+        SlowSection ss("submit/ensure pack");
+        PC_HIP(j.h_pack.ensure(j.pack_bytes));
+        PC_HIP(ctx->lk_pack.ensure(j.pack_bytes));
+    }
+    j.frame1 = frame1;
+    j.n_kps = n;
+    j.detected = detected;
+    j.n_targets = n_targets;
+    for (int t = 0; t < n_targets; t++) j.targets[t] = targets[t];
+    // (3) LK on the main stream, into output set `set`; its compaction (status filter), the device-log copies and the
+    // downloads on the copy stream, so that the next LK launch starts right behind this one
+    const int set = (int)(a->submitted & 1);
+    hipStream_t post = ctx->copy_stream;
+    ctx->prep_dirty = true;   // stage-level calls must order themselves behind the side streams
+    if (n_targets > 0) {
+        if (a->fopt.window_size != s1->frame->win) return fail(PC_E_INVALID, "window size mismatch");
+        // the compaction of the job two submits ago read this output set
+        SlowSection ss("submit/run_lk");
+        if (a->set_free[set]) PC_HIP(hipStreamWaitEvent(ctx->stream, a->set_free[set], 0));
+        if ((rc = run_lk(ctx, s1->frame, tg, n_targets, &a->fopt, set)) != PC_OK) return rc;
+    }
+    SlowSection ss_post("submit/post-stream enqueue");
+    PC_HIP(hipEventRecord(j.lk_done, ctx->stream));
+    s1->last_read = j.lk_done;
+    for (int t = 0; t < n_targets; t++) find_slot(a, targets[t])->last_read = j.lk_done;
+    PC_HIP(hipStreamWaitEvent(post, j.lk_done, 0));
+    uint8_t* const pack = ctx->lk_pack.p;
+    long long* const p_ro = reinterpret_cast<long long*>(pack);
+    PC_HIP(hipMemsetAsync(pack, 0, 128, post));
+    if (n_targets > 0) {
+        const int nblocks = pc::compact_num_blocks(n);
+        PC_HIP(ctx->lk_block_counts.ensure((size_t)nblocks * n_targets + 1));
+        // the previous job's download reads the pack: it precedes this compaction on the same stream
+        ScopedTimer t(ctx, PC_K_COMPACT, post);
+        pc::launch_compact(ctx->lk_xy[set].p, ctx->lk_status[set].p, ctx->lk_err[set].p, n, n_targets, ctx->lk_block_counts.p, p_ro,
+                           reinterpret_cast<uint32_t*>(pack + j.o_idx), reinterpret_cast<float2*>(pack + j.o_xy),
+                           reinterpret_cast<float*>(pack + j.o_err), post);
+    }
+    pc::launch_copy_keypoints(s1->frame->d_kps, reinterpret_cast<float2*>(pack + j.o_kps), n, post);
+    if (a->d_log) {
+        // device log: header from pinned memory, the record itself is the pack (one device-to-device copy)
+        const size_t o_hdr = a->log_used, end = o_hdr + 128 + j.pack_bytes;
+        if (end > a->log_cap) return fail(PC_E_CAPACITY, "device log full (%zu of %zu bytes)", end, a->log_cap);
+        const size_t slot_i = (a->job_head + a->job_count) % a->jobs.size();
+        if (a->log_hdr.size() != a->jobs.size()) a->log_hdr.resize(a->jobs.size());
+        PC_HIP(a->log_hdr[slot_i].ensure(16));
+        long long* hh = a->log_hdr[slot_i].p;
+        for (int k = 0; k < 16; k++) hh[k] = 0;
+        hh[0] = PC_LOG_MAGIC;
+        hh[1] = frame1;
+        hh[2] = n;
+        hh[3] = n_targets;
+        for (int t = 0; t < n_targets; t++) hh[4 + t] = targets[t];
+        hh[12] = (long long)rows;
+        PC_HIP(hipMemcpyAsync(a->d_log + o_hdr, hh, 128, hipMemcpyHostToDevice, post));
+        PC_HIP(hipMemcpyAsync(a->d_log + o_hdr + 128, pack, j.pack_bytes, hipMemcpyDeviceToDevice, post));
+        a->log_used = end;
+    }
+    PC_HIP(hipEventRecord(j.computed, post));
+    a->set_free[set] = j.computed;
+    a->submitted++;
+    // (4) download, behind the compaction on the same stream: ONE copy with fixed endpoints (the context's pack ->
+    // the job's pinned pack).  The runtime stalls the host for 5-8 ms the first time it sees a buffer as a copy
+    // source, so per-frame buffers must not appear here.
+    PC_HIP(hipMemcpyAsync(j.h_pack.p, pack, j.pack_bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    PC_HIP(hipEventRecord(j.done, ctx->copy_stream));
+    a->job_count++;
+    // (5) while this LK launch runs: order the keypoints of the next frame1
+    SlowSection ss("submit/preorder");
+    return preorder_if_ready(a, frame1 + 1);
+}
+
+int pc_analyzer_pending(const pc_analyzer* a) { return a ? (int)a->job_count : 0; }
+
+int pc_analyzer_set_device_log(pc_analyzer* a, void* d_log, size_t capacity_bytes) {
+    if (!a) return fail(PC_E_INVALID, "null analyzer");
+    if (d_log && (reinterpret_cast<uintptr_t>(d_log) & 15)) return fail(PC_E_INVALID, "device log must be 16-byte aligned");
+    PC_HIP(hipStreamSynchronize(a->ctx->prep_stream));
+    PC_HIP(hipStreamSynchronize(a->ctx->stream));
+    a->d_log = static_cast<uint8_t*>(d_log);
+    a->log_cap = d_log ? capacity_bytes : 0;
+    a->log_used = 0;
+    return PC_OK;
+}
+
+int pc_analyzer_device_log_used(const pc_analyzer* a, size_t* bytes) {
+    if (!a || !bytes) return fail(PC_E_INVALID, "null argument");
+    *bytes = a->log_used;
+    return PC_OK;
+}
+
+int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out) {
+    if (!a || !out) return fail(PC_E_INVALID, "null argument");
+    if (a->job_count == 0) return fail(PC_E_STATE, "no job in flight");
+    Job& j = a->jobs[a->job_head];
+    PC_HIP(hipEventSynchronize(j.done));
+    // let the runtime retire the finished commands of the other streams now, a few at a time: left alone it does
+    // so in one batch of several milliseconds every couple of hundred frames, inside some later launch
+    (void)hipStreamQuery(a->ctx->stream);
+    (void)hipStreamQuery(a->ctx->prep_stream);
+    out->frame1 = j.frame1;
+    out->n_keypoints = j.n_kps;
+    out->keypoints_detected = j.detected ? 1 : 0;
+    out->keypoints_xy = reinterpret_cast<const float*>(j.h_pack.p + j.o_kps);
+    out->n_targets = j.n_targets;
+    for (int t = 0; t < PC_MAX_TARGETS; t++) out->targets[t] = t < j.n_targets ? j.targets[t] : 0;
+    const long long* h_ro = reinterpret_cast<const long long*>(j.h_pack.p);
+    for (int t = 0; t <= PC_MAX_TARGETS; t++) out->row_offset[t] = (int64_t)h_ro[std::min(t, j.n_targets)];
+    out->src_indices = reinterpret_cast<const uint32_t*>(j.h_pack.p + j.o_idx);
+    out->tgt_xy = reinterpret_cast<const float*>(j.h_pack.p + j.o_xy);
+    out->flow_err = reinterpret_cast<const float*>(j.h_pack.p + j.o_err);
+    a->job_head = (a->job_head + 1) % a->jobs.size();
+    a->job_count--;
+    return PC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,497 @@
+// api_tracker.hip -- C ABI of the tracking and refinement paths: meshes + LBVH ray casting, PnP accumulation
+// (reference cpp/tracker.cc, cpp/pnp/*), and the refiner's per-edge sweeps (cpp/refiner.cc, cpp/pnp/lev_marq.h).
+#include "api_internal.hpp"
+
+using namespace pc_api;
+
+// =============================================================================================
+// tracker path: meshes, batched ray casting, PnP accumulation
+// =============================================================================================
+
+struct pc_mesh {
+    pc_context* ctx = nullptr;
+    int n_vertices = 0, n_triangles = 0;
+    DevBuf<float> verts;
+    DevBuf<uint32_t> tris, mask;
+    // LBVH (bvh.hpp): n_triangles - 1 internal nodes + the sorted leaf order
+    DevBuf<pc::BvhNode> bvh_nodes;
+    DevBuf<uint32_t> bvh_leaf_tri;
+    pc::BvhView bvh() const {
+        pc::BvhView v;
+        v.nodes = bvh_nodes.p;
+        v.leaf_tri = bvh_leaf_tri.p;
+        v.verts = verts.p;
+        v.tris = tris.p;
+        v.n_tris = n_triangles;
+        return v;
+    }
+    // per-call scratch
+    DevBuf<float2> d_xy;
+    DevBuf<uint8_t> d_hit;
+    DevBuf<float> d_pos, d_uvt;
+    DevBuf<uint32_t> d_prim;
+};
+
+struct pc_pnp_problem {
+    pc_context* ctx = nullptr;
+    int n = 0;
+    bool has_weights = false;
+    DevBuf<float> X, x, w, partials, out;
+    PinBuf<float> h_out;
+};
+
+extern "C" {
+
+int pc_mesh_create(pc_context* ctx, const float* vertices, int n_vertices, const uint32_t* triangles,
+                   int n_triangles, pc_mesh** out) {
+    if (!ctx || !out || n_vertices < 0 || n_triangles < 0 || (n_vertices > 0 && !vertices) ||
+        (n_triangles > 0 && !triangles))
+        return fail(PC_E_INVALID, "bad argument");
+    *out = nullptr;
+    for (int i = 0; i < 3 * n_triangles; i++)
+        if (triangles[i] >= (uint32_t)n_vertices) return fail(PC_E_INVALID, "triangle index %u out of range", triangles[i]);
+    PC_HIP(hipSetDevice(ctx->device));
+    pc_mesh* m = new (std::nothrow) pc_mesh();
+    if (!m) return fail(PC_E_INVALID, "out of host memory");
+    m->ctx = ctx;
+    m->n_vertices = n_vertices;
+    m->n_triangles = n_triangles;
+    const int words = (n_triangles + 31) / 32 + 4;
+    hipError_t e = m->verts.ensure((size_t)std::max(1, n_vertices) * 3);
+    if (e == hipSuccess) e = m->tris.ensure((size_t)std::max(1, n_triangles) * 3);
+    if (e == hipSuccess) e = m->mask.ensure((size_t)words);
+    if (e == hipSuccess && n_vertices) e = hipMemcpyAsync(m->verts.p, vertices, (size_t)n_vertices * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n_triangles) e = hipMemcpyAsync(m->tris.p, triangles, (size_t)n_triangles * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(m->mask.p, 0, (size_t)words * sizeof(uint32_t), ctx->stream);
+    // acceleration structure (rtcCommitScene in the reference, ray_casting.cc:23-63): LBVH built on the GPU
+    if (e == hipSuccess && n_triangles > 0) {
+        const size_t n = (size_t)n_triangles;
+        float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        for (int v = 0; v < n_vertices; v++)
+            for (int k = 0; k < 3; k++) {
+                const float x = vertices[3 * (size_t)v + k];
+                if (v == 0 || x < lo[k]) lo[k] = x;
+                if (v == 0 || x > hi[k]) hi[k] = x;
+            }
+        const float extent = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+        const float pad = 1e-5f * extent + 1e-30f;
+        DevBuf<unsigned long long> keys_in, keys_out;
+        DevBuf<float> box_lo, box_hi;
+        DevBuf<int> links;      // parent (2n-1) | visits (n) | left (n) | right (n)
+        DevBuf<uint32_t> bounds;
+        DevBuf<uint8_t> sort_temp;
+        const size_t temp_bytes = pc::bvh_sort_temp_bytes(n_triangles);
+        e = m->bvh_nodes.ensure(n);
+        if (e == hipSuccess) e = m->bvh_leaf_tri.ensure(n);
+        if (e == hipSuccess) e = keys_in.ensure(n);
+        if (e == hipSuccess) e = keys_out.ensure(n);
+        if (e == hipSuccess) e = box_lo.ensure(3 * (2 * n));
+        if (e == hipSuccess) e = box_hi.ensure(3 * (2 * n));
+        if (e == hipSuccess) e = links.ensure(5 * n + 8);
+        if (e == hipSuccess) e = bounds.ensure(8);
+        if (e == hipSuccess) e = sort_temp.ensure(temp_bytes + 16);
+        if (e == hipSuccess) {
+            pc::BvhBuildScratch sc;
+            sc.keys_in = keys_in.p;
+            sc.keys_out = keys_out.p;
+            sc.box_lo = box_lo.p;
+            sc.box_hi = box_hi.p;
+            sc.parent = links.p;
+            sc.visits = links.p + 2 * n;
+            sc.left = links.p + 3 * n;
+            sc.right = links.p + 4 * n;
+            sc.bounds = bounds.p;
+            e = pc::bvh_build(m->verts.p, m->tris.p, n_triangles, pad, sc, sort_temp.p, temp_bytes, m->bvh_nodes.p,
+                              m->bvh_leaf_tri.p, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        keys_in.release();
+        keys_out.release();
+        box_lo.release();
+        box_hi.release();
+        links.release();
+        bounds.release();
+        sort_temp.release();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        pc_mesh_destroy(m);
+        return fail(PC_E_HIP, "mesh upload failed: %s", hipGetErrorString(e));
+    }
+    *out = m;
+    return PC_OK;
+}
+
+int pc_mesh_set_mask(pc_context* ctx, pc_mesh* mesh, const uint32_t* mask_words, int n_words) {
+    if (!ctx || !mesh || !mask_words) return fail(PC_E_INVALID, "null argument");
+    const int need = (mesh->n_triangles + 31) / 32;
+    if (n_words < need) return fail(PC_E_INVALID, "mask has %d words, %d needed", n_words, need);
+    if (need > 0) {
+        PC_HIP(hipMemcpyAsync(mesh->mask.p, mask_words, (size_t)need * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        PC_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PC_OK;
+}
+
+void pc_mesh_destroy(pc_mesh* m) {
+    if (!m) return;
+    if (m->ctx) {
+        (void)hipSetDevice(m->ctx->device);
+        (void)hipStreamSynchronize(m->ctx->stream);
+    }
+    m->verts.release();
+    m->tris.release();
+    m->mask.release();
+    m->bvh_nodes.release();
+    m->bvh_leaf_tri.release();
+    m->d_xy.release();
+    m->d_hit.release();
+    m->d_pos.release();
+    m->d_uvt.release();
+    m->d_prim.release();
+    delete m;
+}
+
+static int raycast_pixels(pc_context* ctx, const pc_mesh* mesh_c, const pc_ray_camera* cam, const float* xy, int n,
+                          int check_mask, uint8_t* hit, float* pos, uint32_t* prim, float* uvt, bool sweep) {
+    if (!ctx || !mesh_c || !cam || n < 0) return fail(PC_E_INVALID, "bad argument");
+    if (n == 0) return PC_OK;
+    if (!xy || !hit || !pos || !prim || !uvt) return fail(PC_E_INVALID, "null buffer");
+    pc_mesh* mesh = const_cast<pc_mesh*>(mesh_c);
+    PC_HIP(hipSetDevice(ctx->device));
+    PC_HIP(mesh->d_xy.ensure((size_t)n));
+    PC_HIP(mesh->d_hit.ensure((size_t)n));
+    PC_HIP(mesh->d_pos.ensure((size_t)n * 3));
+    PC_HIP(mesh->d_uvt.ensure((size_t)n * 3));
+    PC_HIP(mesh->d_prim.ensure((size_t)n));
+    pc::RayCamera rc;
+    std::memcpy(rc.m, cam->dir_matrix, sizeof(rc.m));
+    std::memcpy(rc.origin, cam->origin, sizeof(rc.origin));
+    rc.fx = cam->fx;
+    rc.fy = cam->fy;
+    rc.cx = cam->cx;
+    rc.cy = cam->cy;
+    rc.sign = cam->unproject_sign;
+    PC_HIP(hipMemcpyAsync(mesh->d_xy.p, xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    if (sweep)
+        pc::launch_raycast_sweep(mesh->verts.p, mesh->tris.p, mesh->n_triangles, mesh->mask.p, check_mask, rc, mesh->d_xy.p, n,
+                                 mesh->d_hit.p, mesh->d_pos.p, mesh->d_prim.p, mesh->d_uvt.p, ctx->stream);
+    else
+        pc::launch_raycast(mesh->bvh(), mesh->mask.p, check_mask, rc, mesh->d_xy.p, n, mesh->d_hit.p, mesh->d_pos.p,
+                           mesh->d_prim.p, mesh->d_uvt.p, ctx->stream);
+    PC_HIP(hipMemcpyAsync(hit, mesh->d_hit.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipMemcpyAsync(pos, mesh->d_pos.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipMemcpyAsync(prim, mesh->d_prim.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipMemcpyAsync(uvt, mesh->d_uvt.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    return PC_OK;
+}
+
+int pc_raycast_pixels(pc_context* ctx, const pc_mesh* mesh, const pc_ray_camera* cam, const float* xy, int n, int check_mask,
+                      uint8_t* hit, float* pos, uint32_t* prim, float* uvt) {
+    return raycast_pixels(ctx, mesh, cam, xy, n, check_mask, hit, pos, prim, uvt, false);
+}
+
+int pc_raycast_pixels_sweep(pc_context* ctx, const pc_mesh* mesh, const pc_ray_camera* cam, const float* xy, int n,
+                            int check_mask, uint8_t* hit, float* pos, uint32_t* prim, float* uvt) {
+    return raycast_pixels(ctx, mesh, cam, xy, n, check_mask, hit, pos, prim, uvt, true);
+}
+
+int pc_pnp_problem_create(pc_context* ctx, const float* X, const float* x, const float* weights, int n,
+                          pc_pnp_problem** out) {
+    if (!ctx || !out || n < 1 || !X || !x) return fail(PC_E_INVALID, "bad argument");
+    *out = nullptr;
+    PC_HIP(hipSetDevice(ctx->device));
+    pc_pnp_problem* p = new (std::nothrow) pc_pnp_problem();
+    if (!p) return fail(PC_E_INVALID, "out of host memory");
+    p->ctx = ctx;
+    p->n = n;
+    p->has_weights = weights != nullptr;
+    const int nb = pc::pnp_num_blocks(n);
+    hipError_t e = p->X.ensure((size_t)n * 3);
+    if (e == hipSuccess) e = p->x.ensure((size_t)n * 2);
+    if (e == hipSuccess && weights) e = p->w.ensure((size_t)n);
+    if (e == hipSuccess) e = p->partials.ensure((size_t)nb * 56);
+    if (e == hipSuccess) e = p->out.ensure(64);
+    if (e == hipSuccess) e = p->h_out.ensure(64);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->X.p, X, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->x.p, x, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && weights) e = hipMemcpyAsync(p->w.p, weights, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        pc_pnp_problem_destroy(p);
+        return fail(PC_E_HIP, "PnP upload failed: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return PC_OK;
+}
+
+void pc_pnp_problem_destroy(pc_pnp_problem* p) {
+    if (!p) return;
+    if (p->ctx) {
+        (void)hipSetDevice(p->ctx->device);
+        (void)hipStreamSynchronize(p->ctx->stream);
+    }
+    p->X.release();
+    p->x.release();
+    p->w.release();
+    p->partials.release();
+    p->out.release();
+    p->h_out.release();
+    delete p;
+}
+
+static pc::PnPParams to_kernel_params(const pc_pnp_params* q) {
+    pc::PnPParams p;
+    std::memcpy(p.R, q->R, sizeof(p.R));
+    std::memcpy(p.t, q->t, sizeof(p.t));
+    p.fx = q->fx;
+    p.fy = q->fy;
+    p.cx = q->cx;
+    p.cy = q->cy;
+    p.aspect_ratio = q->aspect_ratio;
+    p.convention_opencv = q->convention_opencv;
+    p.optimize_focal = q->optimize_focal_length;
+    p.optimize_pp = q->optimize_principal_point;
+    p.loss_type = q->loss_type;
+    p.loss_scale = q->loss_scale;
+    return p;
+}
+
+int pc_pnp_normal_equations(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,
+                            float* jtj_lower45, float* jtr9, int* valid) {
+    if (!ctx || !prob || !params || !jtj_lower45 || !jtr9) return fail(PC_E_INVALID, "null argument");
+    if (params->loss_type < 0 || params->loss_type > 2) return fail(PC_E_INVALID, "Unknown loss type: %d", params->loss_type);
+    PC_HIP(hipSetDevice(ctx->device));
+    pc::launch_pnp_normal_eq(prob->X.p, prob->x.p, prob->has_weights ? prob->w.p : nullptr, prob->n,
+                             to_kernel_params(params), prob->partials.p, prob->out.p, ctx->stream);
+    PC_HIP(hipMemcpyAsync(prob->h_out.p, prob->out.p, 56 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    std::memcpy(jtj_lower45, prob->h_out.p, 45 * sizeof(float));
+    std::memcpy(jtr9, prob->h_out.p + 45, 9 * sizeof(float));
+    if (valid) *valid = (int)prob->h_out.p[54];
+    return PC_OK;
+}
+
+int pc_pnp_total_cost(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,
+                      float max_inlier_error_sq, float* cost, int* valid, int* inliers) {
+    if (!ctx || !prob || !params || !cost) return fail(PC_E_INVALID, "null argument");
+    if (params->loss_type < 0 || params->loss_type > 2) return fail(PC_E_INVALID, "Unknown loss type: %d", params->loss_type);
+    PC_HIP(hipSetDevice(ctx->device));
+    pc::launch_pnp_cost(prob->X.p, prob->x.p, prob->has_weights ? prob->w.p : nullptr, prob->n, to_kernel_params(params),
+                        max_inlier_error_sq, prob->partials.p, prob->out.p, ctx->stream);
+    PC_HIP(hipMemcpyAsync(prob->h_out.p, prob->out.p, 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    *cost = prob->h_out.p[0];
+    if (valid) *valid = (int)prob->h_out.p[1];
+    if (inliers) *inliers = (int)prob->h_out.p[2];
+    return PC_OK;
+}
+
+
+// =============================================================================================
+// refiner path
+// =============================================================================================
+}  // extern "C"
+
+struct pc_refine_problem {
+    pc_context* ctx = nullptr;
+    const pc_mesh* mesh = nullptr;
+    int n_frames = 0, n_edges = 0, block_len = 6, opt_f = 0, opt_pp = 0;
+    size_t n_kp = 0, n_res = 0;
+    DevBuf<int> kp_offset, edge_src, edge_tgt, edge_offset, edge_valid;
+    DevBuf<float2> kp_xy, res_tgt_xy;
+    DevBuf<double2> edge_cost;
+    DevBuf<uint32_t> res_src_kp, prim_cache;
+    DevBuf<float> edge_weight;
+    DevBuf<double> edge_blocks;
+    DevBuf<uint8_t> frame_fixed;
+    DevBuf<pc::RefineCamera> cams;
+    PinBuf<double2> h_edge_cost;
+    std::vector<float> h_edge_weight;
+    float model[16], model_inv[16];
+};
+
+namespace {
+
+pc::RefineProblemView refine_view(const pc_refine_problem* p) {
+    pc::RefineProblemView v;
+    v.n_frames = p->n_frames;
+    v.n_edges = p->n_edges;
+    v.n_tris = p->mesh->n_triangles;
+    v.kp_offset = p->kp_offset.p;
+    v.kp_xy = p->kp_xy.p;
+    v.edge_src = p->edge_src.p;
+    v.edge_tgt = p->edge_tgt.p;
+    v.edge_offset = p->edge_offset.p;
+    v.res_src_kp = p->res_src_kp.p;
+    v.res_tgt_xy = p->res_tgt_xy.p;
+    v.edge_weight = p->edge_weight.p;
+    v.frame_fixed = p->frame_fixed.p;
+    v.prim_cache = p->prim_cache.p;
+    v.verts = p->mesh->verts.p;
+    v.tris = p->mesh->tris.p;
+    v.mask = p->mesh->mask.p;
+    v.bvh = p->mesh->bvh();
+    std::memcpy(v.model, p->model, sizeof(v.model));
+    std::memcpy(v.model_inv, p->model_inv, sizeof(v.model_inv));
+    return v;
+}
+
+int upload_cameras(pc_context* ctx, pc_refine_problem* p, const pc_refine_camera* cameras) {
+    std::vector<pc::RefineCamera> h((size_t)p->n_frames);
+    for (int f = 0; f < p->n_frames; f++) {
+        std::memcpy(h[f].R, cameras[f].R, sizeof(h[f].R));
+        std::memcpy(h[f].t, cameras[f].t, sizeof(h[f].t));
+        h[f].fx = cameras[f].fx;
+        h[f].fy = cameras[f].fy;
+        h[f].cx = cameras[f].cx;
+        h[f].cy = cameras[f].cy;
+        h[f].aspect = cameras[f].aspect_ratio;
+        h[f].sign = cameras[f].unproject_sign;
+    }
+    PC_HIP(hipMemcpyAsync(p->cams.p, h.data(), h.size() * sizeof(pc::RefineCamera), hipMemcpyHostToDevice, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));  // `h` is pageable and local
+    return PC_OK;
+}
+
+template <typename T, typename U>
+hipError_t upload(DevBuf<T>& dst, const U* src, size_t n, hipStream_t s) {
+    static_assert(sizeof(T) == sizeof(U) || sizeof(T) == 2 * sizeof(U), "layout");
+    hipError_t e = dst.ensure(n ? n : 1);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(dst.p, src, n * sizeof(T), hipMemcpyHostToDevice, s);
+    return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pc_refine_problem_create(pc_context* ctx, const pc_mesh* mesh, const pc_refine_desc* d, pc_refine_problem** out) {
+    if (!ctx || !mesh || !d || !out) return fail(PC_E_INVALID, "null argument");
+    *out = nullptr;
+    if (d->n_frames < 3) return fail(PC_E_INVALID, "a segment needs more than 2 frames");  // CHECK(traj.Count() > 2)
+    if (d->n_edges < 0 || (d->block_len != 6 && d->block_len != 9)) return fail(PC_E_INVALID, "bad problem description");
+    if (!d->kp_offset || !d->edge_offset || (d->n_edges > 0 && (!d->edge_src || !d->edge_tgt || !d->edge_weight)))
+        return fail(PC_E_INVALID, "null array");
+    const size_t n_kp = (size_t)d->kp_offset[d->n_frames], n_res = (size_t)d->edge_offset[d->n_edges];
+    for (int e = 0; e < d->n_edges; e++) {
+        if (d->edge_src[e] < 0 || d->edge_src[e] >= d->n_frames || d->edge_tgt[e] < 0 || d->edge_tgt[e] >= d->n_frames ||
+            d->edge_src[e] == d->edge_tgt[e])
+            return fail(PC_E_INVALID, "edge %d connects invalid frames", e);
+        const size_t src_kps = (size_t)(d->kp_offset[d->edge_src[e] + 1] - d->kp_offset[d->edge_src[e]]);
+        for (int r = d->edge_offset[e]; r < d->edge_offset[e + 1]; r++)
+            if (d->res_src_kp[r] >= src_kps) return fail(PC_E_INVALID, "edge %d references keypoint %u of %zu", e, d->res_src_kp[r], src_kps);
+    }
+    PC_HIP(hipSetDevice(ctx->device));
+    pc_refine_problem* p = new (std::nothrow) pc_refine_problem();
+    if (!p) return fail(PC_E_INVALID, "out of host memory");
+    p->ctx = ctx;
+    p->mesh = mesh;
+    p->n_frames = d->n_frames;
+    p->n_edges = d->n_edges;
+    p->block_len = d->block_len;
+    p->opt_f = d->optimize_focal_length ? 1 : 0;
+    p->opt_pp = d->optimize_principal_point ? 1 : 0;
+    p->n_kp = n_kp;
+    p->n_res = n_res;
+    std::memcpy(p->model, d->model_matrix, sizeof(p->model));
+    std::memcpy(p->model_inv, d->model_matrix_inv, sizeof(p->model_inv));
+    std::vector<uint8_t> fixed((size_t)d->n_frames, 0);
+    fixed.front() = fixed.back() = 1;  // IsGroundTruth (refiner.cc:268-271)
+    const int B2 = 2 * d->block_len, nacc = B2 * (B2 + 1) / 2 + B2;
+    hipStream_t s = ctx->stream;
+    hipError_t e = upload(p->kp_offset, d->kp_offset, (size_t)d->n_frames + 1, s);
+    if (e == hipSuccess) e = upload(p->kp_xy, d->kp_xy, n_kp, s);
+    if (e == hipSuccess) e = upload(p->edge_src, d->edge_src, (size_t)d->n_edges, s);
+    if (e == hipSuccess) e = upload(p->edge_tgt, d->edge_tgt, (size_t)d->n_edges, s);
+    if (e == hipSuccess) e = upload(p->edge_offset, d->edge_offset, (size_t)d->n_edges + 1, s);
+    if (e == hipSuccess) e = upload(p->res_src_kp, d->res_src_kp, n_res, s);
+    if (e == hipSuccess) e = upload(p->res_tgt_xy, d->res_tgt_xy, n_res, s);
+    if (e == hipSuccess) e = upload(p->edge_weight, d->edge_weight, (size_t)d->n_edges, s);
+    if (e == hipSuccess) e = upload(p->frame_fixed, fixed.data(), fixed.size(), s);
+    if (e == hipSuccess) e = p->prim_cache.ensure(n_kp ? n_kp : 1);
+    if (e == hipSuccess) e = hipMemsetAsync(p->prim_cache.p, 0xff, (n_kp ? n_kp : 1) * sizeof(uint32_t), s);
+    if (e == hipSuccess) e = p->edge_cost.ensure((size_t)std::max(1, d->n_edges));
+    if (e == hipSuccess) e = p->h_edge_cost.ensure((size_t)std::max(1, d->n_edges));
+    if (e == hipSuccess) e = p->edge_valid.ensure((size_t)std::max(1, d->n_edges));
+    if (e == hipSuccess) e = p->edge_blocks.ensure((size_t)std::max(1, d->n_edges) * nacc);
+    if (e == hipSuccess) e = p->cams.ensure((size_t)d->n_frames);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        pc_refine_problem_destroy(p);
+        return fail(PC_E_HIP, "refine problem upload failed: %s", hipGetErrorString(e));
+    }
+    p->h_edge_weight.assign(d->edge_weight, d->edge_weight + d->n_edges);
+    *out = p;
+    return PC_OK;
+}
+
+void pc_refine_problem_destroy(pc_refine_problem* p) {
+    if (!p) return;
+    if (p->ctx) {
+        (void)hipSetDevice(p->ctx->device);
+        (void)hipStreamSynchronize(p->ctx->stream);
+    }
+    p->kp_offset.release();
+    p->edge_src.release();
+    p->edge_tgt.release();
+    p->edge_offset.release();
+    p->edge_valid.release();
+    p->kp_xy.release();
+    p->res_tgt_xy.release();
+    p->edge_cost.release();
+    p->res_src_kp.release();
+    p->prim_cache.release();
+    p->edge_weight.release();
+    p->edge_blocks.release();
+    p->frame_fixed.release();
+    p->cams.release();
+    p->h_edge_cost.release();
+    delete p;
+}
+
+int pc_refine_total_cost(pc_context* ctx, pc_refine_problem* p, const pc_refine_camera* cameras, int loss_type,
+                         float loss_scale, double* cost) {
+    if (!ctx || !p || !cameras || !cost) return fail(PC_E_INVALID, "null argument");
+    if (loss_type < 0 || loss_type > 2) return fail(PC_E_INVALID, "Unknown loss type: %d", loss_type);
+    PC_HIP(hipSetDevice(ctx->device));
+    int rc = upload_cameras(ctx, p, cameras);
+    if (rc != PC_OK) return rc;
+    *cost = 0.0;
+    if (p->n_edges == 0) return PC_OK;
+    pc::launch_refine_cost(refine_view(p), p->cams.p, loss_type, loss_scale, p->edge_cost.p, ctx->stream);
+    PC_HIP(hipMemcpyAsync(p->h_edge_cost.p, p->edge_cost.p, (size_t)p->n_edges * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    // cost = sum_e edge_weight * (edge loss sum / valid)   (lev_marq.h:812-820), fixed edge order
+    double total = 0.0;
+    for (int e = 0; e < p->n_edges; e++) {
+        const float w = p->h_edge_weight[(size_t)e];
+        if (w == 0.0f) continue;
+        double edge_cost = p->h_edge_cost.p[e].x;
+        if (p->h_edge_cost.p[e].y > 0.0) edge_cost /= p->h_edge_cost.p[e].y;
+        total += (double)w * edge_cost;
+    }
+    *cost = total;
+    return PC_OK;
+}
+
+int pc_refine_normal_equations(pc_context* ctx, pc_refine_problem* p, const pc_refine_camera* cameras, int loss_type,
+                               float loss_scale, double* edge_blocks, int* edge_valid) {
+    if (!ctx || !p || !cameras || !edge_blocks) return fail(PC_E_INVALID, "null argument");
+    if (loss_type < 0 || loss_type > 2) return fail(PC_E_INVALID, "Unknown loss type: %d", loss_type);
+    PC_HIP(hipSetDevice(ctx->device));
+    int rc = upload_cameras(ctx, p, cameras);
+    if (rc != PC_OK) return rc;
+    if (p->n_edges == 0) return PC_OK;
+    const int B2 = 2 * p->block_len, nacc = B2 * (B2 + 1) / 2 + B2;
+    pc::launch_refine_normal_eq(refine_view(p), p->cams.p, loss_type, loss_scale, p->block_len, p->opt_f, p->opt_pp,
+                                p->edge_blocks.p, p->edge_valid.p, ctx->stream);
+    PC_HIP(hipMemcpyAsync(edge_blocks, p->edge_blocks.p, (size_t)p->n_edges * nacc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (edge_valid)
+        PC_HIP(hipMemcpyAsync(edge_valid, p->edge_valid.p, (size_t)p->n_edges * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    return PC_OK;
+}
+
+}  // extern "C"
