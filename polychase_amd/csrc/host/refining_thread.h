@@ -7,7 +7,7 @@
 #include <memory>
 #include <variant>
 
-#include "refiner.h"
+#include "trajectory_refiner.h"
 #include "worker.h"
 
 using RefinerThreadMessage = std::variant<RefineTrajectoryUpdate, bool, CppException>;

@@ -1,4 +1,4 @@
-// refiner.cc -- host side of "Refine Sequence".
+// trajectory_refiner.cc -- host side of "Refine Sequence".
 //   segment loading   : CachedDatabase (cpp/refiner.cc:18-197) flattened into the CSR arrays the GPU
 //                       problem wants (keypoints per frame, residuals per edge)
 //   LM driver         : LevMarqSparseSolver::Solve (cpp/pnp/lev_marq.h:503-601), Step
@@ -6,7 +6,7 @@
 //   linear algebra    : the frames of a segment only connect to frames at most `max |i-j|` apart, so
 //                       J^T J is block-banded; a banded Cholesky (fp64) replaces Eigen::SimplicialLLT
 //   residual sweeps   : on the GPU through pc_refine_* (kernels_refiner.hip), one workgroup per edge
-#include "refiner.h"
+#include "trajectory_refiner.h"
 
 #include <cmath>
 #include <cstdio>

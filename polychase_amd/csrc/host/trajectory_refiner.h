@@ -1,4 +1,4 @@
-// refiner.h -- "Refine Sequence": joint refinement of all camera poses of a tracked segment against
+// trajectory_refiner.h -- "Refine Sequence": joint refinement of all camera poses of a tracked segment against
 // the optical-flow database (reference cpp/refiner.h:13-27, cpp/refiner.cc:506-725).
 #pragma once
 
