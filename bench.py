@@ -152,28 +152,49 @@ def main():
     gc.collect()
     gc.disable()
     an.run(range(f1_first, f1_first + W), sink)
-    log = None
+    log = stitch = None
     if dist_path:
         # device-resident record log: the stitch all-gathers these bytes, no host copy of the payload
         from polychase_amd import distributed as D
         max_kp = int(1.5 * max(n_kps + [1024])) + 4096
         log = torch.empty(D.log_capacity_bytes(K + 2, max_kp), dtype=torch.uint8, device=dev)
         an.an.set_device_log(log)
+        # sizes of the log pieces are agreed on over gloo so that the exchange never waits for an RCCL transfer
+        side = dist.new_group(backend="gloo") if world > 1 else None
+        stitch = D.ChunkedLogStitch(log, side_group=side)
     n_kps.clear()
     n_rows.clear()
     barrier()
     ctx.enable_timing(["lk"])   # HIP events around the dominant kernel only (2 records per step)
     ctx.reset_timing()
     t0 = time.perf_counter()
-    an.run(range(f1_first + W, f1_first + W + K), sink, copy=False)
-    if dist_path:
-        # stitch the flow database: one size exchange + one RCCL all-gather of the device logs
-        ctx.synchronize()
-        used = an.an.device_log_used
-        if world > 1:
-            gathered, sizes = D.all_gather_device_log(log, used)
-        else:
-            gathered, sizes = log[:used][None], [used]
+    timed = range(f1_first + W, f1_first + W + K)
+    if not dist_path:
+        an.run(timed, sink, copy=False)
+    else:
+        # the same loop as ClipAnalyzer.run, plus: whenever the last frame1 of a piece has been collected (its log
+        # bytes are complete), all-gather that piece over RCCL -- the transfer runs beside the LK launches of the
+        # following frames; only the last piece is exposed (the one collective of the path)
+        piece = max(1, K // 8)
+        log_end = {}                      # frame1 -> log offset after its record
+        piece_start = 0
+
+        def collect_one():
+            nonlocal piece_start
+            r = an.an.collect(False)
+            sink(*r)
+            done = r[0] - timed.start + 1
+            if done % piece == 0 or done == K:
+                stitch.gather(piece_start, log_end[r[0]])
+                piece_start = log_end[r[0]]
+
+        for f in timed:
+            if an.an.pending == an.max_jobs:
+                collect_one()
+            an.submit(f)
+            log_end[f] = an.an.device_log_used
+        while an.an.pending:
+            collect_one()
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -182,13 +203,13 @@ def main():
     if dist_path:
         # outside the timed region: every rank's shard must parse and hold exactly K records in frame order
         an.an.set_device_log(None)
-        for r in range(len(sizes)):
-            recs = D.parse_device_log(gathered[r].cpu().numpy(), sizes[r])
+        for r, (buf, used) in enumerate(stitch.rank_logs()):
+            recs = D.parse_device_log(buf, used)
             exp0 = 1 + r * (K + W) + 8 + W
             assert [x[0] for x in recs] == list(range(exp0, exp0 + K)), "stitched log is not the expected frame range"
             if r == rank:
                 assert [len(x[1]) for x in recs] == n_kps and [sum(len(v[0]) for v in x[2].values()) for x in recs] == n_rows
-        del gathered, log
+        del stitch, log
     # per-class kernel breakdown from a short extra pass over the same frames (not part of `value`)
     an.close()
     breakdown = None

@@ -148,6 +148,57 @@ def all_gather_device_log(log, used: int, group=None):
     return out, sizes
 
 
+class ChunkedLogStitch:
+    """All-gathers a device log piece by piece WHILE the analysis keeps running, so that only the last piece
+    is exposed at the end (a single all-gather of a whole shard's log costs 10-40 ms per 100 frames at 8 ranks,
+    a sizeable part of the step time; in pieces it hides behind the LK launches of the following frames).
+
+    gather(start, end): bytes [start, end) of the local log are complete (the job that wrote the last of them has
+    been collected).  The piece sizes are agreed on through `side_group` -- a gloo group, so that the exchange does not
+    queue behind the previous piece's payload on the NCCL stream -- then the payload all-gather is enqueued and the
+    call returns.  world == 1 (or no process group): the pieces are views of the local log."""
+
+    def __init__(self, log, group=None, side_group=None):
+        import torch.distributed as dist
+
+        self.log, self.group, self.side = log, group, side_group
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.world = self.dist.get_world_size(group) if self.dist else 1
+        self.pieces = []   # (gathered [world, padded] uint8, sizes [world])
+
+    def gather(self, start: int, end: int):
+        import torch
+
+        n = end - start
+        if self.world == 1:
+            self.pieces.append((self.log[start:end][None], [n]))
+            return
+        dist = self.dist
+        sizes_t = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+        dist.all_gather(sizes_t, torch.tensor([n], dtype=torch.int64), group=self.side)   # CPU tensors, gloo
+        sizes = [int(t.item()) for t in sizes_t]
+        mx = max(16, (max(sizes) + 15) // 16 * 16)
+        if start + mx > self.log.numel():
+            raise RuntimeError("device log has no slack for the padded piece")
+        out = torch.empty((self.world, mx), dtype=torch.uint8, device=self.log.device)
+        # bytes past `end` may still be written by the next frames: they are padding, never parsed
+        piece = self.log[start:start + mx]
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(out.view(-1), piece, group=self.group)   # straight into `out`, no staging copy
+        else:
+            dist.all_gather(list(out.unbind(0)), piece, group=self.group)        # gloo (CPU tests)
+        self.pieces.append((out, sizes))
+
+    def rank_logs(self):
+        """-> per rank: (numpy uint8 log, used bytes), the pieces concatenated in order."""
+        out = []
+        for r in range(self.world):
+            parts = [g[r, :sz[r]].cpu().numpy() for g, sz in self.pieces]
+            buf = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+            out.append((buf, len(buf)))
+        return out
+
+
 def parse_device_log(buf: np.ndarray, used: int):
     """buf: uint8 array of one rank's log.  -> records like pack_records' input."""
     out, o = [], 0

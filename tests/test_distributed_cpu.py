@@ -78,3 +78,76 @@ def test_two_ranks_stitch_to_the_single_rank_result(tmp_path, n):
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / f"h{r}.npy"), h_ref)
         assert np.array_equal(np.load(tmp_path / f"p{r}.npy"), p_ref)
+
+
+def _fake_log(frames, first, n):
+    """a device-log image (pc_analyzer_set_device_log layout) of fake records, plus the piece boundaries"""
+    up16 = lambda v: (v + 15) & ~15
+    chunks, bounds = [], [0]
+    for f in frames:
+        frame1, kps, flows = fake_record(f, first, n)
+        items = sorted(flows.items())
+        rows = len(kps) * len(items)
+        hdr = np.zeros(16, np.int64)
+        hdr[0], hdr[1], hdr[2], hdr[3], hdr[12] = D.LOG_MAGIC, frame1, len(kps), len(items), rows
+        off = np.zeros(16, np.int64)
+        idx, xy, err = np.zeros(rows, np.uint32), np.zeros((rows, 2), np.float32), np.zeros(rows, np.float32)
+        o = 0
+        for t, (f2, (i_, x_, e_)) in enumerate(items):
+            hdr[4 + t] = f2
+            idx[o:o + len(i_)], xy[o:o + len(i_)], err[o:o + len(i_)] = i_, x_, e_
+            o += len(i_)
+            off[t + 1] = o
+        rec = bytearray()
+        for part in (hdr.tobytes(), off.tobytes(), kps.tobytes()):
+            rec += part
+        for part in (idx.tobytes(), xy.tobytes(), err.tobytes()):
+            rec += b"\0" * (up16(len(rec)) - len(rec)) + part
+        rec += b"\0" * (up16(len(rec)) - len(rec))
+        chunks.append(bytes(rec))
+        bounds.append(bounds[-1] + len(rec))
+    return np.frombuffer(b"".join(chunks), np.uint8).copy(), bounds
+
+
+def _stitch_worker(rank, world, port, first, n, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    side = dist.new_group(backend="gloo")
+    b, e = D.shard_range(first, n, world, rank)
+    log_np, bounds = _fake_log(range(b, e), first, n)
+    log = torch.zeros(len(log_np) + 4096, dtype=torch.uint8)     # slack for the padded pieces
+    log[:len(log_np)] = torch.from_numpy(log_np)
+    st = D.ChunkedLogStitch(log, side_group=side)
+    per = 3                                                        # frames per piece (the last piece is ragged)
+    n_pieces = (max(D.shard_range(first, n, world, r)[1] - D.shard_range(first, n, world, r)[0] for r in range(world)) + per - 1) // per
+    for c in range(n_pieces):                                      # every rank issues the same number of collectives
+        lo, hi = min(c * per, e - b), min((c + 1) * per, e - b)
+        st.gather(bounds[lo], bounds[hi])
+    recs = []
+    for buf, used in st.rank_logs():
+        recs += D.parse_device_log(buf, used)
+    h, p = D.pack_records(sorted(recs, key=lambda r: r[0]))
+    np.save(os.path.join(out_dir, f"sh{rank}.npy"), h)
+    np.save(os.path.join(out_dir, f"sp{rank}.npy"), p)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chunked_log_stitch_two_ranks(tmp_path):
+    """The overlapped stitch of the bench's N > 1 path: pieces of the device logs all-gathered one by one, sizes agreed
+    on a gloo side group; every rank ends up with every record, identical to the single-rank record set."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    first, n = 4, 17                      # shards of 8 and 9 frames: ragged pieces, one rank with an empty last piece
+    mp.spawn(_stitch_worker, args=(2, port, first, n, str(tmp_path)), nprocs=2, join=True)
+    ref = []
+    for f in range(first, first + n):     # what the log carries: flows keep capacity rows only up to their offsets
+        ref.append(fake_record(f, first, n))
+    h_ref, p_ref = D.pack_records(ref)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"sh{r}.npy"), h_ref)
+        assert np.array_equal(np.load(tmp_path / f"sp{r}.npy"), p_ref)
