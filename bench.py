@@ -109,6 +109,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # the container hostname may not resolve
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -160,7 +161,12 @@ def main():
         log = torch.empty(D.log_capacity_bytes(K + 2, max_kp), dtype=torch.uint8, device=dev)
         an.an.set_device_log(log)
         # sizes of the log pieces are agreed on over gloo so that the exchange never waits for an RCCL transfer
-        side = dist.new_group(backend="gloo") if world > 1 else None
+        side = None
+        if world > 1:
+            try:
+                side = dist.new_group(backend="gloo")
+            except Exception as e:   # no usable interface for gloo: the sizes go over the main group instead
+                print(f"[bench] gloo side group unavailable ({e}); exchanging piece sizes over RCCL", file=sys.stderr)
         stitch = D.ChunkedLogStitch(log, side_group=side)
     n_kps.clear()
     n_rows.clear()

@@ -174,8 +174,13 @@ class ChunkedLogStitch:
             self.pieces.append((self.log[start:end][None], [n]))
             return
         dist = self.dist
-        sizes_t = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
-        dist.all_gather(sizes_t, torch.tensor([n], dtype=torch.int64), group=self.side)   # CPU tensors, gloo
+        if self.side is not None:   # CPU tensors over gloo: independent of whatever the NCCL stream is doing
+            sizes_t = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+            dist.all_gather(sizes_t, torch.tensor([n], dtype=torch.int64), group=self.side)
+        else:                       # no side group: same exchange on the main group (waits for the previous piece)
+            dev = self.log.device
+            sizes_t = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+            dist.all_gather(sizes_t, torch.tensor([n], dtype=torch.int64, device=dev), group=self.group)
         sizes = [int(t.item()) for t in sizes_t]
         mx = max(16, (max(sizes) + 15) // 16 * 16)
         if start + mx > self.log.numel():

@@ -109,12 +109,12 @@ def _fake_log(frames, first, n):
     return np.frombuffer(b"".join(chunks), np.uint8).copy(), bounds
 
 
-def _stitch_worker(rank, world, port, first, n, out_dir):
+def _stitch_worker(rank, world, port, first, n, out_dir, use_side):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    side = dist.new_group(backend="gloo")
+    side = dist.new_group(backend="gloo") if use_side else None
     b, e = D.shard_range(first, n, world, rank)
     log_np, bounds = _fake_log(range(b, e), first, n)
     log = torch.zeros(len(log_np) + 4096, dtype=torch.uint8)     # slack for the padded pieces
@@ -135,7 +135,8 @@ def _stitch_worker(rank, world, port, first, n, out_dir):
     dist.destroy_process_group()
 
 
-def test_chunked_log_stitch_two_ranks(tmp_path):
+@pytest.mark.parametrize("use_side", [True, False])   # sizes over the gloo side group / over the main group
+def test_chunked_log_stitch_two_ranks(tmp_path, use_side):
     """The overlapped stitch of the bench's N > 1 path: pieces of the device logs all-gathered one by one, sizes agreed
     on a gloo side group; every rank ends up with every record, identical to the single-rank record set."""
     import torch.multiprocessing as mp
@@ -143,7 +144,7 @@ def test_chunked_log_stitch_two_ranks(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     first, n = 4, 17                      # shards of 8 and 9 frames: ragged pieces, one rank with an empty last piece
-    mp.spawn(_stitch_worker, args=(2, port, first, n, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_stitch_worker, args=(2, port, first, n, str(tmp_path), use_side), nprocs=2, join=True)
     ref = []
     for f in range(first, first + n):     # what the log carries: flows keep capacity rows only up to their offsets
         ref.append(fake_record(f, first, n))
