@@ -168,6 +168,7 @@ def main():
             except Exception as e:   # no usable interface for gloo: the sizes go over the main group instead
                 print(f"[bench] gloo side group unavailable ({e}); exchanging piece sizes over RCCL", file=sys.stderr)
         stitch = D.ChunkedLogStitch(log, side_group=side)
+        stitch.warm_up()
     n_kps.clear()
     n_rows.clear()
     barrier()

@@ -166,6 +166,27 @@ class ChunkedLogStitch:
         self.world = self.dist.get_world_size(group) if self.dist else 1
         self.pieces = []   # (gathered [world, padded] uint8, sizes [world])
 
+    def warm_up(self):
+        """One tiny exchange per group before anything is timed: the first collective of a communicator sets up its
+        connections (hundreds of milliseconds for RCCL)."""
+        import torch
+
+        if self.world == 1:
+            return
+        dist = self.dist
+        if self.side is not None:
+            dist.all_gather([torch.zeros(1, dtype=torch.int64) for _ in range(self.world)], torch.zeros(1, dtype=torch.int64),
+                            group=self.side)
+        dev = self.log.device
+        tiny = torch.zeros(16, dtype=torch.uint8, device=dev)
+        out = torch.empty((self.world, 16), dtype=torch.uint8, device=dev)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(out.view(-1), tiny, group=self.group)
+        else:
+            dist.all_gather(list(out.unbind(0)), tiny, group=self.group)
+        dist.all_gather([torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)],
+                        torch.zeros(1, dtype=torch.int64, device=dev), group=self.group)
+
     def gather(self, start: int, end: int):
         import torch
 
