@@ -13,7 +13,7 @@ plain C) this script runs the same calls the reference makes and compares them w
                                                                        bit-exact (OpenCV's SIMD path may differ in the
                                                                        last fp32 bit of the accumulated mismatch vector)
 
-    python tools/opencv_crosscheck.py [--width 640 --height 360]
+    python tests/opencv_crosscheck.py [--width 640 --height 360]
 
 Exit code 0: everything within tolerance; 1: a mismatch (printed); 2: cv2 is not importable.
 """
@@ -25,7 +25,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main() -> int:

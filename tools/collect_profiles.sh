@@ -11,11 +11,13 @@ cd /tmp
 for c in c2 c3; do
   python "$ROOT/bench.py" --config $c 2>/dev/null | tail -1 > "$OUT/${TAG}_${c}_bench.json"
 done
-# per-kernel durations (rocprofv3 --kernel-trace --stats) of the default bench command
-rm -rf /tmp/kstats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats -- python "$ROOT/bench.py" --no-cpu-baseline --no-breakdown > /tmp/kstats.log 2>&1
-grep "^{" /tmp/kstats.log | tail -1 > "$OUT/${TAG}_c2_bench_under_rocprofv3.json"
-f=$(find /tmp/kstats -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && cp "$f" "$OUT/${TAG}_c2_rocprofv3_kernel_stats.csv"
+# per-kernel durations (rocprofv3 --kernel-trace --stats) of the default bench command, and of the 4K configuration
+for c in c2 c3; do
+  rm -rf /tmp/kstats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats -- python "$ROOT/bench.py" --no-cpu-baseline --no-breakdown --config $c > /tmp/kstats.log 2>&1
+  grep "^{" /tmp/kstats.log | tail -1 > "$OUT/${TAG}_${c}_bench_under_rocprofv3.json"
+  f=$(find /tmp/kstats -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" "$OUT/${TAG}_${c}_rocprofv3_kernel_stats.csv"
+done
 # HBM traffic of the LK launch: FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one)
 for c in c2 c3; do
   python "$ROOT/tools/pmc_collect.py" --kernel lk2_kernel --config $c --steps 10 --out "$OUT/${TAG}_${c}_lk_hbm_pmc.json" FETCH_SIZE WRITE_SIZE > /dev/null 2>&1
