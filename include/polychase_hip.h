@@ -74,11 +74,15 @@ void pc_context_destroy(pc_context* ctx);
 int pc_context_synchronize(pc_context* ctx);
 /* hipStream_t the context enqueues on (for callers that time with HIP events / torch streams). */
 void* pc_context_stream(pc_context* ctx);
-/* Timing of the context's kernels with HIP events on the context stream.  `class_mask` bit k
+/* Timing of the context's kernels with HIP events on the stream each launch is enqueued on.  `class_mask` bit k
  * enables kernel class PC_K_k (0 = off, 0xff = all); enabled classes accumulate (launches, total ms).
- * Two event records per timed launch: keep the mask to the class of interest inside timed regions. */
+ * Two event records per timed launch: keep the mask to the class of interest inside timed regions.
+ * pc_analyzer overlaps the LK launches of consecutive frames (two job lanes), so `total_ms` -- the sum of the
+ * launches' own start-to-end durations -- exceeds the time the class kept the GPU busy; pc_context_get_busy_time
+ * returns that: the length of the union of the launches' intervals. */
 int pc_context_enable_timing(pc_context* ctx, int class_mask);
 int pc_context_get_timing(pc_context* ctx, int kernel_class, int* launches, double* total_ms);
+int pc_context_get_busy_time(pc_context* ctx, int kernel_class, double* busy_ms);
 int pc_context_reset_timing(pc_context* ctx);
 #define PC_K_GRAY 0
 #define PC_K_PYRAMID 1

@@ -20,16 +20,37 @@ int collect_timing(pc_context* c) {
     if (c->ranges.empty()) return PC_OK;
     PC_HIP(hipStreamSynchronize(c->prep_stream));
     PC_HIP(hipStreamSynchronize(c->stream));
+    PC_HIP(hipStreamSynchronize(c->stream_b));
+    // launches of one class may overlap (the analyzer's two job lanes): besides the sum of the durations keep the
+    // length of the union of the intervals, placed on one time axis relative to the first range's start event
+    std::vector<std::pair<float, float>> spans[PC_K_COUNT];
+    hipEvent_t const origin = c->ranges.front().a;
     for (auto& r : c->ranges) {
-        float ms = 0.f;
+        float ms = 0.f, t0 = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             c->launches[r.cls] += 1;
             c->total_ms[r.cls] += ms;
+            if (hipEventElapsedTime(&t0, origin, r.a) == hipSuccess) spans[r.cls].emplace_back(t0, t0 + ms);
         }
         c->event_pool.push_back(r.a);
         c->event_pool.push_back(r.b);
     }
     c->ranges.clear();
+    for (int k = 0; k < PC_K_COUNT; k++) {
+        auto& v = spans[k];
+        std::sort(v.begin(), v.end());
+        float lo = 0.f, hi = -1.f;
+        for (auto& sp : v) {
+            if (hi < lo || sp.first > hi) {
+                if (hi >= lo) c->busy_ms[k] += hi - lo;
+                lo = sp.first;
+                hi = sp.second;
+            } else if (sp.second > hi) {
+                hi = sp.second;
+            }
+        }
+        if (hi >= lo) c->busy_ms[k] += hi - lo;
+    }
     return PC_OK;
 }
 
@@ -181,7 +202,7 @@ int join_prep(pc_context* ctx) {
     if (!ctx->prep_dirty) return PC_OK;
     PC_HIP(hipEventRecord(ctx->prep_fence, ctx->prep_stream));
     PC_HIP(hipStreamWaitEvent(ctx->stream, ctx->prep_fence, 0));
-    PC_HIP(hipEventRecord(ctx->prep_fence, ctx->copy_stream));
+    PC_HIP(hipEventRecord(ctx->prep_fence, ctx->stream_b));
     PC_HIP(hipStreamWaitEvent(ctx->stream, ctx->prep_fence, 0));
     ctx->prep_dirty = false;
     return PC_OK;
@@ -224,6 +245,7 @@ int check_lk_args(pc_context* ctx, const pc_frame* frame1, const pc_frame* const
 
 int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targets, int n_targets,
            const pc_flow_options* opt, int set) {
+    hipStream_t const lk_stream = ctx->lane_stream(set);
     const int n = frame1->n_kps;
     const size_t rows = (size_t)n * n_targets;
     PC_HIP(ctx->lk_xy[set].ensure(rows + 1));
@@ -250,7 +272,7 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
     } else {
         PC_HIP(ctx->lk_perm.ensure((size_t)n));
         PC_HIP(ctx->lk_hist.ensure((size_t)pc::bin_num_tiles(frame1->w, frame1->h) + 1));
-        pc::launch_spatial_bins(frame1->d_kps, n, frame1->w, frame1->h, ctx->lk_hist.p, ctx->lk_perm.p, ctx->stream);
+        pc::launch_spatial_bins(frame1->d_kps, n, frame1->w, frame1->h, ctx->lk_hist.p, ctx->lk_perm.p, lk_stream);
         p.perm = ctx->lk_perm.p;
     }
     // TermCriteria clamps of calcOpticalFlowPyrLK
@@ -261,8 +283,8 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
     p.out_xy = ctx->lk_xy[set].p;
     p.out_status = ctx->lk_status[set].p;
     p.out_err = ctx->lk_err[set].p;
-    ScopedTimer tm(ctx, PC_K_LK, ctx->stream);
-    if (!pc::launch_lk(p, frame1->win, ctx->stream)) return fail(PC_E_INVALID, "unsupported window size %d", frame1->win);
+    ScopedTimer tm(ctx, PC_K_LK, lk_stream);
+    if (!pc::launch_lk(p, frame1->win, lk_stream)) return fail(PC_E_INVALID, "unsupported window size %d", frame1->win);
     return PC_OK;
 }
 
@@ -307,7 +329,7 @@ int pc_context_create(int device_index, pc_context** out) {
     if (!c) return fail(PC_E_INVALID, "out of host memory");
     c->device = device_index;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->prep_fence, hipEventDisableTiming);
     c->work = c->stream;
@@ -350,16 +372,16 @@ void pc_context_destroy(pc_context* c) {
     c->lk_err[1].release();
     c->lk_cerr.release();
     c->lk_cidx.release();
-    c->lk_block_counts.release();
+    for (auto& b : c->lk_block_counts) b.release();
     c->lk_perm.release();
     c->lk_hist.release();
     c->prep_hist.release();
     c->lk_row_offset.release();
     c->h_row_offset.release();
-    c->lk_pack.release();
-    if (c->copy_stream) {
-        (void)hipStreamSynchronize(c->copy_stream);
-        (void)hipStreamDestroy(c->copy_stream);
+    for (auto& b : c->lk_pack) b.release();
+    if (c->stream_b) {
+        (void)hipStreamSynchronize(c->stream_b);
+        (void)hipStreamDestroy(c->stream_b);
     }
     if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
     if (c->prep_fence) (void)hipEventDestroy(c->prep_fence);
@@ -371,7 +393,7 @@ int pc_context_synchronize(pc_context* c) {
     if (!c) return fail(PC_E_INVALID, "null context");
     PC_HIP(hipStreamSynchronize(c->prep_stream));
     PC_HIP(hipStreamSynchronize(c->stream));
-    PC_HIP(hipStreamSynchronize(c->copy_stream));
+    PC_HIP(hipStreamSynchronize(c->stream_b));
     c->prep_dirty = false;
     return PC_OK;
 }
@@ -394,12 +416,21 @@ int pc_context_get_timing(pc_context* c, int k, int* launches, double* total_ms)
     return PC_OK;
 }
 
+int pc_context_get_busy_time(pc_context* c, int k, double* busy_ms) {
+    if (!c || !busy_ms || k < 0 || k >= PC_K_COUNT) return fail(PC_E_INVALID, "bad kernel class");
+    int rc = collect_timing(c);
+    if (rc != PC_OK) return rc;
+    *busy_ms = c->busy_ms[k];
+    return PC_OK;
+}
+
 int pc_context_reset_timing(pc_context* c) {
     if (!c) return fail(PC_E_INVALID, "null context");
     int rc = collect_timing(c);
     for (int k = 0; k < PC_K_COUNT; k++) {
         c->launches[k] = 0;
         c->total_ms[k] = 0;
+        c->busy_ms[k] = 0;
     }
     return rc;
 }
@@ -475,7 +506,7 @@ void pc_frame_destroy(pc_frame* f) {
         (void)hipSetDevice(f->ctx->device);
         (void)hipStreamSynchronize(f->ctx->prep_stream);
         (void)hipStreamSynchronize(f->ctx->stream);
-        (void)hipStreamSynchronize(f->ctx->copy_stream);
+        (void)hipStreamSynchronize(f->ctx->stream_b);
         if (f->ctx->eig_owner == f) f->ctx->eig_owner = nullptr;
     }
     if (f->slab) (void)hipFree(f->slab);
@@ -687,12 +718,12 @@ int pc_lk_track_filtered(pc_context* ctx, const pc_frame* frame1, const pc_frame
     PC_HIP(ctx->lk_cxy.ensure(rows + 1));
     PC_HIP(ctx->lk_cerr.ensure(rows + 1));
     PC_HIP(ctx->lk_cidx.ensure(rows + 1));
-    PC_HIP(ctx->lk_block_counts.ensure((size_t)nblocks * n_targets + 1));
+    PC_HIP(ctx->lk_block_counts[0].ensure((size_t)nblocks * n_targets + 1));
     PC_HIP(ctx->lk_row_offset.ensure(PC_MAX_TARGETS + 1));
     PC_HIP(ctx->h_row_offset.ensure(PC_MAX_TARGETS + 1));
     {
         ScopedTimer t(ctx, PC_K_COMPACT);
-        pc::launch_compact(ctx->lk_xy[0].p, ctx->lk_status[0].p, ctx->lk_err[0].p, n, n_targets, ctx->lk_block_counts.p,
+        pc::launch_compact(ctx->lk_xy[0].p, ctx->lk_status[0].p, ctx->lk_err[0].p, n, n_targets, ctx->lk_block_counts[0].p,
                            ctx->lk_row_offset.p, ctx->lk_cidx.p, ctx->lk_cxy.p, ctx->lk_cerr.p, ctx->stream);
     }
     PC_HIP(hipMemcpyAsync(ctx->h_row_offset.p, ctx->lk_row_offset.p, (size_t)(n_targets + 1) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));

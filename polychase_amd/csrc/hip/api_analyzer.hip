@@ -20,7 +20,7 @@ struct Slot {
     DetState det = DET_NONE;
     bool supplied = false;  // keypoints came from the caller (database), not from detection
     DetectScratch scratch;
-    hipEvent_t last_read = nullptr;  // `computed` event of the latest job whose LK reads this slot
+    hipEvent_t last_read[2] = {nullptr, nullptr};  // per job lane: `lk_done` of the latest job whose LK reads this slot
     hipEvent_t img_ready = nullptr;  // gray + pyramid of the resident frame are complete (prep stream)
     hipEvent_t kps_ready = nullptr;  // keypoints + visiting order are complete (prep stream)
 };
@@ -33,9 +33,7 @@ struct Job {
     int32_t targets[PC_MAX_TARGETS];
     PinBuf<uint8_t> h_pack;   // the job's records, same layout as pc_context::lk_pack
     size_t o_kps = 0, o_idx = 0, o_xy = 0, o_err = 0, pack_bytes = 0;
-    hipEvent_t done = nullptr;      // records of this job are in pinned memory (copy stream)
-    hipEvent_t computed = nullptr;  // compaction (+ device-log copies) finished (copy stream)
-    hipEvent_t lk_done = nullptr;   // the LK launch finished (main stream)
+    hipEvent_t done = nullptr;      // records of this job are in pinned memory (the job's lane)
 };
 
 }  // namespace
@@ -49,8 +47,12 @@ struct pc_analyzer {
     std::vector<Slot> slots;
     std::vector<Job> jobs;
     size_t job_head = 0, job_count = 0;  // ring of in-flight jobs
-    uint64_t submitted = 0;              // jobs submitted so far: job k writes LK output set k & 1
-    hipEvent_t set_free[2] = {nullptr, nullptr};  // `computed` of the last job that used each LK output set
+    uint64_t submitted = 0;              // jobs submitted so far: job k runs on lane k & 1 (stream, LK output set, pack)
+    // "the LK launch of a job finished", per lane, handed out round-robin.  Slots remember the event of the last job
+    // that read them; an event that has been re-recorded since marks a LATER launch of the same lane, which the
+    // lane's stream order puts behind the remembered one -- waiting for it is still correct.
+    static constexpr int kLaneEvents = 16;
+    hipEvent_t lk_done[2][kLaneEvents] = {};
     uint8_t* d_log = nullptr;            // optional device-resident record log
     size_t log_cap = 0, log_used = 0;
     std::vector<PinBuf<long long>> log_hdr;  // one pinned header per job slot
@@ -140,25 +142,28 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
     }
     if (rc == PC_OK)
         for (auto& j : a->jobs)
-            if (hipEventCreateWithFlags(&j.done, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&j.computed, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&j.lk_done, hipEventDisableTiming) != hipSuccess) {
+            if (hipEventCreateWithFlags(&j.done, hipEventDisableTiming) != hipSuccess) {
                 rc = fail(PC_E_HIP, "hipEventCreate failed");
                 break;
             }
+    if (rc == PC_OK)
+        for (auto& lane : a->lk_done)
+            for (hipEvent_t& e : lane)
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = fail(PC_E_HIP, "hipEventCreate failed");
     if (rc == PC_OK) {
         // Warm the runtime's copy engines: it picks a free SDMA engine per copy and creates an engine's queue the first
         // time it is used (5-8 ms inside some hipMemcpyAsync, observed twice or three times in the first few dozen
         // frames).  A burst of overlapping downloads makes it create them now.
         const size_t chunk = (size_t)4 << 20, burst = 12;
         Job& j0 = a->jobs[0];
-        if (ctx->lk_pack.ensure(chunk) != hipSuccess || j0.h_pack.ensure(chunk * burst) != hipSuccess) {
+        if (ctx->lk_pack[0].ensure(chunk) != hipSuccess || ctx->lk_pack[1].ensure(chunk) != hipSuccess ||
+            j0.h_pack.ensure(chunk * burst) != hipSuccess) {
             rc = fail(PC_E_HIP, "allocation failed");
         } else {
-            hipStream_t streams[3] = {ctx->copy_stream, ctx->prep_stream, ctx->stream};
+            hipStream_t streams[3] = {ctx->stream_b, ctx->prep_stream, ctx->stream};
             for (int round = 0; round < 3 && rc == PC_OK; round++) {
                 for (size_t k = 0; k < burst; k++)
-                    if (hipMemcpyAsync(j0.h_pack.p + k * chunk, ctx->lk_pack.p, chunk, hipMemcpyDeviceToHost, streams[k % 3]) !=
+                    if (hipMemcpyAsync(j0.h_pack.p + k * chunk, ctx->lk_pack[k & 1].p, chunk, hipMemcpyDeviceToHost, streams[k % 3]) !=
                         hipSuccess)
                         rc = fail(PC_E_HIP, "copy engine warm-up failed");
                 for (hipStream_t st : streams) (void)hipStreamSynchronize(st);
@@ -180,7 +185,7 @@ void pc_analyzer_destroy(pc_analyzer* a) {
     (void)hipSetDevice(a->ctx->device);
     (void)hipStreamSynchronize(a->ctx->prep_stream);
     (void)hipStreamSynchronize(a->ctx->stream);
-    (void)hipStreamSynchronize(a->ctx->copy_stream);
+    (void)hipStreamSynchronize(a->ctx->stream_b);
     for (auto& s : a->slots) {
         if (s.frame) pc_frame_destroy(s.frame);
         if (s.img_ready) (void)hipEventDestroy(s.img_ready);
@@ -191,9 +196,10 @@ void pc_analyzer_destroy(pc_analyzer* a) {
     for (auto& j : a->jobs) {
         j.h_pack.release();
         if (j.done) (void)hipEventDestroy(j.done);
-        if (j.computed) (void)hipEventDestroy(j.computed);
-        if (j.lk_done) (void)hipEventDestroy(j.lk_done);
     }
+    for (auto& lane : a->lk_done)
+        for (hipEvent_t e : lane)
+            if (e) (void)hipEventDestroy(e);
     delete a;
 }
 
@@ -205,8 +211,10 @@ static int analyzer_put(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, si
     PC_HIP(hipSetDevice(a->ctx->device));
     PrepScope prep(a->ctx);
     // an LK launch in flight may still read the frame this slot holds
-    if (s.last_read) PC_HIP(hipStreamWaitEvent(a->ctx->prep_stream, s.last_read, 0));
-    s.last_read = nullptr;
+    for (hipEvent_t& e : s.last_read) {
+        if (e) PC_HIP(hipStreamWaitEvent(a->ctx->prep_stream, e, 0));
+        e = nullptr;
+    }
     int rc = set_image(a->ctx, s.frame, rgb, row_pitch, on_device, channels, elem_size);
     if (rc != PC_OK) {
         s.valid = false;
@@ -285,13 +293,15 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
         detected = !s1->supplied;
     }
     Job& j = a->jobs[(a->job_head + a->job_count) % a->jobs.size()];
-    // (2) the LK launch needs this frame's keypoints and the pyramids of the frames it reads -- not the
+    // (2) the job's lane; its LK launch needs this frame's keypoints and the pyramids of the frames it reads -- not the
     // detection of frames that were made resident for later
+    const int lane = (int)(a->submitted & 1);
+    hipStream_t const ls = ctx->lane_stream(lane);
     {
         SlowSection ss("submit/waits");
-        PC_HIP(hipStreamWaitEvent(ctx->stream, s1->kps_ready, 0));
-        PC_HIP(hipStreamWaitEvent(ctx->stream, s1->img_ready, 0));
-        for (int t = 0; t < n_targets; t++) PC_HIP(hipStreamWaitEvent(ctx->stream, find_slot(a, targets[t])->img_ready, 0));
+        PC_HIP(hipStreamWaitEvent(ls, s1->kps_ready, 0));
+        PC_HIP(hipStreamWaitEvent(ls, s1->img_ready, 0));
+        for (int t = 0; t < n_targets; t++) PC_HIP(hipStreamWaitEvent(ls, find_slot(a, targets[t])->img_ready, 0));
     }
     const int n = s1->frame->n_kps;
     const size_t rows = (size_t)n * (size_t)std::max(n_targets, 0);
@@ -305,43 +315,39 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     {
         SlowSection ss("submit/ensure pack");
         PC_HIP(j.h_pack.ensure(j.pack_bytes));
-        PC_HIP(ctx->lk_pack.ensure(j.pack_bytes));
+        PC_HIP(ctx->lk_pack[lane].ensure(j.pack_bytes));
     }
     j.frame1 = frame1;
     j.n_kps = n;
     j.detected = detected;
     j.n_targets = n_targets;
     for (int t = 0; t < n_targets; t++) j.targets[t] = targets[t];
-    // (3) LK on the main stream, into output set `set`; its compaction (status filter), the device-log copies and the
-    // downloads on the copy stream, so that the next LK launch starts right behind this one
-    const int set = (int)(a->submitted & 1);
-    hipStream_t post = ctx->copy_stream;
+    // (3) everything of this job goes onto its lane, in order: LK into the lane's output set, compaction (status
+    // filter) into the lane's pack, device-log append, download.  The other lane holds the neighbouring jobs, so the
+    // next LK launch does not wait for any of it.
     ctx->prep_dirty = true;   // stage-level calls must order themselves behind the side streams
     if (n_targets > 0) {
         if (a->fopt.window_size != s1->frame->win) return fail(PC_E_INVALID, "window size mismatch");
-        // the compaction of the job two submits ago read this output set
         SlowSection ss("submit/run_lk");
-        if (a->set_free[set]) PC_HIP(hipStreamWaitEvent(ctx->stream, a->set_free[set], 0));
-        if ((rc = run_lk(ctx, s1->frame, tg, n_targets, &a->fopt, set)) != PC_OK) return rc;
+        if ((rc = run_lk(ctx, s1->frame, tg, n_targets, &a->fopt, lane)) != PC_OK) return rc;
     }
-    SlowSection ss_post("submit/post-stream enqueue");
-    PC_HIP(hipEventRecord(j.lk_done, ctx->stream));
-    s1->last_read = j.lk_done;
-    for (int t = 0; t < n_targets; t++) find_slot(a, targets[t])->last_read = j.lk_done;
-    PC_HIP(hipStreamWaitEvent(post, j.lk_done, 0));
-    uint8_t* const pack = ctx->lk_pack.p;
+    SlowSection ss_post("submit/post enqueue");
+    hipEvent_t const lk_done = a->lk_done[lane][(a->submitted >> 1) % pc_analyzer::kLaneEvents];
+    PC_HIP(hipEventRecord(lk_done, ls));
+    s1->last_read[lane] = lk_done;
+    for (int t = 0; t < n_targets; t++) find_slot(a, targets[t])->last_read[lane] = lk_done;
+    uint8_t* const pack = ctx->lk_pack[lane].p;
     long long* const p_ro = reinterpret_cast<long long*>(pack);
-    PC_HIP(hipMemsetAsync(pack, 0, 128, post));
+    PC_HIP(hipMemsetAsync(pack, 0, 128, ls));
     if (n_targets > 0) {
         const int nblocks = pc::compact_num_blocks(n);
-        PC_HIP(ctx->lk_block_counts.ensure((size_t)nblocks * n_targets + 1));
-        // the previous job's download reads the pack: it precedes this compaction on the same stream
-        ScopedTimer t(ctx, PC_K_COMPACT, post);
-        pc::launch_compact(ctx->lk_xy[set].p, ctx->lk_status[set].p, ctx->lk_err[set].p, n, n_targets, ctx->lk_block_counts.p, p_ro,
-                           reinterpret_cast<uint32_t*>(pack + j.o_idx), reinterpret_cast<float2*>(pack + j.o_xy),
-                           reinterpret_cast<float*>(pack + j.o_err), post);
+        PC_HIP(ctx->lk_block_counts[lane].ensure((size_t)nblocks * n_targets + 1));
+        ScopedTimer t(ctx, PC_K_COMPACT, ls);
+        pc::launch_compact(ctx->lk_xy[lane].p, ctx->lk_status[lane].p, ctx->lk_err[lane].p, n, n_targets,
+                           ctx->lk_block_counts[lane].p, p_ro, reinterpret_cast<uint32_t*>(pack + j.o_idx),
+                           reinterpret_cast<float2*>(pack + j.o_xy), reinterpret_cast<float*>(pack + j.o_err), ls);
     }
-    pc::launch_copy_keypoints(s1->frame->d_kps, reinterpret_cast<float2*>(pack + j.o_kps), n, post);
+    pc::launch_copy_keypoints(s1->frame->d_kps, reinterpret_cast<float2*>(pack + j.o_kps), n, ls);
     if (a->d_log) {
         // device log: header from pinned memory, the record itself is the pack (one device-to-device copy)
         const size_t o_hdr = a->log_used, end = o_hdr + 128 + j.pack_bytes;
@@ -357,18 +363,15 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
         hh[3] = n_targets;
         for (int t = 0; t < n_targets; t++) hh[4 + t] = targets[t];
         hh[12] = (long long)rows;
-        PC_HIP(hipMemcpyAsync(a->d_log + o_hdr, hh, 128, hipMemcpyHostToDevice, post));
-        PC_HIP(hipMemcpyAsync(a->d_log + o_hdr + 128, pack, j.pack_bytes, hipMemcpyDeviceToDevice, post));
+        PC_HIP(hipMemcpyAsync(a->d_log + o_hdr, hh, 128, hipMemcpyHostToDevice, ls));
+        PC_HIP(hipMemcpyAsync(a->d_log + o_hdr + 128, pack, j.pack_bytes, hipMemcpyDeviceToDevice, ls));
         a->log_used = end;
     }
-    PC_HIP(hipEventRecord(j.computed, post));
-    a->set_free[set] = j.computed;
     a->submitted++;
-    // (4) download, behind the compaction on the same stream: ONE copy with fixed endpoints (the context's pack ->
-    // the job's pinned pack).  The runtime stalls the host for 5-8 ms the first time it sees a buffer as a copy
-    // source, so per-frame buffers must not appear here.
-    PC_HIP(hipMemcpyAsync(j.h_pack.p, pack, j.pack_bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
-    PC_HIP(hipEventRecord(j.done, ctx->copy_stream));
+    // (4) download: ONE copy with fixed endpoints (the lane's pack -> the job's pinned pack).  The runtime stalls the
+    // host for 5-8 ms the first time it sees a buffer as a copy source, so per-frame buffers must not appear here.
+    PC_HIP(hipMemcpyAsync(j.h_pack.p, pack, j.pack_bytes, hipMemcpyDeviceToHost, ls));
+    PC_HIP(hipEventRecord(j.done, ls));
     a->job_count++;
     // (5) while this LK launch runs: order the keypoints of the next frame1
     SlowSection ss("submit/preorder");
@@ -382,6 +385,7 @@ int pc_analyzer_set_device_log(pc_analyzer* a, void* d_log, size_t capacity_byte
     if (d_log && (reinterpret_cast<uintptr_t>(d_log) & 15)) return fail(PC_E_INVALID, "device log must be 16-byte aligned");
     PC_HIP(hipStreamSynchronize(a->ctx->prep_stream));
     PC_HIP(hipStreamSynchronize(a->ctx->stream));
+    PC_HIP(hipStreamSynchronize(a->ctx->stream_b));
     a->d_log = static_cast<uint8_t*>(d_log);
     a->log_cap = d_log ? capacity_bytes : 0;
     a->log_used = 0;
@@ -402,6 +406,7 @@ int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out) {
     // let the runtime retire the finished commands of the other streams now, a few at a time: left alone it does
     // so in one batch of several milliseconds every couple of hundred frames, inside some later launch
     (void)hipStreamQuery(a->ctx->stream);
+    (void)hipStreamQuery(a->ctx->stream_b);
     (void)hipStreamQuery(a->ctx->prep_stream);
     out->frame1 = j.frame1;
     out->n_keypoints = j.n_kps;

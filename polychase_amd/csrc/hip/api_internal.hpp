@@ -70,7 +70,7 @@ int join_prep(pc_context* ctx);
 int order_keypoints_spatially(pc_context* ctx, pc_frame* f, DevBuf<uint32_t>& hist);
 int check_lk_args(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targets, int n_targets,
                   const pc_flow_options* opt);
-// LK launch into output set `set` on `lk_stream` (default: the context's main stream)
+// LK launch into output set `set` on job lane `set` (0: the context's main stream)
 int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targets, int n_targets, const pc_flow_options* opt,
            int set = 0);
 // gray (+ pyramid) of a frame from u8 gray / u8 RGB / float32 RGB(A) pixels, host or device, on the work stream

@@ -120,11 +120,14 @@ struct DetectScratch {
 
 struct pc_context {
     int device = 0;
+    // Stage-level calls run on `stream`.  pc_analyzer alternates its jobs (LK launch + compaction + device-log append +
+    // record download of one frame1) over two job lanes, `stream` and `stream_b`: the launches of consecutive frames
+    // overlap, so the tail of one launch and the gap before the next are filled by the other lane's wavefronts.
+    // (No further stream: HIP multiplexes streams onto 4 hardware queues -- the null stream, the two lanes and the
+    // prep stream -- and a stream that shares a queue waits behind the other's kernels.)
     hipStream_t stream = nullptr;
-    // compaction, device-log copies and result downloads of job f run beside the LK launch of job f+1.  (No
-    // further stream: HIP multiplexes streams onto 4 hardware queues, and a stream that shares a queue with the
-    // prep stream waits behind its kernels.)
-    hipStream_t copy_stream = nullptr;
+    hipStream_t stream_b = nullptr;
+    hipStream_t lane_stream(int lane) const { return lane ? stream_b : stream; }
     // pc_analyzer runs frame preparation (gray, pyramid, detection, keypoint ordering) on its own
     // stream so that it overlaps the LK launch of the previous frame1 on `stream`.  `work` is the stream
     // the image / detection helpers enqueue on: `stream` by default, `prep_stream` inside the analyzer.
@@ -146,15 +149,15 @@ struct pc_context {
     DevBuf<uint8_t> sort_temp;
     const pc_frame* eig_owner = nullptr;
     // LK scratch
-    // raw LK outputs: two sets, so that the analyzer can launch LK(f+1) while LK(f)'s are being compacted
+    // raw LK outputs, compaction scratch and packed records: one set per job lane of the analyzer (set 0: stage-level calls)
     DevBuf<float2> lk_xy[2], lk_cxy;
     DevBuf<uint8_t> lk_status[2];
     DevBuf<float> lk_err[2], lk_cerr;
-    DevBuf<uint32_t> lk_cidx, lk_block_counts, lk_perm, lk_hist, prep_hist;
+    DevBuf<uint32_t> lk_cidx, lk_block_counts[2], lk_perm, lk_hist, prep_hist;
     DevBuf<long long> lk_row_offset;
     // the analyzer's compacted records of one job, packed like a device-log record without its header:
     // row offsets (128 B) | keypoints | src indices | tgt xy | errors, every part 16-byte aligned
-    DevBuf<uint8_t> lk_pack;
+    DevBuf<uint8_t> lk_pack[2];
     PinBuf<long long> h_row_offset;
     // timing
     unsigned timing_mask = 0;   // bit k: time kernel class k with HIP events
@@ -162,6 +165,7 @@ struct pc_context {
     std::vector<hipEvent_t> event_pool;
     int launches[PC_K_COUNT] = {0};
     double total_ms[PC_K_COUNT] = {0};
+    double busy_ms[PC_K_COUNT] = {0};    // time during which at least one launch of the class was executing
 };
 
 struct pc_frame {

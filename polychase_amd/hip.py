@@ -20,7 +20,7 @@ KERNEL_CLASSES = ["gray", "pyramid", "min_eig", "nms", "sort", "suppress", "lk",
 SYMBOLS = [
     "pc_gftt_default_options", "pc_flow_default_options", "pc_last_error", "pc_version",
     "pc_context_create", "pc_context_destroy", "pc_context_synchronize", "pc_context_stream",
-    "pc_context_enable_timing", "pc_context_get_timing", "pc_context_reset_timing",
+    "pc_context_enable_timing", "pc_context_get_timing", "pc_context_get_busy_time", "pc_context_reset_timing",
     "pc_frame_create", "pc_frame_destroy", "pc_frame_set_rgb", "pc_frame_set_rgb_f32", "pc_frame_set_gray",
     "pc_host_buffer_alloc", "pc_host_buffer_free",
     "pc_frame_num_levels", "pc_frame_level_size", "pc_frame_download_gray", "pc_frame_download_level",
@@ -97,6 +97,7 @@ def load():
     L.pc_context_stream.restype = vp
     L.pc_context_enable_timing.argtypes = [vp, C.c_int]
     L.pc_context_get_timing.argtypes = [vp, C.c_int, ip, C.POINTER(C.c_double)]
+    L.pc_context_get_busy_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.pc_context_reset_timing.argtypes = [vp]
     L.pc_frame_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.pc_frame_destroy.argtypes = [vp]
@@ -198,6 +199,12 @@ class Context:
             _check(load().pc_context_get_timing(self._h, k, C.byref(n), C.byref(ms)))
             out[name] = (n.value, ms.value)
         return out
+
+    def busy_ms(self, kernel_class: str) -> float:
+        """wall time during which at least one launch of the class was executing (launches may overlap)"""
+        ms = C.c_double()
+        _check(load().pc_context_get_busy_time(self._h, KERNEL_CLASSES.index(kernel_class), C.byref(ms)))
+        return ms.value
 
 
 def _ptr(a):
