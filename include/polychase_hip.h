@@ -161,8 +161,9 @@ int pc_lk_track_filtered(pc_context* ctx, const pc_frame* frame1, const pc_frame
  * image and pyramid ONCE (the reference rebuilds them per pair, opticalflow.cc:298-302), and runs
  * frame1 jobs asynchronously: submit() enqueues, collect() hands back the records of the oldest
  * job in pinned host memory.  Internally three HIP streams: frame preparation (gray, pyramid,
- * detection, keypoint ordering), the LK launches, and compaction + record download; per-slot events
- * carry the dependencies, so preparation and downloads run beside the LK launch of another frame.
+ * detection, keypoint ordering) and two job lanes that take the frame1 jobs alternately -- a job's LK
+ * launch, its compaction, device-log append and record download stay on one lane, so the launches of
+ * consecutive frames overlap; per-slot events carry the dependencies.
  * One analyzer per context; calls are not thread-safe. */
 typedef struct pc_analyzer pc_analyzer;
 
