@@ -2,6 +2,8 @@
 // file format and therefore identical to the reference (cpp/database.cc:76-135, :353-399).
 #include "flow_database.h"
 
+#include <cctype>
+
 #include <cstdlib>
 
 #include <cstring>
@@ -140,6 +142,26 @@ void Database::Close() {
     FinalizeAll();
     sqlite3_close_v2(db_);
     db_ = nullptr;
+}
+
+std::string Database::SetJournalMode(const char* mode) {
+    sqlite3_stmt* stmt = nullptr;
+    const std::string sql = mode[0] ? std::string("PRAGMA journal_mode=") + mode : std::string("PRAGMA journal_mode");
+    SQL_OK(sqlite3_prepare_v2(db_, sql.c_str(), -1, &stmt, nullptr));
+    std::string now;
+    const int rc = sqlite3_step(stmt);
+    if (rc == SQLITE_ROW) {
+        if (const unsigned char* t = sqlite3_column_text(stmt, 0)) now = reinterpret_cast<const char*>(t);
+    }
+    sqlite3_finalize(stmt);
+    if (rc == SQLITE_BUSY || rc == SQLITE_LOCKED) {
+        // another connection holds the file: the mode stays what it is -- report that instead of failing
+        if (!mode[0]) SQL_OK(rc);
+        return SetJournalMode("");   // empty mode: query only
+    }
+    if (rc != SQLITE_ROW && rc != SQLITE_DONE) SQL_OK(rc);
+    for (char& c : now) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+    return now;
 }
 
 void Database::Begin() { Exec("BEGIN", __LINE__); }

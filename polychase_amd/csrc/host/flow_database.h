@@ -72,6 +72,11 @@ class Database {
     // Not in the reference: explicit transactions, so one frame's rows go in as one batch.
     void Begin();
     void Commit();
+    // Not in the reference: `PRAGMA journal_mode=<mode>`; returns the mode now in effect (lower case).  The analysis
+    // driver loads its rows under a rollback journal ("truncate") and puts the file back into WAL mode -- what the
+    // reference's Open() sets (cpp/database.cc:88-92) -- when it is done: with 5 MB of blobs per frame, WAL mode
+    // writes every page twice (log, then checkpoint), a rollback journal writes new pages once.
+    std::string SetJournalMode(const char* mode);
 
    private:
     enum Statement {

@@ -115,6 +115,7 @@ PYBIND11_MODULE(polychase_core, m) {
         .def(py::init<const std::string&>(), py::arg("path"))
         .def("open", &Database::Open, py::arg("path"))
         .def("close", &Database::Close)
+        .def("_set_journal_mode", &Database::SetJournalMode, py::arg("mode"))   // not in the reference (tests)
         .def("read_keypoints", [](const Database& db, int32_t id) { return VecToNumpy<2>(db.ReadKeypoints(id)); },
              py::arg("image_id"))
         .def("write_keypoints",

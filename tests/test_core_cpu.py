@@ -141,3 +141,31 @@ def test_optional_page_size_keeps_the_database_interchangeable(core, tmp_path, m
     pc_, sc, rc = page_size(c)
     assert pa == 4096 and pb == 32768 and pc_ == 4096
     assert sa == sb == sc and ra == rb == rc
+
+
+def test_bulk_load_journal_mode_round_trip(core, tmp_path):
+    """The analysis driver inserts under a rollback journal and restores WAL mode at the end: the switch keeps the
+    rows, the final header says WAL (file-format bytes 18/19 == 2) exactly like a database the reference wrote, and a
+    second connection keeps the file in WAL mode (the switch then reports "wal" and the driver stays in WAL mode)."""
+    path = str(tmp_path / "j.db")
+    kp = np.arange(20, dtype=np.float32).reshape(10, 2)
+    db = core.Database(path)
+    db.write_keypoints(1, kp)
+    assert open(path, "rb").read(20)[18:20] == b"\x02\x02"          # Open() set WAL, like cpp/database.cc:88-92
+    assert db._set_journal_mode("TRUNCATE") == "truncate"
+    db.write_keypoints(2, kp)
+    db.write_image_pair_flow(2, 1, np.arange(5, dtype=np.uint32), kp[:5], np.ones(5, np.float32))
+    assert open(path, "rb").read(20)[18:20] == b"\x01\x01"
+    assert db._set_journal_mode("WAL") == "wal"
+    db.close()
+    assert open(path, "rb").read(20)[18:20] == b"\x02\x02"
+    con = sqlite3.connect(path)
+    assert con.execute("select count(*) from keypoints").fetchone()[0] == 2
+    assert con.execute("select count(*) from optical_flow").fetchone()[0] == 1
+    assert con.execute("PRAGMA journal_mode").fetchone()[0] == "wal"
+    db2 = core.Database(path)                                        # with a second connection open the mode cannot change
+    con.execute("select * from keypoints").fetchall()
+    assert db2._set_journal_mode("TRUNCATE") == "wal"              # refused: stays WAL, no error
+    assert db2._set_journal_mode("WAL") == "wal"
+    db2.close()
+    con.close()

@@ -61,6 +61,11 @@ def _dump(path):
     return k, f
 
 
+def _journal_header(path):
+    """file-format write/read version of the SQLite header: 2, 2 = WAL (what the reference's Open() leaves)"""
+    return open(path, "rb").read(20)[18:20]
+
+
 def _expect(frames, first, **kw):
     kps, flows = oracle.analyze_clip(frames, first_frame=first, threads=4, **kw)
     k = {f: (len(v), v.tobytes()) for f, v in kps.items()}
@@ -91,6 +96,8 @@ def test_cancel_then_resume_gives_identical_database(core, tmp_path):
     assert not e
     _, progress, e = _run_thread(core, frames, 1, part, stop_after=9)
     assert not e and progress[-1] == (1.0, "Cancelled")
+    # the driver loads under a rollback journal and hands the file back in WAL mode -- also when cancelled
+    assert _journal_header(full) == b"\x02\x02" and _journal_header(part) == b"\x02\x02"
     k_part, f_part = _dump(part)
     assert 0 < len(f_part) < 8 * 24 - 30
     requested, progress, e = _run_thread(core, frames, 1, part)        # resume (opticalflow.cc:168-178, :286)
@@ -99,6 +106,22 @@ def test_cancel_then_resume_gives_identical_database(core, tmp_path):
     # a third run finds everything present: nothing is recomputed or rewritten
     _, _, e = _run_thread(core, frames, 1, part)
     assert not e and _dump(part) == _dump(full)
+    assert _journal_header(part) == b"\x02\x02"
+
+
+def test_bulk_load_can_be_switched_off_and_gives_the_same_rows(core, tmp_path, monkeypatch):
+    clip = synth.NoiseClip(256, 192, 12)
+    frames = [clip.frame(t) for t in range(12)]
+    a, b = str(tmp_path / "bulk.db"), str(tmp_path / "wal.db")
+    _, _, e = _run_thread(core, frames, 1, a)
+    assert not e
+    monkeypatch.setenv("POLYCHASE_DB_BULK_LOAD", "0")
+    _, _, e = _run_thread(core, frames, 1, b)
+    assert not e
+    assert _dump(a) == _dump(b)
+    assert _journal_header(a) == _journal_header(b) == b"\x02\x02"
+    assert open(a, "rb").read(100)[16:18] == open(b, "rb").read(100)[16:18]      # page size
+    assert open(a, "rb").read(100)[52:56] == open(b, "rb").read(100)[52:56]      # auto-vacuum setting
 
 
 def test_sync_binding_with_options_and_errors(core, tmp_path):
