@@ -247,6 +247,32 @@ int pc_raycast_pixels(pc_context* ctx, const pc_mesh* mesh, const pc_ray_camera*
 int pc_raycast_pixels_sweep(pc_context* ctx, const pc_mesh* mesh, const pc_ray_camera* cam, const float* xy, int n,
                             int check_mask, uint8_t* hit, float* pos, uint32_t* prim, float* uvt);
 
+/* ---- 3D-2D correspondences of the frame being solved, built and kept on the GPU (cpp/tracker.cc:52-97) ----
+ * SolveFrame gathers, per source frame that already has a pose, the matches of the flow source -> frame: the
+ * source keypoint is cast onto the mesh under the source camera (tracker.cc:64-78), a hit is moved to world space
+ * with the model matrix (:80-82) and paired with the tracked position (:86).  pc_corr_set_append does that for one
+ * source in one pass on the device -- gather, ray cast, transform, order-preserving compaction -- and appends to
+ * the set; nothing but a counter comes back to the host.  The PnP problem then reads the set in place. */
+typedef struct pc_corr_set pc_corr_set;
+int pc_corr_set_create(pc_context* ctx, pc_corr_set** out);
+void pc_corr_set_destroy(pc_corr_set* set);
+int pc_corr_set_clear(pc_context* ctx, pc_corr_set* set);
+/* keypoints_xy: n_keypoints x 2 of the source frame; src_idx / tgt_xy: the n_matches rows of the flow
+ * (src_keypoints_indices, tgt_keypoints).  Host pointers (pinned memory from pc_host_buffer_alloc is copied
+ * asynchronously: it must stay untouched until pc_corr_set_size or a PnP call has returned).  keypoints_key >= 0
+ * names the keypoint array (e.g. the source frame id): the set keeps the device copies of the last 16 keys and
+ * skips the upload when it sees one again (a frame is a source for up to 8 targets); -1 = always upload.
+ * model_matrix: row-major 4x4, rows 0-2 used.  An index >= n_keypoints is an error (tracker.cc:61). */
+int pc_corr_set_append(pc_context* ctx, pc_corr_set* set, const pc_mesh* mesh, const pc_ray_camera* cam,
+                       const float* model_matrix, long long keypoints_key, const float* keypoints_xy, int n_keypoints,
+                       const uint32_t* src_idx, const float* tgt_xy, int n_matches, int check_mask);
+/* number of correspondences so far (waits for the appends). */
+int pc_corr_set_size(pc_context* ctx, pc_corr_set* set, int* n);
+/* debugging / tests: world points n x 3 and image points n x 2, in append order. */
+int pc_corr_set_download(pc_context* ctx, pc_corr_set* set, float* world_xyz, float* image_xy);
+/* A PnP problem over the set's arrays, no copy: the set must stay unchanged while the problem is alive. */
+int pc_pnp_problem_from_set(pc_context* ctx, pc_corr_set* set, pc_pnp_problem** out);
+
 /* PnPProblem (cpp/pnp/pnp_problem.h:11-142): object points X n x 3, image points x n x 2,
  * optional per-residual weights (NULL = 1). Host pointers; copied to the GPU once per frame. */
 int pc_pnp_problem_create(pc_context* ctx, const float* X, const float* x, const float* weights, int n,
@@ -267,6 +293,11 @@ typedef struct pc_pnp_params {
  * clamp: JtJ lower triangle packed row-major (45), Jtr (9), number of valid residuals. */
 int pc_pnp_normal_equations(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,
                             float* jtj_lower45, float* jtr9, int* valid);
+/* The same sweep also returns TotalCost of `params` (bit for bit what pc_pnp_total_cost returns): the LM loop
+ * (lev_marq.h:132-228) gets a candidate's cost and -- should the step be accepted -- the next iteration's normal
+ * equations from one launch and one read-back instead of two. */
+int pc_pnp_normal_equations_cost(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,
+                                 float* jtj_lower45, float* jtr9, int* valid, float* cost);
 /* LevMarqDenseSolver::TotalCost (lev_marq.h:316-356) and the inlier count of SolvePnPIterative
  * (cpp/pnp/solvers.cc:31-47) in one pass. */
 int pc_pnp_total_cost(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,

@@ -36,7 +36,40 @@ struct pc_pnp_problem {
     pc_context* ctx = nullptr;
     int n = 0;
     bool has_weights = false;
-    DevBuf<float> X, x, w, partials, out;
+    // what the sweeps read and write: the problem's own buffers, or those of the pc_corr_set it was made from
+    const float *X = nullptr, *x = nullptr, *w = nullptr;
+    float *partials = nullptr, *out = nullptr, *h_out = nullptr;
+    DevBuf<float> own_X, own_x, own_w, own_partials, own_out;
+    PinBuf<float> own_h_out;
+};
+
+// 3D-2D correspondences of the frame being solved (include/polychase_hip.h)
+struct pc_corr_set {
+    pc_context* ctx = nullptr;
+    DevBuf<float> X;             // world points, capacity x 3
+    DevBuf<float2> x;            // image points
+    size_t capacity = 0;
+    int upper = 0;               // matches appended so far (>= the number of hits): the capacity the arrays need
+    DevBuf<int> counter;         // [0] correspondences, [1] bad-index flag
+    PinBuf<int> h_counter;
+    // per-append scratch
+    DevBuf<uint8_t> flag;
+    DevBuf<float> world;
+    DevBuf<int> block_counts, block_offsets;
+    DevBuf<uint32_t> d_idx;
+    DevBuf<float2> d_tgt;
+    // device copies of recently used keypoint arrays
+    struct Cached {
+        long long key = -1;
+        int n = 0;
+        uint64_t stamp = 0;
+        DevBuf<float2> xy;
+    };
+    Cached cache[16];
+    DevBuf<float2> uncached_kps;
+    uint64_t clock = 0;
+    // PnP scratch shared by the problems made from this set
+    DevBuf<float> partials, out;
     PinBuf<float> h_out;
 };
 
@@ -197,6 +230,183 @@ int pc_raycast_pixels_sweep(pc_context* ctx, const pc_mesh* mesh, const pc_ray_c
     return raycast_pixels(ctx, mesh, cam, xy, n, check_mask, hit, pos, prim, uvt, true);
 }
 
+// ---- correspondence set ----------------------------------------------------------------------
+int pc_corr_set_create(pc_context* ctx, pc_corr_set** out) {
+    if (!ctx || !out) return fail(PC_E_INVALID, "null argument");
+    *out = nullptr;
+    PC_HIP(hipSetDevice(ctx->device));
+    pc_corr_set* s = new (std::nothrow) pc_corr_set();
+    if (!s) return fail(PC_E_INVALID, "out of host memory");
+    s->ctx = ctx;
+    hipError_t e = s->counter.ensure(2);
+    if (e == hipSuccess) e = s->h_counter.ensure(2);
+    if (e == hipSuccess) e = s->out.ensure(64);
+    if (e == hipSuccess) e = s->h_out.ensure(64);
+    if (e == hipSuccess) e = hipMemsetAsync(s->counter.p, 0, 2 * sizeof(int), ctx->stream);
+    if (e != hipSuccess) {
+        pc_corr_set_destroy(s);
+        return fail(PC_E_HIP, "correspondence set: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return PC_OK;
+}
+
+void pc_corr_set_destroy(pc_corr_set* s) {
+    if (!s) return;
+    if (s->ctx) {
+        (void)hipSetDevice(s->ctx->device);
+        (void)hipStreamSynchronize(s->ctx->stream);
+    }
+    s->X.release();
+    s->x.release();
+    s->counter.release();
+    s->h_counter.release();
+    s->flag.release();
+    s->world.release();
+    s->block_counts.release();
+    s->block_offsets.release();
+    s->d_idx.release();
+    s->d_tgt.release();
+    for (auto& c : s->cache) c.xy.release();
+    s->uncached_kps.release();
+    s->partials.release();
+    s->out.release();
+    s->h_out.release();
+    delete s;
+}
+
+int pc_corr_set_clear(pc_context* ctx, pc_corr_set* s) {
+    if (!ctx || !s) return fail(PC_E_INVALID, "null argument");
+    PC_HIP(hipSetDevice(ctx->device));
+    PC_HIP(hipMemsetAsync(s->counter.p, 0, 2 * sizeof(int), ctx->stream));
+    s->upper = 0;
+    return PC_OK;
+}
+
+// grow X / x to `need` correspondences, keeping what they hold
+static int corr_reserve(pc_context* ctx, pc_corr_set* s, size_t need) {
+    if (need <= s->capacity) return PC_OK;
+    const size_t want = need + need / 2 + 4096;
+    DevBuf<float> nX;
+    DevBuf<float2> nx;
+    PC_HIP(nX.ensure(want * 3));
+    hipError_t e = nx.ensure(want);
+    if (e != hipSuccess) {
+        nX.release();
+        return fail(PC_E_HIP, "correspondence set: %s", hipGetErrorString(e));
+    }
+    if (s->capacity) {   // at most `capacity` entries are live; stream order puts the copies behind the appends
+        (void)hipMemcpyAsync(nX.p, s->X.p, s->capacity * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
+        (void)hipMemcpyAsync(nx.p, s->x.p, s->capacity * sizeof(float2), hipMemcpyDeviceToDevice, ctx->stream);
+        PC_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    s->X.release();
+    s->x.release();
+    s->X = nX;
+    s->x = nx;
+    s->capacity = want;
+    return PC_OK;
+}
+
+int pc_corr_set_append(pc_context* ctx, pc_corr_set* s, const pc_mesh* mesh, const pc_ray_camera* cam, const float* model_matrix,
+                       long long keypoints_key, const float* keypoints_xy, int n_keypoints, const uint32_t* src_idx,
+                       const float* tgt_xy, int n_matches, int check_mask) {
+    if (!ctx || !s || !mesh || !cam || !model_matrix || n_matches < 0 || n_keypoints < 0) return fail(PC_E_INVALID, "bad argument");
+    if (n_matches == 0) return PC_OK;
+    if (!keypoints_xy || !src_idx || !tgt_xy) return fail(PC_E_INVALID, "null buffer");
+    PC_HIP(hipSetDevice(ctx->device));
+    int rc = corr_reserve(ctx, s, (size_t)s->upper + (size_t)n_matches);
+    if (rc != PC_OK) return rc;
+    const int nb = pc::corr_num_blocks(n_matches);
+    PC_HIP(s->flag.ensure((size_t)n_matches));
+    PC_HIP(s->world.ensure((size_t)n_matches * 3));
+    PC_HIP(s->block_counts.ensure((size_t)nb));
+    PC_HIP(s->block_offsets.ensure((size_t)nb));
+    PC_HIP(s->d_idx.ensure((size_t)n_matches));
+    PC_HIP(s->d_tgt.ensure((size_t)n_matches));
+    // keypoints: cached by key (a frame is a source for up to 8 targets)
+    const float2* d_kps = nullptr;
+    if (keypoints_key >= 0) {
+        pc_corr_set::Cached* slot = nullptr;
+        for (auto& c : s->cache)
+            if (c.key == keypoints_key && c.n == n_keypoints) slot = &c;
+        if (!slot) {
+            slot = &s->cache[0];
+            for (auto& c : s->cache)
+                if (c.stamp < slot->stamp) slot = &c;
+            PC_HIP(slot->xy.ensure((size_t)std::max(n_keypoints, 1)));
+            PC_HIP(hipMemcpyAsync(slot->xy.p, keypoints_xy, (size_t)n_keypoints * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+            slot->key = keypoints_key;
+            slot->n = n_keypoints;
+        }
+        slot->stamp = ++s->clock;
+        d_kps = slot->xy.p;
+    } else {
+        PC_HIP(s->uncached_kps.ensure((size_t)std::max(n_keypoints, 1)));
+        PC_HIP(hipMemcpyAsync(s->uncached_kps.p, keypoints_xy, (size_t)n_keypoints * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+        d_kps = s->uncached_kps.p;
+    }
+    PC_HIP(hipMemcpyAsync(s->d_idx.p, src_idx, (size_t)n_matches * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    PC_HIP(hipMemcpyAsync(s->d_tgt.p, tgt_xy, (size_t)n_matches * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    pc::RayCamera rcam;
+    std::memcpy(rcam.m, cam->dir_matrix, sizeof(rcam.m));
+    std::memcpy(rcam.origin, cam->origin, sizeof(rcam.origin));
+    rcam.fx = cam->fx;
+    rcam.fy = cam->fy;
+    rcam.cx = cam->cx;
+    rcam.cy = cam->cy;
+    rcam.sign = cam->unproject_sign;
+    pc::CorrModel mm;
+    std::memcpy(mm.m, model_matrix, sizeof(mm.m));
+    pc::launch_corr_append(mesh->bvh(), mesh->mask.p, check_mask, rcam, mm, d_kps, n_keypoints, s->d_idx.p, s->d_tgt.p, n_matches,
+                           s->flag.p, s->world.p, s->block_counts.p, s->block_offsets.p, s->counter.p, s->counter.p + 1, s->X.p,
+                           s->x.p, ctx->stream);
+    s->upper += n_matches;
+    return PC_OK;
+}
+
+int pc_corr_set_size(pc_context* ctx, pc_corr_set* s, int* n) {
+    if (!ctx || !s || !n) return fail(PC_E_INVALID, "null argument");
+    PC_HIP(hipSetDevice(ctx->device));
+    PC_HIP(hipMemcpyAsync(s->h_counter.p, s->counter.p, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    if (s->h_counter.p[1]) return fail(PC_E_INVALID, "a source keypoint index is out of range");
+    *n = s->h_counter.p[0];
+    return PC_OK;
+}
+
+int pc_corr_set_download(pc_context* ctx, pc_corr_set* s, float* world_xyz, float* image_xy) {
+    int n = 0;
+    int rc = pc_corr_set_size(ctx, s, &n);
+    if (rc != PC_OK) return rc;
+    if (n == 0) return PC_OK;
+    if (world_xyz) PC_HIP(hipMemcpyAsync(world_xyz, s->X.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (image_xy) PC_HIP(hipMemcpyAsync(image_xy, s->x.p, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    return PC_OK;
+}
+
+int pc_pnp_problem_from_set(pc_context* ctx, pc_corr_set* s, pc_pnp_problem** out) {
+    if (!ctx || !s || !out) return fail(PC_E_INVALID, "null argument");
+    *out = nullptr;
+    int n = 0;
+    int rc = pc_corr_set_size(ctx, s, &n);
+    if (rc != PC_OK) return rc;
+    if (n < 1) return fail(PC_E_INVALID, "the correspondence set is empty");
+    PC_HIP(s->partials.ensure((size_t)pc::pnp_num_blocks(n) * 56));
+    pc_pnp_problem* p = new (std::nothrow) pc_pnp_problem();
+    if (!p) return fail(PC_E_INVALID, "out of host memory");
+    p->ctx = ctx;
+    p->n = n;
+    p->X = s->X.p;
+    p->x = reinterpret_cast<const float*>(s->x.p);
+    p->partials = s->partials.p;
+    p->out = s->out.p;
+    p->h_out = s->h_out.p;
+    *out = p;
+    return PC_OK;
+}
+
 int pc_pnp_problem_create(pc_context* ctx, const float* X, const float* x, const float* weights, int n,
                           pc_pnp_problem** out) {
     if (!ctx || !out || n < 1 || !X || !x) return fail(PC_E_INVALID, "bad argument");
@@ -208,16 +418,23 @@ int pc_pnp_problem_create(pc_context* ctx, const float* X, const float* x, const
     p->n = n;
     p->has_weights = weights != nullptr;
     const int nb = pc::pnp_num_blocks(n);
-    hipError_t e = p->X.ensure((size_t)n * 3);
-    if (e == hipSuccess) e = p->x.ensure((size_t)n * 2);
-    if (e == hipSuccess && weights) e = p->w.ensure((size_t)n);
-    if (e == hipSuccess) e = p->partials.ensure((size_t)nb * 56);
-    if (e == hipSuccess) e = p->out.ensure(64);
-    if (e == hipSuccess) e = p->h_out.ensure(64);
-    if (e == hipSuccess) e = hipMemcpyAsync(p->X.p, X, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(p->x.p, x, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && weights) e = hipMemcpyAsync(p->w.p, weights, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = p->own_X.ensure((size_t)n * 3);
+    if (e == hipSuccess) e = p->own_x.ensure((size_t)n * 2);
+    if (e == hipSuccess && weights) e = p->own_w.ensure((size_t)n);
+    if (e == hipSuccess) e = p->own_partials.ensure((size_t)nb * 56);
+    if (e == hipSuccess) e = p->own_out.ensure(64);
+    if (e == hipSuccess) e = p->own_h_out.ensure(64);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->own_X.p, X, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->own_x.p, x, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && weights)
+        e = hipMemcpyAsync(p->own_w.p, weights, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    p->X = p->own_X.p;
+    p->x = p->own_x.p;
+    p->w = p->own_w.p;
+    p->partials = p->own_partials.p;
+    p->out = p->own_out.p;
+    p->h_out = p->own_h_out.p;
     if (e != hipSuccess) {
         pc_pnp_problem_destroy(p);
         return fail(PC_E_HIP, "PnP upload failed: %s", hipGetErrorString(e));
@@ -232,12 +449,12 @@ void pc_pnp_problem_destroy(pc_pnp_problem* p) {
         (void)hipSetDevice(p->ctx->device);
         (void)hipStreamSynchronize(p->ctx->stream);
     }
-    p->X.release();
-    p->x.release();
-    p->w.release();
-    p->partials.release();
-    p->out.release();
-    p->h_out.release();
+    p->own_X.release();
+    p->own_x.release();
+    p->own_w.release();
+    p->own_partials.release();
+    p->own_out.release();
+    p->own_h_out.release();
     delete p;
 }
 
@@ -260,16 +477,22 @@ static pc::PnPParams to_kernel_params(const pc_pnp_params* q) {
 
 int pc_pnp_normal_equations(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,
                             float* jtj_lower45, float* jtr9, int* valid) {
+    return pc_pnp_normal_equations_cost(ctx, prob, params, jtj_lower45, jtr9, valid, nullptr);
+}
+
+int pc_pnp_normal_equations_cost(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,
+                                 float* jtj_lower45, float* jtr9, int* valid, float* cost) {
     if (!ctx || !prob || !params || !jtj_lower45 || !jtr9) return fail(PC_E_INVALID, "null argument");
     if (params->loss_type < 0 || params->loss_type > 2) return fail(PC_E_INVALID, "Unknown loss type: %d", params->loss_type);
     PC_HIP(hipSetDevice(ctx->device));
-    pc::launch_pnp_normal_eq(prob->X.p, prob->x.p, prob->has_weights ? prob->w.p : nullptr, prob->n,
-                             to_kernel_params(params), prob->partials.p, prob->out.p, ctx->stream);
-    PC_HIP(hipMemcpyAsync(prob->h_out.p, prob->out.p, 56 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    pc::launch_pnp_normal_eq(prob->X, prob->x, prob->has_weights ? prob->w : nullptr, prob->n,
+                             to_kernel_params(params), prob->partials, prob->out, ctx->stream);
+    PC_HIP(hipMemcpyAsync(prob->h_out, prob->out, 56 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PC_HIP(hipStreamSynchronize(ctx->stream));
-    std::memcpy(jtj_lower45, prob->h_out.p, 45 * sizeof(float));
-    std::memcpy(jtr9, prob->h_out.p + 45, 9 * sizeof(float));
-    if (valid) *valid = (int)prob->h_out.p[54];
+    std::memcpy(jtj_lower45, prob->h_out, 45 * sizeof(float));
+    std::memcpy(jtr9, prob->h_out + 45, 9 * sizeof(float));
+    if (valid) *valid = (int)prob->h_out[54];
+    if (cost) *cost = prob->h_out[55];
     return PC_OK;
 }
 
@@ -278,13 +501,13 @@ int pc_pnp_total_cost(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_
     if (!ctx || !prob || !params || !cost) return fail(PC_E_INVALID, "null argument");
     if (params->loss_type < 0 || params->loss_type > 2) return fail(PC_E_INVALID, "Unknown loss type: %d", params->loss_type);
     PC_HIP(hipSetDevice(ctx->device));
-    pc::launch_pnp_cost(prob->X.p, prob->x.p, prob->has_weights ? prob->w.p : nullptr, prob->n, to_kernel_params(params),
-                        max_inlier_error_sq, prob->partials.p, prob->out.p, ctx->stream);
-    PC_HIP(hipMemcpyAsync(prob->h_out.p, prob->out.p, 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    pc::launch_pnp_cost(prob->X, prob->x, prob->has_weights ? prob->w : nullptr, prob->n, to_kernel_params(params),
+                        max_inlier_error_sq, prob->partials, prob->out, ctx->stream);
+    PC_HIP(hipMemcpyAsync(prob->h_out, prob->out, 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PC_HIP(hipStreamSynchronize(ctx->stream));
-    *cost = prob->h_out.p[0];
-    if (valid) *valid = (int)prob->h_out.p[1];
-    if (inliers) *inliers = (int)prob->h_out.p[2];
+    *cost = prob->h_out[0];
+    if (valid) *valid = (int)prob->h_out[1];
+    if (inliers) *inliers = (int)prob->h_out[2];
     return PC_OK;
 }
 

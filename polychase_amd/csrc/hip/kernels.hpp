@@ -108,8 +108,17 @@ void launch_raycast(const BvhView& bvh, const uint32_t* mask, int check_mask, co
 void launch_raycast_sweep(const float* verts, const uint32_t* tris, int n_tris, const uint32_t* mask, int check_mask,
                           const RayCamera& cam, const float2* xy, int n, uint8_t* hit, float* pos, uint32_t* prim,
                           float* uvt, hipStream_t s);
+// correspondences of one source frame (tracker.cc:52-92): gather + cast + model transform + order-preserving append
+struct CorrModel {
+    float m[12];       // rows 0-2 of the model matrix, row-major
+};
+int corr_num_blocks(int n);
+void launch_corr_append(const BvhView& bvh, const uint32_t* mask, int check_mask, const RayCamera& cam, const CorrModel& model,
+                        const float2* kps, int n_kps, const uint32_t* src_idx, const float2* tgt, int n, uint8_t* flag,
+                        float* world, int* block_counts, int* block_offsets, int* counter, int* bad_index, float* X, float2* x,
+                        hipStream_t s);
 int pnp_num_blocks(int n);
-// out56: [0..44] JtJ lower triangle (row-major packed), [45..53] Jtr, [54] valid residual count
+// out56: [0..44] JtJ lower triangle (row-major packed), [45..53] Jtr, [54] valid residual count, [55] cost
 void launch_pnp_normal_eq(const float* X, const float* x, const float* w, int n, const PnPParams& p, float* partials,
                           float* out56, hipStream_t s);
 // out4: [0] cost, [1] valid residuals, [2] inliers (r^2 < max_err_sq)

@@ -156,6 +156,125 @@ void launch_raycast(const BvhView& bvh, const uint32_t* mask, int check_mask, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// K12b correspondences of one source frame (cpp/tracker.cc:52-92), built on the device:
+//   pass 1  per match: pixel = keypoints[src_idx], closest hit under the source camera (the code of
+//           raycast_bvh_kernel), world = model * hit; flag + world point stay in scratch, the block's hit
+//           count goes to block_counts
+//   pass 2  one block: exclusive scan of the block counts on top of the set's running size
+//   pass 3  per block: order-preserving scatter of the hits behind the block's offset
+// Match order is kept, so the arrays equal what the host loop of the reference would have appended.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RC_BLOCK) void corr_cast_kernel(BvhView B, const uint32_t* __restrict__ mask, int check_mask,
+                                                             RayCamera cam, CorrModel model, const float2* __restrict__ kps,
+                                                             int n_kps, const uint32_t* __restrict__ src_idx, int n,
+                                                             uint8_t* __restrict__ flag, float* __restrict__ world,
+                                                             int* __restrict__ block_counts, int* __restrict__ bad_index) {
+    __shared__ int s_stack[kBvhStack][RC_BLOCK];
+    __shared__ int s_count[RC_BLOCK / 64];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = false;
+    if (i < n) {
+        const uint32_t k = src_idx[i];
+        if (k >= (uint32_t)n_kps) {
+            atomicExch(bad_index, 1);   // CHECK_LT(idx, keypoints.size()), tracker.cc:61
+        } else {
+            const float2 p = kps[k];
+            const float ux = cam.sign * ((p.x - cam.cx) / cam.fx), uy = cam.sign * ((p.y - cam.cy) / cam.fy), uz = cam.sign;
+            const float dx = cam.m[0] * ux + cam.m[1] * uy + cam.m[2] * uz;
+            const float dy = cam.m[3] * ux + cam.m[4] * uy + cam.m[5] * uz;
+            const float dz = cam.m[6] * ux + cam.m[7] * uy + cam.m[8] * uz;
+            float best_t, best_u, best_v;
+            const int best = bvh_closest_hit(B, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz,
+                                             &s_stack[0][threadIdx.x], RC_BLOCK, &best_t, &best_u, &best_v);
+            ok = best >= 0;
+            if (ok && check_mask && ((mask[best >> 5] >> (best & 31)) & 1u)) ok = false;
+            if (ok) {
+                const uint32_t a = B.tris[3 * best], b = B.tris[3 * best + 1], c = B.tris[3 * best + 2];
+                const float w0 = 1.0f - best_u - best_v;
+                float pos[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++)  // Triangle::Barycentric (geometry.h:17-19)
+                    pos[q] = w0 * B.verts[3 * a + q] + best_u * B.verts[3 * b + q] + best_v * B.verts[3 * c + q];
+#pragma unroll
+                for (int r = 0; r < 3; r++)   // model_matrix * hit (tracker.cc:80-82), left to right like the host code
+                    world[3 * (size_t)i + r] = model.m[4 * r] * pos[0] + model.m[4 * r + 1] * pos[1] + model.m[4 * r + 2] * pos[2] +
+                                               model.m[4 * r + 3];
+            }
+        }
+        flag[i] = ok ? 1 : 0;
+    }
+    const unsigned long long b = __ballot(ok);
+    if ((threadIdx.x & 63) == 0) s_count[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int w = 0; w < RC_BLOCK / 64; w++) c += s_count[w];
+        block_counts[blockIdx.x] = c;
+    }
+}
+
+// counter[0] = correspondences in the set; block_offsets[b] = where block b's hits go
+__global__ __launch_bounds__(256) void corr_scan_kernel(const int* __restrict__ block_counts, int nblocks, int* __restrict__ counter,
+                                                        int* __restrict__ block_offsets) {
+    __shared__ int s_sum[256];
+    const int per = (nblocks + 255) / 256;
+    const int lo = threadIdx.x * per, hi = min(lo + per, nblocks);
+    int local = 0;
+    for (int b = lo; b < hi; b++) local += block_counts[b];
+    s_sum[threadIdx.x] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = counter[0];
+        for (int t = 0; t < 256; t++) {
+            const int v = s_sum[t];
+            s_sum[t] = run;
+            run += v;
+        }
+        counter[0] = run;
+    }
+    __syncthreads();
+    int run = s_sum[threadIdx.x];
+    for (int b = lo; b < hi; b++) {
+        block_offsets[b] = run;
+        run += block_counts[b];
+    }
+}
+
+__global__ __launch_bounds__(RC_BLOCK) void corr_scatter_kernel(const uint8_t* __restrict__ flag, const float* __restrict__ world,
+                                                                const float2* __restrict__ tgt, int n,
+                                                                const int* __restrict__ block_offsets, float* __restrict__ X,
+                                                                float2* __restrict__ x) {
+    __shared__ int s_count[RC_BLOCK / 64];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = i < n && flag[i];
+    const unsigned long long b = __ballot(ok);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_count[wave] = __popcll(b);
+    __syncthreads();
+    if (!ok) return;
+    int off = block_offsets[blockIdx.x] + __popcll(b & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; w++) off += s_count[w];
+    X[3 * (size_t)off] = world[3 * (size_t)i];
+    X[3 * (size_t)off + 1] = world[3 * (size_t)i + 1];
+    X[3 * (size_t)off + 2] = world[3 * (size_t)i + 2];
+    x[off] = tgt[i];
+}
+
+int corr_num_blocks(int n) { return (n + RC_BLOCK - 1) / RC_BLOCK; }
+
+void launch_corr_append(const BvhView& bvh, const uint32_t* mask, int check_mask, const RayCamera& cam, const CorrModel& model,
+                        const float2* kps, int n_kps, const uint32_t* src_idx, const float2* tgt, int n, uint8_t* flag,
+                        float* world, int* block_counts, int* block_offsets, int* counter, int* bad_index, float* X, float2* x,
+                        hipStream_t s) {
+    if (n <= 0) return;
+    const int nb = corr_num_blocks(n);
+    hipLaunchKernelGGL(corr_cast_kernel, dim3(nb), dim3(RC_BLOCK), 0, s, bvh, mask, check_mask, cam, model, kps, n_kps, src_idx, n,
+                       flag, world, block_counts, bad_index);
+    hipLaunchKernelGGL(corr_scan_kernel, dim3(1), dim3(256), 0, s, block_counts, nb, counter, block_offsets);
+    hipLaunchKernelGGL(corr_scatter_kernel, dim3(nb), dim3(RC_BLOCK), 0, s, flag, world, tgt, n, block_offsets, X, x);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K11 PnP
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float loss_weight(int type, float scale, float r2) {
@@ -179,7 +298,7 @@ __device__ __forceinline__ float loss_value(int type, float scale, float r2) {
     return sq * log1pf(r2 * (1.0f / sq));
 }
 
-constexpr int PNP_ACC = 56;  // 45 (JtJ lower) + 9 (Jtr) + 1 (valid count) + 1 pad
+constexpr int PNP_ACC = 56;  // 45 (JtJ lower) + 9 (Jtr) + 1 (valid count) + 1 (cost, summed exactly like pnp_cost_kernel)
 
 // block-wide sum of NV values per thread (256 threads); result valid in thread 0
 template <int NV>
@@ -250,6 +369,10 @@ __global__ __launch_bounds__(256) void pnp_normal_eq_kernel(const float* __restr
 #pragma unroll
         for (int a = 0; a < 9; a++) acc[45 + a] += J0[a] * (tw * rx) + J1[a] * (tw * ry);
         acc[54] += 1.0f;
+        // the cost of these parameters, term for term what pnp_cost_kernel adds (same per-thread order, same
+        // reduction tree): the LM loop gets the candidate's cost and its normal equations from ONE sweep
+        const bool behind = p.convention_opencv ? (az < 0.0f) : (az > 0.0f);
+        acc[55] += weight * loss_value(p.loss_type, p.loss_scale, behind ? __builtin_inff() : r2n);
     }
     block_reduce<PNP_ACC>(acc, s_part);
     if (threadIdx.x == 0)
@@ -289,14 +412,19 @@ __global__ __launch_bounds__(256) void pnp_cost_kernel(const float* __restrict__
         for (int k = 0; k < 4; k++) partials[(size_t)blockIdx.x * 4 + k] = acc[k];
 }
 
-// second stage: fixed-order sum of the per-block partials (deterministic run to run)
-__global__ __launch_bounds__(64) void pnp_finalize_kernel(const float* __restrict__ partials, int nblocks, int nv,
-                                                          float* __restrict__ out) {
-    const int k = threadIdx.x;
-    if (k >= nv) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; b++) s += partials[(size_t)b * nv + k];
-    out[k] = s;
+// second stage: fixed-order sum of the per-block partials (deterministic run to run).  One wavefront per value:
+// lane l adds partials l, l+64, ... in order, then the 64 lane sums go through a fixed shuffle tree.  (A single
+// lane walking all <= 512 partials of a value, one dependent load after the other, took longer than the sweep itself.)
+__global__ __launch_bounds__(1024) void pnp_finalize_kernel(const float* __restrict__ partials, int nblocks, int nv,
+                                                            float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < nv; k += 16) {
+        float s = 0.f;
+        for (int b = lane; b < nblocks; b += 64) s += partials[(size_t)b * nv + k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+        if (lane == 0) out[k] = s;
+    }
 }
 
 int pnp_num_blocks(int n) {
@@ -308,14 +436,14 @@ void launch_pnp_normal_eq(const float* X, const float* x, const float* w, int n,
                           float* out56, hipStream_t s) {
     const int nb = pnp_num_blocks(n);
     hipLaunchKernelGGL(pnp_normal_eq_kernel, dim3(nb), dim3(256), 0, s, X, x, w, n, p, partials);
-    hipLaunchKernelGGL(pnp_finalize_kernel, dim3(1), dim3(64), 0, s, partials, nb, PNP_ACC, out56);
+    hipLaunchKernelGGL(pnp_finalize_kernel, dim3(1), dim3(1024), 0, s, partials, nb, PNP_ACC, out56);
 }
 
 void launch_pnp_cost(const float* X, const float* x, const float* w, int n, const PnPParams& p, float max_err_sq,
                      float* partials, float* out4, hipStream_t s) {
     const int nb = pnp_num_blocks(n);
     hipLaunchKernelGGL(pnp_cost_kernel, dim3(nb), dim3(256), 0, s, X, x, w, n, p, max_err_sq, partials);
-    hipLaunchKernelGGL(pnp_finalize_kernel, dim3(1), dim3(64), 0, s, partials, nb, 4, out4);
+    hipLaunchKernelGGL(pnp_finalize_kernel, dim3(1), dim3(1024), 0, s, partials, nb, 4, out4);
 }
 
 }  // namespace pc

@@ -59,6 +59,7 @@ constexpr const char* kStatementSql[] = {
     "INSERT INTO keypoints(image_id, rows, keypoints) VALUES(?, ?, ?);",
     "SELECT rows, src_keypoints_indices, tgt_keypoints, flow_errors FROM optical_flow WHERE image_id_from = ? AND "
     "image_id_to = ?;",
+    "SELECT rows, src_keypoints_indices, tgt_keypoints FROM optical_flow WHERE image_id_from = ? AND image_id_to = ?;",
     "INSERT INTO optical_flow(image_id_from, image_id_to, rows, src_keypoints_indices, tgt_keypoints, "
     "flow_errors) VALUES(?, ?, ?, ?, ?, ?);",
     "SELECT image_id_to FROM optical_flow WHERE image_id_from = ?",
@@ -239,6 +240,19 @@ void Database::ReadImagePairFlow(int32_t from, int32_t to, ImagePairFlow& out) c
     BlobToVector(stmt, 3, rows, out.flow_errors);
     out.image_id_from = from;
     out.image_id_to = to;
+}
+
+void Database::ReadImagePairMatches(int32_t from, int32_t to, KeypointsIndices& idx, Keypoints& tgt) const {
+    idx.clear();
+    tgt.clear();
+    sqlite3_stmt* stmt = Stmt(kReadMatches);
+    Resetter reset{stmt};
+    SQL_OK(sqlite3_bind_int(stmt, 1, from));
+    SQL_OK(sqlite3_bind_int(stmt, 2, to));
+    if (SQL_OK(sqlite3_step(stmt)) != SQLITE_ROW) return;
+    const size_t rows = static_cast<size_t>(sqlite3_column_int(stmt, 0));
+    BlobToVector(stmt, 1, rows, idx);
+    BlobToVector(stmt, 2, rows, tgt);
 }
 
 ImagePairFlow Database::ReadImagePairFlow(int32_t from, int32_t to) const {

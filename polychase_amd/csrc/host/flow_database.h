@@ -59,6 +59,9 @@ class Database {
     bool ImagePairFlowExists(int32_t image_id_from, int32_t image_id_to) const;
     ImagePairFlow ReadImagePairFlow(int32_t image_id_from, int32_t image_id_to) const;
     void ReadImagePairFlow(int32_t image_id_from, int32_t image_id_to, ImagePairFlow& out) const;
+    // Not in the reference: the two columns the tracker consumes (tracker.cc:56-86), without flow_errors
+    void ReadImagePairMatches(int32_t image_id_from, int32_t image_id_to, KeypointsIndices& src_kps_indices,
+                              Keypoints& tgt_kps) const;
     void WriteImagePairFlow(const ImagePairFlow& flow);
     void WriteImagePairFlow(int32_t image_id_from, int32_t image_id_to, const KeypointsIndices& src_kps_indices,
                             const Keypoints& tgt_kps, const FlowErrors& flow_errors);
@@ -83,6 +86,7 @@ class Database {
         kReadKeypoints,
         kWriteKeypoints,
         kReadFlow,
+        kReadMatches,
         kWriteFlow,
         kFlowsFrom,
         kFlowsTo,

@@ -7,6 +7,7 @@
 #include <stdexcept>
 
 #include "gpu_context.h"
+#include "stage_clock.h"
 
 namespace {
 
@@ -47,15 +48,28 @@ void SolvePnPIterative(const float* object_points, const float* image_points, co
     CHECK_GE(n, static_cast<size_t>(3));  // solvers.cc:54-55
     const int lt = static_cast<int>(opts.bundle_opts.loss_type);
     if (lt < 0 || lt > 2) throw std::runtime_error("Unknown loss type: " + std::to_string(lt));
+    GpuProblem gp{SharedGpuContext()};
+    {
+        StageClock::Scope sc("pnp/create+upload");
+        if (pc_pnp_problem_create(gp.ctx, object_points, image_points, weights, static_cast<int>(n), &gp.prob) != PC_OK)
+            ThrowHip("pc_pnp_problem_create");
+    }
+    SolvePnPIterativeOnGpu(gp.prob, n, opts, result);
+}
+
+void SolvePnPIterativeOnGpu(pc_pnp_problem* problem, size_t n, const PnPOptions& opts, PnPResult& result) {
+    CHECK_GE(n, static_cast<size_t>(3));  // solvers.cc:54-55
+    const int lt = static_cast<int>(opts.bundle_opts.loss_type);
+    if (lt < 0 || lt > 2) throw std::runtime_error("Unknown loss type: " + std::to_string(lt));
     const BundleOptions& bo = opts.bundle_opts;
     // PnPProblem: intrinsics are only optimised with more than 3 points (pnp_problem.h:34-35)
     const bool opt_f = opts.optimize_focal_length && n > 3;
     const bool opt_pp = opts.optimize_principal_point && n > 3;
     const CameraIntrinsics::Bounds bounds = result.camera.intrinsics.GetBounds();
-
-    GpuProblem gp{SharedGpuContext()};
-    if (pc_pnp_problem_create(gp.ctx, object_points, image_points, weights, static_cast<int>(n), &gp.prob) != PC_OK)
-        ThrowHip("pc_pnp_problem_create");
+    struct {
+        pc_context* ctx;
+        pc_pnp_problem* prob;
+    } gp{SharedGpuContext(), problem};
 
     Params params{result.camera, result.camera.pose.R()};
     Params params_new = params;
@@ -68,9 +82,27 @@ void SolvePnPIterative(const float* object_points, const float* image_points, co
         return cost;  // kShouldNormalize == false
     };
 
+    // One sweep returns the cost of a parameter set AND its normal equations (pc_pnp_normal_equations_cost): the
+    // candidate of every LM step is evaluated that way, so an accepted step already holds the system the
+    // reference would build at the top of the next iteration (lev_marq.h:146-160) -- same numbers, half the
+    // GPU round trips.
+    struct System {
+        float lower[45];
+        float Jtr[9];
+        float cost = 0;
+    };
+    auto sweep = [&](const Params& p, System& out) {
+        const pc_pnp_params g = ToGpu(p, opt_f, opt_pp, bo);
+        int valid = 0;
+        if (pc_pnp_normal_equations_cost(gp.ctx, gp.prob, &g, out.lower, out.Jtr, &valid, &out.cost) != PC_OK)
+            ThrowHip("pc_pnp_normal_equations");
+    };
+
     // ---- LevMarqDenseSolver::Solve (lev_marq.h:132-228) ----
     BundleStats stats;
-    stats.cost = total_cost(params, nullptr, 0.f);
+    System current, candidate;
+    sweep(params, current);
+    stats.cost = current.cost;
     stats.initial_cost = stats.cost;
     stats.grad_norm = -1;
     stats.step_norm = -1;
@@ -83,13 +115,10 @@ void SolvePnPIterative(const float* object_points, const float* image_points, co
     bool rebuild = true;
     for (stats.iterations = 0; stats.iterations < bo.max_iterations; ++stats.iterations) {
         if (rebuild) {
-            const pc_pnp_params g = ToGpu(params, opt_f, opt_pp, bo);
-            float lower[45];
-            int valid = 0;
-            if (pc_pnp_normal_equations(gp.ctx, gp.prob, &g, lower, Jtr, &valid) != PC_OK) ThrowHip("pc_pnp_normal_equations");
             int o = 0;
             for (int a = 0; a < 9; a++)
-                for (int b = 0; b <= a; b++) JtJ[9 * a + b] = lower[o++];
+                for (int b = 0; b <= a; b++) JtJ[9 * a + b] = current.lower[o++];
+            for (int a = 0; a < 9; a++) Jtr[a] = current.Jtr[a];
             // JtJ_diag = diag.cwiseMax(1e-6).cwiseMin(1e32)  (:296)
             for (int a = 0; a < 9; a++) diag[a] = std::min(std::max(JtJ[10 * a], 1e-6f), 1e32f);
             float g2 = 0;
@@ -139,7 +168,8 @@ void SolvePnPIterative(const float* object_points, const float* image_points, co
             }
             params_new.R = nw.pose.R();
         }
-        const Float cost_new = total_cost(params_new, nullptr, 0.f);
+        sweep(params_new, candidate);
+        const Float cost_new = candidate.cost;
 
         if (cost_new < stats.cost) {
             const Float actual = cost_new - stats.cost;
@@ -156,6 +186,7 @@ void SolvePnPIterative(const float* object_points, const float* image_points, co
                 stats.lambda = std::clamp(static_cast<Float>(stats.lambda * factor), bo.min_lambda, bo.max_lambda);
             }
             params = params_new;
+            current = candidate;
             stats.cost = cost_new;
             v = 2;
             rebuild = true;

@@ -15,15 +15,16 @@ AcceleratedMesh::AcceleratedMesh(std::vector<float> vertices, std::vector<uint32
 
 AcceleratedMesh::~AcceleratedMesh() { pc_mesh_destroy(gpu_); }
 
-void AcceleratedMesh::RayCastPixels(const SceneTransformations& st, const float* xy, size_t n, bool check_mask,
-                                    std::vector<std::optional<RayHit>>& hits, bool exhaustive) const {
-    hits.assign(n, std::nullopt);
-    if (n == 0) return;
-    pc_context* ctx = SharedGpuContext();
-    // GetRayObjectSpace (cpp/ray_casting.h:53-63)
+void AcceleratedMesh::SyncMask() const {
+    if (pc_mesh_set_mask(SharedGpuContext(), gpu_, mesh_.masked_triangles.data(),
+                         static_cast<int>(mesh_.masked_triangles.size())) != PC_OK)
+        throw std::runtime_error(std::string("pc_mesh_set_mask: ") + pc_last_error());
+}
+
+void MakeRayCamera(const SceneTransformations& st, pc_ray_camera* out) {
     Mat4f inv;
     if (!Inverse4(MatMul4(st.view_matrix, st.model_matrix), &inv)) throw std::runtime_error("view * model is singular");
-    pc_ray_camera cam;
+    pc_ray_camera& cam = *out;
     for (int r = 0; r < 3; r++) {
         for (int c = 0; c < 3; c++) cam.dir_matrix[3 * r + c] = inv[4 * r + c];
         cam.origin[r] = inv[4 * r + 3];
@@ -33,10 +34,17 @@ void AcceleratedMesh::RayCastPixels(const SceneTransformations& st, const float*
     cam.cx = st.intrinsics.cx;
     cam.cy = st.intrinsics.cy;
     cam.unproject_sign = st.intrinsics.convention == CameraConvention::OpenCV ? 1.0f : -1.0f;
+}
+
+void AcceleratedMesh::RayCastPixels(const SceneTransformations& st, const float* xy, size_t n, bool check_mask,
+                                    std::vector<std::optional<RayHit>>& hits, bool exhaustive) const {
+    hits.assign(n, std::nullopt);
+    if (n == 0) return;
+    pc_context* ctx = SharedGpuContext();
+    pc_ray_camera cam;
+    MakeRayCamera(st, &cam);
     // the mask can be edited through inner_mut(): always send the current bits
-    if (check_mask && pc_mesh_set_mask(ctx, gpu_, mesh_.masked_triangles.data(),
-                                       static_cast<int>(mesh_.masked_triangles.size())) != PC_OK)
-        throw std::runtime_error(std::string("pc_mesh_set_mask: ") + pc_last_error());
+    if (check_mask) SyncMask();
     hit_.resize(n);
     pos_.resize(3 * n);
     uvt_.resize(3 * n);

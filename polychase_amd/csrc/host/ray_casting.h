@@ -21,6 +21,8 @@ class AcceleratedMesh {
     const Mesh& Inner() const { return mesh_; }
     Mesh& InnerMut() { return mesh_; }
     pc_mesh* Gpu() const { return gpu_; }
+    // sends the current masked_triangles bits to the GPU copy (they can be edited through InnerMut())
+    void SyncMask() const;
 
     // Batched RayCast(accel_mesh, scene_transform, pos, check_mask): hits[i] is empty on a miss.
     // exhaustive: sweep over every triangle instead of walking the hierarchy (validation only)
@@ -34,6 +36,10 @@ class AcceleratedMesh {
     mutable std::vector<float> pos_, uvt_;
     mutable std::vector<uint32_t> prim_;
 };
+
+struct pc_ray_camera;
+// GetRayObjectSpace (cpp/ray_casting.h:53-63) as the camera block the GPU kernels take
+void MakeRayCamera(const SceneTransformations& scene_transform, pc_ray_camera* out);
 
 std::optional<RayHit> RayCast(const AcceleratedMesh& accel_mesh, const SceneTransformations& scene_transform, Vec2f pos,
                               bool check_mask);

@@ -12,62 +12,82 @@
 #include <optional>
 #include <stdexcept>
 
+#include "gpu_context.h"
 #include "pnp.h"
+#include "stage_clock.h"
 
 namespace {
 
 constexpr float kMaxInlierError = 12.0f;  // tracker.cc:123 ("FIXME: Make this customizable")
 
-struct Correspondences {
-    std::vector<float> world_points;  // n x 3
-    std::vector<float> image_points;  // n x 2
-    size_t size() const { return image_points.size() / 2; }
-    void clear() {
-        world_points.clear();
-        image_points.clear();
-    }
-};
-
+// Host-side state that outlives one frame: the device-resident correspondence set, the keypoints of recently used
+// source frames (a frame is a source for up to 8 targets: read from SQLite once) and the blobs of the current flow.
 struct Scratch {
+    pc_context* ctx = nullptr;
+    pc_corr_set* set = nullptr;
     std::vector<int32_t> sources;
-    Keypoints keypoints;
-    ImagePairFlow flow;
-    std::vector<float> pixels;
-    std::vector<std::optional<RayHit>> hits;
+    struct CachedKeypoints {
+        int32_t frame = 0;
+        bool valid = false;
+        uint64_t stamp = 0;
+        Keypoints keypoints;
+    };
+    CachedKeypoints cache[16];
+    uint64_t clock = 0;
+    KeypointsIndices indices;
+    Keypoints targets;
+
+    Scratch() : ctx(SharedGpuContext()) {
+        if (pc_corr_set_create(ctx, &set) != PC_OK) throw std::runtime_error(std::string("pc_corr_set_create: ") + pc_last_error());
+    }
+    Scratch(const Scratch&) = delete;
+    Scratch& operator=(const Scratch&) = delete;
+    ~Scratch() { pc_corr_set_destroy(set); }
+
+    const Keypoints& KeypointsOf(const Database& db, int32_t frame) {
+        CachedKeypoints* slot = &cache[0];
+        for (auto& c : cache) {
+            if (c.valid && c.frame == frame) {
+                c.stamp = ++clock;
+                return c.keypoints;
+            }
+            if (c.stamp < slot->stamp) slot = &c;
+        }
+        db.ReadKeypoints(frame, slot->keypoints);
+        slot->frame = frame;
+        slot->valid = true;
+        slot->stamp = ++clock;
+        return slot->keypoints;
+    }
 };
 
-Vec3f ToWorld(const Mat4f& model, const Vec3f& p) {
-    return {model[0] * p[0] + model[1] * p[1] + model[2] * p[2] + model[3],
-            model[4] * p[0] + model[5] * p[1] + model[6] * p[2] + model[7],
-            model[8] * p[0] + model[9] * p[1] + model[10] * p[2] + model[11]};
-}
+[[noreturn]] void ThrowHip(const char* what) { throw std::runtime_error(std::string(what) + ": " + pc_last_error()); }
 
-// correspondences contributed by one source frame (tracker.cc:52-92)
+// correspondences contributed by one source frame (tracker.cc:52-92): the gather, the ray cast, the model
+// transform and the append run on the GPU (pc_corr_set_append); the host only feeds the database blobs
 void AppendFromSource(const Database& db, int32_t source_frame, int32_t target_frame, const CameraState& source_camera,
-                      const Mat4f& model_matrix, const AcceleratedMesh& mesh, Scratch& s, Correspondences& out) {
-    db.ReadKeypoints(source_frame, s.keypoints);
-    db.ReadImagePairFlow(source_frame, target_frame, s.flow);
-    CHECK_EQ(s.flow.src_kps_indices.size(), s.flow.tgt_kps.size());
-    const size_t matches = s.flow.src_kps_indices.size();
-    s.pixels.resize(2 * matches);
-    for (size_t i = 0; i < matches; i++) {
-        const uint32_t k = s.flow.src_kps_indices[i];
-        CHECK_LT(k, s.keypoints.size());
-        s.pixels[2 * i] = s.keypoints[k][0];
-        s.pixels[2 * i + 1] = s.keypoints[k][1];
+                      const Mat4f& model_matrix, const AcceleratedMesh& mesh, Scratch& s) {
+    const Keypoints* keypoints;
+    {
+        StageClock::Scope sc("track/db read");
+        keypoints = &s.KeypointsOf(db, source_frame);
+        db.ReadImagePairMatches(source_frame, target_frame, s.indices, s.targets);
     }
+    CHECK_EQ(s.indices.size(), s.targets.size());
+    if (s.indices.empty()) return;
+    StageClock::Scope sc("track/append (enqueue)");
     SceneTransformations scene;
     scene.model_matrix = model_matrix;
     scene.view_matrix = source_camera.pose.Rt4x4();
     scene.intrinsics = source_camera.intrinsics;
-    mesh.RayCastPixels(scene, s.pixels.data(), matches, /*check_mask=*/true, s.hits);
-    for (size_t i = 0; i < matches; i++) {
-        if (!s.hits[i]) continue;
-        const Vec3f w = ToWorld(model_matrix, s.hits[i]->pos);
-        out.world_points.insert(out.world_points.end(), w.begin(), w.end());
-        out.image_points.push_back(s.flow.tgt_kps[i][0]);
-        out.image_points.push_back(s.flow.tgt_kps[i][1]);
-    }
+    pc_ray_camera cam;
+    MakeRayCamera(scene, &cam);
+    static const float kNoKeypoint[2] = {0.f, 0.f};
+    if (pc_corr_set_append(s.ctx, s.set, mesh.Gpu(), &cam, model_matrix.data(), source_frame,
+                           keypoints->empty() ? kNoKeypoint : keypoints->front().data(), static_cast<int>(keypoints->size()),
+                           s.indices.data(), s.targets.front().data(), static_cast<int>(s.indices.size()),
+                           /*check_mask=*/1) != PC_OK)
+        ThrowHip("pc_corr_set_append");
 }
 
 // "The solution should be very close to the previous/next pose" (tracker.cc:111-119)
@@ -78,20 +98,42 @@ CameraState InitialGuess(const CameraTrajectory& traj, int32_t frame) {
 }
 
 std::optional<PnPResult> SolveFrame(const Database& db, const CameraTrajectory& traj, const Mat4f& model_matrix,
-                                    int32_t frame, const AcceleratedMesh& mesh, const PnPOptions& pnp_opts, Scratch& s,
-                                    Correspondences& corr) {
-    corr.clear();
+                                    int32_t frame, const AcceleratedMesh& mesh, const PnPOptions& pnp_opts, Scratch& s) {
+    if (pc_corr_set_clear(s.ctx, s.set) != PC_OK) ThrowHip("pc_corr_set_clear");
     s.sources.clear();
     db.FindOpticalFlowsToImage(frame, s.sources);
+    bool mask_sent = false;
     for (int32_t source : s.sources) {
         CHECK_NE(source, frame);
         if (!traj.IsFrameFilled(source)) continue;  // only frames that already have a pose (:48)
-        AppendFromSource(db, source, frame, *traj.Get(source), model_matrix, mesh, s, corr);
+        if (!mask_sent) {   // the mask can be edited between frames through inner_mut(): send the current bits
+            mesh.SyncMask();
+            mask_sent = true;
+        }
+        AppendFromSource(db, source, frame, *traj.Get(source), model_matrix, mesh, s);
     }
-    if (corr.size() < 3) return std::nullopt;  // :95-97
+    int n = 0;
+    {
+        StageClock::Scope sc("track/wait for the appends");
+        if (pc_corr_set_size(s.ctx, s.set, &n) != PC_OK) {
+            // an index past the source's keypoints: the reference's CHECK_LT (tracker.cc:61)
+            CHECK(std::string(pc_last_error()).find("out of range") == std::string::npos);
+            ThrowHip("pc_corr_set_size");
+        }
+    }
+    if (n < 3) return std::nullopt;  // :95-97
     PnPResult result;
     result.camera = InitialGuess(traj, frame);
-    SolvePnPIterative(corr.world_points.data(), corr.image_points.data(), nullptr, corr.size(), pnp_opts, result);
+    {
+        StageClock::Scope sc("track/pnp");
+        pc_pnp_problem* prob = nullptr;
+        if (pc_pnp_problem_from_set(s.ctx, s.set, &prob) != PC_OK) ThrowHip("pc_pnp_problem_from_set");
+        struct Guard {
+            pc_pnp_problem* p;
+            ~Guard() { pc_pnp_problem_destroy(p); }
+        } guard{prob};
+        SolvePnPIterativeOnGpu(prob, static_cast<size_t>(n), pnp_opts, result);
+    }
     return result;
 }
 
@@ -112,10 +154,9 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
 
     const int32_t step = frame_from < frame_to_inclusive ? 1 : -1;
     Scratch scratch;
-    Correspondences corr;
     for (int32_t frame = frame_from + step; frame != frame_to_inclusive + step; frame += step) {
         const std::optional<PnPResult> solved =
-            SolveFrame(database, camera_traj, model_matrix, frame, accel_mesh, pnp_opts, scratch, corr);
+            SolveFrame(database, camera_traj, model_matrix, frame, accel_mesh, pnp_opts, scratch);
         if (!solved)
             throw std::runtime_error("Could not track to frame: " + std::to_string(frame) + ". Not enough features.");
         if (callback) {
@@ -129,6 +170,7 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
         }
         camera_traj.Set(frame, solved->camera);
     }
+    StageClock::Report("TrackCameraTrajectory");
 }
 
 void TrackSequence(const std::string& database_path, int32_t frame_from, int32_t frame_to_inclusive,

@@ -32,7 +32,10 @@ SYMBOLS = [
     "pc_analyzer_set_keypoints", "pc_analyzer_submit", "pc_analyzer_pending", "pc_analyzer_collect",
     "pc_analyzer_set_device_log", "pc_analyzer_device_log_used",
     "pc_mesh_create", "pc_mesh_set_mask", "pc_mesh_destroy", "pc_raycast_pixels", "pc_raycast_pixels_sweep",
-    "pc_pnp_problem_create", "pc_pnp_problem_destroy", "pc_pnp_normal_equations", "pc_pnp_total_cost",
+    "pc_corr_set_create", "pc_corr_set_destroy", "pc_corr_set_clear", "pc_corr_set_append", "pc_corr_set_size",
+    "pc_corr_set_download", "pc_pnp_problem_from_set",
+    "pc_pnp_problem_create", "pc_pnp_problem_destroy", "pc_pnp_normal_equations", "pc_pnp_normal_equations_cost",
+    "pc_pnp_total_cost",
     "pc_refine_problem_create", "pc_refine_problem_destroy", "pc_refine_total_cost", "pc_refine_normal_equations",
 ]
 
