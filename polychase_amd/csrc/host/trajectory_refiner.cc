@@ -8,9 +8,17 @@
 //   residual sweeps   : on the GPU through pc_refine_* (kernels_refiner.hip), one workgroup per edge
 #include "trajectory_refiner.h"
 
+#include "stage_clock.h"
+
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <exception>
+#include <memory>
 #include <stdexcept>
+#include <thread>
+#include <utility>
+#include <vector>
 
 #include "band_matrix.h"
 #include "flow_database.h"
@@ -21,14 +29,30 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // segment data
 // ---------------------------------------------------------------------------------------------
+// std::allocator whose resize() leaves trivially constructible elements uninitialised: the gigabyte-sized arrays of
+// a segment are filled by the reader threads right after they are sized, and those threads should be the first to
+// touch the pages
+template <class T>
+struct NoInitAllocator : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = NoInitAllocator<U>;
+    };
+    template <class U, class... Args>
+    void construct(U* p, Args&&... args) {
+        if constexpr (sizeof...(Args) == 0) ::new (static_cast<void*>(p)) U;
+        else ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+    }
+};
+
 struct Segment {
     int32_t first_frame = 0;
     int32_t n_frames = 0;
     std::vector<int32_t> kp_offset;   // n_frames + 1
-    std::vector<float> kp_xy;
+    std::vector<float, NoInitAllocator<float>> kp_xy;
     std::vector<int32_t> edge_src, edge_tgt, edge_offset;
-    std::vector<uint32_t> res_src_kp;
-    std::vector<float> res_tgt_xy;
+    std::vector<uint32_t, NoInitAllocator<uint32_t>> res_src_kp;
+    std::vector<float, NoInitAllocator<float>> res_tgt_xy;
     std::vector<float> edge_weight;
     int32_t NumEdges() const { return static_cast<int32_t>(edge_src.size()); }
 };
@@ -74,18 +98,21 @@ Box2 ProjectedMeshBox(const Mesh& mesh, const CameraState& state, const Mat4f& m
     return box;
 }
 
-Segment LoadSegment(const Database& db, const CameraTrajectory& traj, const Mesh& mesh, const Mat4f& model_matrix) {
+// frames [frame_lo, frame_hi] of the segment, offsets relative to the part
+Segment LoadSegmentPart(const Database& db, const CameraTrajectory& traj, const Mesh& mesh, const Mat4f& model_matrix,
+                        int32_t frame_lo, int32_t frame_hi) {
     constexpr uint32_t kDropped = std::numeric_limits<uint32_t>::max();
     Segment seg;
     seg.first_frame = traj.FirstFrame();
-    seg.n_frames = static_cast<int32_t>(traj.Count());
+    seg.n_frames = frame_hi - frame_lo + 1;
     seg.kp_offset.push_back(0);
     seg.edge_offset.push_back(0);
     Keypoints kps;
     std::vector<uint32_t> remap;
     std::vector<int32_t> targets;
-    ImagePairFlow flow;
-    for (int32_t frame = traj.FirstFrame(); frame <= traj.LastFrame(); frame++) {
+    KeypointsIndices src_indices;
+    Keypoints tgt_kps;
+    for (int32_t frame = frame_lo; frame <= frame_hi; frame++) {
         // keypoints inside the projected mesh box, order preserved (FilterKeypoints, refiner.cc:162-186)
         kps.clear();
         db.ReadKeypoints(frame, kps);
@@ -106,24 +133,102 @@ Segment LoadSegment(const Database& db, const CameraTrajectory& traj, const Mesh
         const float dist = static_cast<float>(std::min(frame - traj.FirstFrame(), traj.LastFrame() - frame));
         for (int32_t to : targets) {
             if (!traj.IsValidFrame(to)) continue;
-            flow.Clear();
-            db.ReadImagePairFlow(frame, to, flow);
-            size_t rows = 0;
-            for (size_t j = 0; j < flow.tgt_kps.size(); j++) {
-                const uint32_t src = flow.src_kps_indices[j];
+            db.ReadImagePairMatches(frame, to, src_indices, tgt_kps);   // flow_errors are not used (refiner.cc:117-160)
+            CHECK_EQ(src_indices.size(), tgt_kps.size());
+            const size_t before = seg.res_src_kp.size();
+            for (size_t j = 0; j < tgt_kps.size(); j++) {
+                const uint32_t src = src_indices[j];
                 CHECK_LT(static_cast<size_t>(src), remap.size());
                 if (remap[src] == kDropped) continue;
                 seg.res_src_kp.push_back(remap[src]);
-                seg.res_tgt_xy.push_back(flow.tgt_kps[j][0]);
-                seg.res_tgt_xy.push_back(flow.tgt_kps[j][1]);
-                rows++;
+                seg.res_tgt_xy.push_back(tgt_kps[j][0]);
+                seg.res_tgt_xy.push_back(tgt_kps[j][1]);
             }
-            if (rows == 0) continue;
+            if (seg.res_src_kp.size() == before) continue;
             seg.edge_src.push_back(frame - seg.first_frame);
             seg.edge_tgt.push_back(to - seg.first_frame);
             seg.edge_offset.push_back(static_cast<int32_t>(seg.res_src_kp.size()));
             seg.edge_weight.push_back(1.0f / (dist + 1.0f));  // FrameWeight(image_id_from), refiner.cc:249-256
         }
+    }
+    return seg;
+}
+
+// The whole segment (CachedDatabase, refiner.cc:71-197).  A 300-frame 1080p clip holds 1.5 GB of blobs: the frames
+// are dealt out to reader threads, each with its own read connection (the file is in WAL mode: readers do not
+// block each other), and the parts are joined in frame order -- the result does not depend on the thread count.
+Segment LoadSegment(const std::string& database_path, const CameraTrajectory& traj, const Mesh& mesh, const Mat4f& model_matrix) {
+    const int32_t n = static_cast<int32_t>(traj.Count());
+    int n_threads = static_cast<int>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())));
+    if (const char* env = std::getenv("POLYCHASE_DB_READERS")) n_threads = std::max(1, std::atoi(env));
+    n_threads = std::max(1, std::min(n_threads, n / 8));   // short segments: not worth a second connection
+    std::vector<Segment> parts(static_cast<size_t>(n_threads));
+    std::vector<std::exception_ptr> errors(static_cast<size_t>(n_threads));
+    // opened one after the other: Open() issues pragmas and CREATE TABLE IF NOT EXISTS, which take the write lock
+    std::vector<std::unique_ptr<Database>> connections;
+    for (int t = 0; t < n_threads; t++) connections.push_back(std::make_unique<Database>(database_path));
+    auto work = [&](int t) {
+        try {
+            const Database& db = *connections[static_cast<size_t>(t)];
+            const int32_t lo = traj.FirstFrame() + static_cast<int32_t>(static_cast<int64_t>(n) * t / n_threads);
+            const int32_t hi = traj.FirstFrame() + static_cast<int32_t>(static_cast<int64_t>(n) * (t + 1) / n_threads) - 1;
+            parts[static_cast<size_t>(t)] = LoadSegmentPart(db, traj, mesh, model_matrix, lo, hi);
+        } catch (...) {
+            errors[static_cast<size_t>(t)] = std::current_exception();
+        }
+    };
+    {
+        std::vector<std::thread> threads;
+        for (int t = 1; t < n_threads; t++) threads.emplace_back(work, t);
+        work(0);
+        for (auto& th : threads) th.join();
+    }
+    for (const auto& e : errors)
+        if (e) std::rethrow_exception(e);
+    if (n_threads == 1) {
+        parts[0].n_frames = n;
+        return std::move(parts[0]);
+    }
+    // join: sizes first, then every thread copies its part to its place
+    Segment seg;
+    seg.first_frame = traj.FirstFrame();
+    seg.n_frames = n;
+    size_t n_kp = 0, n_res = 0, n_edges = 0;
+    std::vector<size_t> kp_base, res_base, edge_base;
+    for (const Segment& p : parts) {
+        kp_base.push_back(n_kp);
+        res_base.push_back(n_res);
+        edge_base.push_back(n_edges);
+        n_kp += p.kp_xy.size() / 2;
+        n_res += p.res_src_kp.size();
+        n_edges += p.edge_src.size();
+    }
+    CHECK_LT(n_res, static_cast<size_t>(std::numeric_limits<int32_t>::max()));
+    seg.kp_offset.push_back(0);
+    seg.edge_offset.push_back(0);
+    for (size_t t = 0; t < parts.size(); t++) {
+        const Segment& p = parts[t];
+        for (size_t f = 1; f < p.kp_offset.size(); f++) seg.kp_offset.push_back(static_cast<int32_t>(kp_base[t]) + p.kp_offset[f]);
+        for (size_t e = 1; e < p.edge_offset.size(); e++) seg.edge_offset.push_back(static_cast<int32_t>(res_base[t]) + p.edge_offset[e]);
+        seg.edge_src.insert(seg.edge_src.end(), p.edge_src.begin(), p.edge_src.end());
+        seg.edge_tgt.insert(seg.edge_tgt.end(), p.edge_tgt.begin(), p.edge_tgt.end());
+        seg.edge_weight.insert(seg.edge_weight.end(), p.edge_weight.begin(), p.edge_weight.end());
+    }
+    seg.kp_xy.resize(2 * n_kp);
+    seg.res_src_kp.resize(n_res);
+    seg.res_tgt_xy.resize(2 * n_res);
+    auto place = [&](int t) {
+        const Segment& p = parts[static_cast<size_t>(t)];
+        std::copy(p.kp_xy.begin(), p.kp_xy.end(), seg.kp_xy.begin() + static_cast<ptrdiff_t>(2 * kp_base[static_cast<size_t>(t)]));
+        // keypoint indices are relative to their frame: they do not move
+        std::copy(p.res_src_kp.begin(), p.res_src_kp.end(), seg.res_src_kp.begin() + static_cast<ptrdiff_t>(res_base[static_cast<size_t>(t)]));
+        std::copy(p.res_tgt_xy.begin(), p.res_tgt_xy.end(), seg.res_tgt_xy.begin() + static_cast<ptrdiff_t>(2 * res_base[static_cast<size_t>(t)]));
+    };
+    {
+        std::vector<std::thread> threads;
+        for (int t = 1; t < n_threads; t++) threads.emplace_back(place, t);
+        place(0);
+        for (auto& th : threads) th.join();
     }
     return seg;
 }
@@ -188,8 +293,8 @@ class RefineSession {
         CHECK(traj.Count() > 2);  // refiner.cc:660
         for (int32_t frame = traj.FirstFrame(); frame <= traj.LastFrame(); frame++) CHECK(traj.IsFrameFilled(frame));
         {
-            Database database{database_path};
-            seg_ = LoadSegment(database, traj, mesh.Inner(), model_matrix);
+            StageClock::Scope sc("refine/load segment (SQLite)");
+            seg_ = LoadSegment(database_path, traj, mesh.Inner(), model_matrix);
         }
         Mat4f model_inv;
         if (!Inverse4(model_matrix, &model_inv)) throw std::runtime_error("model_matrix is singular");
@@ -213,7 +318,10 @@ class RefineSession {
         if (pc_mesh_set_mask(ctx_, mesh.Gpu(), mesh.Inner().masked_triangles.data(),
                              static_cast<int>(mesh.Inner().masked_triangles.size())) != PC_OK)
             ThrowHip("pc_mesh_set_mask");
-        if (pc_refine_problem_create(ctx_, mesh.Gpu(), &desc, &gpu_.p) != PC_OK) ThrowHip("pc_refine_problem_create");
+        {
+            StageClock::Scope sc("refine/upload");
+            if (pc_refine_problem_create(ctx_, mesh.Gpu(), &desc, &gpu_.p) != PC_OK) ThrowHip("pc_refine_problem_create");
+        }
 
         // J^T J pattern (lev_marq.h:421-487): diagonal blocks + one off-diagonal block per connected pair
         int reach = 0;
@@ -235,6 +343,7 @@ class RefineSession {
     double TotalCost(const CameraTrajectory& traj) {
         PackCameras(traj, cams_);
         double cost = 0.0;
+        StageClock::Scope sc("refine/cost sweep");
         if (pc_refine_total_cost(ctx_, gpu_.p, cams_.data(), loss_type_, opts_.loss_scale, &cost) != PC_OK)
             ThrowHip("pc_refine_total_cost");
         return cost;
@@ -243,6 +352,7 @@ class RefineSession {
     // LevMarqSparseSolver::BuildNormalEquations (lev_marq.h:653-771) -> JtJ, Jtr, diag
     void BuildNormalEquations(const CameraTrajectory& traj) {
         PackCameras(traj, cams_);
+        StageClock::Scope sc("refine/normal equations (sweep + host assembly)");
         if (pc_refine_normal_equations(ctx_, gpu_.p, cams_.data(), loss_type_, opts_.loss_scale, edge_blocks_.data(), nullptr) !=
             PC_OK)
             ThrowHip("pc_refine_normal_equations");
@@ -333,7 +443,12 @@ void RefineTrajectory(const std::string& database_path, CameraTrajectory& traj, 
             damped.At(i, i) = diag[i] * (1.0 + stats.lambda);
             JtJ.At(i, i) = diag[i];
         }
-        if (!damped.Factorize()) {
+        bool factorized;
+        {
+            StageClock::Scope sc("refine/banded Cholesky");
+            factorized = damped.Factorize();
+        }
+        if (!factorized) {
             stats.invalid_steps++;
             if (stats.lambda == opts.max_lambda) break;
             stats.lambda = std::min(opts.max_lambda, stats.lambda * v);
@@ -384,6 +499,7 @@ void RefineTrajectory(const std::string& database_path, CameraTrajectory& traj, 
         if (!report(stats)) break;
     }
     report(stats);
+    StageClock::Report("RefineTrajectory");
 }
 
 RefinementSystem EvaluateRefinementSystem(const std::string& database_path, const CameraTrajectory& traj,
