@@ -97,8 +97,9 @@ CameraState InitialGuess(const CameraTrajectory& traj, int32_t frame) {
     return CameraState{};
 }
 
-std::optional<PnPResult> SolveFrame(const Database& db, const CameraTrajectory& traj, const Mat4f& model_matrix,
-                                    int32_t frame, const AcceleratedMesh& mesh, const PnPOptions& pnp_opts, Scratch& s) {
+// fills s.set with the correspondences of `frame`; returns their number
+int GatherCorrespondences(const Database& db, const CameraTrajectory& traj, const Mat4f& model_matrix, int32_t frame,
+                          const AcceleratedMesh& mesh, Scratch& s) {
     if (pc_corr_set_clear(s.ctx, s.set) != PC_OK) ThrowHip("pc_corr_set_clear");
     s.sources.clear();
     db.FindOpticalFlowsToImage(frame, s.sources);
@@ -121,6 +122,12 @@ std::optional<PnPResult> SolveFrame(const Database& db, const CameraTrajectory& 
             ThrowHip("pc_corr_set_size");
         }
     }
+    return n;
+}
+
+std::optional<PnPResult> SolveFrame(const Database& db, const CameraTrajectory& traj, const Mat4f& model_matrix,
+                                    int32_t frame, const AcceleratedMesh& mesh, const PnPOptions& pnp_opts, Scratch& s) {
+    const int n = GatherCorrespondences(db, traj, model_matrix, frame, mesh, s);
     if (n < 3) return std::nullopt;  // :95-97
     PnPResult result;
     result.camera = InitialGuess(traj, frame);
@@ -138,6 +145,17 @@ std::optional<PnPResult> SolveFrame(const Database& db, const CameraTrajectory& 
 }
 
 }  // namespace
+
+void FrameCorrespondences(const Database& database, const CameraTrajectory& camera_traj, const Mat4f& model_matrix,
+                          int32_t frame, const AcceleratedMesh& accel_mesh, std::vector<float>& world_points,
+                          std::vector<float>& image_points) {
+    Scratch scratch;
+    const int n = GatherCorrespondences(database, camera_traj, model_matrix, frame, accel_mesh, scratch);
+    world_points.assign(3 * static_cast<size_t>(n), 0.f);
+    image_points.assign(2 * static_cast<size_t>(n), 0.f);
+    if (pc_corr_set_download(scratch.ctx, scratch.set, world_points.data(), image_points.data()) != PC_OK)
+        ThrowHip("pc_corr_set_download");
+}
 
 void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_traj, int32_t frame_from,
                            int32_t frame_to_inclusive, const Mat4f& model_matrix, const AcceleratedMesh& accel_mesh,

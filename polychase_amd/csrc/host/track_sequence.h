@@ -23,3 +23,9 @@ void TrackSequence(const std::string& database_path, int32_t frame_from, int32_t
                    const SceneTransformations& scene_transform, const AcceleratedMesh& accel_mesh,
                    TrackingCallback callback, bool optimize_focal_length, bool optimize_principal_point,
                    BundleOptions opts);
+
+// The 3D-2D correspondences SolveFrame (tracker.cc:36-97) would hand to PnP for `frame` under the poses in
+// camera_traj -- built on the GPU like in TrackCameraTrajectory, then downloaded (tests / debugging).
+void FrameCorrespondences(const Database& database, const CameraTrajectory& camera_traj, const Mat4f& model_matrix,
+                          int32_t frame, const AcceleratedMesh& accel_mesh, std::vector<float>& world_points,
+                          std::vector<float>& image_points);

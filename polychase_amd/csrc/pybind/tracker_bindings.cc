@@ -152,7 +152,13 @@ void BindTracker(py::module_& m) {
             })
         .def_property(
             "t", [](const Pose& p) { return ArrToNumpy<3>(p.t); },
-            [](Pose& p, const F32Array& a) { p.t = NumpyToArr<3>(a); });
+            [](Pose& p, const F32Array& a) { p.t = NumpyToArr<3>(a); })
+        .def("_Rt4x4", [](const Pose& p) {   // not in the reference's binding: the view matrix the tracker derives (tests)
+            const Mat4f m = p.Rt4x4();
+            py::array_t<float> out({py::ssize_t{4}, py::ssize_t{4}});
+            std::memcpy(out.mutable_data(), m.data(), sizeof(float) * 16);
+            return out;
+        });
 
     py::class_<CameraState>(m, "CameraState")
         .def(py::init<>())
@@ -364,6 +370,29 @@ void BindTracker(py::module_& m) {
         },
         py::arg("accel_mesh"), py::arg("scene_transform"), py::arg("xy"), py::arg("check_mask"),
         py::arg("exhaustive") = false);   // exhaustive: sweep over all triangles instead of the BVH (validation)
+
+    // the correspondences SolveFrame builds on the GPU for one frame (tests)
+    m.def(
+        "_frame_correspondences",
+        [](const std::string& database_path, const CameraTrajectory& traj, const F32Array& model_matrix, int32_t frame,
+           const AcceleratedMesh& mesh) {
+            if (model_matrix.size() != 16) throw py::value_error("expected a 4x4 model matrix");
+            Mat4f model;
+            std::memcpy(model.data(), model_matrix.data(), sizeof(float) * 16);
+            std::vector<float> world, image;
+            {
+                const Database db{database_path};
+                FrameCorrespondences(db, traj, model, frame, mesh, world, image);
+            }
+            const py::ssize_t n = static_cast<py::ssize_t>(image.size() / 2);
+            py::array_t<float> w({n, py::ssize_t{3}}), x({n, py::ssize_t{2}});
+            if (n) {
+                std::memcpy(w.mutable_data(), world.data(), world.size() * sizeof(float));
+                std::memcpy(x.mutable_data(), image.data(), image.size() * sizeof(float));
+            }
+            return py::make_tuple(w, x);
+        },
+        py::arg("database_path"), py::arg("trajectory"), py::arg("model_matrix"), py::arg("frame"), py::arg("accel_mesh"));
 
     // 9x9 lower Cholesky solve used by the LM step (known-answer test of
     // cpp/examples/levmarq_ill_conditioned_float32_issue.cpp)

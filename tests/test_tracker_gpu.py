@@ -243,6 +243,53 @@ def test_track_sequence_on_synthetic_database(core, tmp_path, direction):
         assert inl > 0.9
 
 
+def test_device_built_correspondences_equal_the_reference_loop(core, tmp_path):
+    """pc_corr_set_append (gather + ray cast + model transform + ordered append on the GPU) against the loop of
+    tracker.cc:52-92 done on the host with the batched ray cast: same points, same order, bit for bit -- with
+    misses, masked triangles, several sources and a source frame that has no pose yet."""
+    verts, tris = grid_mesh(n=16)
+    model = np.array([[1.5, 0, 0, 0.1], [0, 1.4, 0, -0.2], [0, 0, 1.6, 0.05], [0, 0, 0, 1]], np.float32)
+    n_frames, target = 12, 9
+    path = str(tmp_path / "corr.db")
+    _build_flow_db(core, path, verts, tris, np.diag([1.5, 1.4, 1.6, 1.0]).astype(np.float32), n_frames, n_kp=700, noise=0.3)
+    masked = np.zeros((len(tris) + 31) // 32, np.uint32)
+    for t in (3, 40, 41, 200, 333):
+        masked[t >> 5] |= np.uint32(1 << (t & 31))
+    mesh = core.AcceleratedMesh(verts, tris, masked)
+    traj = core.CameraTrajectory(1, n_frames)
+    filled = [f for f in range(1, n_frames + 1) if f not in (target, 11)]        # 11 -> 9 exists in the database: skipped
+    for f in filled:
+        R, t = true_pose(f)
+        pose = core.Pose()
+        pose.q, pose.t = po.R_to_quat(R).astype(np.float32), t.astype(np.float32)
+        traj.set(f, core.CameraState(intr(core), pose))
+    got_w, got_x = core._frame_correspondences(path, traj, model, target, mesh)
+
+    db = core.Database(path)
+    want_w, want_x = [], []
+    for src in db.find_optical_flows_to_image(target):
+        if src not in filled:
+            continue
+        kps = db.read_keypoints(src)
+        fl = db.read_image_pair_flow(src, target)
+        st = core.SceneTransformations(model, traj.get(src).pose._Rt4x4(), intr(core))
+        hits = core._ray_cast_pixels(mesh, st, np.ascontiguousarray(kps[fl.src_kps_indices]), True)
+        for h, x in zip(hits, fl.tgt_kps):
+            if h is None:
+                continue
+            p = np.asarray(h.pos, np.float32)
+            w = [np.float32(np.float32(np.float32(np.float32(model[r, 0] * p[0]) + np.float32(model[r, 1] * p[1])) +
+                                       np.float32(model[r, 2] * p[2])) + model[r, 3]) for r in range(3)]
+            want_w.append(w)
+            want_x.append(x)
+    db.close()
+    want_w, want_x = np.array(want_w, np.float32), np.array(want_x, np.float32)
+    assert len(want_w) > 1500 and len(want_w) < 700 * 7          # several sources; misses and masked hits dropped
+    assert got_w.shape == want_w.shape and got_x.shape == want_x.shape
+    assert np.array_equal(got_x.view(np.uint32), want_x.view(np.uint32))
+    assert np.array_equal(got_w.view(np.uint32), want_w.view(np.uint32))
+
+
 def test_tracker_thread_protocol_and_errors(core, tmp_path):
     import time
     verts, tris = grid_mesh()
