@@ -92,7 +92,7 @@ void BindBlob(sqlite3_stmt* stmt, int col, const void* data, size_t bytes, int l
 
 }  // namespace
 
-Database::Database(Database&& other) noexcept : db_(std::exchange(other.db_, nullptr)) {
+Database::Database(Database&& other) noexcept : db_(std::exchange(other.db_, nullptr)), path_(std::move(other.path_)) {
     statements_ = other.statements_;
     other.statements_.fill(nullptr);
 }
@@ -115,6 +115,7 @@ void Database::Exec(const char* sql, int line) const {
 
 void Database::Open(const std::string& path) {
     Close();
+    path_ = path;
     // NOMUTEX like the reference: callers serialise access (one writer thread here)
     SQL_OK(sqlite3_open_v2(path.c_str(), &db_, SQLITE_OPEN_READWRITE | SQLITE_OPEN_CREATE | SQLITE_OPEN_NOMUTEX, nullptr));
     // Opt-in, not in the reference: POLYCHASE_DB_PAGE_SIZE=32768 creates NEW databases with larger pages (the blobs of

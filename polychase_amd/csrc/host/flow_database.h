@@ -45,6 +45,7 @@ class Database {
 
     void Open(const std::string& path);
     void Close();
+    const std::string& Path() const { return path_; }   // what Open() was given (a second read connection can be opened on it)
 
     // ---- keypoints(image_id PK, rows, keypoints BLOB) ----
     bool KeypointsExist(int32_t image_id) const;
@@ -104,5 +105,6 @@ class Database {
     int32_t ScalarOrInvalid(Statement s) const;
 
     sqlite3* db_ = nullptr;
+    std::string path_;
     std::array<sqlite3_stmt*, kNumStatements> statements_{};
 };

@@ -8,9 +8,13 @@
 // (pnp.cc).  Sequential over frames by construction: frame k needs the poses solved before it.
 #include "track_sequence.h"
 
+#include <condition_variable>
 #include <cstdlib>
+#include <memory>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
+#include <thread>
 
 #include "gpu_context.h"
 #include "pnp.h"
@@ -19,6 +23,124 @@
 namespace {
 
 constexpr float kMaxInlierError = 12.0f;  // tracker.cc:123 ("FIXME: Make this customizable")
+
+// Reads the blobs the NEXT frame will need -- the matches of every flow into it from a source that has, or is about to
+// get, a pose, and the keypoints of the frame being solved right now (the one new source) -- on a second read
+// connection while the GPU works on the current frame.  SQLite reads were a third of a frame's time.
+class FlowPrefetcher {
+   public:
+    struct Flow {
+        int32_t source = 0;
+        KeypointsIndices indices;
+        Keypoints targets;
+    };
+    struct Batch {
+        int32_t frame = 0;
+        bool valid = false;
+        std::vector<Flow> flows;     // entries [0, n_flows) are meaningful (the vectors are recycled)
+        size_t n_flows = 0;
+        int32_t keypoints_frame = 0;
+        bool has_keypoints = false;
+        Keypoints keypoints;
+    };
+
+    explicit FlowPrefetcher(const std::string& path) {
+        const char* env = std::getenv("POLYCHASE_TRACK_PREFETCH");
+        if ((env && env[0] == '0') || path.empty() || path == ":memory:") return;
+        try {
+            db_ = std::make_unique<Database>(path);
+        } catch (...) {
+            return;   // no second connection: the tracker reads synchronously
+        }
+        thread_ = std::thread([this] { Run(); });
+    }
+    ~FlowPrefetcher() {
+        if (!thread_.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(mtx_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        thread_.join();
+    }
+    bool Enabled() const { return thread_.joinable(); }
+
+    // ask for the blobs of `frame`: flows from `sources` into it, and the keypoints of `keypoints_frame`
+    void Request(int32_t frame, std::vector<int32_t> sources, int32_t keypoints_frame) {
+        if (!Enabled()) return;
+        {
+            std::lock_guard<std::mutex> lk(mtx_);
+            req_frame_ = frame;
+            req_sources_ = std::move(sources);
+            req_keypoints_frame_ = keypoints_frame;
+            has_request_ = true;
+            done_ = false;
+        }
+        cv_.notify_all();
+    }
+    // the batch of the last request if it was for `frame` (waits for the reader), else nullptr
+    Batch* Take(int32_t frame) {
+        if (!Enabled()) return nullptr;
+        std::unique_lock<std::mutex> lk(mtx_);
+        if (!has_request_ && !done_) return nullptr;
+        cv_.wait(lk, [this] { return done_ || stop_; });
+        Batch& b = batches_[ready_];
+        return (done_ && b.valid && b.frame == frame) ? &b : nullptr;
+    }
+
+   private:
+    void Run() {
+        for (;;) {
+            int32_t frame, kp_frame;
+            std::vector<int32_t> sources;
+            {
+                std::unique_lock<std::mutex> lk(mtx_);
+                cv_.wait(lk, [this] { return has_request_ || stop_; });
+                if (stop_) return;
+                frame = req_frame_;
+                kp_frame = req_keypoints_frame_;
+                sources = std::move(req_sources_);
+                has_request_ = false;
+            }
+            Batch& b = batches_[1 - ready_];   // the consumer may still be reading batches_[ready_]
+            b.frame = frame;
+            b.valid = false;
+            b.n_flows = 0;
+            b.has_keypoints = false;
+            try {
+                for (int32_t src : sources) {
+                    if (b.flows.size() <= b.n_flows) b.flows.emplace_back();
+                    Flow& f = b.flows[b.n_flows++];
+                    f.source = src;
+                    db_->ReadImagePairMatches(src, frame, f.indices, f.targets);
+                }
+                b.keypoints_frame = kp_frame;
+                b.keypoints.clear();
+                db_->ReadKeypoints(kp_frame, b.keypoints);
+                b.has_keypoints = true;
+                b.valid = true;
+            } catch (...) {
+                b.valid = false;   // the consumer falls back to its own connection and reports the error there
+            }
+            {
+                std::lock_guard<std::mutex> lk(mtx_);
+                ready_ = 1 - ready_;
+                done_ = true;
+            }
+            cv_.notify_all();
+        }
+    }
+
+    std::unique_ptr<Database> db_;
+    std::thread thread_;
+    std::mutex mtx_;
+    std::condition_variable cv_;
+    bool stop_ = false, has_request_ = false, done_ = false;
+    int32_t req_frame_ = 0, req_keypoints_frame_ = 0;
+    std::vector<int32_t> req_sources_;
+    Batch batches_[2];
+    int ready_ = 0;
+};
 
 // Host-side state that outlives one frame: the device-resident correspondence set, the keypoints of recently used
 // source frames (a frame is a source for up to 8 targets: read from SQLite once) and the blobs of the current flow.
@@ -44,7 +166,7 @@ struct Scratch {
     Scratch& operator=(const Scratch&) = delete;
     ~Scratch() { pc_corr_set_destroy(set); }
 
-    const Keypoints& KeypointsOf(const Database& db, int32_t frame) {
+    const Keypoints& KeypointsOf(const Database& db, int32_t frame, FlowPrefetcher::Batch* batch) {
         CachedKeypoints* slot = &cache[0];
         for (auto& c : cache) {
             if (c.valid && c.frame == frame) {
@@ -53,7 +175,12 @@ struct Scratch {
             }
             if (c.stamp < slot->stamp) slot = &c;
         }
-        db.ReadKeypoints(frame, slot->keypoints);
+        if (batch && batch->has_keypoints && batch->keypoints_frame == frame) {
+            slot->keypoints.swap(batch->keypoints);   // read ahead by the prefetcher
+            batch->has_keypoints = false;
+        } else {
+            db.ReadKeypoints(frame, slot->keypoints);
+        }
         slot->frame = frame;
         slot->valid = true;
         slot->stamp = ++clock;
@@ -66,15 +193,25 @@ struct Scratch {
 // correspondences contributed by one source frame (tracker.cc:52-92): the gather, the ray cast, the model
 // transform and the append run on the GPU (pc_corr_set_append); the host only feeds the database blobs
 void AppendFromSource(const Database& db, int32_t source_frame, int32_t target_frame, const CameraState& source_camera,
-                      const Mat4f& model_matrix, const AcceleratedMesh& mesh, Scratch& s) {
+                      const Mat4f& model_matrix, const AcceleratedMesh& mesh, Scratch& s, FlowPrefetcher::Batch* batch) {
     const Keypoints* keypoints;
+    const KeypointsIndices* indices = &s.indices;
+    const Keypoints* targets = &s.targets;
     {
         StageClock::Scope sc("track/db read");
-        keypoints = &s.KeypointsOf(db, source_frame);
-        db.ReadImagePairMatches(source_frame, target_frame, s.indices, s.targets);
+        keypoints = &s.KeypointsOf(db, source_frame, batch);
+        bool prefetched = false;
+        if (batch)
+            for (size_t k = 0; k < batch->n_flows && !prefetched; k++)
+                if (batch->flows[k].source == source_frame) {
+                    indices = &batch->flows[k].indices;
+                    targets = &batch->flows[k].targets;
+                    prefetched = true;
+                }
+        if (!prefetched) db.ReadImagePairMatches(source_frame, target_frame, s.indices, s.targets);
     }
-    CHECK_EQ(s.indices.size(), s.targets.size());
-    if (s.indices.empty()) return;
+    CHECK_EQ(indices->size(), targets->size());
+    if (indices->empty()) return;
     StageClock::Scope sc("track/append (enqueue)");
     SceneTransformations scene;
     scene.model_matrix = model_matrix;
@@ -85,7 +222,7 @@ void AppendFromSource(const Database& db, int32_t source_frame, int32_t target_f
     static const float kNoKeypoint[2] = {0.f, 0.f};
     if (pc_corr_set_append(s.ctx, s.set, mesh.Gpu(), &cam, model_matrix.data(), source_frame,
                            keypoints->empty() ? kNoKeypoint : keypoints->front().data(), static_cast<int>(keypoints->size()),
-                           s.indices.data(), s.targets.front().data(), static_cast<int>(s.indices.size()),
+                           indices->data(), targets->front().data(), static_cast<int>(indices->size()),
                            /*check_mask=*/1) != PC_OK)
         ThrowHip("pc_corr_set_append");
 }
@@ -99,7 +236,7 @@ CameraState InitialGuess(const CameraTrajectory& traj, int32_t frame) {
 
 // fills s.set with the correspondences of `frame`; returns their number
 int GatherCorrespondences(const Database& db, const CameraTrajectory& traj, const Mat4f& model_matrix, int32_t frame,
-                          const AcceleratedMesh& mesh, Scratch& s) {
+                          const AcceleratedMesh& mesh, Scratch& s, FlowPrefetcher::Batch* batch = nullptr) {
     if (pc_corr_set_clear(s.ctx, s.set) != PC_OK) ThrowHip("pc_corr_set_clear");
     s.sources.clear();
     db.FindOpticalFlowsToImage(frame, s.sources);
@@ -111,7 +248,7 @@ int GatherCorrespondences(const Database& db, const CameraTrajectory& traj, cons
             mesh.SyncMask();
             mask_sent = true;
         }
-        AppendFromSource(db, source, frame, *traj.Get(source), model_matrix, mesh, s);
+        AppendFromSource(db, source, frame, *traj.Get(source), model_matrix, mesh, s, batch);
     }
     int n = 0;
     {
@@ -126,8 +263,9 @@ int GatherCorrespondences(const Database& db, const CameraTrajectory& traj, cons
 }
 
 std::optional<PnPResult> SolveFrame(const Database& db, const CameraTrajectory& traj, const Mat4f& model_matrix,
-                                    int32_t frame, const AcceleratedMesh& mesh, const PnPOptions& pnp_opts, Scratch& s) {
-    const int n = GatherCorrespondences(db, traj, model_matrix, frame, mesh, s);
+                                    int32_t frame, const AcceleratedMesh& mesh, const PnPOptions& pnp_opts, Scratch& s,
+                                    FlowPrefetcher::Batch* batch) {
+    const int n = GatherCorrespondences(db, traj, model_matrix, frame, mesh, s, batch);
     if (n < 3) return std::nullopt;  // :95-97
     PnPResult result;
     result.camera = InitialGuess(traj, frame);
@@ -172,9 +310,23 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
 
     const int32_t step = frame_from < frame_to_inclusive ? 1 : -1;
     Scratch scratch;
+    FlowPrefetcher prefetcher(database.Path());
+    std::vector<int32_t> next_sources, wanted;
     for (int32_t frame = frame_from + step; frame != frame_to_inclusive + step; frame += step) {
+        FlowPrefetcher::Batch* batch = prefetcher.Take(frame);
+        // while this frame is solved: read what the next one needs -- flows from the frames that have a pose by
+        // then (this one included) and this frame's keypoints, the one array the host cache does not hold yet
+        const int32_t next = frame + step;
+        if (prefetcher.Enabled() && next != frame_to_inclusive + step) {
+            next_sources.clear();
+            wanted.clear();
+            database.FindOpticalFlowsToImage(next, next_sources);
+            for (int32_t src : next_sources)
+                if (src == frame || camera_traj.IsFrameFilled(src)) wanted.push_back(src);
+            prefetcher.Request(next, wanted, frame);
+        }
         const std::optional<PnPResult> solved =
-            SolveFrame(database, camera_traj, model_matrix, frame, accel_mesh, pnp_opts, scratch);
+            SolveFrame(database, camera_traj, model_matrix, frame, accel_mesh, pnp_opts, scratch, batch);
         if (!solved)
             throw std::runtime_error("Could not track to frame: " + std::to_string(frame) + ". Not enough features.");
         if (callback) {
