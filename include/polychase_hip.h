@@ -298,6 +298,35 @@ int pc_pnp_normal_equations(pc_context* ctx, const pc_pnp_problem* prob, const p
  * equations from one launch and one read-back instead of two. */
 int pc_pnp_normal_equations_cost(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,
                                  float* jtj_lower45, float* jtr9, int* valid, float* cost);
+/* ---- the whole of SolvePnPIterative on the device (cpp/pnp/solvers.cc:11-71, lev_marq.h:132-228) ----
+ * The LM loop alternates residual sweeps with 9x9 algebra that decides what to evaluate next; driven from the
+ * host every decision costs a launch + read-back + synchronisation.  pc_pnp_solve keeps the solver's state in
+ * device memory: a one-lane kernel takes the decision (same fp32 arithmetic, same order of operations), the host
+ * enqueues [sweep, reduce, decide] rounds without waiting and reads the state back once per batch of rounds. */
+typedef struct pc_pnp_camera {
+    float q_xyzw[4];          /* pose rotation (Eigen order) */
+    float t[3];
+    float fx, fy, cx, cy, aspect_ratio;
+    int convention_opencv;
+} pc_pnp_camera;
+typedef struct pc_pnp_solve_options {
+    int max_iterations;                                   /* BundleOptions (pnp/types.h:200-215) */
+    float initial_lambda, min_lambda, max_lambda, gradient_tol, step_tol;
+    int loss_type;
+    float loss_scale;
+    int optimize_focal_length, optimize_principal_point;
+    float f_low, f_high, cx_low, cx_high, cy_low, cy_high; /* CameraIntrinsics::GetBounds (types.h:156-192) */
+    float max_inlier_error;                               /* <= 0: no inlier pass */
+    int rounds_hint;                                      /* rounds enqueued before the first read-back (0 = default) */
+} pc_pnp_solve_options;
+typedef struct pc_pnp_solve_result {
+    pc_pnp_camera camera;
+    int iterations, invalid_steps;                        /* BundleStats (pnp/types.h:217-225) */
+    float initial_cost, cost, lambda, step_norm, grad_norm;
+    int inliers;                                          /* residuals below max_inlier_error (solvers.cc:31-47) */
+} pc_pnp_solve_result;
+int pc_pnp_solve(pc_context* ctx, pc_pnp_problem* prob, const pc_pnp_camera* initial, const pc_pnp_solve_options* options,
+                 pc_pnp_solve_result* result);
 /* LevMarqDenseSolver::TotalCost (lev_marq.h:316-356) and the inlier count of SolvePnPIterative
  * (cpp/pnp/solvers.cc:31-47) in one pass. */
 int pc_pnp_total_cost(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,

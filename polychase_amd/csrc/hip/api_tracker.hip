@@ -1,6 +1,7 @@
 // api_tracker.hip -- C ABI of the tracking and refinement paths: meshes + LBVH ray casting, PnP accumulation
 // (reference cpp/tracker.cc, cpp/pnp/*), and the refiner's per-edge sweeps (cpp/refiner.cc, cpp/pnp/lev_marq.h).
 #include "api_internal.hpp"
+#include "pnp_lm.hpp"
 
 using namespace pc_api;
 
@@ -41,6 +42,12 @@ struct pc_pnp_problem {
     float *partials = nullptr, *out = nullptr, *h_out = nullptr;
     DevBuf<float> own_X, own_x, own_w, own_partials, own_out;
     PinBuf<float> own_h_out;
+    // pc_pnp_solve: the solver's state on the device, its pinned mirror, partials of the inlier pass (own or the set's)
+    pc::LmState *lm_state = nullptr, *lm_host = nullptr;
+    float* lm_partials4 = nullptr;
+    DevBuf<pc::LmState> own_lm_state;
+    PinBuf<pc::LmState> own_lm_host;
+    DevBuf<float> own_lm_partials4;
 };
 
 // 3D-2D correspondences of the frame being solved (include/polychase_hip.h)
@@ -69,8 +76,10 @@ struct pc_corr_set {
     DevBuf<float2> uncached_kps;
     uint64_t clock = 0;
     // PnP scratch shared by the problems made from this set
-    DevBuf<float> partials, out;
+    DevBuf<float> partials, out, lm_partials4;
     PinBuf<float> h_out;
+    DevBuf<pc::LmState> lm_state;
+    PinBuf<pc::LmState> lm_host;
 };
 
 extern "C" {
@@ -242,6 +251,8 @@ int pc_corr_set_create(pc_context* ctx, pc_corr_set** out) {
     if (e == hipSuccess) e = s->h_counter.ensure(2);
     if (e == hipSuccess) e = s->out.ensure(64);
     if (e == hipSuccess) e = s->h_out.ensure(64);
+    if (e == hipSuccess) e = s->lm_state.ensure(1);
+    if (e == hipSuccess) e = s->lm_host.ensure(1);
     if (e == hipSuccess) e = hipMemsetAsync(s->counter.p, 0, 2 * sizeof(int), ctx->stream);
     if (e != hipSuccess) {
         pc_corr_set_destroy(s);
@@ -272,6 +283,9 @@ void pc_corr_set_destroy(pc_corr_set* s) {
     s->partials.release();
     s->out.release();
     s->h_out.release();
+    s->lm_partials4.release();
+    s->lm_state.release();
+    s->lm_host.release();
     delete s;
 }
 
@@ -394,6 +408,7 @@ int pc_pnp_problem_from_set(pc_context* ctx, pc_corr_set* s, pc_pnp_problem** ou
     if (rc != PC_OK) return rc;
     if (n < 1) return fail(PC_E_INVALID, "the correspondence set is empty");
     PC_HIP(s->partials.ensure((size_t)pc::pnp_num_blocks(n) * 56));
+    PC_HIP(s->lm_partials4.ensure((size_t)pc::pnp_num_blocks(n) * 4));
     pc_pnp_problem* p = new (std::nothrow) pc_pnp_problem();
     if (!p) return fail(PC_E_INVALID, "out of host memory");
     p->ctx = ctx;
@@ -403,6 +418,9 @@ int pc_pnp_problem_from_set(pc_context* ctx, pc_corr_set* s, pc_pnp_problem** ou
     p->partials = s->partials.p;
     p->out = s->out.p;
     p->h_out = s->h_out.p;
+    p->lm_state = s->lm_state.p;
+    p->lm_host = s->lm_host.p;
+    p->lm_partials4 = s->lm_partials4.p;
     *out = p;
     return PC_OK;
 }
@@ -455,6 +473,9 @@ void pc_pnp_problem_destroy(pc_pnp_problem* p) {
     p->own_partials.release();
     p->own_out.release();
     p->own_h_out.release();
+    p->own_lm_state.release();
+    p->own_lm_host.release();
+    p->own_lm_partials4.release();
     delete p;
 }
 
@@ -493,6 +514,97 @@ int pc_pnp_normal_equations_cost(pc_context* ctx, const pc_pnp_problem* prob, co
     std::memcpy(jtr9, prob->h_out + 45, 9 * sizeof(float));
     if (valid) *valid = (int)prob->h_out[54];
     if (cost) *cost = prob->h_out[55];
+    return PC_OK;
+}
+
+int pc_pnp_solve(pc_context* ctx, pc_pnp_problem* prob, const pc_pnp_camera* initial, const pc_pnp_solve_options* o,
+                 pc_pnp_solve_result* result) {
+    if (!ctx || !prob || !initial || !o || !result) return fail(PC_E_INVALID, "null argument");
+    if (o->loss_type < 0 || o->loss_type > 2) return fail(PC_E_INVALID, "Unknown loss type: %d", o->loss_type);
+    PC_HIP(hipSetDevice(ctx->device));
+    const int nb = pc::pnp_num_blocks(prob->n);
+    if (!prob->lm_state) {   // a stand-alone problem: its own solver scratch, on first use
+        PC_HIP(prob->own_lm_state.ensure(1));
+        PC_HIP(prob->own_lm_host.ensure(1));
+        PC_HIP(prob->own_lm_partials4.ensure((size_t)nb * 4));
+        prob->lm_state = prob->own_lm_state.p;
+        prob->lm_host = prob->own_lm_host.p;
+        prob->lm_partials4 = prob->own_lm_partials4.p;
+    }
+    pc::LmState& h = *prob->lm_host;
+    std::memset(&h, 0, sizeof(h));
+    h.cfg.max_iterations = o->max_iterations;
+    h.cfg.initial_lambda = o->initial_lambda;
+    h.cfg.min_lambda = o->min_lambda;
+    h.cfg.max_lambda = o->max_lambda;
+    h.cfg.gradient_tol = o->gradient_tol;
+    h.cfg.step_tol = o->step_tol;
+    h.cfg.f_low = o->f_low;
+    h.cfg.f_high = o->f_high;
+    h.cfg.cx_low = o->cx_low;
+    h.cfg.cx_high = o->cx_high;
+    h.cfg.cy_low = o->cy_low;
+    h.cfg.cy_high = o->cy_high;
+    h.cfg.optimize_focal = o->optimize_focal_length ? 1 : 0;
+    h.cfg.optimize_pp = o->optimize_principal_point ? 1 : 0;
+    h.cfg.loss_type = o->loss_type;
+    h.cfg.loss_scale = o->loss_scale;
+    h.cfg.max_inlier_err_sq = o->max_inlier_error > 0.0f ? o->max_inlier_error * o->max_inlier_error : 0.0f;
+    h.cam.qx = initial->q_xyzw[0];
+    h.cam.qy = initial->q_xyzw[1];
+    h.cam.qz = initial->q_xyzw[2];
+    h.cam.qw = initial->q_xyzw[3];
+    for (int i = 0; i < 3; i++) h.cam.t[i] = initial->t[i];
+    h.cam.fx = initial->fx;
+    h.cam.fy = initial->fy;
+    h.cam.cx = initial->cx;
+    h.cam.cy = initial->cy;
+    h.cam.aspect_ratio = initial->aspect_ratio;
+    h.cam.convention_opencv = initial->convention_opencv;
+    h.cam_new = h.cam;
+    h.lambda = o->initial_lambda;
+    h.v = 2.0f;
+    h.grad_norm = -1.0f;
+    h.step_norm = -1.0f;
+    h.rebuild = 1;
+    pc::lm_make_params(h.cam, h.cfg, &h.sweep);   // phase 0: evaluate the initial parameters
+    PC_HIP(hipMemcpyAsync(prob->lm_state, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+    // every round evaluates one parameter set; the first one is the initial set, Cholesky failures take no round
+    int rounds = o->rounds_hint > 0 ? o->rounds_hint : 13;
+    int enqueued = 0;
+    const int limit = o->max_iterations + 2;
+    const float* w = prob->has_weights ? prob->w : nullptr;
+    for (;;) {
+        rounds = std::max(1, std::min(rounds, limit - enqueued));
+        pc::launch_pnp_lm_rounds(prob->X, prob->x, w, prob->n, prob->lm_state, rounds, prob->partials, prob->lm_partials4,
+                                 prob->out + 56, ctx->stream);
+        enqueued += rounds;
+        PC_HIP(hipMemcpyAsync(&h, prob->lm_state, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        PC_HIP(hipMemcpyAsync(prob->h_out, prob->out + 56, 4 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        PC_HIP(hipStreamSynchronize(ctx->stream));
+        if (h.done) break;
+        if (enqueued >= limit) return fail(PC_E_STATE, "the PnP solver did not finish within %d rounds", enqueued);
+        rounds = 6;
+    }
+    result->camera.q_xyzw[0] = h.cam.qx;
+    result->camera.q_xyzw[1] = h.cam.qy;
+    result->camera.q_xyzw[2] = h.cam.qz;
+    result->camera.q_xyzw[3] = h.cam.qw;
+    for (int i = 0; i < 3; i++) result->camera.t[i] = h.cam.t[i];
+    result->camera.fx = h.cam.fx;
+    result->camera.fy = h.cam.fy;
+    result->camera.cx = h.cam.cx;
+    result->camera.cy = h.cam.cy;
+    result->camera.aspect_ratio = h.cam.aspect_ratio;
+    result->camera.convention_opencv = h.cam.convention_opencv;
+    result->iterations = h.iterations;
+    result->invalid_steps = h.invalid_steps;
+    result->initial_cost = h.initial_cost;
+    result->cost = h.cost;
+    result->lambda = h.lambda;
+    result->step_norm = h.step_norm;
+    result->grad_norm = h.grad_norm;
+    result->inliers = o->max_inlier_error > 0.0f ? (int)prob->h_out[2] : 0;
     return PC_OK;
 }
 

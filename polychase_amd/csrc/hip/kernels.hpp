@@ -121,6 +121,10 @@ int pnp_num_blocks(int n);
 // out56: [0..44] JtJ lower triangle (row-major packed), [45..53] Jtr, [54] valid residual count, [55] cost
 void launch_pnp_normal_eq(const float* X, const float* x, const float* w, int n, const PnPParams& p, float* partials,
                           float* out56, hipStream_t s);
+// device-resident LM (pnp_lm.hpp)
+struct LmState;
+void launch_pnp_lm_rounds(const float* X, const float* x, const float* w, int n, LmState* st, int iterations, float* partials,
+                          float* partials4, float* out4, hipStream_t s);
 // out4: [0] cost, [1] valid residuals, [2] inliers (r^2 < max_err_sq)
 void launch_pnp_cost(const float* X, const float* x, const float* w, int n, const PnPParams& p, float max_err_sq,
                      float* partials, float* out4, hipStream_t s);

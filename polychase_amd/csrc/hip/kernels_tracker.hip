@@ -8,6 +8,7 @@
 //        cpp/pnp/lev_marq.h:231-356), deterministic two-stage reduction.
 // fp32 throughout like the reference (Float = float, cpp/eigen_typedefs.h).
 #include "bvh.hpp"
+#include "pnp_lm.hpp"
 #include "kernels.hpp"
 
 namespace pc {
@@ -318,9 +319,9 @@ __device__ __forceinline__ void block_reduce(float (&v)[NV], float (*s_part)[NV]
         for (int k = 0; k < NV; k++) v[k] = (s_part[0][k] + s_part[1][k]) + (s_part[2][k] + s_part[3][k]);
 }
 
-__global__ __launch_bounds__(256) void pnp_normal_eq_kernel(const float* __restrict__ X, const float* __restrict__ x,
-                                                            const float* __restrict__ w, int n, PnPParams p,
-                                                            float* __restrict__ partials) {
+__device__ __forceinline__ void pnp_normal_eq_body(const float* __restrict__ X, const float* __restrict__ x,
+                                                   const float* __restrict__ w, int n, const PnPParams& p,
+                                                   float* __restrict__ partials) {
     __shared__ float s_part[4][PNP_ACC];
     float acc[PNP_ACC];
 #pragma unroll
@@ -377,13 +378,27 @@ __global__ __launch_bounds__(256) void pnp_normal_eq_kernel(const float* __restr
     block_reduce<PNP_ACC>(acc, s_part);
     if (threadIdx.x == 0)
 #pragma unroll
-        for (int k = 0; k < PNP_ACC; k++) partials[(size_t)blockIdx.x * PNP_ACC + k] = acc[k];
+        for (int k = 0; k < PNP_ACC; k++) partials[(size_t)k * gridDim.x + blockIdx.x] = acc[k];   // value-major: the second stage reads rows
+}
+
+__global__ __launch_bounds__(256) void pnp_normal_eq_kernel(const float* __restrict__ X, const float* __restrict__ x,
+                                                            const float* __restrict__ w, int n, PnPParams p,
+                                                            float* __restrict__ partials) {
+    pnp_normal_eq_body(X, x, w, n, p, partials);
+}
+// the same sweep for the device-resident solver: parameters from its state, nothing to do once it has finished
+__global__ __launch_bounds__(256) void pnp_normal_eq_lm_kernel(const float* __restrict__ X, const float* __restrict__ x,
+                                                               const float* __restrict__ w, int n,
+                                                               const LmState* __restrict__ st, float* __restrict__ partials) {
+    if (st->done) return;
+    const PnPParams p = st->sweep;
+    pnp_normal_eq_body(X, x, w, n, p, partials);
 }
 
 // cost (lev_marq.h:316-356) and inlier count (solvers.cc:31-47) in one pass: acc = {cost, valid, inliers, pad}
-__global__ __launch_bounds__(256) void pnp_cost_kernel(const float* __restrict__ X, const float* __restrict__ x,
-                                                       const float* __restrict__ w, int n, PnPParams p,
-                                                       float max_inlier_err_sq, float* __restrict__ partials) {
+__device__ __forceinline__ void pnp_cost_body(const float* __restrict__ X, const float* __restrict__ x,
+                                              const float* __restrict__ w, int n, const PnPParams& p,
+                                              float max_inlier_err_sq, float* __restrict__ partials) {
     __shared__ float s_part[4][4];
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -409,7 +424,48 @@ __global__ __launch_bounds__(256) void pnp_cost_kernel(const float* __restrict__
     block_reduce<4>(acc, s_part);
     if (threadIdx.x == 0)
 #pragma unroll
-        for (int k = 0; k < 4; k++) partials[(size_t)blockIdx.x * 4 + k] = acc[k];
+        for (int k = 0; k < 4; k++) partials[(size_t)k * gridDim.x + blockIdx.x] = acc[k];
+}
+
+__global__ __launch_bounds__(256) void pnp_cost_kernel(const float* __restrict__ X, const float* __restrict__ x,
+                                                       const float* __restrict__ w, int n, PnPParams p,
+                                                       float max_inlier_err_sq, float* __restrict__ partials) {
+    pnp_cost_body(X, x, w, n, p, max_inlier_err_sq, partials);
+}
+// inlier pass of the device-resident solver (on the accepted parameters; meaningful once the solver has finished)
+__global__ __launch_bounds__(256) void pnp_cost_lm_kernel(const float* __restrict__ X, const float* __restrict__ x,
+                                                          const float* __restrict__ w, int n, const LmState* __restrict__ st,
+                                                          float* __restrict__ partials) {
+    if (!st->done) return;
+    const PnPParams p = st->sweep;
+    pnp_cost_body(X, x, w, n, p, st->cfg.max_inlier_err_sq, partials);
+}
+// second reduction stage of a sweep + the decision step between two sweeps (pnp_lm.hpp): the 56 sums are formed like
+// in pnp_finalize_kernel (one wavefront per value, fixed order), then one lane runs the solver's 9x9 algebra on a copy
+// of the state in LDS
+__global__ __launch_bounds__(1024) void pnp_lm_reduce_consume_kernel(const float* __restrict__ partials, int nblocks,
+                                                                      LmState* __restrict__ st) {
+    __shared__ float s_out[PNP_ACC];
+    __shared__ LmState s_state;
+    if (st->done) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < PNP_ACC; k += 16) {
+        float s = 0.f;
+        for (int b = lane; b < nblocks; b += 64) s += partials[(size_t)k * nblocks + b];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+        if (lane == 0) s_out[k] = s;
+    }
+    constexpr int kWords = (int)(sizeof(LmState) / sizeof(uint32_t));
+    static_assert(sizeof(LmState) % sizeof(uint32_t) == 0, "LmState is copied word by word");
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(st);
+    uint32_t* cpy = reinterpret_cast<uint32_t*>(&s_state);
+    for (int i = threadIdx.x; i < kWords; i += blockDim.x) cpy[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) lm_consume(s_state, s_out);
+    __syncthreads();
+    uint32_t* dst = reinterpret_cast<uint32_t*>(st);
+    for (int i = threadIdx.x; i < kWords; i += blockDim.x) dst[i] = cpy[i];
 }
 
 // second stage: fixed-order sum of the per-block partials (deterministic run to run).  One wavefront per value:
@@ -420,11 +476,24 @@ __global__ __launch_bounds__(1024) void pnp_finalize_kernel(const float* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k = wave; k < nv; k += 16) {
         float s = 0.f;
-        for (int b = lane; b < nblocks; b += 64) s += partials[(size_t)b * nv + k];
+        for (int b = lane; b < nblocks; b += 64) s += partials[(size_t)k * nblocks + b];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
         if (lane == 0) out[k] = s;
     }
+}
+
+// `iterations` rounds of [sweep of the state's parameters, reduce, decide]; then the inlier pass (a no-op unless
+// the solver has finished) -- all enqueued without waiting
+void launch_pnp_lm_rounds(const float* X, const float* x, const float* w, int n, LmState* st, int iterations, float* partials,
+                          float* partials4, float* out4, hipStream_t s) {
+    const int nb = pnp_num_blocks(n);
+    for (int k = 0; k < iterations; k++) {
+        hipLaunchKernelGGL(pnp_normal_eq_lm_kernel, dim3(nb), dim3(256), 0, s, X, x, w, n, st, partials);
+        hipLaunchKernelGGL(pnp_lm_reduce_consume_kernel, dim3(1), dim3(1024), 0, s, partials, nb, st);
+    }
+    hipLaunchKernelGGL(pnp_cost_lm_kernel, dim3(nb), dim3(256), 0, s, X, x, w, n, st, partials4);
+    hipLaunchKernelGGL(pnp_finalize_kernel, dim3(1), dim3(1024), 0, s, partials4, nb, 4, out4);
 }
 
 int pnp_num_blocks(int n) {

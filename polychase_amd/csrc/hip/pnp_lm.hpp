@@ -1,0 +1,228 @@
+// pnp_lm.hpp -- LevMarqDenseSolver::Solve (reference cpp/pnp/lev_marq.h:132-228) + PnPProblem::Step
+// (cpp/pnp/pnp_problem.h:101-131) as a state machine that lives in device memory.
+//
+// The solver alternates residual sweeps (kernels over all correspondences) with a few hundred flops of 9x9
+// algebra that decide what to evaluate next.  Run from the host, every decision costs a launch, a read-back and
+// a stream synchronisation (~50 us) -- more than the sweep.  Here the decision step is a one-lane kernel
+// (lm_consume): the host enqueues [sweep, reduce, decide] a dozen times without waiting and reads the state
+// once; kernels enqueued past convergence see `done` and return at once.
+//
+// Arithmetic: fp32 like the reference, the same operation order as the former host loop.
+#pragma once
+
+#include <cmath>
+
+#include "kernels.hpp"
+
+#define PC_HD __host__ __device__ __forceinline__
+
+namespace pc {
+
+struct LmCamera {
+    float qx, qy, qz, qw;     // pose rotation, Eigen order
+    float t[3];
+    float fx, fy, cx, cy, aspect_ratio;
+    int convention_opencv;
+};
+
+struct LmConfig {
+    int max_iterations;
+    float initial_lambda, min_lambda, max_lambda, gradient_tol, step_tol;
+    float f_low, f_high, cx_low, cx_high, cy_low, cy_high;   // CameraIntrinsics::GetBounds (types.h:156-192)
+    int optimize_focal, optimize_pp, loss_type;
+    float loss_scale;
+    float max_inlier_err_sq;
+};
+
+struct LmState {
+    LmConfig cfg;
+    LmCamera cam, cam_new;
+    PnPParams sweep;          // the parameters the next sweep evaluates (the final ones once done)
+    float cur_lower[45], cur_Jtr[9];
+    float JtJ[81], diag[9], Jtr[9], step[9];
+    float cost, initial_cost, lambda, v, grad_norm, step_norm;
+    int iterations, invalid_steps, rebuild, phase, done;
+};
+
+PC_HD float lm_clamp(float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); }   // std::clamp
+
+// Eigen::Quaternion::toRotationMatrix + the intrinsics, as the sweep kernels want them
+PC_HD void lm_make_params(const LmCamera& c, const LmConfig& cfg, PnPParams* p) {
+    const float tx = 2 * c.qx, ty = 2 * c.qy, tz = 2 * c.qz;
+    const float twx = tx * c.qw, twy = ty * c.qw, twz = tz * c.qw;
+    const float txx = tx * c.qx, txy = ty * c.qx, txz = tz * c.qx;
+    const float tyy = ty * c.qy, tyz = tz * c.qy, tzz = tz * c.qz;
+    p->R[0] = 1 - (tyy + tzz); p->R[1] = txy - twz;       p->R[2] = txz + twy;
+    p->R[3] = txy + twz;       p->R[4] = 1 - (txx + tzz); p->R[5] = tyz - twx;
+    p->R[6] = txz - twy;       p->R[7] = tyz + twx;       p->R[8] = 1 - (txx + tyy);
+    for (int i = 0; i < 3; i++) p->t[i] = c.t[i];
+    p->fx = c.fx;
+    p->fy = c.fy;
+    p->cx = c.cx;
+    p->cy = c.cy;
+    p->aspect_ratio = c.aspect_ratio;
+    p->convention_opencv = c.convention_opencv;
+    p->optimize_focal = cfg.optimize_focal;
+    p->optimize_pp = cfg.optimize_pp;
+    p->loss_type = cfg.loss_type;
+    p->loss_scale = cfg.loss_scale;
+}
+
+// In-place lower Cholesky of a 9x9 row-major matrix, left-looking like Eigen's unblocked llt_inplace
+PC_HD bool lm_cholesky9(float* a) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        float x = a[k * 9 + k];
+        for (int j = 0; j < k; j++) x -= a[k * 9 + j] * a[k * 9 + j];
+        if (!(x > 0.0f)) return false;
+        x = sqrtf(x);
+        a[k * 9 + k] = x;
+        for (int i = k + 1; i < 9; i++) {
+            float s = a[i * 9 + k];
+            for (int j = 0; j < k; j++) s -= a[i * 9 + j] * a[k * 9 + j];
+            a[i * 9 + k] = s / x;
+        }
+    }
+    return true;
+}
+PC_HD void lm_cholesky9_solve(const float* l, const float* b, float* x) {
+    float y[9];
+    for (int i = 0; i < 9; i++) {
+        float s = b[i];
+        for (int j = 0; j < i; j++) s -= l[i * 9 + j] * y[j];
+        y[i] = s / l[i * 9 + i];
+    }
+    for (int i = 8; i >= 0; i--) {
+        float s = y[i];
+        for (int j = i + 1; j < 9; j++) s -= l[j * 9 + i] * x[j];
+        x[i] = s / l[i * 9 + i];
+    }
+}
+
+// PnPProblem::Step (pnp_problem.h:101-131): q <- q * AngleAxis(step[0..2]), t += step[3..5], clamped intrinsics
+PC_HD void lm_step_camera(const LmCamera& c, const float* step, const LmConfig& cfg, LmCamera* out) {
+    *out = c;
+    const float angle = sqrtf(step[0] * step[0] + step[1] * step[1] + step[2] * step[2]);
+    if (angle > 0) {   // QuatStepPost (cpp/pnp/quaternion.h:11-20)
+        const float inv = 1.0f / angle;
+        const float ax = step[0] * inv, ay = step[1] * inv, az = step[2] * inv;
+        const float s = sinf(0.5f * angle), co = cosf(0.5f * angle);
+        const float bx = ax * s, by = ay * s, bz = az * s, bw = co;
+        out->qx = c.qw * bx + c.qx * bw + c.qy * bz - c.qz * by;
+        out->qy = c.qw * by + c.qy * bw + c.qz * bx - c.qx * bz;
+        out->qz = c.qw * bz + c.qz * bw + c.qx * by - c.qy * bx;
+        out->qw = c.qw * bw - c.qx * bx - c.qy * by - c.qz * bz;
+    }
+    for (int i = 0; i < 3; i++) out->t[i] = c.t[i] + step[3 + i];
+    if (cfg.optimize_focal) {
+        out->fy = c.fy + step[6];
+        out->fx = out->fy * out->aspect_ratio;
+        out->fy = lm_clamp(out->fy, cfg.f_low, cfg.f_high);
+        out->fx = lm_clamp(out->fx, cfg.f_low, cfg.f_high);
+    }
+    if (cfg.optimize_pp) {
+        out->cx = lm_clamp(c.cx + step[7], cfg.cx_low, cfg.cx_high);
+        out->cy = lm_clamp(c.cy + step[8], cfg.cy_low, cfg.cy_high);
+    }
+}
+
+PC_HD void lm_finish(LmState& s) {
+    s.done = 1;
+    lm_make_params(s.cam, s.cfg, &s.sweep);   // the inlier pass runs on the accepted parameters
+}
+
+// The top of the solver's loop (lev_marq.h:146-181) up to the point where a candidate has to be evaluated:
+// leaves cam_new / sweep set and phase = 1, or finishes.
+PC_HD void lm_advance(LmState& s) {
+    while (s.iterations < s.cfg.max_iterations) {
+        if (s.rebuild) {
+            int o = 0;
+            for (int a = 0; a < 9; a++)
+                for (int b = 0; b <= a; b++) s.JtJ[9 * a + b] = s.cur_lower[o++];
+            for (int a = 0; a < 9; a++) s.Jtr[a] = s.cur_Jtr[a];
+            // JtJ_diag = diag.cwiseMax(1e-6).cwiseMin(1e32)  (:296)
+            for (int a = 0; a < 9; a++) s.diag[a] = fminf(fmaxf(s.JtJ[10 * a], 1e-6f), 1e32f);
+            float g2 = 0;
+            for (int a = 0; a < 9; a++) g2 += s.Jtr[a] * s.Jtr[a];
+            s.grad_norm = sqrtf(g2);
+            if (s.grad_norm < s.cfg.gradient_tol) break;
+        }
+        // ComputeStep (:299-314): multiplicative damping, LLT of the lower triangle
+        float L[81];
+        for (int a = 0; a < 9; a++)
+            for (int b = 0; b <= a; b++) L[9 * a + b] = s.JtJ[9 * a + b];
+        for (int a = 0; a < 9; a++) L[10 * a] = s.diag[a] * (1.0f + s.lambda);
+        for (int a = 0; a < 9; a++) s.JtJ[10 * a] = s.diag[a];  // "remove dampening" leaves the clamped diagonal
+        if (!lm_cholesky9(L)) {
+            s.invalid_steps++;
+            if (s.lambda == s.cfg.max_lambda) break;
+            s.lambda = fminf(s.cfg.max_lambda, s.lambda * s.v);
+            s.v = 2 * s.v;
+            s.rebuild = 0;
+            s.iterations++;
+            continue;
+        }
+        lm_cholesky9_solve(L, s.Jtr, s.step);
+        for (int a = 0; a < 9; a++) s.step[a] = -s.step[a];
+        float s2 = 0;
+        for (int a = 0; a < 9; a++) s2 += s.step[a] * s.step[a];
+        s.step_norm = sqrtf(s2);
+        if (s.step_norm < s.cfg.step_tol) break;
+        lm_step_camera(s.cam, s.step, s.cfg, &s.cam_new);
+        lm_make_params(s.cam_new, s.cfg, &s.sweep);
+        s.phase = 1;
+        return;   // evaluate cam_new
+    }
+    lm_finish(s);
+}
+
+// out56 = the sweep of s.sweep: [0..44] JtJ lower, [45..53] Jtr, [54] valid, [55] cost
+PC_HD void lm_consume(LmState& s, const float* out56) {
+    if (s.done) return;
+    if (s.phase == 0) {   // the initial parameters (lev_marq.h:139-144)
+        for (int k = 0; k < 45; k++) s.cur_lower[k] = out56[k];
+        for (int k = 0; k < 9; k++) s.cur_Jtr[k] = out56[45 + k];
+        s.cost = out56[55];
+        s.initial_cost = s.cost;
+        s.rebuild = 1;
+        lm_advance(s);
+        return;
+    }
+    const float cost_new = out56[55];
+    if (cost_new < s.cost) {
+        const float actual = cost_new - s.cost;
+        // step^T (2 Jtr + JtJ_sym step)   (:183-186), fp32 like the reference
+        float expected = 0;
+        for (int a = 0; a < 9; a++) {
+            float row = 0;
+            for (int b = 0; b < 9; b++) row += (b <= a ? s.JtJ[9 * a + b] : s.JtJ[9 * b + a]) * s.step[b];
+            expected += s.step[a] * (2.0f * s.Jtr[a] + row);
+        }
+        const float rho = actual / expected;
+        if (rho > 0) {  // ill-conditioned JtJ can make `expected` positive (:189-197)
+            const double d = 2.0 * (double)rho - 1.0;
+            const double f = 1.0 - d * d * d;
+            const double factor = f > 1.0 / 3.0 ? f : 1.0 / 3.0;
+            s.lambda = lm_clamp((float)((double)s.lambda * factor), s.cfg.min_lambda, s.cfg.max_lambda);
+        }
+        s.cam = s.cam_new;
+        for (int k = 0; k < 45; k++) s.cur_lower[k] = out56[k];
+        for (int k = 0; k < 9; k++) s.cur_Jtr[k] = out56[45 + k];
+        s.cost = cost_new;
+        s.v = 2;
+        s.rebuild = 1;
+    } else {
+        s.invalid_steps++;
+        if (s.lambda == s.cfg.max_lambda) {
+            lm_finish(s);
+            return;
+        }
+        s.lambda = fminf(s.cfg.max_lambda, s.lambda * s.v);
+        s.v = 2 * s.v;
+        s.rebuild = 0;
+    }
+    s.iterations++;
+    lm_advance(s);
+}
+
+}  // namespace pc

@@ -4,6 +4,7 @@
 #include "pnp.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "gpu_context.h"
@@ -70,6 +71,69 @@ void SolvePnPIterativeOnGpu(pc_pnp_problem* problem, size_t n, const PnPOptions&
         pc_context* ctx;
         pc_pnp_problem* prob;
     } gp{SharedGpuContext(), problem};
+
+    // The solver runs on the device (pc_pnp_solve: the LM state lives in device memory, a one-lane kernel takes the
+    // decisions between the residual sweeps).  POLYCHASE_PNP_HOST_LM=1 runs the same loop on the host instead,
+    // one read-back per sweep -- the cross-check of the device state machine.
+    const char* host_lm_env = std::getenv("POLYCHASE_PNP_HOST_LM");   // read per call: the tests flip it
+    const bool host_lm = host_lm_env && host_lm_env[0] == '1';
+    if (!host_lm) {
+        pc_pnp_camera init;
+        const CameraState& c0 = result.camera;
+        init.q_xyzw[0] = c0.pose.q.x;
+        init.q_xyzw[1] = c0.pose.q.y;
+        init.q_xyzw[2] = c0.pose.q.z;
+        init.q_xyzw[3] = c0.pose.q.w;
+        for (int i = 0; i < 3; i++) init.t[i] = c0.pose.t[i];
+        init.fx = c0.intrinsics.fx;
+        init.fy = c0.intrinsics.fy;
+        init.cx = c0.intrinsics.cx;
+        init.cy = c0.intrinsics.cy;
+        init.aspect_ratio = c0.intrinsics.aspect_ratio;
+        init.convention_opencv = c0.intrinsics.convention == CameraConvention::OpenCV ? 1 : 0;
+        pc_pnp_solve_options so;
+        so.max_iterations = static_cast<int>(bo.max_iterations);
+        so.initial_lambda = bo.initial_lambda;
+        so.min_lambda = bo.min_lambda;
+        so.max_lambda = bo.max_lambda;
+        so.gradient_tol = bo.gradient_tol;
+        so.step_tol = bo.step_tol;
+        so.loss_type = lt;
+        so.loss_scale = bo.loss_scale;
+        so.optimize_focal_length = opt_f ? 1 : 0;
+        so.optimize_principal_point = opt_pp ? 1 : 0;
+        so.f_low = bounds.f_low;
+        so.f_high = bounds.f_high;
+        so.cx_low = bounds.cx_low;
+        so.cx_high = bounds.cx_high;
+        so.cy_low = bounds.cy_low;
+        so.cy_high = bounds.cy_high;
+        so.max_inlier_error = opts.max_inlier_error;
+        so.rounds_hint = 0;
+        pc_pnp_solve_result sr;
+        if (pc_pnp_solve(gp.ctx, gp.prob, &init, &so, &sr) != PC_OK) ThrowHip("pc_pnp_solve");
+        CameraState& c = result.camera;
+        c.pose.q.x = sr.camera.q_xyzw[0];
+        c.pose.q.y = sr.camera.q_xyzw[1];
+        c.pose.q.z = sr.camera.q_xyzw[2];
+        c.pose.q.w = sr.camera.q_xyzw[3];
+        for (int i = 0; i < 3; i++) c.pose.t[i] = sr.camera.t[i];
+        c.intrinsics.fx = sr.camera.fx;
+        c.intrinsics.fy = sr.camera.fy;
+        c.intrinsics.cx = sr.camera.cx;
+        c.intrinsics.cy = sr.camera.cy;
+        BundleStats st;
+        st.iterations = static_cast<size_t>(sr.iterations);
+        st.invalid_steps = static_cast<size_t>(sr.invalid_steps);
+        st.initial_cost = sr.initial_cost;
+        st.cost = sr.cost;
+        st.lambda = sr.lambda;
+        st.step_norm = sr.step_norm;
+        st.grad_norm = sr.grad_norm;
+        result.bundle_stats = st;
+        result.inlier_ratio = static_cast<Float>(sr.inliers) / static_cast<Float>(n);
+        return;
+    }
 
     Params params{result.camera, result.camera.pose.R()};
     Params params_new = params;

@@ -290,6 +290,49 @@ def test_device_built_correspondences_equal_the_reference_loop(core, tmp_path):
     assert np.array_equal(got_w.view(np.uint32), want_w.view(np.uint32))
 
 
+@pytest.mark.parametrize("loss,opt_f,opt_pp", [("Cauchy", False, False), ("Huber", True, True), ("Trivial", True, False)])
+def test_device_resident_lm_equals_the_host_driven_loop(core, monkeypatch, loss, opt_f, opt_pp):
+    """pc_pnp_solve keeps the LM state on the GPU and decides between sweeps in a one-lane kernel; with
+    POLYCHASE_PNP_HOST_LM=1 the same loop runs on the host with one read-back per sweep.  Same algorithm, same fp32
+    operations (only sin/cos of the rotation step and one cube come from different libraries): the trajectories of
+    the two solvers agree step for step."""
+    rng = np.random.default_rng(17)
+    verts, tris = grid_mesh()
+    R, t = true_pose(5)
+    cam = ocam(R, t)
+    Xw = rng.uniform([-2, -2, -0.3], [2, 2, 0.3], (4000, 3))
+    x, Z = cam.project_world(Xw)
+    ok = Z[:, 2] < 0
+    Xw, x = Xw[ok], x[ok] + rng.normal(0, 0.4, (ok.sum(), 2))
+    x[::37] += rng.uniform(-80, 80, x[::37].shape)                      # outliers for the robust losses
+    init = core.CameraState()
+    init.intrinsics = intr(core)
+    if opt_f:
+        k = init.intrinsics
+        init.intrinsics = core.CameraIntrinsics(fx=k.fx * 1.02, fy=k.fy * 1.02, cx=k.cx + 3, cy=k.cy - 2, aspect_ratio=1.0,
+                                                width=W, height=H, convention=core.CameraConvention.OpenGL)
+    p = core.Pose()
+    R0 = rot([0.3, 1, 0.2], 0.02) @ R
+    p.q, p.t = po.R_to_quat(R0).astype(np.float32), (t + [0.05, -0.04, 0.1]).astype(np.float32)
+    init.pose = p
+    bo = core.BundleOptions()
+    bo.loss_type = getattr(core.LossType, loss)
+    bo.loss_scale = 1.5
+    args = (Xw.astype(np.float32), x.astype(np.float32), init, bo, 12.0, opt_f, opt_pp)
+    monkeypatch.delenv("POLYCHASE_PNP_HOST_LM", raising=False)
+    dev = core._solve_pnp_iterative(*args)
+    monkeypatch.setenv("POLYCHASE_PNP_HOST_LM", "1")
+    host = core._solve_pnp_iterative(*args)
+    sd, sh = dev.bundle_stats, host.bundle_stats
+    assert sd.iterations == sh.iterations and sd.invalid_steps == sh.invalid_steps and sd.iterations >= 4
+    assert sd.initial_cost == sh.initial_cost                          # the first sweep is the same kernel on the same input
+    assert abs(sd.cost - sh.cost) <= 1e-5 * abs(sh.cost)
+    assert np.allclose(np.array(dev.camera.pose.q), np.array(host.camera.pose.q), atol=2e-6)
+    assert np.allclose(np.array(dev.camera.pose.t), np.array(host.camera.pose.t), atol=2e-5)
+    assert abs(dev.camera.intrinsics.fy - host.camera.intrinsics.fy) <= 1e-4 * abs(host.camera.intrinsics.fy)
+    assert dev.inlier_ratio == host.inlier_ratio
+
+
 def test_tracker_thread_protocol_and_errors(core, tmp_path):
     import time
     verts, tris = grid_mesh()
