@@ -157,7 +157,9 @@ def main():
     if dist_path:
         # device-resident record log: the stitch all-gathers these bytes, no host copy of the payload
         from polychase_amd import distributed as D
-        max_kp = int(1.5 * max(n_kps + [1024])) + 4096
+        # capacity per record: 1.5x the keypoints seen in the warm-up; without a warm-up the densest packing the
+        # 5-px minimum distance allows (one keypoint per ~21.6 px^2)
+        max_kp = (int(1.5 * max(n_kps)) if n_kps else w * h // 20) + 4096
         log = torch.empty(D.log_capacity_bytes(K + 2, max_kp), dtype=torch.uint8, device=dev)
         an.an.set_device_log(log)
         # sizes of the log pieces are agreed on over gloo so that the exchange never waits for an RCCL transfer
