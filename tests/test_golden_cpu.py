@@ -26,3 +26,24 @@ def test_oracle_reproduces_golden_vectors():
         assert np.array_equal(st, G[f"lk_status_{k}"])
         assert np.array_equal(xy.view(np.uint32), G[f"lk_xy_{k}"].view(np.uint32))
         assert np.array_equal(err.view(np.uint32), G[f"lk_err_{k}"].view(np.uint32))
+
+
+def test_pnp_oracle_reproduces_golden_vector():
+    """tests/golden/pnp_small.npz (make_pnp_fixture.py): the float64 restatement of SolvePnPIterative on a frozen
+    problem.  float64 numpy on another machine may differ in the last bits: 1e-9 is far below anything the GPU
+    comparison (1e-4) could notice, far above such noise."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pnp_oracle as po
+
+    P = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pnp_small.npz"))
+    fx, fy, cx, cy, ar, w, h = P["intrinsics"]
+    init = po.Camera(fx=fx, fy=fy, cx=cx, cy=cy, aspect_ratio=ar, width=w, height=h, opencv=False, q=P["init_q_wxyz"],
+                     t=P["init_t"])
+    for kind in ("trivial", "huber", "cauchy"):
+        cam, st = po.solve_pnp(P["X"], P["x"], init, kind=kind, scale=1.5)
+        assert np.allclose(cam.q, P[f"{kind}_q_wxyz"], atol=1e-9, rtol=0)
+        assert np.allclose(cam.t, P[f"{kind}_t"], atol=1e-9, rtol=0)
+        want = P[f"{kind}_stats"]
+        assert abs(st["cost"] - want[1]) <= 1e-9 * want[1] and st["iterations"] == int(want[2])
+        assert st["inlier_ratio"] == want[3]

@@ -333,6 +333,31 @@ def test_device_resident_lm_equals_the_host_driven_loop(core, monkeypatch, loss,
     assert dev.inlier_ratio == host.inlier_ratio
 
 
+@pytest.mark.parametrize("loss", ["Trivial", "Huber", "Cauchy"])
+def test_pnp_against_the_committed_golden_vector(core, loss):
+    """tests/golden/pnp_small.npz: frozen inputs + the float64 restatement's result (committed, so the target cannot
+    drift with the oracle).  Rotation <= 1e-4 rad, translation <= 1e-4 |t|."""
+    P = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pnp_small.npz"))
+    fx, fy, cx, cy, ar, w, h = (float(v) for v in P["intrinsics"])
+    init = core.CameraState()
+    init.intrinsics = core.CameraIntrinsics(fx=fx, fy=fy, cx=cx, cy=cy, aspect_ratio=ar, width=w, height=h,
+                                            convention=core.CameraConvention.OpenGL)
+    p = core.Pose()
+    p.q, p.t = P["init_q_wxyz"].astype(np.float32), P["init_t"].astype(np.float32)
+    init.pose = p
+    bo = core.BundleOptions()
+    bo.loss_type = getattr(core.LossType, loss)
+    bo.loss_scale = 1.5
+    res = core._solve_pnp_iterative(P["X"], P["x"], init, bo, 12.0, False, False)
+    kind = loss.lower()
+    Rw, tw = po.quat_to_R(P[f"{kind}_q_wxyz"]), P[f"{kind}_t"]
+    assert _angle(po.quat_to_R(np.array(res.camera.pose.q, float)), Rw) <= 1e-4
+    assert np.linalg.norm(np.array(res.camera.pose.t, float) - tw) <= 1e-4 * np.linalg.norm(tw)
+    want = P[f"{kind}_stats"]
+    assert abs(res.bundle_stats.cost - want[1]) <= 1e-3 * want[1]
+    assert abs(res.inlier_ratio - want[3]) <= 1.0 / len(P["X"]) + 1e-6
+
+
 def test_tracker_thread_protocol_and_errors(core, tmp_path):
     import time
     verts, tris = grid_mesh()
