@@ -166,7 +166,10 @@ Segment LoadSegment(const std::string& database_path, const CameraTrajectory& tr
     std::vector<std::exception_ptr> errors(static_cast<size_t>(n_threads));
     // opened one after the other: Open() issues pragmas and CREATE TABLE IF NOT EXISTS, which take the write lock
     std::vector<std::unique_ptr<Database>> connections;
-    for (int t = 0; t < n_threads; t++) connections.push_back(std::make_unique<Database>(database_path));
+    {
+        StageClock::Scope sc("refine/load: open connections");
+        for (int t = 0; t < n_threads; t++) connections.push_back(std::make_unique<Database>(database_path));
+    }
     auto work = [&](int t) {
         try {
             const Database& db = *connections[static_cast<size_t>(t)];
@@ -178,6 +181,7 @@ Segment LoadSegment(const std::string& database_path, const CameraTrajectory& tr
         }
     };
     {
+        StageClock::Scope sc("refine/load: parallel read");
         std::vector<std::thread> threads;
         for (int t = 1; t < n_threads; t++) threads.emplace_back(work, t);
         work(0);
@@ -190,6 +194,7 @@ Segment LoadSegment(const std::string& database_path, const CameraTrajectory& tr
         return std::move(parts[0]);
     }
     // join: sizes first, then every thread copies its part to its place
+    StageClock::Scope sc_join("refine/load: join parts");
     Segment seg;
     seg.first_frame = traj.FirstFrame();
     seg.n_frames = n;
