@@ -185,6 +185,24 @@ def test_refiner_thread_protocol_cancel_and_errors(core, tmp_path):
         core.refine_trajectory(sc["path"], short, model, mesh, False, False, None, _opts(core))
 
 
+def test_reader_thread_count_does_not_change_the_result(core, tmp_path, monkeypatch):
+    """The segment is loaded by several read connections (POLYCHASE_DB_READERS) and joined in frame order: the
+    system the GPU sees, and therefore the refined trajectory, is identical for 1, 3 and 8 readers."""
+    sc = _scene(core, tmp_path, n=40, noise=0.1, n_kp=200, seed=5, model=np.eye(4), rate=0.3)
+    mesh = core.AcceleratedMesh(sc["verts"], sc["tris"])
+    results = []
+    for readers in ("1", "3", "8"):
+        monkeypatch.setenv("POLYCHASE_DB_READERS", readers)
+        traj = S.to_core_trajectory(core, sc["cams"], 1)
+        sysm = core._refinement_system(sc["path"], traj, np.eye(4, dtype=np.float32), mesh, False, False, _opts(core))
+        core.refine_trajectory(sc["path"], traj, np.eye(4, dtype=np.float32), mesh, False, False, None, _opts(core, max_iterations=10))
+        poses = np.array([np.concatenate([np.array(traj.get(f).pose.q), np.array(traj.get(f).pose.t)]) for f in range(1, 41)])
+        results.append((sysm["num_edges"], sysm["num_keypoints"], sysm["num_residuals"], float(sysm["cost"]), poses))
+    for r in results[1:]:
+        assert r[:4] == results[0][:4]
+        assert np.array_equal(r[4], results[0][4])
+
+
 def test_refine_a_long_segment(core, tmp_path):
     """120 frames x 400 keypoints: ~0.3M residuals per sweep, block-banded system of 720 unknowns."""
     sc = _scene(core, tmp_path, n=120, noise=0.1, n_kp=400, seed=11, model=np.eye(4), rate=0.2)

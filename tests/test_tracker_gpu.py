@@ -358,6 +358,38 @@ def test_pnp_against_the_committed_golden_vector(core, loss):
     assert abs(res.inlier_ratio - want[3]) <= 1.0 / len(P["X"]) + 1e-6
 
 
+def test_read_ahead_does_not_change_the_poses(core, tmp_path, monkeypatch):
+    """The tracker reads the next frame's blobs ahead on a second connection (POLYCHASE_TRACK_PREFETCH=0 switches
+    that off): same database, same poses bit for bit, forward and backward."""
+    verts, tris = grid_mesh()
+    model = np.diag([1.5, 1.5, 1.5, 1.0]).astype(np.float32)
+    n_frames = 20
+    path = str(tmp_path / "flow.db")
+    _build_flow_db(core, path, verts, tris, model, n_frames, noise=0.05)
+    mesh = core.AcceleratedMesh(verts, tris)
+    bo = core.BundleOptions()
+    bo.loss_type = core.LossType.Cauchy
+
+    def run(a, b):
+        R0, t0 = true_pose(a)
+        st = core.SceneTransformations(model, view4(R0, t0), intr(core))
+        got = {}
+        core.track_sequence(path, a, b, st, mesh,
+                            lambda r: got.update({r.frame: (np.array(r.pose.q), np.array(r.pose.t), r.inlier_ratio,
+                                                            r.bundle_stats.iterations)}) or True, False, False, bo)
+        return got
+
+    for a, b in ((1, n_frames), (n_frames, 1)):
+        monkeypatch.delenv("POLYCHASE_TRACK_PREFETCH", raising=False)
+        ahead = run(a, b)
+        monkeypatch.setenv("POLYCHASE_TRACK_PREFETCH", "0")
+        plain = run(a, b)
+        assert sorted(ahead) == sorted(plain) and len(ahead) == n_frames - 1
+        for f in ahead:
+            assert np.array_equal(ahead[f][0], plain[f][0]) and np.array_equal(ahead[f][1], plain[f][1]), f
+            assert ahead[f][2:] == plain[f][2:], f
+
+
 def test_tracker_thread_protocol_and_errors(core, tmp_path):
     import time
     verts, tris = grid_mesh()
