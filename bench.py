@@ -171,6 +171,9 @@ def main():
                 print(f"[bench] gloo side group unavailable ({e}); exchanging piece sizes over RCCL", file=sys.stderr)
         stitch = D.ChunkedLogStitch(log, side_group=side)
         stitch.warm_up()
+        # receive buffers of the pieces, allocated before the timed region
+        piece_frames = max(1, K // 8)
+        stitch.reserve((K + piece_frames - 1) // piece_frames + 1, D.log_capacity_bytes(piece_frames + 1, max_kp))
     n_kps.clear()
     n_rows.clear()
     barrier()

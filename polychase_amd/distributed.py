@@ -165,6 +165,17 @@ class ChunkedLogStitch:
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.world = self.dist.get_world_size(group) if self.dist else 1
         self.pieces = []   # (gathered [world, padded] uint8, sizes [world])
+        self._pool = []    # receive buffers allocated ahead of the timed region (reserve)
+
+    def reserve(self, n_pieces: int, max_piece_bytes: int):
+        """Allocates the receive buffers of the next `n_pieces` gathers now (world x max_piece_bytes each): a fresh
+        allocation of half a gigabyte inside the timed region is a hipMalloc that stalls the device."""
+        import torch
+
+        if self.world == 1:
+            return
+        mx = max(16, (int(max_piece_bytes) + 15) // 16 * 16)
+        self._pool = [torch.empty(self.world * mx, dtype=torch.uint8, device=self.log.device) for _ in range(n_pieces)]
 
     def warm_up(self):
         """One tiny exchange per group before anything is timed: the first collective of a communicator sets up its
@@ -206,7 +217,10 @@ class ChunkedLogStitch:
         mx = max(16, (max(sizes) + 15) // 16 * 16)
         if start + mx > self.log.numel():
             raise RuntimeError("device log has no slack for the padded piece")
-        out = torch.empty((self.world, mx), dtype=torch.uint8, device=self.log.device)
+        if self._pool and self._pool[-1].numel() >= self.world * mx:
+            out = self._pool.pop()[: self.world * mx].view(self.world, mx)
+        else:
+            out = torch.empty((self.world, mx), dtype=torch.uint8, device=self.log.device)
         # bytes past `end` may still be written by the next frames: they are padding, never parsed
         piece = self.log[start:start + mx]
         if dist.get_backend(self.group) == "nccl":

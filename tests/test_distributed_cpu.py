@@ -121,6 +121,7 @@ def _stitch_worker(rank, world, port, first, n, out_dir, use_side):
     log[:len(log_np)] = torch.from_numpy(log_np)
     st = D.ChunkedLogStitch(log, side_group=side)
     st.warm_up()
+    st.reserve(2, 1 << 15)                                         # two pooled receive buffers, the rest allocated on demand
     per = 3                                                        # frames per piece (the last piece is ragged)
     n_pieces = (max(D.shard_range(first, n, world, r)[1] - D.shard_range(first, n, world, r)[0] for r in range(world)) + per - 1) // per
     for c in range(n_pieces):                                      # every rank issues the same number of collectives
