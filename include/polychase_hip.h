@@ -84,6 +84,12 @@ int pc_context_enable_timing(pc_context* ctx, int class_mask);
 int pc_context_get_timing(pc_context* ctx, int kernel_class, int* launches, double* total_ms);
 int pc_context_get_busy_time(pc_context* ctx, int kernel_class, double* busy_ms);
 int pc_context_reset_timing(pc_context* ctx);
+/* Diagnostics of the LK kernel (only a library compiled with -DPC_LK_PROFILE counts anything; otherwise all zeros):
+ * shader-clock cycles summed over the wavefronts of the latest launch, per phase --
+ * [0] I-side staging, [1] I-side evaluation + 2x2 system, [2] patch pick-up, [3] J-region staging, [4] iterations,
+ * [5] error pass, [6] wavefront life time, [7] wavefronts, [8] wavefront-iterations, [9] region stagings. */
+#define PC_LK_PROFILE_SLOTS 16
+int pc_debug_lk_profile(pc_context* ctx, unsigned long long* out /* [PC_LK_PROFILE_SLOTS] */);
 #define PC_K_GRAY 0
 #define PC_K_PYRAMID 1
 #define PC_K_MINEIG 2

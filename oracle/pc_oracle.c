@@ -417,6 +417,15 @@ const int16_t* pco_pyramid_deriv(const pco_pyramid* p, int level) { return p->de
 static inline int cv_round_f(float v) { return (int)lrintf(v); }
 static inline int cv_floor_f(float v) { return (int)floorf(v); }
 
+/* Optional diagnostic: iterations executed per (point, level), for scheduling studies of the GPU
+ * kernel (tools/lk_divergence.py).  Not thread safe; NULL (default) disables it. */
+static uint8_t* g_iter_trace = NULL;
+static int g_iter_trace_levels = 0;
+void pco_set_lk_iter_trace(uint8_t* buf, int levels) {
+    g_iter_trace = buf;
+    g_iter_trace_levels = levels;
+}
+
 static void lk_range(const pco_pyramid* P, const pco_pyramid* N, const float* pts, int i0, int i1,
                      int max_level, int max_iters, double eps_sq, float min_eig_thr,
                      float* next_pts, uint8_t* status, float* err) {
@@ -511,6 +520,8 @@ static void lk_range(const pco_pyramid* P, const pco_pyramid* N, const float* pt
                     if (level == 0) status[pt] = 0;
                     break;
                 }
+                if (g_iter_trace && level < g_iter_trace_levels)
+                    g_iter_trace[(size_t)pt * g_iter_trace_levels + level] = (uint8_t)(j + 1);
                 a = qx - (float)iqx;
                 b = qy - (float)iqy;
                 iw00 = cv_round_f((1.f - a) * (1.f - b) * (float)(1 << W_BITS));

@@ -111,6 +111,10 @@ int pco_analyze_clip(const uint8_t* const* frames, int n_frames, int w, int h, i
                      const pco_flow_options* fopt, int threads, int feature_threads,
                      pco_record_cb cb, void* user);
 
+/* Diagnostic only: when buf != NULL, pco_lk records the iterations it ran for (point, level) at
+ * buf[point * levels + level] (0 = level skipped).  Single-threaded callers only. */
+void pco_set_lk_iter_trace(uint8_t* buf, int levels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ LIB_DIR = os.path.join(PKG, "lib")
 OBJ_DIR = os.path.join(PKG, "lib", "obj")
 HIP_DIR = os.path.join(PKG, "csrc", "hip")
 
-HIP_SOURCES = ["kernels_image.hip", "kernels_gftt.hip", "kernels_lk.hip", "kernels_lk2.hip", "kernels_tracker.hip", "kernels_refiner.hip", "kernels_bvh.hip", "api.hip", "api_analyzer.hip", "api_tracker.hip"]
+HIP_SOURCES = ["kernels_image.hip", "kernels_gftt.hip", "kernels_lk.hip", "kernels_lk2.hip", "kernels_lk3.hip", "kernels_tracker.hip", "kernels_refiner.hip", "kernels_bvh.hip", "api.hip", "api_analyzer.hip", "api_tracker.hip"]
 # -ffp-contract=off: the float stages must match the oracle bit-for-bit (no FMA fusion).
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
              "-Wno-unused-function"]
@@ -37,14 +37,35 @@ def _run(cmd: list[str]) -> None:
 
 
 def hip_library_path() -> str:
-    return os.path.join(LIB_DIR, "libpolychase_hip.so")
+    # POLYCHASE_HIP_LIB: an alternative build of the same C ABI (tools/lk_variants.py compares kernel variants)
+    return os.environ.get("POLYCHASE_HIP_LIB") or os.path.join(LIB_DIR, "libpolychase_hip.so")
+
+
+def build_hip_variant(tag: str, extra_flags: list[str]) -> str:
+    """lib/variants/libpolychase_hip_<tag>.so: the same sources compiled with extra -D flags (experiments only)."""
+    vdir = os.path.join(LIB_DIR, "variants")
+    odir = os.path.join(LIB_DIR, "obj_" + tag)
+    os.makedirs(vdir, exist_ok=True)
+    os.makedirs(odir, exist_ok=True)
+    out = os.path.join(vdir, f"libpolychase_hip_{tag}.so")
+    srcs = [os.path.join(HIP_DIR, s) for s in HIP_SOURCES]
+    objs = [os.path.join(odir, os.path.splitext(s)[0] + ".o") for s in HIP_SOURCES]
+
+    def compile_one(pair):
+        src, obj = pair
+        _run(["hipcc", *HIP_FLAGS, *extra_flags, "-c", src, "-o", obj])
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        list(ex.map(compile_one, zip(srcs, objs)))
+    _run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs])
+    return out
 
 
 def build_hip(force: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     headers = [os.path.join(HIP_DIR, h) for h in os.listdir(HIP_DIR) if h.endswith(".hpp")]
     headers.append(os.path.join(ROOT, "include", "polychase_hip.h"))
-    out = hip_library_path()
+    out = os.path.join(LIB_DIR, "libpolychase_hip.so")
     srcs = [os.path.join(HIP_DIR, s) for s in HIP_SOURCES]
     if not force and _newer(out, srcs + headers):
         return out

@@ -89,6 +89,7 @@ void build_pyramid(pc_context* c, pc_frame* f) {
     for (int l = 0; l < f->nlevels; l++) {
         if (l > 0) pc::launch_pyrdown(f->levels[l - 1], f->levels[l], c->work);
         pc::launch_border(f->levels[l], f->win, c->work);
+        pc::launch_widen(f->levels[l], f->win, c->work);
         pc::launch_scharr(f->levels[l], c->work);
     }
 }
@@ -219,11 +220,11 @@ int order_keypoints_spatially(pc_context* ctx, pc_frame* f, DevBuf<uint32_t>& hi
         if (f->d_perm) PC_HIP(hipFree(f->d_perm));
         f->d_perm = nullptr;
         f->perm_cap = 0;
-        PC_HIP(hipMalloc(&f->d_perm, (size_t)cap * sizeof(uint32_t)));
+        PC_HIP(hipMalloc(&f->d_perm, (size_t)cap * 2 * sizeof(uint32_t)));   // order + inverse
         f->perm_cap = cap;
     }
     PC_HIP(hist.ensure((size_t)pc::bin_num_tiles(f->w, f->h) + 1));
-    pc::launch_spatial_bins(f->d_kps, n, f->w, f->h, hist.p, f->d_perm, ctx->work);
+    pc::launch_spatial_bins(f->d_kps, n, f->w, f->h, hist.p, f->d_perm, f->d_perm + f->perm_cap, ctx->work);
     f->perm_valid = true;
     return PC_OK;
 }
@@ -248,9 +249,9 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
     hipStream_t const lk_stream = ctx->lane_stream(set);
     const int n = frame1->n_kps;
     const size_t rows = (size_t)n * n_targets;
-    PC_HIP(ctx->lk_xy[set].ensure(rows + 1));
-    PC_HIP(ctx->lk_status[set].ensure(rows + 1));
-    PC_HIP(ctx->lk_err[set].ensure(rows + 1));
+    (void)rows;
+    PC_HIP(ctx->lk_rec[set].ensure(((size_t)n + 1) * pc::kRecStride));
+    ctx->lk_slot_of[set] = nullptr;
     if (n == 0) return PC_OK;
     pc::LKParams p;
     std::memset(&p, 0, sizeof(p));
@@ -259,7 +260,10 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
     if (max_level < 0) max_level = 0;
     for (int l = 0; l <= max_level; l++) {
         p.src[l] = frame1->levels[l];
-        for (int t = 0; t < n_targets; t++) p.tgt[t][l] = targets[t]->levels[l].img;
+        for (int t = 0; t < n_targets; t++) {
+            p.tgt[t][l] = targets[t]->levels[l].img;
+            p.tgt16[t][l] = targets[t]->levels[l].img16;
+        }
     }
     p.n_targets = n_targets;
     p.max_level = max_level;
@@ -269,20 +273,27 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
     // prepares it together with the keypoints, the stage-level calls compute it here
     if (frame1->perm_valid) {
         p.perm = frame1->d_perm;
+        ctx->lk_slot_of[set] = frame1->d_perm + frame1->perm_cap;
     } else {
-        PC_HIP(ctx->lk_perm.ensure((size_t)n));
+        PC_HIP(ctx->lk_perm.ensure((size_t)n * 2));
         PC_HIP(ctx->lk_hist.ensure((size_t)pc::bin_num_tiles(frame1->w, frame1->h) + 1));
-        pc::launch_spatial_bins(frame1->d_kps, n, frame1->w, frame1->h, ctx->lk_hist.p, ctx->lk_perm.p, lk_stream);
+        pc::launch_spatial_bins(frame1->d_kps, n, frame1->w, frame1->h, ctx->lk_hist.p, ctx->lk_perm.p, ctx->lk_perm.p + n, lk_stream);
         p.perm = ctx->lk_perm.p;
+        ctx->lk_slot_of[set] = ctx->lk_perm.p + n;
     }
     // TermCriteria clamps of calcOpticalFlowPyrLK
     p.max_iters = std::min(std::max(opt->term_max_iters, 0), 100);
     const double eps = std::min(std::max(opt->term_epsilon, 0.), 10.);
     p.eps_sq = eps * eps;
     p.min_eig_thr = (float)opt->min_eigen_threshold;
-    p.out_xy = ctx->lk_xy[set].p;
-    p.out_status = ctx->lk_status[set].p;
-    p.out_err = ctx->lk_err[set].p;
+    p.out_rec = ctx->lk_rec[set].p;
+    p.prof = nullptr;
+    if (pc::lk_profile_enabled()) {   // diagnostics build: 16 words per wavefront, the latest launch only
+        ctx->lk_prof_rows = (size_t)n / 2 + 1;
+        PC_HIP(ctx->lk_prof.ensure(ctx->lk_prof_rows * PC_LK_PROFILE_SLOTS));
+        PC_HIP(hipMemsetAsync(ctx->lk_prof.p, 0, ctx->lk_prof_rows * PC_LK_PROFILE_SLOTS * sizeof(unsigned long long), lk_stream));
+        p.prof = ctx->lk_prof.p;
+    }
     ScopedTimer tm(ctx, PC_K_LK, lk_stream);
     if (!pc::launch_lk(p, frame1->win, lk_stream)) return fail(PC_E_INVALID, "unsupported window size %d", frame1->win);
     return PC_OK;
@@ -363,17 +374,15 @@ void pc_context_destroy(pc_context* c) {
     }
     c->keys_out.release();
     c->sort_temp.release();
-    c->lk_xy[0].release();
-    c->lk_xy[1].release();
+    c->lk_rec[0].release();
+    c->lk_rec[1].release();
     c->lk_cxy.release();
-    c->lk_status[0].release();
-    c->lk_status[1].release();
-    c->lk_err[0].release();
-    c->lk_err[1].release();
+    c->lk_ustatus.release();
     c->lk_cerr.release();
     c->lk_cidx.release();
     for (auto& b : c->lk_block_counts) b.release();
     c->lk_perm.release();
+    c->lk_prof.release();
     c->lk_hist.release();
     c->prep_hist.release();
     c->lk_row_offset.release();
@@ -424,6 +433,19 @@ int pc_context_get_busy_time(pc_context* c, int k, double* busy_ms) {
     return PC_OK;
 }
 
+int pc_debug_lk_profile(pc_context* c, unsigned long long* out) {
+    if (!c || !out) return fail(PC_E_INVALID, "null argument");
+    for (int k = 0; k < PC_LK_PROFILE_SLOTS; k++) out[k] = 0;
+    if (!c->lk_prof.p || c->lk_prof_rows == 0) return PC_OK;
+    PC_HIP(hipStreamSynchronize(c->stream));
+    PC_HIP(hipStreamSynchronize(c->stream_b));
+    std::vector<unsigned long long> h(c->lk_prof_rows * PC_LK_PROFILE_SLOTS);
+    PC_HIP(hipMemcpy(h.data(), c->lk_prof.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < c->lk_prof_rows; r++)
+        for (int k = 0; k < PC_LK_PROFILE_SLOTS; k++) out[k] += h[r * PC_LK_PROFILE_SLOTS + k];
+    return PC_OK;
+}
+
 int pc_context_reset_timing(pc_context* c) {
     if (!c) return fail(PC_E_INVALID, "null context");
     int rc = collect_timing(c);
@@ -455,7 +477,7 @@ int pc_frame_create(pc_context* ctx, int width, int height, int window_size, int
     // level geometry: stop when the next level would be <= winSize (lkpyramid.cpp)
     int lw = width, lh = height;
     size_t total = 0;
-    size_t img_off[PC_MAX_LEVELS], der_off[PC_MAX_LEVELS];
+    size_t img_off[PC_MAX_LEVELS], der_off[PC_MAX_LEVELS], i16_off[PC_MAX_LEVELS];
     for (int l = 0; l <= max_level; l++) {
         pc::Level& L = f->levels[l];
         L.w = lw;
@@ -466,6 +488,8 @@ int pc_frame_create(pc_context* ctx, int width, int height, int window_size, int
         total += align_up(rows * L.pitch, 256);
         der_off[l] = total;
         total += align_up(rows * L.pitch * sizeof(int32_t), 256);
+        i16_off[l] = total;
+        total += align_up((rows + 2 * pc::kImg16SlackRows) * L.pitch * sizeof(uint16_t), 256);
         f->nlevels = l + 1;
         lw = (lw + 1) / 2;
         lh = (lh + 1) / 2;
@@ -489,6 +513,7 @@ int pc_frame_create(pc_context* ctx, int width, int height, int window_size, int
         const size_t interior = (size_t)window_size * L.pitch + pc::kPadX;
         L.img = f->slab + img_off[l] + interior;
         L.der = reinterpret_cast<int32_t*>(f->slab + der_off[l]) + interior;
+        L.img16 = reinterpret_cast<uint16_t*>(f->slab + i16_off[l]) + interior + (size_t)pc::kImg16SlackRows * L.pitch;
     }
     int rc = ensure_kp_capacity(f, std::max(4096, (int)((long long)width * height / 16)));
     if (rc != PC_OK) {
@@ -694,9 +719,15 @@ int pc_lk_track(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* 
     if (rc != PC_OK) return rc;
     const size_t rows = (size_t)frame1->n_kps * n_targets;
     if (rows > 0) {
-        PC_HIP(hipMemcpyAsync(next_xy, ctx->lk_xy[0].p, rows * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
-        PC_HIP(hipMemcpyAsync(status, ctx->lk_status[0].p, rows, hipMemcpyDeviceToHost, ctx->stream));
-        PC_HIP(hipMemcpyAsync(err, ctx->lk_err[0].p, rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        // the kernel's records are in visiting order: bring them into the [target][n] arrays of the call
+        PC_HIP(ctx->lk_cxy.ensure(rows));
+        PC_HIP(ctx->lk_cerr.ensure(rows));
+        PC_HIP(ctx->lk_ustatus.ensure(rows));
+        pc::launch_unpack_records(ctx->lk_rec[0].p, ctx->lk_slot_of[0], frame1->n_kps, n_targets, ctx->lk_cxy.p,
+                                  ctx->lk_ustatus.p, ctx->lk_cerr.p, ctx->stream);
+        PC_HIP(hipMemcpyAsync(next_xy, ctx->lk_cxy.p, rows * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+        PC_HIP(hipMemcpyAsync(status, ctx->lk_ustatus.p, rows, hipMemcpyDeviceToHost, ctx->stream));
+        PC_HIP(hipMemcpyAsync(err, ctx->lk_cerr.p, rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     }
     PC_HIP(hipStreamSynchronize(ctx->stream));
     return PC_OK;
@@ -723,7 +754,7 @@ int pc_lk_track_filtered(pc_context* ctx, const pc_frame* frame1, const pc_frame
     PC_HIP(ctx->h_row_offset.ensure(PC_MAX_TARGETS + 1));
     {
         ScopedTimer t(ctx, PC_K_COMPACT);
-        pc::launch_compact(ctx->lk_xy[0].p, ctx->lk_status[0].p, ctx->lk_err[0].p, n, n_targets, ctx->lk_block_counts[0].p,
+        pc::launch_compact(ctx->lk_rec[0].p, ctx->lk_slot_of[0], n, n_targets, ctx->lk_block_counts[0].p,
                            ctx->lk_row_offset.p, ctx->lk_cidx.p, ctx->lk_cxy.p, ctx->lk_cerr.p, ctx->stream);
     }
     PC_HIP(hipMemcpyAsync(ctx->h_row_offset.p, ctx->lk_row_offset.p, (size_t)(n_targets + 1) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));

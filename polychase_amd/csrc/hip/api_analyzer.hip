@@ -129,7 +129,7 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
         // room for a typical frame's keypoints up front: growing later frees device memory, which synchronises
         const int kp0 = std::max(16384, (width * height) / 32);
         if ((rc = ensure_kp_capacity(s.frame, kp0)) != PC_OK) break;
-        if (hipMalloc(reinterpret_cast<void**>(&s.frame->d_perm), (size_t)kp0 * sizeof(uint32_t)) != hipSuccess) {
+        if (hipMalloc(reinterpret_cast<void**>(&s.frame->d_perm), (size_t)kp0 * 2 * sizeof(uint32_t)) != hipSuccess) {
             rc = fail(PC_E_HIP, "hipMalloc failed");
             break;
         }
@@ -332,10 +332,6 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
         if ((rc = run_lk(ctx, s1->frame, tg, n_targets, &a->fopt, lane)) != PC_OK) return rc;
     }
     SlowSection ss_post("submit/post enqueue");
-    hipEvent_t const lk_done = a->lk_done[lane][(a->submitted >> 1) % pc_analyzer::kLaneEvents];
-    PC_HIP(hipEventRecord(lk_done, ls));
-    s1->last_read[lane] = lk_done;
-    for (int t = 0; t < n_targets; t++) find_slot(a, targets[t])->last_read[lane] = lk_done;
     uint8_t* const pack = ctx->lk_pack[lane].p;
     long long* const p_ro = reinterpret_cast<long long*>(pack);
     PC_HIP(hipMemsetAsync(pack, 0, 128, ls));
@@ -343,11 +339,17 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
         const int nblocks = pc::compact_num_blocks(n);
         PC_HIP(ctx->lk_block_counts[lane].ensure((size_t)nblocks * n_targets + 1));
         ScopedTimer t(ctx, PC_K_COMPACT, ls);
-        pc::launch_compact(ctx->lk_xy[lane].p, ctx->lk_status[lane].p, ctx->lk_err[lane].p, n, n_targets,
+        pc::launch_compact(ctx->lk_rec[lane].p, ctx->lk_slot_of[lane], n, n_targets,
                            ctx->lk_block_counts[lane].p, p_ro, reinterpret_cast<uint32_t*>(pack + j.o_idx),
                            reinterpret_cast<float2*>(pack + j.o_xy), reinterpret_cast<float*>(pack + j.o_err), ls);
     }
     pc::launch_copy_keypoints(s1->frame->d_kps, reinterpret_cast<float2*>(pack + j.o_kps), n, ls);
+    // Everything that reads the resident frames is enqueued: the pyramids (LK), frame1's keypoints (LK, the copy
+    // above) and its inverse visiting order (compaction).  A slot may be overwritten once this event has fired.
+    hipEvent_t const lk_done = a->lk_done[lane][(a->submitted >> 1) % pc_analyzer::kLaneEvents];
+    PC_HIP(hipEventRecord(lk_done, ls));
+    s1->last_read[lane] = lk_done;
+    for (int t = 0; t < n_targets; t++) find_slot(a, targets[t])->last_read[lane] = lk_done;
     if (a->d_log) {
         // device log: header from pinned memory, the record itself is the pack (one device-to-device copy)
         const size_t o_hdr = a->log_used, end = o_hdr + 128 + j.pack_bytes;

@@ -17,12 +17,18 @@ constexpr int kPadX = 16;
 // padding (win rows above/below, kPadX bytes left, >= win bytes right) is addressable with negative
 // offsets.  `der` is the Scharr plane: one int32 per pixel = (int16 dx) | (int16 dy << 16), zero in
 // the padding (OpenCV derivBorder = BORDER_CONSTANT); its pitch in pixels equals `pitch`.
+// `img16` is the image once more as uint16 = pixel << 7 (same pitch in pixels, same REFLECT_101 padding, plus
+// kImg16SlackRows addressable zero rows above and below): the operand format of the LK inner loop
+// (kernels_lk3.hip: a v_dot2_i32_i16 of two such pixels with the 14-bit bilinear weights is 128 x the
+// interpolated value, so the rounding shift of CV_DESCALE comes for free as "the high half of the register").
 struct Level {
     uint8_t* img;
     int32_t* der;
+    uint16_t* img16;
     int w, h;
-    int pitch;  // bytes per image row == int32 per derivative row
+    int pitch;  // bytes per image row == int32 per derivative row == uint16 per img16 row
 };
+constexpr int kImg16SlackRows = 2;
 
 // cv::borderInterpolate(p, len, BORDER_REFLECT_101)
 __host__ __device__ __forceinline__ int reflect101(int p, int len) {

@@ -150,10 +150,14 @@ struct pc_context {
     const pc_frame* eig_owner = nullptr;
     // LK scratch
     // raw LK outputs, compaction scratch and packed records: one set per job lane of the analyzer (set 0: stage-level calls)
-    DevBuf<float2> lk_xy[2], lk_cxy;
-    DevBuf<uint8_t> lk_status[2];
-    DevBuf<float> lk_err[2], lk_cerr;
+    DevBuf<float4> lk_rec[2];              // raw records in visiting order (kernels.hpp LKParams::out_rec)
+    const uint32_t* lk_slot_of[2] = {nullptr, nullptr};   // inverse visiting order of the latest launch into the set
+    DevBuf<float2> lk_cxy;
+    DevBuf<uint8_t> lk_ustatus;            // pc_lk_track: unpacked status
+    DevBuf<float> lk_cerr;
     DevBuf<uint32_t> lk_cidx, lk_block_counts[2], lk_perm, lk_hist, prep_hist;
+    DevBuf<unsigned long long> lk_prof;    // pc_debug_lk_profile: 16 words per wavefront of the latest launch
+    size_t lk_prof_rows = 0;
     DevBuf<long long> lk_row_offset;
     // the analyzer's compacted records of one job, packed like a device-log record without its header:
     // row offsets (128 B) | keypoints | src indices | tgt xy | errors, every part 16-byte aligned
@@ -178,7 +182,7 @@ struct pc_frame {
     int kp_cap = 0;
     int n_kps = -1;   // -1: none
     int n_cands = -1;
-    uint32_t* d_perm = nullptr;   // LK visiting order of d_kps (spatial bins), valid iff perm_valid
+    uint32_t* d_perm = nullptr;   // LK visiting order of d_kps (spatial bins) [perm_cap], then its inverse [perm_cap]; valid iff perm_valid
     int perm_cap = 0;
     bool perm_valid = false;
 };

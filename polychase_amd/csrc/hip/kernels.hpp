@@ -17,6 +17,8 @@ void launch_copy_gray(const uint8_t* gray, size_t gray_pitch, const Level& l0, h
 void launch_pyrdown(const Level& src, const Level& dst, hipStream_t s);
 // REFLECT_101 border of width `win` around the interior
 void launch_border(const Level& l, int win, hipStream_t s);
+// padded u8 plane -> the uint16 (pixel << 7) plane the LK kernel reads (needs the border to be filled)
+void launch_widen(const Level& l, int win, hipStream_t s);
 // K6: Scharr derivative plane of the interior (needs the 1-px border to be filled)
 void launch_scharr(const Level& l, hipStream_t s);
 
@@ -53,6 +55,7 @@ hipError_t sort_keys_desc(void* temp, size_t& temp_bytes, unsigned long long* ke
 struct LKParams {
     Level src[8];             // frame1 levels
     const uint8_t* tgt[8][8]; // [target][level] interior origins (same geometry as src)
+    const uint16_t* tgt16[8][8];  // the same levels as uint16 (pixel << 7) planes (Level::img16)
     int n_targets;
     int max_level;            // effective (min over pyramids)
     int n;                    // number of keypoints
@@ -62,24 +65,36 @@ struct LKParams {
     int max_iters;
     double eps_sq;
     float min_eig_thr;
-    float2* out_xy;           // [target][n]
-    uint8_t* out_status;      // [target][n]
-    float* out_err;           // [target][n]
+    // Raw result records in VISITING order: out_rec[slot * 8 + target] = (next.x, next.y, err, bits(status)); slot s
+    // tracks keypoint perm[s].  A wavefront's 16 results are 256 contiguous bytes (they used to be 48 scattered
+    // 8/4/1-byte stores through the permutation: 8x write amplification, profiles/lk_hbm_traffic.json of round 1).
+    float4* out_rec;
+    unsigned long long* prof; // per-phase cycle sums (PC_LK_PROFILE builds), or null
 };
+constexpr int kRecStride = 8;   // records per slot (= PC_MAX_TARGETS)
 // K8-K10: pyramidal LK, one 16-lane DPP row per (keypoint, target).  Returns false if the window
 // size is unsupported.
 bool launch_lk(const LKParams& p, int win, hipStream_t s);
 // the same with two keypoints per wavefront (kernels_lk2.hip); window sizes 4..11
 bool launch_lk2(const LKParams& p, int win, hipStream_t s);
+// two keypoints per wavefront on the uint16 planes, dword-per-position LDS regions (kernels_lk3.hip); windows 4..11
+bool launch_lk3(const LKParams& p, int win, hipStream_t s);
+bool lk_profile_enabled();   // library compiled with -DPC_LK_PROFILE: LKParams::prof takes 16 words per wavefront
 // counting sort of keypoint indices by 64x64 tile -> perm[n]; hist: bin_num_tiles(w, h) words of scratch
 int bin_num_tiles(int w, int h);
-void launch_spatial_bins(const float2* pts, int n, int w, int h, uint32_t* hist, uint32_t* perm, hipStream_t s);
+// slot_of[i] = position of keypoint i in perm (the inverse permutation)
+void launch_spatial_bins(const float2* pts, int n, int w, int h, uint32_t* hist, uint32_t* perm, uint32_t* slot_of,
+                         hipStream_t s);
 
 // Ordered compaction of status==1 rows per target (opticalflow.cc:130-147).
+// rec / slot_of: the LK kernel's raw records (visiting order) and the inverse visiting order.
 // block_counts: [n_targets][nblocks] scratch, row_offset: [n_targets+1] int64 (device).
-void launch_compact(const float2* xy, const uint8_t* status, const float* err, int n, int n_targets,
+void launch_compact(const float4* rec, const uint32_t* slot_of, int n, int n_targets,
                     uint32_t* block_counts, long long* row_offset, uint32_t* out_idx, float2* out_xy,
                     float* out_err, hipStream_t s);
+// raw records -> [target][n] arrays in keypoint order (pc_lk_track)
+void launch_unpack_records(const float4* rec, const uint32_t* slot_of, int n, int n_targets, float2* xy, uint8_t* status,
+                           float* err, hipStream_t s);
 int compact_num_blocks(int n);
 // keypoints -> packed record buffer (both 16-byte aligned)
 void launch_copy_keypoints(const float2* src, float2* dst, int n, hipStream_t s);

@@ -193,6 +193,26 @@ void launch_border(const Level& l, int win, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// uint16 copy of a padded plane, value = pixel << 7 (Level::img16): every row of the padded plane, the whole
+// pitch (4 pixels per lane; the bytes outside [-win, w + win) are never consumed, they only have to be addressable).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void widen_kernel(const uint8_t* __restrict__ img, uint16_t* __restrict__ img16, int pitch,
+                                                    int y0) {
+    const int gx = blockIdx.x * blockDim.x + threadIdx.x;   // dword of the row, counted from the plane's left edge
+    if (gx * 4 >= pitch) return;
+    const ptrdiff_t o = (ptrdiff_t)(y0 + (int)blockIdx.y) * pitch - kPadX + 4 * gx;
+    const uint32_t d = *reinterpret_cast<const uint32_t*>(img + o);
+    const uint32_t lo = __builtin_amdgcn_perm(0u, d, 0x0c010c00u) << 7;   // (p0, p1) as 16-bit lanes
+    const uint32_t hi = __builtin_amdgcn_perm(0u, d, 0x0c030c02u) << 7;   // (p2, p3)
+    *reinterpret_cast<uint2*>(img16 + o) = make_uint2(lo, hi);
+}
+
+void launch_widen(const Level& l, int win, hipStream_t s) {
+    dim3 grid((l.pitch / 4 + 255) / 256, l.h + 2 * win);
+    hipLaunchKernelGGL(widen_kernel, grid, dim3(256), 0, s, l.img, l.img16, l.pitch, -win);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K6  Scharr derivative plane (OpenCV ScharrDerivInvoker): t0 = 3*(above+below) + 10*cur,
 // t1 = below - above; dx = t0[x+1] - t0[x-1]; dy = 3*(t1[x+1] + t1[x-1]) + 10*t1[x].
 // REFLECT_101 inside the level == the already filled 1-px image border.

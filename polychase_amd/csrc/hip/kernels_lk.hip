@@ -113,13 +113,11 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
         const uint32_t wrow0 = wI.r0, wrow1 = wI.r1;
 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        stage_pairs_auto<WIN, 64>(L.img, pitch, L.h, ipx & ~3, ipy, WIN + 1, ibuf, lane);
         {
-            const int32_t* __restrict__ Dbase = L.der + (ptrdiff_t)(ipy * pitch + ipx);
-            for (int i = lane; i < (WIN + 1) * (WIN + 1); i += 64) {
-                const int r = i / (WIN + 1), c = i - r * (WIN + 1);
-                reinterpret_cast<int32_t*>(dbuf)[i] = Dbase[r * pitch + c];
-            }
+            DerivWindow<WIN, 64> dw;
+            dw.load(L.der + (ptrdiff_t)(ipy * pitch + ipx), pitch, lane);
+            stage_pairs_auto<WIN, 64, WIN + 1>(L.img, pitch, L.h, ipx & ~3, ipy, ibuf, lane);
+            dw.store(reinterpret_cast<int32_t*>(dbuf), lane);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         int sA11 = 0, sA12 = 0, sA22 = 0;
@@ -196,7 +194,7 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
                 rx0 = (iqx - G::MX) & ~3;
                 ry0 = iqy - G::MY;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                stage_pairs_auto<WIN, GL>(J, pitch, L.h, rx0, ry0, G::RH, jbuf, lg);
+                stage_pairs_auto<WIN, GL, G::RH>(J, pitch, L.h, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 staged = true;
             }
@@ -260,7 +258,7 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
                 rx0 = (iex - G::MX) & ~3;
                 ry0 = iey - G::MY;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                stage_pairs_auto<WIN, GL>(J, pitch, L.h, rx0, ry0, G::RH, jbuf, lg);
+                stage_pairs_auto<WIN, GL, G::RH>(J, pitch, L.h, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 staged = true;
             }
@@ -289,12 +287,9 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
         }
     }
 
-    if (lg == 0 && tgt_active) {
-        const size_t o = (size_t)tgt * p.n + feat;
-        p.out_xy[o] = make_float2(nx, ny);
-        p.out_status[o] = status ? 1 : 0;
-        p.out_err[o] = status ? err : 0.f;
-    }
+    // one 16-byte record per (slot, target): the wavefront's results are contiguous
+    if (lg == 0 && tgt_active)
+        p.out_rec[(size_t)slot * kRecStride + tgt] = make_float4(nx, ny, status ? err : 0.f, __uint_as_float(status ? 1u : 0u));
 }
 
 template <int WIN>
@@ -306,7 +301,8 @@ static void launch_lk_t(const LKParams& p0, hipStream_t s) {
     hipLaunchKernelGGL((lk_kernel<WIN>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(256), 0, s, p);
 }
 
-// POLYCHASE_LK_VARIANT=1 forces the one-keypoint-per-wavefront kernel, =2 the two-keypoint kernel
+// POLYCHASE_LK_VARIANT=1 forces the one-keypoint-per-wavefront kernel, =2 the two-keypoint kernel on the u8 planes;
+// default: the two-keypoint kernel on the uint16 planes (kernels_lk3.hip) where the window allows it
 static int lk_variant() {
     static const int v = [] {
         const char* e = getenv("POLYCHASE_LK_VARIANT");
@@ -316,7 +312,9 @@ static int lk_variant() {
 }
 
 bool launch_lk(const LKParams& p, int win, hipStream_t s) {
-    if (lk_variant() != 1 && win >= 4 && win <= 11 && launch_lk2(p, win, s)) return true;
+    const int v = lk_variant();
+    if ((v == 0 || v == 3) && launch_lk3(p, win, s)) return true;
+    if (v != 1 && win >= 4 && win <= 11 && launch_lk2(p, win, s)) return true;
     switch (win) {
 #define PC_LK_CASE(W) case W: launch_lk_t<W>(p, s); return true;
         PC_LK_CASE(3) PC_LK_CASE(4) PC_LK_CASE(5) PC_LK_CASE(6) PC_LK_CASE(7) PC_LK_CASE(8) PC_LK_CASE(9)
@@ -367,39 +365,57 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t* __restrict__ h
 }
 
 __global__ __launch_bounds__(256) void bin_scatter_kernel(const float2* __restrict__ pts, int n, int tiles_x, int n_tiles,
-                                                          uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm) {
+                                                          uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm,
+                                                          uint32_t* __restrict__ slot_of) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float2 p = pts[i];
     const int t = min(n_tiles - 1, max(0, ((int)p.y >> BIN_SHIFT) * tiles_x + ((int)p.x >> BIN_SHIFT)));
-    perm[atomicAdd(&cursor[t], 1u)] = (uint32_t)i;
+    const uint32_t pos = atomicAdd(&cursor[t], 1u);
+    perm[pos] = (uint32_t)i;
+    slot_of[i] = pos;
 }
 
 int bin_num_tiles(int w, int h) { return ((w + 63) >> BIN_SHIFT) * ((h + 63) >> BIN_SHIFT); }
 
-void launch_spatial_bins(const float2* pts, int n, int w, int h, uint32_t* hist, uint32_t* perm, hipStream_t s) {
+void launch_spatial_bins(const float2* pts, int n, int w, int h, uint32_t* hist, uint32_t* perm, uint32_t* slot_of,
+                         hipStream_t s) {
     if (n <= 0) return;
     const int tiles_x = (w + 63) >> BIN_SHIFT, n_tiles = bin_num_tiles(w, h);
     (void)hipMemsetAsync(hist, 0, (size_t)n_tiles * sizeof(uint32_t), s);
     hipLaunchKernelGGL(bin_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, tiles_x, n_tiles, hist);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, hist, n_tiles);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, tiles_x, n_tiles, hist, perm);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, tiles_x, n_tiles, hist, perm, slot_of);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Ordered compaction of status == 1 rows (opticalflow.cc:130-147): count per 1024-keypoint block,
-// exclusive scan of the block counts (one small workgroup), scatter.
+// Ordered compaction of status == 1 rows (opticalflow.cc:130-147): count per block of 128 keypoints,
+// exclusive scan of the block counts (one small workgroup), scatter.  The LK kernel leaves its records
+// in visiting order (8 per slot, 128 contiguous bytes); here lane = (keypoint i, target t) with t the
+// fast index, so the 8 lanes of a keypoint read exactly that line through the inverse permutation
+// and write one run per target in ascending keypoint order.
 // ------------------------------------------------------------------------------------------------
-constexpr int CB = 1024;
-int compact_num_blocks(int n) { return (n + CB - 1) / CB; }
+constexpr int CF = 128;   // keypoints per 1024-lane workgroup
+int compact_num_blocks(int n) { return (n + CF - 1) / CF; }
 
-__global__ __launch_bounds__(1024) void compact_count_kernel(const uint8_t* __restrict__ status, int n, int nblocks,
+__device__ __forceinline__ unsigned long long target_lanes(int t) { return 0x0101010101010101ull << t; }
+
+__global__ __launch_bounds__(1024) void compact_count_kernel(const float4* __restrict__ rec, const uint32_t* __restrict__ slot_of,
+                                                             int n, int n_targets, int nblocks,
                                                              uint32_t* __restrict__ block_counts) {
-    const int t = blockIdx.y;
-    const int i = blockIdx.x * CB + threadIdx.x;
-    const bool keep = (i < n) && (status[(size_t)t * n + i] == 1);
-    const int c = __syncthreads_count(keep);
-    if (threadIdx.x == 0) block_counts[(size_t)t * nblocks + blockIdx.x] = (uint32_t)c;
+    __shared__ uint32_t s_cnt[kRecStride];
+    const int t = threadIdx.x & 7, i = blockIdx.x * CF + (int)(threadIdx.x >> 3), lane = threadIdx.x & 63;
+    if (threadIdx.x < kRecStride) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    bool keep = false;
+    if (i < n && t < n_targets) keep = __float_as_uint(rec[(size_t)slot_of[i] * kRecStride + t].w) == 1u;
+    const unsigned long long b = __ballot(keep);
+    if (lane < kRecStride) {
+        const uint32_t c = (uint32_t)__popcll(b & target_lanes(lane));
+        if (c) atomicAdd(&s_cnt[lane], c);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n_targets) block_counts[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_cnt[threadIdx.x];
 }
 
 // one workgroup: turns block_counts into exclusive offsets (global, target-major) + row_offset[]
@@ -434,29 +450,48 @@ __global__ __launch_bounds__(256) void compact_scan_kernel(uint32_t* __restrict_
         for (int t = 0; t <= n_targets; t++) row_offset[t] = 0;
 }
 
-__global__ __launch_bounds__(1024) void compact_scatter_kernel(const float2* __restrict__ xy,
-                                                               const uint8_t* __restrict__ status,
-                                                               const float* __restrict__ err, int n, int nblocks,
+__global__ __launch_bounds__(1024) void compact_scatter_kernel(const float4* __restrict__ rec, const uint32_t* __restrict__ slot_of,
+                                                               int n, int n_targets, int nblocks,
                                                                const uint32_t* __restrict__ block_offsets,
                                                                uint32_t* __restrict__ out_idx,
                                                                float2* __restrict__ out_xy, float* __restrict__ out_err) {
-    __shared__ uint32_t s_wave[16];
-    const int t = blockIdx.y;
-    const int i = blockIdx.x * CB + threadIdx.x;
-    const size_t src = (size_t)t * n + i;
-    const bool keep = (i < n) && (status[src] == 1);
-    const unsigned long long ballot = __ballot(keep);
+    __shared__ uint32_t s_wave[16][kRecStride];
+    const int t = threadIdx.x & 7, i = blockIdx.x * CF + (int)(threadIdx.x >> 3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(ballot);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool live = i < n && t < n_targets;
+    if (live) r = rec[(size_t)slot_of[i] * kRecStride + t];
+    const bool keep = live && __float_as_uint(r.w) == 1u;
+    const unsigned long long b = __ballot(keep);
+    if (lane < kRecStride) s_wave[wave][lane] = (uint32_t)__popcll(b & target_lanes(lane));
     __syncthreads();
-    uint32_t base = block_offsets[(size_t)t * nblocks + blockIdx.x];
-    for (int wv = 0; wv < wave; wv++) base += s_wave[wv];
     if (keep) {
-        const uint32_t pos = base + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+        uint32_t pos = block_offsets[(size_t)t * nblocks + blockIdx.x];
+        for (int wv = 0; wv < wave; wv++) pos += s_wave[wv][t];
+        pos += (uint32_t)__popcll(b & target_lanes(t) & ((1ull << lane) - 1ull));
         out_idx[pos] = (uint32_t)i;
-        out_xy[pos] = xy[src];
-        out_err[pos] = err[src];
+        out_xy[pos] = make_float2(r.x, r.y);
+        out_err[pos] = r.z;
     }
+}
+
+// raw records -> the [target][n] arrays of pc_lk_track, keypoint order
+__global__ __launch_bounds__(256) void unpack_records_kernel(const float4* __restrict__ rec, const uint32_t* __restrict__ slot_of,
+                                                             int n, float2* __restrict__ xy, uint8_t* __restrict__ status,
+                                                             float* __restrict__ err) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (i >= n) return;
+    const float4 r = rec[(size_t)slot_of[i] * kRecStride + t];
+    const size_t o = (size_t)t * n + i;
+    xy[o] = make_float2(r.x, r.y);
+    status[o] = (uint8_t)__float_as_uint(r.w);
+    err[o] = r.z;
+}
+
+void launch_unpack_records(const float4* rec, const uint32_t* slot_of, int n, int n_targets, float2* xy, uint8_t* status,
+                           float* err, hipStream_t s) {
+    if (n <= 0 || n_targets <= 0) return;
+    hipLaunchKernelGGL(unpack_records_kernel, dim3((n + 255) / 256, n_targets), dim3(256), 0, s, rec, slot_of, n, xy, status, err);
 }
 
 // keypoints of frame1 -> the job's packed record buffer (device to device, 16 bytes per lane)
@@ -471,15 +506,15 @@ void launch_copy_keypoints(const float2* src, float2* dst, int n, hipStream_t s)
     hipLaunchKernelGGL(copy_keypoints_kernel, dim3((pairs + 255) / 256), dim3(256), 0, s, src, dst, n);
 }
 
-void launch_compact(const float2* xy, const uint8_t* status, const float* err, int n, int n_targets,
+void launch_compact(const float4* rec, const uint32_t* slot_of, int n, int n_targets,
                     uint32_t* block_counts, long long* row_offset, uint32_t* out_idx, float2* out_xy,
                     float* out_err, hipStream_t s) {
     const int nblocks = compact_num_blocks(n);
     if (nblocks > 0)
-        hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks, n_targets), dim3(CB), 0, s, status, n, nblocks, block_counts);
+        hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(1024), 0, s, rec, slot_of, n, n_targets, nblocks, block_counts);
     hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(256), 0, s, block_counts, nblocks, n_targets, row_offset);
     if (nblocks > 0)
-        hipLaunchKernelGGL(compact_scatter_kernel, dim3(nblocks, n_targets), dim3(CB), 0, s, xy, status, err, n, nblocks,
+        hipLaunchKernelGGL(compact_scatter_kernel, dim3(nblocks), dim3(1024), 0, s, rec, slot_of, n, n_targets, nblocks,
                            block_counts, out_idx, out_xy, out_err);
 }
 

@@ -145,12 +145,10 @@ __global__ __launch_bounds__(64 * PC_LK2_WAVES) void lk2_kernel(const LKParams p
 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous level's J regions are dead
         if (i_in) {
-            stage_pairs_auto<WIN, 32>(L.img, pitch, L.h, ipx & ~3, ipy, WIN + 1, ibuf, l32);
-            const int32_t* __restrict__ Dbase = L.der + (ptrdiff_t)(ipy * pitch + ipx);
-            for (int i = l32; i < (WIN + 1) * (WIN + 1); i += 32) {
-                const int r = i / (WIN + 1), c = i - r * (WIN + 1);
-                reinterpret_cast<int32_t*>(dbuf)[i] = Dbase[r * pitch + c];
-            }
+            DerivWindow<WIN, 32> dw;
+            dw.load(L.der + (ptrdiff_t)(ipy * pitch + ipx), pitch, l32);
+            stage_pairs_auto<WIN, 32, WIN + 1>(L.img, pitch, L.h, ipx & ~3, ipy, ibuf, l32);
+            dw.store(reinterpret_cast<int32_t*>(dbuf), l32);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         int sA11 = 0, sA12 = 0, sA22 = 0;
@@ -241,7 +239,7 @@ __global__ __launch_bounds__(64 * PC_LK2_WAVES) void lk2_kernel(const LKParams p
                 rx0 = (iqx - G::MX) & ~3;
                 ry0 = iqy - G::MY;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                stage_pairs_auto<WIN, GL>(J, pitch, L.h, rx0, ry0, G::RH, jbuf, lg);
+                stage_pairs_auto<WIN, GL, G::RH>(J, pitch, L.h, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 staged = true;
             }
@@ -301,7 +299,7 @@ __global__ __launch_bounds__(64 * PC_LK2_WAVES) void lk2_kernel(const LKParams p
                 rx0 = (iex - G::MX) & ~3;
                 ry0 = iey - G::MY;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                stage_pairs_auto<WIN, GL>(J, pitch, L.h, rx0, ry0, G::RH, jbuf, lg);
+                stage_pairs_auto<WIN, GL, G::RH>(J, pitch, L.h, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 staged = true;
             }
@@ -332,12 +330,9 @@ __global__ __launch_bounds__(64 * PC_LK2_WAVES) void lk2_kernel(const LKParams p
         }
     }
 
-    if (lg == 0 && tgt_active) {
-        const size_t o = (size_t)tgt * p.n + feat;
-        p.out_xy[o] = make_float2(nx, ny);
-        p.out_status[o] = status ? 1 : 0;
-        p.out_err[o] = status ? err : 0.f;
-    }
+    // one 16-byte record per (slot, target): the wavefront's results are contiguous
+    if (lg == 0 && tgt_active)
+        p.out_rec[(size_t)slot * kRecStride + tgt] = make_float4(nx, ny, status ? err : 0.f, __uint_as_float(status ? 1u : 0u));
 }
 
 template <int WIN>

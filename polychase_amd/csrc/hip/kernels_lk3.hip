@@ -1,0 +1,572 @@
+// kernels_lk3.hip -- pyramidal Lucas-Kanade (K8-K10), two keypoints per wavefront, on the uint16 planes.
+//
+// Same arithmetic and results as kernels_lk.hip / kernels_lk2.hip (bit for bit; all follow oracle/pc_oracle.c,
+// which restates cv::calcOpticalFlowPyrLK as called at reference cpp/opticalflow.cc:119-125), same mapping as
+// lk2 -- lanes 0-31 track keypoint A, lanes 32-63 keypoint B, group g = 4 lanes tracks the keypoint into target
+// g, the I side is evaluated once per keypoint by its half-wave -- but another data path for the inner loop:
+//
+//   * The images are read from the uint16 planes (Level::img16, value = pixel << 7).  In LDS a region keeps one
+//     DWORD per position: Q[r][c] = (p[r][c] << 7) | (p[r][c+1] << 7) << 16, i.e. the two horizontal taps of a
+//     bilinear sample as the 16-bit lanes v_dot2_i32_i16 wants.  One pixel of one iteration is then
+//         ds_read_b32 (aligned)                       the row below; the row above is the previous pixel's
+//         v_dot2_i32_i16  x 2                         R = 128 * (sum of the 4 weighted taps) + bias
+//         v_mad_i32_i16 op_sel:[1,...] x 2            b += hi16(R) * (ix, iy)
+//     because hi16(R) = (S + 2^8 - 2^9 * I) >> 9 = CV_DESCALE(S, W_BITS - 5) - I when bias = 2^15 - I * 2^16:
+//     the rounding shift is "the high half of the register" and costs nothing.  lk2 needed, per pixel, an
+//     unaligned ds_read_u16 (5.5 LDS stall cycles each: SQ_LDS_UNALIGNED_STALL was 62 % of the LDS pipe's busy
+//     time, which itself was 65 % of the launch), a v_perm to widen the byte pair and a v_ashr: 6 VALU + a slow
+//     LDS read per pixel then, 4 VALU + a 2-cycle LDS read now.
+//   * A region is (WIN + 1 + 2) rows x (WIN + 2) positions at its exact origin (no 4-byte alignment slack: the
+//     uint16 plane is read with 2-byte aligned dwordx4 loads); 16 regions of a 10 x 10 window are 9.75 KB per
+//     wavefront, so the 12 wavefronts of a CU (3 per SIMD at this register count) fit the 160 KB of LDS.
+//   * The uint16 planes carry two addressable slack rows above and below the padded image: a region never needs
+//     address clamping, there is ONE staging path.
+#include "lk_common.hpp"
+
+namespace pc {
+
+#ifndef PC_LK3_ATTR
+#define PC_LK3_ATTR
+#endif
+#ifndef PC_LK3_WAVES
+#define PC_LK3_WAVES 1   // wavefronts per workgroup
+#endif
+
+// -DPC_LK_PROFILE: per-phase shader-clock sums (pc_debug_lk_profile); costs ~10 % of the launch
+#ifdef PC_LK_PROFILE
+#define PC_PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long prof_t0 = prof_t;
+#define PC_PROF(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[k] += t_ - prof_t; prof_t = t_; } while (0)
+#define PC_PROF_COUNT(k) do { prof_acc[k] += 1; } while (0)
+#else
+#define PC_PROF_DECL
+#define PC_PROF(k) do { } while (0)
+#define PC_PROF_COUNT(k) do { } while (0)
+#endif
+
+template <int WIN>
+struct LK3Geo {
+    static constexpr int GL = 4, NPX = WIN * WIN;
+    static constexpr int MX = 1, MY = 1;                      // search margin of a staged region
+    static constexpr int RWP = WIN + 2 * MX;                  // positions per region row
+    static constexpr int CH = (RWP + 3) / 4;                  // 4-position chunks per row
+    static constexpr int PITCH = 4 * CH;                      // dwords per region row
+    static constexpr int RH = WIN + 1 + 2 * MY;               // region rows
+    static constexpr int J_DW = RH * PITCH;                   // per-group J region (16-byte multiple)
+    static constexpr int I_CH = (WIN + 3) / 4, I_PITCH = 4 * I_CH, I_ROWS = WIN + 1;
+    static constexpr int I_DW = I_ROWS * I_PITCH;             // I window of one keypoint, same format
+    static constexpr int D_PITCH = WIN + 1, D_DW = (WIN + 1) * (WIN + 1);   // raw Scharr window
+    static constexpr int X_DW = 2 * NPX;                      // (bias, Dxy) exchange of one keypoint
+    static constexpr int HALF_I_DW = ((I_DW + D_DW + X_DW + 3) / 4) * 4;
+    static constexpr int WAVE_DW = 16 * J_DW > 2 * HALF_I_DW ? 16 * J_DW : 2 * HALF_I_DW;
+    // window pixels of a lane: NCH column chains (columns lg + 4c) + a run of the remaining columns
+    static constexpr int WM = (WIN / GL) * GL, NCH = WM / GL, KM = NCH * WIN;
+    static constexpr int NEXTRA = (WIN - WM) * WIN, KE = (NEXTRA + GL - 1) / GL, K = KM + KE;
+    // the runs e in [lg * KE, (lg + 1) * KE) of the column-major extra pixels never continue into the next column
+    static constexpr bool RUNS = KE > 0 && ((WIN - WM) == 1 || WIN % (KE > 0 ? KE : 1) == 0);
+};
+
+// one region row in flight: 2 * CHN + 1 dwords of uint16 pixels -> 4 * CHN position dwords
+template <int CHN>
+struct RowRegs {
+    struct __attribute__((packed, aligned(2))) Raw { uint32_t d[2 * CHN + 1]; };
+    Raw v;
+    __device__ __forceinline__ void load(const uint16_t* __restrict__ src) { v = *reinterpret_cast<const Raw*>(src); }
+    __device__ __forceinline__ void store(uint32_t* dst) const {
+#pragma unroll
+        for (int c = 0; c < CHN; c++) {
+            const uint32_t a = v.d[2 * c], b = v.d[2 * c + 1], e = v.d[2 * c + 2];
+            *reinterpret_cast<uint4*>(dst + 4 * c) =
+                make_uint4(a, __builtin_amdgcn_alignbit(b, a, 16), b, __builtin_amdgcn_alignbit(e, b, 16));
+        }
+    }
+};
+
+// R = 128 * (sum of the 4 weighted taps) + bias; hi16(R) is the CV_DESCALEd sample minus the I value (see the header)
+__device__ __forceinline__ int interp_r(uint32_t top, uint32_t bot, const Weights& w, int bias) {
+    const int t = __builtin_amdgcn_sdot2(__builtin_bit_cast(pc_short2, top), __builtin_bit_cast(pc_short2, w.r0), bias, true);
+    return sdot2(bot, w.r1, t);
+}
+__device__ __forceinline__ int bias_of(int ival) { return (1 << 15) - (ival << 16); }
+// acc + hi16(a) * (int16)b.lo / b.hi
+__device__ __forceinline__ int mad16_hl(int a, uint32_t b, int acc) {
+    int d;
+    asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ int mad16_hh(int a, uint32_t b, int acc) {
+    int d;
+    asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+    return d;
+}
+
+__device__ __forceinline__ int half_sum3_i32(int v) {
+    v = group_allreduce_add<16>(v);
+    return v + __shfl_xor(v, 16);
+}
+__device__ __forceinline__ float half_exact_sum3(int partial) {
+    return exact_sum_to_float(half_sum3_i32(partial >> 16), half_sum3_i32(partial & 0xffff));
+}
+// sum over a 4-lane group as ONE rounding of the exact integer
+template <int K>
+__device__ __forceinline__ float group4_exact_sum3(int partial) {
+    if constexpr ((long long)K * 8160 * 4080 < (1ll << 30)) {   // pair sums stay below 2^31: add the pairs in fp64
+        const int v = partial + dpp_i32<0xB1>(partial);
+        const int other = dpp_i32<0x4E>(v);
+        return (float)((double)v + (double)other);
+    } else {
+        int hi = partial >> 16, lo = partial & 0xffff;
+        hi += dpp_i32<0xB1>(hi);
+        hi += dpp_i32<0x4E>(hi);
+        lo += dpp_i32<0xB1>(lo);
+        lo += dpp_i32<0x4E>(lo);
+        return exact_sum_to_float(hi, lo);
+    }
+}
+
+// Stage the J region of one group: rows lg, lg + 4, ... (a lane past the last row repeats it).  PC_LK3_STAGE_ROWS rows
+// of a lane are in flight at a time (7 VGPRs each for the 10-px window): all four would cost one memory latency per
+// region instead of two, but also push the kernel past 144 VGPRs, and three such wavefronts per SIMD then leave no
+// room in the register file for the preparation kernels that run beside LK.
+#ifndef PC_LK3_STAGE_ROWS
+#define PC_LK3_STAGE_ROWS 1
+#endif
+template <int WIN>
+__device__ __forceinline__ void stage_region(const uint16_t* __restrict__ J16, int pitch, int rx0, int ry0, uint32_t* jbuf, int lg) {
+    using G = LK3Geo<WIN>;
+    constexpr int TRIPS = (G::RH + G::GL - 1) / G::GL;
+    constexpr int B = TRIPS < PC_LK3_STAGE_ROWS ? TRIPS : PC_LK3_STAGE_ROWS;
+    const uint16_t* const base = J16 + (ptrdiff_t)(ry0 * pitch) + rx0;
+#pragma unroll
+    for (int k0 = 0; k0 < TRIPS; k0 += B) {
+        RowRegs<G::CH> rows[B];
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            const int k = k0 + b;
+            if (k < TRIPS) {
+                int r = lg + G::GL * k;
+                if (G::GL * (k + 1) > G::RH) r = min(r, G::RH - 1);
+                rows[b].load(base + (ptrdiff_t)(r * pitch));
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            const int k = k0 + b;
+            if (k < TRIPS) {
+                int r = lg + G::GL * k;
+                if (G::GL * (k + 1) > G::RH) r = min(r, G::RH - 1);
+                rows[b].store(jbuf + r * G::PITCH);
+            }
+        }
+        if (k0 + B < TRIPS) __builtin_amdgcn_sched_barrier(0);   // or the next batch's loads are hoisted up here
+    }
+}
+
+template <int WIN>
+__global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(const LKParams p) {
+    using G = LK3Geo<WIN>;
+    constexpr int GL = G::GL, NPX = G::NPX, NCH = G::NCH, KM = G::KM, KE = G::KE, K = G::K;
+    constexpr int KW = (NPX + 31) / 32;   // pixels per lane in the half-wave I-side pass
+    // + slack: slots past a lane's run of extra pixels read up to KE rows below the last region (and contribute 0)
+    constexpr int WAVE_DW = G::WAVE_DW + (KE > 0 ? (KE + 1) * G::PITCH : 0);
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[PC_LK3_WAVES][WAVE_DW];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, l32 = lane & 31, grp = (lane >> 2) & 7, lg = lane & 3;
+    // Workgroup b runs on XCD b % 8; each XCD takes one contiguous eighth of the (spatially binned) keypoint order
+    const int lb = (int)(blockIdx.x & 7u) * p.blocks_per_xcd + (int)(blockIdx.x >> 3);
+    const int first = (lb * PC_LK3_WAVES + wave) * 2;  // first of this wave's two keypoint slots
+    if ((int)(blockIdx.x >> 3) >= p.blocks_per_xcd || first >= p.n) return;   // whole waves exit together
+    const int slot = first + half;
+    const bool kp_valid = slot < p.n;                 // n odd: the last wave's second half idles
+    const int slot_c = kp_valid ? slot : first;
+    const int feat = p.perm ? (int)p.perm[slot_c] : slot_c;
+    const bool tgt_active = kp_valid && grp < p.n_targets;
+    const int tgt = grp < p.n_targets ? grp : 0;
+
+    uint32_t* const wbase = &s_buf[wave][0];
+    uint32_t* const ibuf = wbase + half * G::HALF_I_DW;                          // I window, position dwords
+    int32_t* const dbuf = reinterpret_cast<int32_t*>(ibuf + G::I_DW);            // raw Scharr window
+    uint32_t* const xbuf = ibuf + G::I_DW + G::D_DW;                             // (bias, Dxy) exchange
+    uint32_t* const jbuf = wbase + (half * 8 + grp) * G::J_DW;                   // aliases the above
+
+    // the lane's run of the columns that do not fill a chain (column-major order of those pixels)
+    int e_off = 0, e_len = 0, e_q0 = 0;          // RUNS: first top position (dwords from the window origin), length, pixel index
+    int offE[KE > 0 ? KE : 1], qE[KE > 0 ? KE : 1];
+    if constexpr (KE > 0) {
+        if constexpr (G::RUNS) {
+            const int e0 = lg * KE;
+            e_len = max(0, min(KE, G::NEXTRA - e0));
+            const int col = G::WM + (e_len > 0 ? e0 / WIN : 0), row0 = e_len > 0 ? e0 % WIN : 0;
+            e_off = row0 * G::PITCH + col;
+            e_q0 = row0 * WIN + col;
+        } else {
+#pragma unroll
+            for (int e = 0; e < KE; e++) {
+                const int r = lg * KE + e;
+                const int col = G::WM + r / WIN, row = r - (r / WIN) * WIN;
+                const bool ok = r < G::NEXTRA;
+                offE[e] = ok ? row * G::PITCH + col : 0;   // slots past the window read pixel 0, contribute 0
+                qE[e] = ok ? row * WIN + col : -1;
+            }
+        }
+    }
+
+    const float2 pt = p.pts[feat];
+    const float half_win = (float)(WIN - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (float)(1 << 20);
+    float nx = 0.f, ny = 0.f;
+    bool status = true;
+    float err = 0.f;
+    PC_PROF_DECL
+
+    for (int level = p.max_level; level >= 0; --level) {
+        const Level L = p.src[level];
+        const uint16_t* __restrict__ J16 = p.tgt16[tgt][level];
+        const int pitch = L.pitch;
+        const float lscale = 1.f / (float)(1 << level);
+        float px = pt.x * lscale, py = pt.y * lscale;
+        float qx, qy;
+        if (level == p.max_level) {
+            qx = px;
+            qy = py;
+        } else {
+            qx = nx * 2.f;
+            qy = ny * 2.f;
+        }
+        nx = qx;
+        ny = qy;
+
+        // ---- I side: identical for all targets of a keypoint -> computed once by its half-wave ----
+        px -= half_win;
+        py -= half_win;
+        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        const bool i_in = !(ipx < -WIN || ipx >= L.w || ipy < -WIN || ipy >= L.h);   // uniform per half
+        if (!i_in && level == 0) {
+            status = false;
+            err = 0.f;
+        }
+        const Weights wI = bilinear_weights(px - (float)ipx, py - (float)ipy);
+        const uint32_t wrow0 = wI.r0, wrow1 = wI.r1;
+
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous level's J regions are dead
+        if (i_in) {
+            DerivWindow<WIN, 32> dw;
+            dw.load(L.der + (ptrdiff_t)(ipy * pitch + ipx), pitch, l32);
+            // I window: lane r < WIN + 1 stages row r (the other lanes repeat the last row)
+            RowRegs<G::I_CH> row;
+            const int r = min(l32, G::I_ROWS - 1);
+            row.load(L.img16 + (ptrdiff_t)((ipy + r) * pitch) + ipx);
+            row.store(ibuf + r * G::I_PITCH);
+            dw.store(dbuf, l32);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        PC_PROF(0);
+        int sA11 = 0, sA12 = 0, sA22 = 0;
+        if (i_in) {
+#pragma unroll
+            for (int m = 0; m < KW; m++) {
+                const int q = l32 + 32 * m;
+                if (q < NPX) {
+                    const int y = q / WIN, x = q - y * WIN;
+                    const uint32_t* qp = ibuf + y * G::I_PITCH + x;
+                    const int ival = interp_r(qp[0], qp[G::I_PITCH], wI, 1 << 15) >> 16;
+                    const uint32_t* d = reinterpret_cast<const uint32_t*>(dbuf) + y * G::D_PITCH + x;
+                    const uint32_t d00 = d[0], d01 = d[1], d10 = d[G::D_PITCH], d11 = d[G::D_PITCH + 1];
+                    // (dx00, dx01), (dx10, dx11), (dy00, dy01), (dy10, dy11)
+                    const uint32_t dx0 = __builtin_amdgcn_perm(d01, d00, 0x05040100u);
+                    const uint32_t dx1 = __builtin_amdgcn_perm(d11, d10, 0x05040100u);
+                    const uint32_t dy0 = __builtin_amdgcn_perm(d01, d00, 0x07060302u);
+                    const uint32_t dy1 = __builtin_amdgcn_perm(d11, d10, 0x07060302u);
+                    const int ix = sdot2(dx1, wrow1, sdot2(dx0, wrow0, 1 << (W_BITS - 1))) >> W_BITS;
+                    const int iy = sdot2(dy1, wrow1, sdot2(dy0, wrow0, 1 << (W_BITS - 1))) >> W_BITS;
+                    xbuf[2 * q] = (uint32_t)bias_of(ival);
+                    xbuf[2 * q + 1] = (uint32_t)(ix & 0xffff) | ((uint32_t)iy << 16);
+                    sA11 += __mul24(ix, ix);   // |ix|, |iy| <= 4080
+                    sA12 += __mul24(ix, iy);
+                    sA22 += __mul24(iy, iy);
+                }
+            }
+        }
+        // per-lane partials fit int32; the half's totals are reduced as exact (hi, lo) halves
+        const float A11 = half_exact_sum3(sA11) * FLT_SCALE;
+        const float A12 = half_exact_sum3(sA12) * FLT_SCALE;
+        const float A22 = half_exact_sum3(sA22) * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float tdiff = A11 - A22;
+        const float min_eig = (A22 + A11 - sqrtf(tdiff * tdiff + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+        bool lvl_ok = i_in;
+        if (i_in && (min_eig < p.min_eig_thr || D < 1.1920928955078125e-07f /* FLT_EPSILON */)) {
+            if (level == 0) status = false;
+            lvl_ok = false;
+        }
+        D = 1.f / D;
+        lvl_ok = lvl_ok && tgt_active;   // idle groups only help with the I side
+
+        // every group picks up the pixels it owns
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        PC_PROF(1);
+        int Bias[K];  // 2^15 - ival * 2^16: the accumulator init of interp_r
+        int Dxy[K];   // (int16 ix) | (int16 iy << 16); 0 for slots without a pixel
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            Bias[k] = 0;
+            Dxy[k] = 0;
+        }
+        if (lvl_ok) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int r = 0; r < WIN; r++) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(xbuf + 2 * (r * WIN + lg + GL * c));
+                    Bias[c * WIN + r] = (int)v.x;
+                    Dxy[c * WIN + r] = (int)v.y;
+                }
+#pragma unroll
+            for (int e = 0; e < KE; e++) {
+                uint2 v = make_uint2(0u, 0u);
+                if constexpr (G::RUNS) {
+                    if (e < e_len) v = *reinterpret_cast<const uint2*>(xbuf + 2 * (e_q0 + e * WIN));
+                } else {
+                    if (qE[e] >= 0) v = *reinterpret_cast<const uint2*>(xbuf + 2 * qE[e]);
+                }
+                Bias[KM + e] = (int)v.x;
+                Dxy[KM + e] = (int)v.y;
+            }
+        }
+        // the J regions alias the I-side buffers of BOTH halves: no group may stage before every group has read
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        PC_PROF(2);
+        if (!lvl_ok) continue;
+
+        // ---- iterations on the staged J region ----
+        qx -= half_win;
+        qy -= half_win;
+        float pdx = 0.f, pdy = 0.f;
+        int rx0 = 0, ry0 = 0;
+        bool staged = false;
+        for (int j = 0; j < p.max_iters; j++) {
+            PC_PROF_COUNT(8);
+            const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
+            if (iqx < -WIN || iqx >= L.w || iqy < -WIN || iqy >= L.h) {
+                if (level == 0) status = false;
+                break;
+            }
+            if (!staged || iqx < rx0 || iqx > rx0 + 2 * G::MX || iqy < ry0 || iqy > ry0 + 2 * G::MY) {
+                rx0 = iqx - G::MX;
+                ry0 = iqy - G::MY;
+                PC_PROF(4);   // the timer reads are slow (scalar memory path): only around the rare staging, not per iteration
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                stage_region<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                staged = true;
+                PC_PROF_COUNT(9);
+                PC_PROF(3);
+            }
+            const Weights wJ = bilinear_weights(qx - (float)iqx, qy - (float)iqy);
+            const uint32_t* jq = jbuf + (iqy - ry0) * G::PITCH + (iqx - rx0);
+            int sb1 = 0, sb2 = 0;  // per-lane partials: <= K * 8160 * 4080
+            // A pixel is a dependent chain dot2 -> dot2 -> mad with wait states after each dot product; walked one
+            // pixel after the other that chain, not instruction issue, sets the pace (lk2 and a first version of this
+            // loop: 2 x s_nop 2 per pixel).  So the lane's pixels are cut into NR independent vertical runs -- every
+            // column chain in two halves, plus the run of the remaining columns -- and step s handles pixel s of all
+            // runs: all first dot products, then all second ones, then the accumulations.
+            {
+                constexpr int H1 = (WIN + 1) / 2, H2 = WIN - H1;          // rows of a chain's upper / lower half
+                constexpr int NRC = 2 * NCH;                              // chain halves
+                constexpr int NR = NRC + ((KE > 0 && G::RUNS) ? 1 : 0);
+                constexpr int STEPS = (KE > 0 && G::RUNS && KE > H1) ? KE : H1;
+                uint32_t top[NR > 0 ? NR : 1];
+                const uint32_t* rb[NR > 0 ? NR : 1];
+                int tb1 = 0, tb2 = 0;
+#pragma unroll
+                for (int u = 0; u < NRC; u++) {
+                    rb[u] = jq + lg + GL * (u >> 1) + ((u & 1) ? H1 * G::PITCH : 0);
+                    top[u] = rb[u][0];
+                }
+                if constexpr (NR > NRC) {
+                    rb[NRC] = jq + e_off;
+                    top[NRC] = rb[NRC][0];
+                }
+                // the LDS reads run one step ahead of the arithmetic (a ds_read takes 60+ cycles to return)
+                uint32_t bot[NR > 0 ? NR : 1], nxt[NR > 0 ? NR : 1];
+#pragma unroll
+                for (int u = 0; u < NR; u++) bot[u] = rb[u][G::PITCH];
+#pragma unroll
+                for (int st = 0; st < STEPS; st++) {
+                    int R[NR > 0 ? NR : 1];
+#pragma unroll
+                    for (int u = 0; u < NR; u++) {
+                        const int len = u < NRC ? ((u & 1) ? H2 : H1) : KE;
+                        if (st + 1 < len) nxt[u] = rb[u][(st + 2) * G::PITCH];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < NR; u++) {
+                        const int len = u < NRC ? ((u & 1) ? H2 : H1) : KE;
+                        const int k = u < NRC ? (u >> 1) * WIN + ((u & 1) ? H1 : 0) + st : KM + st;
+                        if (st < len)
+                            R[u] = __builtin_amdgcn_sdot2(__builtin_bit_cast(pc_short2, top[u]), __builtin_bit_cast(pc_short2, wJ.r0), Bias[k], true);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < NR; u++) {
+                        const int len = u < NRC ? ((u & 1) ? H2 : H1) : KE;
+                        if (st < len) {
+                            R[u] = sdot2(bot[u], wJ.r1, R[u]);
+                            top[u] = bot[u];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < NR; u++) {
+                        const int len = u < NRC ? ((u & 1) ? H2 : H1) : KE;
+                        const int k = u < NRC ? (u >> 1) * WIN + ((u & 1) ? H1 : 0) + st : KM + st;
+                        if (st < len) {   // slots past a lane's run of extra pixels: Dxy == 0
+                            // two accumulator pairs, alternating: a mad reading the previous mad's result needs a wait state
+                            if (u & 1) {
+                                tb1 = mad16_hl(R[u], (uint32_t)Dxy[k], tb1);
+                                tb2 = mad16_hh(R[u], (uint32_t)Dxy[k], tb2);
+                            } else {
+                                sb1 = mad16_hl(R[u], (uint32_t)Dxy[k], sb1);
+                                sb2 = mad16_hh(R[u], (uint32_t)Dxy[k], sb2);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < NR; u++) bot[u] = nxt[u];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                sb1 += tb1;   // integer sums: any order gives the same bits
+                sb2 += tb2;
+            }
+            if constexpr (KE > 0 && !G::RUNS) {
+                int R[KE];
+#pragma unroll
+                for (int e = 0; e < KE; e++)
+                    R[e] = __builtin_amdgcn_sdot2(__builtin_bit_cast(pc_short2, jq[offE[e]]), __builtin_bit_cast(pc_short2, wJ.r0), Bias[KM + e], true);
+#pragma unroll
+                for (int e = 0; e < KE; e++) R[e] = sdot2(jq[offE[e] + G::PITCH], wJ.r1, R[e]);
+#pragma unroll
+                for (int e = 0; e < KE; e++) {
+                    sb1 = mad16_hl(R[e], (uint32_t)Dxy[KM + e], sb1);
+                    sb2 = mad16_hh(R[e], (uint32_t)Dxy[KM + e], sb2);
+                }
+            }
+            const float b1 = group4_exact_sum3<K>(sb1) * FLT_SCALE;
+            const float b2 = group4_exact_sum3<K>(sb2) * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D;
+            const float dy = (A12 * b1 - A11 * b2) * D;
+            qx += dx;
+            qy += dy;
+            nx = qx + half_win;
+            ny = qy + half_win;
+            if ((double)dx * (double)dx + (double)dy * (double)dy <= p.eps_sq) break;
+            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+                nx -= dx * 0.5f;
+                ny -= dy * 0.5f;
+                break;
+            }
+            pdx = dx;
+            pdy = dy;
+        }
+
+        // ---- L1 patch error at level 0 ----
+        PC_PROF(4);
+        if (status && level == 0) {
+            const float ex = nx - half_win, ey = ny - half_win;
+            const int iex = (int)floorf(ex), iey = (int)floorf(ey);
+            if (iex < -WIN || iex >= L.w || iey < -WIN || iey >= L.h) {
+                status = false;
+                continue;
+            }
+            if (!staged || iex < rx0 || iex > rx0 + 2 * G::MX || iey < ry0 || iey > ry0 + 2 * G::MY) {
+                rx0 = iex - G::MX;
+                ry0 = iey - G::MY;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                stage_region<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                staged = true;
+            }
+            const Weights wE = bilinear_weights(ex - (float)iex, ey - (float)iey);
+            const uint32_t* jq = jbuf + (iey - ry0) * G::PITCH + (iex - rx0);
+            int se = 0;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const uint32_t* cb = jq + lg + GL * c;
+                uint32_t top = cb[0];
+#pragma unroll
+                for (int r = 0; r < WIN; r++) {
+                    const uint32_t bot = cb[(r + 1) * G::PITCH];
+                    const int diff = interp_r(top, bot, wE, Bias[c * WIN + r]) >> 16;
+                    top = bot;
+                    se += diff < 0 ? -diff : diff;
+                }
+            }
+            if constexpr (KE > 0) {
+                if constexpr (G::RUNS) {
+                    const uint32_t* cb = jq + e_off;
+                    uint32_t top = cb[0];
+#pragma unroll
+                    for (int e = 0; e < KE; e++) {
+                        const uint32_t bot = cb[(e + 1) * G::PITCH];
+                        const int diff = interp_r(top, bot, wE, Bias[KM + e]) >> 16;
+                        top = bot;
+                        se += (e < e_len) ? (diff < 0 ? -diff : diff) : 0;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < KE; e++) {
+                        const uint32_t* q = jq + offE[e];
+                        const int diff = interp_r(q[0], q[G::PITCH], wE, Bias[KM + e]) >> 16;
+                        se += (qE[e] >= 0) ? (diff < 0 ? -diff : diff) : 0;
+                    }
+                }
+            }
+            se += dpp_i32<0xB1>(se);   // <= 256 * 8160 < 2^24: exact in fp32 too
+            se += dpp_i32<0x4E>(se);
+            err = ((float)se * 1.f) / (float)(32 * WIN * WIN);
+        }
+        PC_PROF(5);
+    }
+#ifdef PC_LK_PROFILE
+    if (lane == 0 && p.prof) {   // one row per wavefront, summed on the host (atomics on ten words would clog the L2)
+        prof_acc[6] = __builtin_readcyclecounter() - prof_t0;
+        prof_acc[7] = 1;
+        for (int k = 0; k < 10; k++) p.prof[(size_t)(first >> 1) * 16 + k] = prof_acc[k];
+    }
+#endif
+
+    // one 16-byte record per (slot, target): the wavefront's results are contiguous
+    if (lg == 0 && tgt_active)
+        p.out_rec[(size_t)slot * kRecStride + tgt] = make_float4(nx, ny, status ? err : 0.f, __uint_as_float(status ? 1u : 0u));
+}
+
+template <int WIN>
+static void launch_lk3_t(const LKParams& p0, hipStream_t s) {
+    LKParams p = p0;
+    const int per_block = 2 * PC_LK3_WAVES;   // two keypoints per wavefront
+    const int blocks = (p.n + per_block - 1) / per_block;
+    if (blocks == 0) return;
+    p.blocks_per_xcd = (blocks + 7) / 8;
+    hipLaunchKernelGGL((lk3_kernel<WIN>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(64 * PC_LK3_WAVES), 0, s, p);
+}
+
+bool lk_profile_enabled() {
+#ifdef PC_LK_PROFILE
+    return true;
+#else
+    return false;
+#endif
+}
+
+bool launch_lk3(const LKParams& p, int win, hipStream_t s) {
+    if (!p.src[0].img16) return false;
+    switch (win) {
+#define PC_LK_CASE(W) case W: launch_lk3_t<W>(p, s); return true;
+        PC_LK_CASE(4) PC_LK_CASE(5) PC_LK_CASE(6) PC_LK_CASE(7) PC_LK_CASE(8) PC_LK_CASE(9) PC_LK_CASE(10) PC_LK_CASE(11)
+#undef PC_LK_CASE
+        default: return false;
+    }
+}
+
+}  // namespace pc

@@ -9,6 +9,12 @@
 namespace pc {
 
 constexpr int W_BITS = 14;
+#ifndef PC_LK_STAGE_BATCH
+#define PC_LK_STAGE_BATCH 13   // region rows a lane keeps in flight while staging (4 VGPRs each)
+#endif
+#ifndef PC_LK_STAGE_BATCH_IRR
+#define PC_LK_STAGE_BATCH_IRR 3   // the same for windows whose regions do not map onto whole rows per group
+#endif
 #ifndef PC_LK_MARGIN
 #define PC_LK_MARGIN 1
 #endif
@@ -151,43 +157,101 @@ __device__ __forceinline__ void stage_pairs(const uint8_t* __restrict__ img, int
     }
 }
 
-// The same staging for a region that lies inside the padded plane, with the (row, dword) walk done
-// on running pointers: no multiplication and no clamping per item.
-template <int WIN, int NL>
-__device__ __forceinline__ void stage_pairs_inside(const uint8_t* __restrict__ img, int pitch, int rx0, int ry0, int nrows,
-                                                   uint8_t* buf, int l) {
+// The same staging for a region that lies inside the padded plane.  ALL of a lane's global loads are issued
+// before the first one is consumed: the loop used to be "load, wait, permute, store" per trip, i.e. one exposed
+// memory latency per region row (13 per J region, 19 per pyramid level and wavefront), and with three
+// wavefronts per SIMD nothing covers them -- that serialisation, not instruction issue, was most of a
+// wavefront's life time.  Costs 2 * TRIPS VGPRs while the loads are in flight.
+// one batch of trips [k0, k0 + B): loads first, then permute + store.  const_k: k0 is a compile-time constant at
+// the (inlined) call site, so only a trip that can run past the end clamps its index (a clamped index is a per-lane
+// VGPR value; the other trips keep constant row numbers).
+template <int WIN, int NL, int TOTAL, int B>
+__device__ __forceinline__ void stage_pairs_batch(const uint8_t* base, int pitch, uint8_t* buf, int l, int k0, bool const_k) {
     using G = LKGeo<WIN>;
-    constexpr int DR = NL / G::RW_DW, DM = NL % G::RW_DW;   // one trip advances DR rows and DM dwords
-    const int total = nrows * G::RW_DW;
-    int r = l / G::RW_DW, m = l - r * G::RW_DW;
-    const uint8_t* src = img + (ptrdiff_t)((ry0 + r) * pitch) + (rx0 + 4 * m);
-    uint8_t* dst = buf + r * G::PAIR_PITCH + 8 * m;
-    const int src_step = DR * pitch + 4 * DM, src_wrap = pitch - 4 * G::RW_DW;
-    constexpr int dst_step = DR * G::PAIR_PITCH + 8 * DM, dst_wrap = G::PAIR_PITCH - 8 * G::RW_DW;
-#pragma unroll 1
-    for (int i = l; i < total; i += NL) {
-        const uint32_t d0 = *reinterpret_cast<const uint32_t*>(src);
-        const uint32_t d1 = *reinterpret_cast<const uint32_t*>(src + 4);
-        const uint32_t p0 = __builtin_amdgcn_perm(d1, d0, 0x02010100u);  // (A0,A1),(A1,A2)
-        const uint32_t p1 = __builtin_amdgcn_perm(d1, d0, 0x04030302u);  // (A2,A3),(A3,A4)
-        *reinterpret_cast<uint2*>(dst) = make_uint2(p0, p1);
-        m += DM;
-        const bool wrap = m >= G::RW_DW;
-        m -= wrap ? G::RW_DW : 0;
-        src += src_step + (wrap ? src_wrap : 0);
-        dst += dst_step + (wrap ? dst_wrap : 0);
+    uint32_t d0[B], d1[B];
+    int r[B], m[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        // lanes past the end handle the last item once more (same address, same value) instead of branching:
+        // a predicated tail makes the compiler sink its load behind the first wait
+        int i = l + NL * (k0 + b);
+        if (!const_k || NL * (k0 + b + 1) > TOTAL) i = min(i, TOTAL - 1);
+        r[b] = i / G::RW_DW;
+        m[b] = i - r[b] * G::RW_DW;
+        const uint8_t* src = base + (ptrdiff_t)(r[b] * pitch) + 4 * m[b];
+        d0[b] = *reinterpret_cast<const uint32_t*>(src);
+        d1[b] = *reinterpret_cast<const uint32_t*>(src + 4);
+    }
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+        const uint32_t p0 = __builtin_amdgcn_perm(d1[b], d0[b], 0x02010100u);  // (A0,A1),(A1,A2)
+        const uint32_t p1 = __builtin_amdgcn_perm(d1[b], d0[b], 0x04030302u);  // (A2,A3),(A3,A4)
+        *reinterpret_cast<uint2*>(buf + r[b] * G::PAIR_PITCH + 8 * m[b]) = make_uint2(p0, p1);
     }
 }
 
-template <int WIN, int NL>
-__device__ __forceinline__ void stage_pairs_auto(const uint8_t* __restrict__ img, int pitch, int lh, int rx0, int ry0,
-                                                 int nrows, uint8_t* buf, int l) {
+template <int WIN, int NL, int NROWS>
+__device__ __forceinline__ void stage_pairs_inside(const uint8_t* __restrict__ img, int pitch, int rx0, int ry0,
+                                                   uint8_t* buf, int l) {
     using G = LKGeo<WIN>;
-    const bool inside = (ry0 >= -WIN) && (ry0 + nrows <= lh + WIN) && (rx0 >= -kPadX) &&
-                        (rx0 + G::RWB + 4 <= pitch - kPadX);
-    if (inside) stage_pairs_inside<WIN, NL>(img, pitch, rx0, ry0, nrows, buf, l);
-    else stage_pairs<WIN, NL, true>(img, pitch, lh, rx0, ry0, nrows, buf, l);
+    constexpr int TOTAL = NROWS * G::RW_DW;
+    constexpr int TRIPS = (TOTAL + NL - 1) / NL;
+    // When the lanes of a group map onto whole region rows (NL % RW_DW == 0: windows 7..10 with 4-lane groups) the
+    // (row, dword) of every trip is a constant plus the lane's, and the trips are unrolled in batches of
+    // PC_LK_STAGE_BATCH.  Otherwise the indices are per-lane values: fully unrolled, the compiler hoists one set per
+    // trip out of the iteration loops and keeps them in registers for the whole kernel (250 VGPRs at WIN = 11) --
+    // those windows walk a real loop of batches.
+    constexpr bool REGULAR = (NL % G::RW_DW == 0) || (G::RW_DW % NL == 0);
+    const uint8_t* const base = img + (ptrdiff_t)(ry0 * pitch) + rx0;
+    if constexpr (REGULAR) {
+        constexpr int B = TRIPS <= PC_LK_STAGE_BATCH ? TRIPS : PC_LK_STAGE_BATCH;
+        constexpr int FULL = TRIPS / B, REST = TRIPS - FULL * B;
+#pragma unroll
+        for (int q = 0; q < FULL; q++) {
+            stage_pairs_batch<WIN, NL, TOTAL, B>(base, pitch, buf, l, q * B, true);
+            if (q + 1 < FULL || REST > 0) __builtin_amdgcn_sched_barrier(0);   // keep the next batch's loads below
+        }
+        if constexpr (REST > 0) stage_pairs_batch<WIN, NL, TOTAL, REST>(base, pitch, buf, l, FULL * B, true);
+    } else {
+        constexpr int B = TRIPS < PC_LK_STAGE_BATCH_IRR ? TRIPS : PC_LK_STAGE_BATCH_IRR;
+#pragma unroll 1
+        for (int k0 = 0; k0 < TRIPS; k0 += B) stage_pairs_batch<WIN, NL, TOTAL, B>(base, pitch, buf, l, k0, false);
+    }
 }
+
+template <int WIN, int NL, int NROWS>
+__device__ __forceinline__ void stage_pairs_auto(const uint8_t* __restrict__ img, int pitch, int lh, int rx0, int ry0,
+                                                 uint8_t* buf, int l) {
+    using G = LKGeo<WIN>;
+    const bool inside = (ry0 >= -WIN) && (ry0 + NROWS <= lh + WIN) && (rx0 >= -kPadX) &&
+                        (rx0 + G::RWB + 4 <= pitch - kPadX);
+    if (inside) stage_pairs_inside<WIN, NL, NROWS>(img, pitch, rx0, ry0, buf, l);
+    else stage_pairs<WIN, NL, true>(img, pitch, lh, rx0, ry0, NROWS, buf, l);
+}
+
+// Raw Scharr window ((WIN+1)^2 dwords at `Dbase`, row pitch `pitch` dwords) -> LDS with NL lanes.  load() only
+// issues the loads, so the caller can put the I-window staging between load() and store() and pay one memory
+// latency for both.
+template <int WIN, int NL>
+struct DerivWindow {
+    static constexpr int TOTAL = (WIN + 1) * (WIN + 1);
+    static constexpr int TRIPS = (TOTAL + NL - 1) / NL;
+    int32_t v[TRIPS];
+    __device__ __forceinline__ void load(const int32_t* __restrict__ Dbase, int pitch, int l) {
+#pragma unroll
+        for (int k = 0; k < TRIPS; k++) {
+            const int i = min(l + NL * k, TOTAL - 1);   // lanes past the end repeat the last item (see stage_pairs_inside)
+            const int r = i / (WIN + 1), c = i - r * (WIN + 1);
+            v[k] = Dbase[r * pitch + c];
+        }
+    }
+    __device__ __forceinline__ void store(int32_t* dbuf, int l) const {
+#pragma unroll
+        for (int k = 0; k < TRIPS; k++) {
+            dbuf[min(l + NL * k, TOTAL - 1)] = v[k];
+        }
+    }
+};
 
 // wave-wide exact integer sum -> fp32: DPP inside each 16-lane row, then the 4 row results
 // (lanes 0,16,32,48) through readlane

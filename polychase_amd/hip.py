@@ -21,6 +21,7 @@ SYMBOLS = [
     "pc_gftt_default_options", "pc_flow_default_options", "pc_last_error", "pc_version",
     "pc_context_create", "pc_context_destroy", "pc_context_synchronize", "pc_context_stream",
     "pc_context_enable_timing", "pc_context_get_timing", "pc_context_get_busy_time", "pc_context_reset_timing",
+    "pc_debug_lk_profile",
     "pc_frame_create", "pc_frame_destroy", "pc_frame_set_rgb", "pc_frame_set_rgb_f32", "pc_frame_set_gray",
     "pc_host_buffer_alloc", "pc_host_buffer_free",
     "pc_frame_num_levels", "pc_frame_level_size", "pc_frame_download_gray", "pc_frame_download_level",
@@ -102,6 +103,7 @@ def load():
     L.pc_context_get_timing.argtypes = [vp, C.c_int, ip, C.POINTER(C.c_double)]
     L.pc_context_get_busy_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.pc_context_reset_timing.argtypes = [vp]
+    L.pc_debug_lk_profile.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     L.pc_frame_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.pc_frame_destroy.argtypes = [vp]
     L.pc_frame_destroy.restype = None
@@ -202,6 +204,12 @@ class Context:
             _check(load().pc_context_get_timing(self._h, k, C.byref(n), C.byref(ms)))
             out[name] = (n.value, ms.value)
         return out
+
+    def lk_profile(self) -> list:
+        """per-phase cycle sums of the LK kernel since the last call (zeros unless the library was built with -DPC_LK_PROFILE)"""
+        out = (C.c_ulonglong * 16)()
+        _check(load().pc_debug_lk_profile(self._h, out))
+        return list(out)
 
     def busy_ms(self, kernel_class: str) -> float:
         """wall time during which at least one launch of the class was executing (launches may overlap)"""
