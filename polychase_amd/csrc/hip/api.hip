@@ -83,10 +83,28 @@ int ensure_kp_capacity(pc_frame* f, int n) {
     return PC_OK;
 }
 
-// gray already in level-0 interior -> borders, pyrDown chain, Scharr planes
-void build_pyramid(pc_context* c, pc_frame* f) {
+// POLYCHASE_PYRAMID_VARIANT=1: the unfused kernels of kernels_image.hip (gray, pyrDown, border, widen, Scharr: the
+// cross-check of the fused level kernel)
+static bool unfused_pyramid() {
+    static const bool v = [] {
+        const char* e = getenv("POLYCHASE_PYRAMID_VARIANT");
+        return e && atoi(e) == 1;
+    }();
+    return v;
+}
+static bool level_fits_fused(const pc::Level& L, int win) { return L.w > win + 1 && L.h > win + 1; }
+
+// gray already in level-0 interior -> borders, pyrDown chain, Scharr planes (levels [first, nlevels))
+void build_pyramid(pc_context* c, pc_frame* f, int first) {
     ScopedTimer t(c, PC_K_PYRAMID);
-    for (int l = 0; l < f->nlevels; l++) {
+    for (int l = first; l < f->nlevels; l++) {
+        if (l > 0 && !unfused_pyramid() && level_fits_fused(f->levels[l], f->win)) {
+            pc::LevelSource in{};
+            in.kind = pc::SRC_PYR;
+            in.parent = f->levels[l - 1];
+            pc::launch_level(in, f->levels[l], f->win, c->work);
+            continue;
+        }
         if (l > 0) pc::launch_pyrdown(f->levels[l - 1], f->levels[l], c->work);
         pc::launch_border(f->levels[l], f->win, c->work);
         pc::launch_widen(f->levels[l], f->win, c->work);
@@ -112,26 +130,21 @@ int validate_gftt(const pc_gftt_options* opt, int w, int h, pc::GfttGrid* g) {
     return PC_OK;
 }
 
-// Dense part of GoodFeaturesToTrack, fully on the GPU and asynchronous: min-eig map + per-cell max
-// (gftt.cc:35,:61-63), threshold + NMS -> candidates (gftt.cc:64-86), exact min-distance suppression
-// (gftt.cc:100-164), accepted candidates -> list.  Counts are copied to pinned memory; `ev` fires after.
+// Phase A of GoodFeaturesToTrack (see DetectScratch), asynchronous: min-eig map + per-cell max (gftt.cc:35,:61-63),
+// threshold + NMS -> candidates (gftt.cc:64-86).  The candidate count is copied to pinned memory; `ev` fires after.
 int detect_phase_a(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const pc_gftt_options& opt,
                    DetectScratch& d) {
     const int w = f->w, h = f->h;
     const size_t npx = (size_t)w * h;
-    PC_HIP(ctx->eig.ensure(npx));
-    PC_HIP(ctx->cmap.ensure(npx));
-    PC_HIP(ctx->state.ensure(npx));
-    PC_HIP(d.keys_in.ensure(npx));
-    PC_HIP(d.acc_keys.ensure(npx));
+    PC_HIP(d.eig.ensure(npx));
+    PC_HIP(d.cstate.ensure(npx + 16));
+    PC_HIP(d.keys.ensure(npx));
+    PC_HIP(d.keys_sorted.ensure(npx));
     PC_HIP(d.counters.ensure(kCounterCells + pc::kMaxGridCells));
-    PC_HIP(d.h_counters.ensure(kCounterCells));
+    PC_HIP(d.per_block.ensure((size_t)pc::suppress_num_blocks((uint32_t)npx) + 1));
+    PC_HIP(d.h_counters.ensure(2 * kCounterCells));
     if (!d.ev) PC_HIP(hipEventCreateWithFlags(&d.ev, hipEventDisableTiming));
-    if (ctx->resident_blocks == 0) {
-        hipDeviceProp_t prop;
-        PC_HIP(hipGetDeviceProperties(&prop, ctx->device));
-        ctx->resident_blocks = std::max(1, prop.multiProcessorCount) * 6;  // 256-lane blocks, 34 VGPRs: 8 fit per CU
-    }
+    if (!d.ev_b) PC_HIP(hipEventCreateWithFlags(&d.ev_b, hipEventDisableTiming));
     const bool suppress = opt.min_distance >= 1;
     if (suppress && ctx->sup_min_distance != opt.min_distance) {
         const std::vector<int2> offs = suppression_offsets(opt.min_distance);
@@ -145,55 +158,73 @@ int detect_phase_a(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const
     uint32_t* cell_max = d.counters.p + kCounterCells;
     {
         ScopedTimer t(ctx, PC_K_MINEIG);
-        pc::launch_min_eig(f->levels[0], ctx->eig.p, grid, cell_max, ctx->work);
+        pc::launch_min_eig(f->levels[0], d.eig.p, grid, cell_max, ctx->work);
     }
-    ctx->eig_owner = f;
     {
         ScopedTimer t(ctx, PC_K_NMS);
-        pc::launch_nms_compact(ctx->eig.p, w, h, grid, cell_max, opt.quality_level, d.keys_in.p, (uint32_t)npx,
-                               d.counters.p, ctx->cmap.p, ctx->state.p, ctx->work);
-    }
-    {
-        ScopedTimer t(ctx, PC_K_SUPPRESS);
-        if (suppress)
-            pc::launch_suppress(d.keys_in.p, d.counters.p, (uint32_t)npx, w, h, ctx->cmap.p, ctx->state.p,
-                                ctx->sup_offsets.p, ctx->n_sup_offsets, d.counters.p + 2, ctx->resident_blocks,
-                                ctx->work);
-        pc::launch_collect_accepted(d.keys_in.p, d.counters.p, (uint32_t)npx, ctx->state.p, suppress ? 0 : 1,
-                                    d.acc_keys.p, d.counters.p + 1, ctx->work);
+        pc::launch_nms(d.eig.p, w, h, grid, cell_max, opt.quality_level, d.keys.p, (uint32_t)npx, d.counters.p, d.cstate.p, ctx->work);
     }
     PC_HIP(hipMemcpyAsync(d.h_counters.p, d.counters.p, kCounterCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
     PC_HIP(hipEventRecord(d.ev, ctx->work));
+    f->n_kps = -1;
+    f->n_cands = -1;
+    f->perm_valid = false;
     return PC_OK;
 }
 
-// Ordering part: sort the accepted corners (value desc, address desc == acceptance order of the
-// greedy loop, gftt.cc:98,:157), truncate to max_corners (gftt.cc:160-162), write float2 keypoints.
-int detect_phase_b(pc_context* ctx, pc_frame* f, const pc_gftt_options& opt, DetectScratch& d) {
+// Phase B: waits (on the host) for the candidate count, then enqueues the candidate sort (value desc, address desc ==
+// the processing order of the greedy loop, gftt.cc:98), the suppression in that order (gftt.cc:100-164), the ordered
+// compaction of the accepted corners into keypoints (truncated to max_corners, gftt.cc:157-162) and their LK visiting
+// order.  The keypoint count is copied to pinned memory; `ev_b` fires after.
+int detect_phase_b(pc_context* ctx, pc_frame* f, const pc_gftt_options& opt, DetectScratch& d, DevBuf<uint32_t>& hist) {
     PC_HIP(hipEventSynchronize(d.ev));
     const uint32_t npx = (uint32_t)((size_t)f->w * f->h);
     const uint32_t n_cand = std::min(d.h_counters.p[0], npx);
-    const uint32_t n_acc = std::min(d.h_counters.p[1], n_cand);
-    if (d.h_counters.p[2] != 0)
-        return fail(PC_E_HIP, "suppression kernel did not converge (%u lanes gave up): grid not resident?", d.h_counters.p[2]);
+    d.n_cand = n_cand;
     f->n_cands = (int)n_cand;
-    int n = (int)n_acc;
-    if (n > 0) {
-        PC_HIP(ctx->keys_out.ensure(n_acc));
+    f->perm_valid = false;
+    if (n_cand > 0) {
         size_t temp_bytes = 0;
-        PC_HIP(pc::sort_keys_desc(nullptr, temp_bytes, d.acc_keys.p, ctx->keys_out.p, n_acc, ctx->work));
+        PC_HIP(pc::sort_keys_desc(nullptr, temp_bytes, d.keys.p, d.keys_sorted.p, n_cand, ctx->work));
         PC_HIP(ctx->sort_temp.ensure(temp_bytes));
         {
             ScopedTimer t(ctx, PC_K_SORT);
-            PC_HIP(pc::sort_keys_desc(ctx->sort_temp.p, temp_bytes, d.acc_keys.p, ctx->keys_out.p, n_acc, ctx->work));
+            PC_HIP(pc::sort_keys_desc(ctx->sort_temp.p, temp_bytes, d.keys.p, d.keys_sorted.p, n_cand, ctx->work));
         }
-        if (opt.max_corners > 0) n = std::min(n, opt.max_corners);
-        int rc = ensure_kp_capacity(f, n);
+        // every candidate may become a keypoint
+        const int cap = opt.max_corners > 0 ? (int)std::min<uint32_t>(n_cand, (uint32_t)opt.max_corners) : (int)n_cand;
+        int rc = ensure_kp_capacity(f, cap);
         if (rc != PC_OK) return rc;
-        pc::launch_keys_to_xy(ctx->keys_out.p, n, f->w, f->d_kps, ctx->work);
+        if (f->perm_cap < cap) {
+            if (f->d_perm) PC_HIP(hipFree(f->d_perm));
+            f->d_perm = nullptr;
+            f->perm_cap = 0;
+            const int want = std::max(cap + cap / 2, 1024);
+            PC_HIP(hipMalloc(&f->d_perm, (size_t)want * 2 * sizeof(uint32_t)));   // order + inverse
+            f->perm_cap = want;
+        }
+        {
+            ScopedTimer t(ctx, PC_K_SUPPRESS);
+            pc::launch_suppress_sorted(d.keys_sorted.p, n_cand, f->w, f->h, d.eig.p, d.cstate.p, ctx->sup_offsets.p, ctx->n_sup_offsets,
+                                       opt.min_distance >= 1, d.per_block.p, d.counters.p + 2, ctx->work);
+            pc::launch_accepted_to_keypoints(d.keys_sorted.p, n_cand, f->w, d.cstate.p, d.per_block.p, (uint32_t)std::max(opt.max_corners, 0),
+                                             f->d_kps, d.counters.p + 1, ctx->work);
+        }
+        PC_HIP(hist.ensure((size_t)pc::bin_num_tiles(f->w, f->h) + 1));
+        pc::launch_spatial_bins(f->d_kps, cap, d.counters.p + 1, f->w, f->h, hist.p, f->d_perm, f->d_perm + f->perm_cap, ctx->work);
     }
-    f->n_kps = n;
-    f->perm_valid = false;
+    PC_HIP(hipMemcpyAsync(d.h_counters.p + kCounterCells, d.counters.p, kCounterCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
+    PC_HIP(hipEventRecord(d.ev_b, ctx->work));
+    return PC_OK;
+}
+
+// Phase C: the keypoint count reaches the host
+int detect_phase_c(pc_context* ctx, pc_frame* f, DetectScratch& d) {
+    PC_HIP(hipEventSynchronize(d.ev_b));
+    const uint32_t* hc = d.h_counters.p + kCounterCells;
+    if (hc[2] != 0) return fail(PC_E_HIP, "suppression kernel did not converge (%u lanes gave up)", hc[2]);
+    f->n_kps = d.n_cand > 0 ? (int)std::min(hc[1], d.n_cand) : 0;
+    f->perm_valid = f->n_kps > 0;
     return PC_OK;
 }
 
@@ -224,7 +255,7 @@ int order_keypoints_spatially(pc_context* ctx, pc_frame* f, DevBuf<uint32_t>& hi
         f->perm_cap = cap;
     }
     PC_HIP(hist.ensure((size_t)pc::bin_num_tiles(f->w, f->h) + 1));
-    pc::launch_spatial_bins(f->d_kps, n, f->w, f->h, hist.p, f->d_perm, f->d_perm + f->perm_cap, ctx->work);
+    pc::launch_spatial_bins(f->d_kps, n, nullptr, f->w, f->h, hist.p, f->d_perm, f->d_perm + f->perm_cap, ctx->work);
     f->perm_valid = true;
     return PC_OK;
 }
@@ -277,7 +308,7 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
     } else {
         PC_HIP(ctx->lk_perm.ensure((size_t)n * 2));
         PC_HIP(ctx->lk_hist.ensure((size_t)pc::bin_num_tiles(frame1->w, frame1->h) + 1));
-        pc::launch_spatial_bins(frame1->d_kps, n, frame1->w, frame1->h, ctx->lk_hist.p, ctx->lk_perm.p, ctx->lk_perm.p + n, lk_stream);
+        pc::launch_spatial_bins(frame1->d_kps, n, nullptr, frame1->w, frame1->h, ctx->lk_hist.p, ctx->lk_perm.p, ctx->lk_perm.p + n, lk_stream);
         p.perm = ctx->lk_perm.p;
         ctx->lk_slot_of[set] = ctx->lk_perm.p + n;
     }
@@ -363,16 +394,12 @@ void pc_context_destroy(pc_context* c) {
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     c->staging.release();
-    c->eig.release();
-    c->cmap.release();
-    c->state.release();
     c->sup_offsets.release();
     if (c->detect) {
         c->detect->release();
         delete c->detect;
         c->detect = nullptr;
     }
-    c->keys_out.release();
     c->sort_temp.release();
     c->lk_rec[0].release();
     c->lk_rec[1].release();
@@ -565,13 +592,28 @@ int pc_api::set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t r
         PC_HIP(hipMemcpy2DAsync(ctx->staging.p, d_pitch, src, row_pitch, row_bytes, f->h, hipMemcpyHostToDevice, ctx->work));
         d_src = ctx->staging.p;
     }
-    {
-        ScopedTimer t(ctx, PC_K_GRAY);
-        if (elem_size == 4) pc::launch_rgbf32_to_gray(reinterpret_cast<const float*>(d_src), d_pitch, channels, f->levels[0], ctx->work);
-        else if (channels == 3) pc::launch_rgb2gray(d_src, d_pitch, f->levels[0], ctx->work);
-        else pc::launch_copy_gray(d_src, d_pitch, f->levels[0], ctx->work);
+    if (!unfused_pyramid() && level_fits_fused(f->levels[0], f->win)) {
+        // level 0 in one pass: gray conversion fused with the padding, the uint16 plane and the Scharr plane
+        pc::LevelSource in{};
+        in.kind = elem_size == 4 ? pc::SRC_RGBF32 : (channels == 3 ? pc::SRC_RGB8 : pc::SRC_GRAY8);
+        in.src = d_src;
+        in.src_pitch = d_pitch;
+        in.channels = channels;
+        in.aligned = ((reinterpret_cast<uintptr_t>(d_src) | d_pitch) & 3) == 0;
+        {
+            ScopedTimer t(ctx, PC_K_PYRAMID);
+            pc::launch_level(in, f->levels[0], f->win, ctx->work);
+        }
+        build_pyramid(ctx, f, 1);
+    } else {
+        {
+            ScopedTimer t(ctx, PC_K_GRAY);
+            if (elem_size == 4) pc::launch_rgbf32_to_gray(reinterpret_cast<const float*>(d_src), d_pitch, channels, f->levels[0], ctx->work);
+            else if (channels == 3) pc::launch_rgb2gray(d_src, d_pitch, f->levels[0], ctx->work);
+            else pc::launch_copy_gray(d_src, d_pitch, f->levels[0], ctx->work);
+        }
+        build_pyramid(ctx, f, 0);
     }
-    build_pyramid(ctx, f);
     f->n_kps = -1;
     f->n_cands = -1;
     f->perm_valid = false;
@@ -654,7 +696,9 @@ int pc_frame_detect(pc_context* ctx, pc_frame* f, const pc_gftt_options* opt) {
     if (int jrc = join_prep(ctx)) return jrc;
     if (!ctx->detect) ctx->detect = new DetectScratch();
     if ((rc = detect_phase_a(ctx, f, g, *opt, *ctx->detect)) != PC_OK) return rc;
-    if ((rc = detect_phase_b(ctx, f, *opt, *ctx->detect)) != PC_OK) return rc;
+    ctx->eig_owner = f;
+    if ((rc = detect_phase_b(ctx, f, *opt, *ctx->detect, ctx->lk_hist)) != PC_OK) return rc;
+    if ((rc = detect_phase_c(ctx, f, *ctx->detect)) != PC_OK) return rc;
     PC_HIP(hipStreamSynchronize(ctx->stream));
     return PC_OK;
 }
@@ -662,8 +706,8 @@ int pc_frame_detect(pc_context* ctx, pc_frame* f, const pc_gftt_options* opt) {
 int pc_frame_download_min_eig(pc_context* ctx, const pc_frame* f, float* out) {
     if (!ctx || !f || !out) return fail(PC_E_INVALID, "null argument");
     if (int jrc = join_prep(ctx)) return jrc;
-    if (ctx->eig_owner != f) return fail(PC_E_STATE, "the min-eig scratch map belongs to another frame (call right after pc_frame_detect)");
-    PC_HIP(hipMemcpyAsync(out, ctx->eig.p, (size_t)f->w * f->h * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->eig_owner != f || !ctx->detect) return fail(PC_E_STATE, "the min-eig scratch map belongs to another frame (call right after pc_frame_detect)");
+    PC_HIP(hipMemcpyAsync(out, ctx->detect->eig.p, (size_t)f->w * f->h * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PC_HIP(hipStreamSynchronize(ctx->stream));
     return PC_OK;
 }

@@ -11,7 +11,7 @@ using namespace pc_api;
 
 namespace {
 
-enum DetState { DET_NONE = 0, DET_DENSE = 1, DET_DONE = 3 };
+enum DetState { DET_NONE = 0, DET_DENSE = 1, DET_ORDERED = 2, DET_DONE = 3 };   // phases A, B enqueued; C done
 
 struct Slot {
     pc_frame* frame = nullptr;
@@ -73,25 +73,36 @@ int detect_dense(pc_analyzer* a, Slot& s) {
     return rc;
 }
 
-int detect_finish(pc_analyzer* a, Slot& s) {
+// phase B (sort, suppression in priority order, keypoints, visiting order) once the candidate count is on the host
+int detect_order(pc_analyzer* a, Slot& s) {
     int rc;
     if (s.det == DET_NONE && (rc = detect_dense(a, s)) != PC_OK) return rc;
-    if ((rc = detect_phase_b(a->ctx, s.frame, a->gopt, s.scratch)) != PC_OK) return rc;
-    if ((rc = order_keypoints_spatially(a->ctx, s.frame, a->ctx->prep_hist)) != PC_OK) return rc;
+    if ((rc = detect_phase_b(a->ctx, s.frame, a->gopt, s.scratch, a->ctx->prep_hist)) != PC_OK) return rc;
     PC_HIP(hipEventRecord(s.kps_ready, a->ctx->prep_stream));
-    s.det = DET_DONE;
+    s.det = DET_ORDERED;
     s.supplied = false;
     return PC_OK;
 }
 
-// Ordering phase of the frame that will most likely be the next frame1, if its dense phase has
-// already delivered its counters: keeps sort + binning off the LK stream's critical path.
+int detect_finish(pc_analyzer* a, Slot& s) {
+    int rc;
+    if (s.det < DET_ORDERED) {
+        PrepScope prep(a->ctx);
+        if ((rc = detect_order(a, s)) != PC_OK) return rc;
+    }
+    if ((rc = detect_phase_c(a->ctx, s.frame, s.scratch)) != PC_OK) return rc;
+    s.det = DET_DONE;
+    return PC_OK;
+}
+
+// Phase B of the frame that will most likely be the next frame1, if its dense phase has already delivered its
+// candidate count: keeps sort + suppression + binning off the LK lanes' critical path.
 int preorder_if_ready(pc_analyzer* a, int32_t frame_id) {
     Slot* s = find_slot(a, frame_id);
     if (!s || s->det != DET_DENSE || !s->scratch.ev) return PC_OK;
     if (hipEventQuery(s->scratch.ev) != hipSuccess) return PC_OK;
     PrepScope prep(a->ctx);
-    return detect_finish(a, *s);
+    return detect_order(a, *s);
 }
 
 }  // namespace
@@ -127,7 +138,7 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
         rc = pc_frame_create(ctx, width, height, flow->window_size, flow->max_level, &s.frame);
         if (rc != PC_OK) break;
         // room for a typical frame's keypoints up front: growing later frees device memory, which synchronises
-        const int kp0 = std::max(16384, (width * height) / 32);
+        const int kp0 = std::max(16384, (width * height) / 16);   // candidates of a textured frame: ~1 per 23 px
         if ((rc = ensure_kp_capacity(s.frame, kp0)) != PC_OK) break;
         if (hipMalloc(reinterpret_cast<void**>(&s.frame->d_perm), (size_t)kp0 * 2 * sizeof(uint32_t)) != hipSuccess) {
             rc = fail(PC_E_HIP, "hipMalloc failed");
@@ -286,7 +297,6 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     bool detected = false;
     if (s1->det != DET_DONE) {
         SlowSection ss("submit/detect_finish");
-        PrepScope prep(a->ctx);
         if ((rc = detect_finish(a, *s1)) != PC_OK) return rc;
         detected = true;
     } else {

@@ -101,20 +101,32 @@ using pc::PinBuf;
 using pc::TimedRange;
 using pc::fail;
 
-// Per-detection buffers that must survive between the dense phase (enqueued when a frame becomes
-// resident) and the ordering phase (run when the frame is used as frame1).
+// Per-detection buffers of one frame.  Detection is three-phase and host-free between the phases:
+//   A (dense)    min-eig map + per-cell max, threshold + NMS -> candidate keys + state bytes; the candidate count goes
+//                to pinned memory (ev_a)
+//   B (ordering) needs that count on the host: sort the candidates, greedy suppression in priority order, ordered
+//                compaction -> keypoints, LK visiting order; the keypoint count goes to pinned memory (ev_b)
+//   C            the host reads the keypoint count
 struct DetectScratch {
-    DevBuf<unsigned long long> keys_in, acc_keys;
-    DevBuf<uint32_t> counters;             // [0] candidates, [1] accepted, [2] stuck lanes, [3] pad, [4..] cell max
-    PinBuf<uint32_t> h_counters;
-    hipEvent_t ev = nullptr;
+    DevBuf<unsigned long long> keys, keys_sorted;
+    DevBuf<float> eig;                     // min-eig map (K2 -> K3, K5)
+    DevBuf<uint8_t> cstate;                // 0 no candidate / 1 candidate / 2 accepted / 3 rejected
+    DevBuf<uint32_t> counters;             // [0] candidates, [1] keypoints, [2] stuck lanes, [3] pad, [4..] cell max
+    DevBuf<uint32_t> per_block;            // accepted candidates per suppression workgroup -> their exclusive scan
+    PinBuf<uint32_t> h_counters;           // [0..3] after phase A, [4..7] after phase B
+    hipEvent_t ev = nullptr, ev_b = nullptr;
+    uint32_t n_cand = 0;
     void release() {
-        keys_in.release();
-        acc_keys.release();
+        keys.release();
+        keys_sorted.release();
+        eig.release();
+        cstate.release();
         counters.release();
+        per_block.release();
         h_counters.release();
         if (ev) (void)hipEventDestroy(ev);
-        ev = nullptr;
+        if (ev_b) (void)hipEventDestroy(ev_b);
+        ev = ev_b = nullptr;
     }
 };
 
@@ -138,13 +150,9 @@ struct pc_context {
     // staging of host-provided frames
     DevBuf<uint8_t> staging;
     // GFTT scratch
-    DevBuf<float> eig;
-    DevBuf<unsigned long long> keys_out;   // sorted accepted keys (consumed in stream order)
-    DevBuf<uint32_t> cmap, state;          // dense candidate priority / decision maps (K5)
     DevBuf<int2> sup_offsets;              // suppression neighbourhood for sup_min_distance
     double sup_min_distance = -1.0;
     int n_sup_offsets = 0;
-    int resident_blocks = 0;               // fully resident grid size for the suppression kernel
     struct DetectScratch* detect = nullptr;  // scratch of the stage-level pc_frame_detect
     DevBuf<uint8_t> sort_temp;
     const pc_frame* eig_owner = nullptr;

@@ -22,6 +22,21 @@ void launch_widen(const Level& l, int win, hipStream_t s);
 // K6: Scharr derivative plane of the interior (needs the 1-px border to be filled)
 void launch_scharr(const Level& l, hipStream_t s);
 
+// ---- kernels_pyramid.hip ----
+// One fused kernel per pyramid level: the level's pixels (gray conversion of the frame for level 0, pyrDown of the
+// parent's padded plane otherwise) -> u8 plane + REFLECT_101 padding + uint16 plane + Scharr plane.
+enum LevelSourceKind { SRC_PYR = 0, SRC_RGB8 = 1, SRC_GRAY8 = 2, SRC_RGBF32 = 3 };
+struct LevelSource {
+    int kind;
+    const uint8_t* src;   // level 0: the frame on the device (u8 RGB, u8 gray or float32 RGB / RGBA)
+    size_t src_pitch;     // bytes per frame row
+    int channels;         // floats per pixel (SRC_RGBF32)
+    int aligned;          // src and src_pitch are multiples of 4: the u8 sources are read as dwords
+    Level parent;         // SRC_PYR
+};
+// requires out.w > win + 1 and out.h > win + 1 (single reflection in the padding); smaller levels take the unfused kernels
+void launch_level(const LevelSource& in, const Level& out, int win, hipStream_t s);
+
 // ---- kernels_gftt.hip ----
 struct GfttGrid {
     int rows, cols;      // grid_rows, grid_cols (>= 1)
@@ -32,21 +47,21 @@ constexpr int kMaxGridCells = 256;
 // cell_max must be zeroed first).
 void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, hipStream_t s);
 // K3: per-cell THRESH_TOZERO + 3x3 dilate + strict-interior local maxima -> 64-bit keys
-// (ordered(value) << 32 | y*w+x) appended to `keys` (capacity `cap`), count in *counter.
-// cmap/state (w*h u32 each, may be null): dense candidate priority map + cleared decision map for K5.
-void launch_nms_compact(const float* eig, int w, int h, const GfttGrid& g, const uint32_t* cell_max,
-                        double quality_level, unsigned long long* keys, uint32_t cap,
-                        uint32_t* counter, uint32_t* cmap, uint32_t* state, hipStream_t s);
-// K5: exact greedy min-distance suppression (gftt.cc:100-164) as a parallel fixed point; the grid
-// (resident_blocks x 256) must be fully resident.  *stuck != 0 afterwards means the spin bound hit.
-void launch_suppress(const unsigned long long* keys, const uint32_t* counter, uint32_t cap, int w, int h,
-                     const uint32_t* cmap, uint32_t* state, const int2* offsets, int n_offsets, uint32_t* stuck,
-                     int resident_blocks, hipStream_t s);
-// take_all: min_distance < 1 (gftt.cc:165-181).
-void launch_collect_accepted(const unsigned long long* keys, const uint32_t* counter, uint32_t cap,
-                             const uint32_t* state, int take_all, unsigned long long* out, uint32_t* out_counter,
-                             hipStream_t s);
-void launch_keys_to_xy(const unsigned long long* keys, int n, int w, float2* xy, hipStream_t s);
+// (ordered(value) << 32 | y*w+x) appended to `keys` (capacity `cap`), count in *counter; cstate (w*h bytes): 1 at
+// candidates, 0 elsewhere, every pixel written.
+void launch_nms(const float* eig, int w, int h, const GfttGrid& g, const uint32_t* cell_max, double quality_level,
+                unsigned long long* keys, uint32_t cap, uint32_t* counter, uint8_t* cstate, hipStream_t s);
+// K5: exact greedy min-distance suppression (gftt.cc:100-164) over the candidates SORTED by priority (keys descending):
+// cstate becomes 2 (accepted) / 3 (rejected) at every candidate; accepted_per_block[suppress_num_blocks(n)] receives
+// the accepted count of each workgroup.  suppress == false: min_distance < 1, everything is accepted
+// (gftt.cc:165-181).  *stuck != 0 afterwards means the spin bound hit.
+int suppress_num_blocks(uint32_t n);
+void launch_suppress_sorted(const unsigned long long* keys, uint32_t n, int w, int h, const float* eig, uint8_t* cstate,
+                            const int2* offsets, int n_offsets, bool suppress, uint32_t* accepted_per_block, uint32_t* stuck,
+                            hipStream_t s);
+// accepted candidates in priority order -> float2 keypoints (truncated to max_corners if > 0); *n_out = their number
+void launch_accepted_to_keypoints(const unsigned long long* keys, uint32_t n, int w, const uint8_t* cstate, uint32_t* per_block,
+                                  uint32_t max_corners, float2* xy, uint32_t* n_out, hipStream_t s);
 // K4: descending radix sort of the candidate keys (rocPRIM).  temp may be null to query bytes.
 hipError_t sort_keys_desc(void* temp, size_t& temp_bytes, unsigned long long* keys_in,
                           unsigned long long* keys_out, uint32_t n, hipStream_t s);
@@ -82,9 +97,10 @@ bool launch_lk3(const LKParams& p, int win, hipStream_t s);
 bool lk_profile_enabled();   // library compiled with -DPC_LK_PROFILE: LKParams::prof takes 16 words per wavefront
 // counting sort of keypoint indices by 64x64 tile -> perm[n]; hist: bin_num_tiles(w, h) words of scratch
 int bin_num_tiles(int w, int h);
-// slot_of[i] = position of keypoint i in perm (the inverse permutation)
-void launch_spatial_bins(const float2* pts, int n, int w, int h, uint32_t* hist, uint32_t* perm, uint32_t* slot_of,
-                         hipStream_t s);
+// slot_of[i] = position of keypoint i in perm (the inverse permutation).  n_dev (may be null): the number of keypoints
+// is read from device memory (<= n, which then only sizes the launch).
+void launch_spatial_bins(const float2* pts, int n, const uint32_t* n_dev, int w, int h, uint32_t* hist, uint32_t* perm,
+                         uint32_t* slot_of, hipStream_t s);
 
 // Ordered compaction of status==1 rows per target (opticalflow.cc:130-147).
 // rec / slot_of: the LK kernel's raw records (visiting order) and the inverse visiting order.

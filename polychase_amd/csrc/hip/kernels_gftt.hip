@@ -1,12 +1,17 @@
-// kernels_gftt.hip -- Shi-Tomasi corner response and candidate extraction on gfx950.
+// kernels_gftt.hip -- Shi-Tomasi corner detection (GoodFeaturesToTrack, reference cpp/feature_detection/gftt.cc:14-192)
+// entirely on gfx950:
+//   K2  cv::cornerMinEigenVal(block 3, Sobel 3) + per-grid-cell cv::minMaxLoc             gftt.cc:35, :61-63
+//   K3  per-cell cv::threshold(THRESH_TOZERO) + cv::dilate 3x3 + strict-interior maxima   gftt.cc:64-86
+//   K4  std::sort(greaterThanPtr) of the candidates                                       gftt.cc:7-12, :98
+//   K5  greedy min-distance suppression in that order                                     gftt.cc:100-164
+//   ordered compaction of the accepted corners -> keypoints in acceptance order            gftt.cc:157-162
+// Float order follows oracle/pc_oracle.c exactly (no FMA contraction; the fp64 box sums are exact, so their
+// summation order is free).
 //
-// Replaces, on the path GoodFeaturesToTrack (reference cpp/feature_detection/gftt.cc:14-192):
-//   K2  cv::cornerMinEigenVal(block 3, Sobel 3)              gftt.cc:35
-//       + per-grid-cell cv::minMaxLoc                         gftt.cc:61-63
-//   K3  per-cell cv::threshold(THRESH_TOZERO)                 gftt.cc:64-65
-//       + cv::dilate 3x3 + strict-interior local maxima       gftt.cc:70-86
-//   K4  std::sort(greaterThanPtr)                             gftt.cc:7-12, :98   (64-bit radix sort)
-// Float order follows oracle/pc_oracle.c exactly (no FMA contraction; fp64 box sums are exact).
+// Dense maps kept per frame: the min-eig map (float, written by K2, read by K3 and K5) and ONE byte per pixel of
+// candidate state (0 no candidate, 1 candidate, 2 accepted, 3 rejected; written by K3, updated by K5).  Round 1 had
+// two more dword maps (priority + decision, 8 bytes per pixel written per frame); a neighbour's priority is now
+// read from the min-eig map itself.
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -15,21 +20,24 @@
 namespace pc {
 
 // ------------------------------------------------------------------------------------------------
-// K2  min-eigenvalue map.  Tile 64x16 outputs per 256-lane workgroup.
-//   LDS stage 1: gray tile with a 2-px REFLECT_101 halo (68 x 20 bytes, stored as u8).
-//   LDS stage 2: covariance products (Dx^2, DxDy, Dy^2) on the tile + 1-px halo (66 x 18 x 3 floats),
-//                evaluated at the REFLECTED coordinate for positions outside the image (boxFilter's
-//                BORDER_REFLECT_101 applies to the covariance image, not to the gray image).
-//   Stage 3: 3x3 box sums in fp64 (exact), min eigenvalue, per-cell max via LDS then global atomicMax.
+// K2  min-eigenvalue map.  Tile 64 x 16 outputs per 256-lane workgroup.
+//   LDS stage 1: gray tile with a 2-px ring, read straight from the level-0 plane (its REFLECT_101 padding is the
+//                reflection cornerMinEigenVal's Sobel wants), as aligned dwords.
+//   LDS stage 2: covariance products (Dx^2, DxDy, Dy^2) on the tile + 1-px ring; a lane walks 6 rows of one column
+//                and keeps the row filters of the 3 x 3 Sobel in registers.  Positions outside the image take the
+//                value AT THE REFLECTED POSITION (boxFilter's BORDER_REFLECT_101 applies to the covariance image,
+//                not to the gray image: DxDy changes sign when evaluated on mirrored pixels).
+//   Stage 3: 3 x 3 box sums in fp64 (exact, so separable: three-term row sums first), min eigenvalue,
+//                per-cell max via LDS, then one global atomicMax per cell and workgroup.
 // ------------------------------------------------------------------------------------------------
 constexpr int TW = 64, TH = 16;
-constexpr int GW = TW + 4, GH = TH + 4;   // gray tile
-constexpr int CW = TW + 2, CH = TH + 2;   // covariance tile
+constexpr int GH = TH + 4, G_PITCH = 72;  // gray tile: columns x0 - 4 .. x0 + 67 (18 aligned dwords), rows y0 - 2 .. y0 + 17
+constexpr int CW = TW + 2, CH = TH + 2;   // covariance tile: x0 - 1 .. x0 + 64, y0 - 1 .. y0 + 16
 
 __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict__ img, int pitch, int w, int h,
                                                       float* __restrict__ eig, GfttGrid g,
                                                       uint32_t* __restrict__ cell_max, float f1, float f0) {
-    __shared__ uint8_t s_gray[GH][GW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_gray[GH][G_PITCH];
     __shared__ float s_cxx[CH][CW + 1];
     __shared__ float s_cxy[CH][CW + 1];
     __shared__ float s_cyy[CH][CW + 1];
@@ -39,68 +47,93 @@ __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict_
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     if (tid < 4) s_max[tid] = 0u;
 
-    // stage 1: gray tile, absolute coords [x0-2, x0+TW+2) x [y0-2, y0+TH+2), reflected into the image
-    for (int i = tid; i < GW * GH; i += 256) {
-        const int ty = i / GW, tx = i - ty * GW;
-        const int ax = reflect101(x0 - 2 + tx, w), ay = reflect101(y0 - 2 + ty, h);
-        s_gray[ty][tx] = img[(size_t)ay * pitch + ax];
-    }
-    __syncthreads();
-
-    // stage 2: Sobel + products at covariance positions [x0-1, x0+TW+1) x [y0-1, y0+TH+1)
-    for (int i = tid; i < CW * CH; i += 256) {
-        const int cy = i / CW, cx = i - cy * CW;
-        // absolute position, reflected into the image, then back to gray-tile coordinates
-        int ax = x0 - 1 + cx, ay = y0 - 1 + cy;
-        float vxx = 0.f, vxy = 0.f, vyy = 0.f;
-        // positions more than one pixel outside the image are never consumed
-        if (ax >= -1 && ax <= w && ay >= -1 && ay <= h) {
-            ax = reflect101(ax, w);
-            ay = reflect101(ay, h);
-            const int tx = ax - (x0 - 2), ty = ay - (y0 - 2);
-            // neighbours of an in-image position: reflect at the image border
-            const int txm = reflect101(ax - 1, w) - (x0 - 2), txp = reflect101(ax + 1, w) - (x0 - 2);
-            const int tym = reflect101(ay - 1, h) - (y0 - 2), typ = reflect101(ay + 1, h) - (y0 - 2);
-            const float g00 = s_gray[tym][txm], g01 = s_gray[tym][tx], g02 = s_gray[tym][txp];
-            const float g10 = s_gray[ty][txm], g11 = s_gray[ty][tx], g12 = s_gray[ty][txp];
-            const float g20 = s_gray[typ][txm], g21 = s_gray[typ][tx], g22 = s_gray[typ][txp];
-            // Dx: row [-1,0,1] then column (S0 + S2)*f1 + S1*f0
-            const float rx0 = g02 - g00, rx1 = g12 - g10, rx2 = g22 - g20;
-            const float dx = (rx0 + rx2) * f1 + rx1 * f0;
-            // Dy: row ((f1*a + f0*b) + f1*c) then column S2 - S0
-            float ry0 = f1 * g00; ry0 += f0 * g01; ry0 += f1 * g02;
-            float ry2 = f1 * g20; ry2 += f0 * g21; ry2 += f1 * g22;
-            const float dy = ry2 - ry0;
-            (void)g11;
-            vxx = dx * dx;
-            vxy = dx * dy;
-            vyy = dy * dy;
+    // stage 1: gray tile.  Rows / columns more than 2 px outside the image are clamped (never consumed).
+    {
+        const int xmax = pitch - kPadX - 4;
+        for (int i = tid; i < GH * (G_PITCH / 4); i += 256) {
+            const int r = i / (G_PITCH / 4), d = i - r * (G_PITCH / 4);
+            const int yy = min(max(y0 - 2 + r, -2), h + 1), xx = min(x0 - 4 + 4 * d, xmax);
+            *reinterpret_cast<uint32_t*>(&s_gray[r][4 * d]) = *reinterpret_cast<const uint32_t*>(img + (ptrdiff_t)yy * pitch + xx);
         }
-        s_cxx[cy][cx] = vxx;
-        s_cxy[cy][cx] = vxy;
-        s_cyy[cy][cx] = vyy;
     }
     __syncthreads();
 
-    // stage 3: 4 outputs per lane (rows ty, ty+4, ty+8, ty+12 of column tx)
-    const int tx = tid & 63, tyb = tid >> 6;
+    // stage 2: lane = (column cx, band of 6 covariance rows); gray rows of covariance row cy are cy .. cy + 2,
+    // gray columns of covariance column cx are cx + 2 .. cx + 4 (tile column 0 is x0 - 4)
+    if (tid < 3 * CW) {
+        const int cx = tid % CW, band = tid / CW;
+        const int ax = x0 - 1 + cx;
+        float rx[3], ry[3];   // row filters of gray rows cy, cy + 1 (the two carried over), cy + 2
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint8_t* gp = &s_gray[6 * band + k][cx + 2];
+            const float a = gp[0], b = gp[1], c = gp[2];
+            rx[k] = c - a;
+            float t = f1 * a;
+            t += f0 * b;
+            t += f1 * c;
+            ry[k] = t;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int cy = 6 * band + k;
+            const uint8_t* gp = &s_gray[cy + 2][cx + 2];
+            const float a = gp[0], b = gp[1], c = gp[2];
+            rx[2] = c - a;
+            float t = f1 * a;
+            t += f0 * b;
+            t += f1 * c;
+            ry[2] = t;
+            // Dx: row [-1,0,1] then column (S0 + S2)*f1 + S1*f0;  Dy: row [1,2,1]*scale then column S2 - S0
+            const float dx = (rx[0] + rx[2]) * f1 + rx[1] * f0;
+            const float dy = ry[2] - ry[0];
+            const int ay = y0 - 1 + cy;
+            const bool in = ax >= 0 && ax < w && ay >= 0 && ay < h;
+            s_cxx[cy][cx] = in ? dx * dx : 0.f;
+            s_cxy[cy][cx] = in ? dx * dy : 0.f;
+            s_cyy[cy][cx] = in ? dy * dy : 0.f;
+            rx[0] = rx[1]; rx[1] = rx[2];
+            ry[0] = ry[1]; ry[1] = ry[2];
+        }
+    }
+    __syncthreads();
+    // covariance ring outside the image <- the reflected (in-image) position; only tiles on the image edge have one
+    if (x0 == 0 || y0 == 0 || x0 + TW >= w || y0 + TH >= h) {
+        for (int i = tid; i < CW * CH; i += 256) {
+            const int cy = i / CW, cx = i - cy * CW;
+            const int ax = x0 - 1 + cx, ay = y0 - 1 + cy;
+            if ((ax < 0 || ax >= w || ay < 0 || ay >= h) && ax >= -1 && ax <= w && ay >= -1 && ay <= h) {
+                const int sx = reflect101(ax, w) - (x0 - 1), sy = reflect101(ay, h) - (y0 - 1);
+                if (sx >= 0 && sx < CW && sy >= 0 && sy < CH) {
+                    s_cxx[cy][cx] = s_cxx[sy][sx];
+                    s_cxy[cy][cx] = s_cxy[sy][sx];
+                    s_cyy[cy][cx] = s_cyy[sy][sx];
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // stage 3: lane = (column tx, 4 consecutive rows): six three-term row sums per channel, then the column sums
+    const int tx = tid & 63, ty0 = (tid >> 6) * 4;
     const int x = x0 + tx;
     const int cell_x0 = x0 / g.cell_w, cell_y0 = y0 / g.cell_h;
     const bool small_cells = (g.cell_w < TW) || (g.cell_h < TH);
+    double hxx[6], hxy[6], hyy[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int cy = ty0 + k;
+        hxx[k] = ((double)s_cxx[cy][tx] + (double)s_cxx[cy][tx + 1]) + (double)s_cxx[cy][tx + 2];
+        hxy[k] = ((double)s_cxy[cy][tx] + (double)s_cxy[cy][tx + 1]) + (double)s_cxy[cy][tx + 2];
+        hyy[k] = ((double)s_cyy[cy][tx] + (double)s_cyy[cy][tx + 1]) + (double)s_cyy[cy][tx + 2];
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int ty = tyb + 4 * k;
-        const int y = y0 + ty;
+        const int y = y0 + ty0 + k;
         if (x < w && y < h) {
-            double sxx = 0.0, sxy = 0.0, syy = 0.0;
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-#pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    sxx += (double)s_cxx[ty + j][tx + i];
-                    sxy += (double)s_cxy[ty + j][tx + i];
-                    syy += (double)s_cyy[ty + j][tx + i];
-                }
+            const double sxx = (hxx[k] + hxx[k + 1]) + hxx[k + 2];
+            const double sxy = (hxy[k] + hxy[k + 1]) + hxy[k + 2];
+            const double syy = (hyy[k] + hyy[k + 1]) + hyy[k + 2];
             const float a = (float)sxx * 0.5f;
             const float b = (float)sxy;
             const float c = (float)syy * 0.5f;
@@ -132,78 +165,121 @@ void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* ce
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3  threshold (per cell of the NEIGHBOUR) + 3x3 dilate + local-max test + wave-ballot compaction.
-// One lane per pixel of the strict interior; keys = ordered(value) << 32 | (y*w + x).
+// K3  threshold (per cell of the NEIGHBOUR) + 3x3 dilate + local-max test.  A workgroup walks a 64 x 64 block as four
+// 64 x 16 tiles of the min-eig map, each staged (already thresholded) in LDS with a 1-px ring; 4 pixels per lane.
+// Writes the candidate byte of EVERY pixel (so the map needs no clearing between frames) and appends keys =
+// ordered(value) << 32 | (y*w + x) with ONE global atomic per workgroup: appends to one counter from different CUs
+// cost ~23 ns each and serialise (a 64 x 16 workgroup per atomic took 0.19 ms at 4K for that reason alone).
 // ------------------------------------------------------------------------------------------------
-constexpr int NMS_R = 16, NMS_TH = 4 * NMS_R;  // rows per lane, tile height
+constexpr int NMS_SUB = 4;   // 64 x 16 tiles per workgroup
 
-__global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restrict__ eig, int w, int h, GfttGrid g,
-                                                          const uint32_t* __restrict__ cell_max,
-                                                          double quality_level,
-                                                          unsigned long long* __restrict__ keys, uint32_t cap,
-                                                          uint32_t* __restrict__ counter,
-                                                          uint32_t* __restrict__ cmap, uint32_t* __restrict__ state) {
+__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ eig, int w, int h, GfttGrid g,
+                                                  const uint32_t* __restrict__ cell_max, double quality_level,
+                                                  unsigned long long* __restrict__ keys, uint32_t cap,
+                                                  uint32_t* __restrict__ counter, uint8_t* __restrict__ cstate) {
     __shared__ float s_thr[kMaxGridCells];
+    __shared__ float s_v[CH][CW + 2];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW;
     const int ncells = g.rows * g.cols;
-    for (int i = threadIdx.x; i < ncells; i += blockDim.x) {
+    for (int i = tid; i < ncells; i += 256) {
         // cv::threshold on CV_32F compares with (float)(maxVal * quality_level), maxVal a double
         const float mx = ordered_to_float(cell_max[i]);
         s_thr[i] = (float)((double)mx * quality_level);
     }
-    __syncthreads();
-
-    // tile 64 x NMS_TH: lane = column, NMS_R rows per lane (wave, wave+4, ...)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lane;
-    float vals[NMS_R];
-    uint32_t flags = 0;
-    const bool x_in = (x >= 1 && x < w - 1);
-    int cxs[3] = {0, 0, 0};
-    if (x_in) {
-        cxs[0] = (x - 1) / g.cell_w;
-        cxs[1] = x / g.cell_w;
-        cxs[2] = (x + 1) / g.cell_w;
-    }
+    const int r = tid >> 4, q = tid & 15;
+    const int x = x0 + 4 * q;
+    uint32_t flags = 0;                 // bit 4 * sub + i: pixel i of this lane's quad in tile `sub` is a candidate
+    float vals[NMS_SUB][4];
 #pragma unroll
-    for (int k = 0; k < NMS_R; k++) {
-        const int y = blockIdx.y * NMS_TH + wave + 4 * k;
-        vals[k] = 0.f;
-        if (x_in && y >= 1 && y < h - 1) {
-            const int cys[3] = {(y - 1) / g.cell_h, y / g.cell_h, (y + 1) / g.cell_h};
-            const float c = eig[(size_t)y * w + x];
-            const float val = (c > s_thr[cys[1] * g.cols + cxs[1]]) ? c : 0.f;
-            if (val != 0.f) {
-                float m = val;
+    for (int sub = 0; sub < NMS_SUB; sub++) {
+        const int y0 = (blockIdx.y * NMS_SUB + sub) * TH;
+        const int y = y0 + r;
+        __syncthreads();   // s_thr is complete / the previous tile's readers are done
+        // thresholded values; outside the image: 0 (cv::dilate ignores those positions, and a candidate is > 0).
+        // A tile + ring spans at most two grid cells per axis when the cells are at least that large: the cell of a
+        // position is then a comparison with the next cell boundary, not a division.
+        const bool big_cells = g.cell_w >= CW && g.cell_h >= CH;
+        const int ccx0 = max(x0 - 1, 0) / g.cell_w, ccy0 = max(y0 - 1, 0) / g.cell_h;     // block-uniform
+        const int bx = (ccx0 + 1) * g.cell_w, by = (ccy0 + 1) * g.cell_h;
+        auto thr_at = [&](int ax, int ay) -> float {
+            const int cx = big_cells ? ccx0 + (ax >= bx) : ax / g.cell_w;
+            const int cy = big_cells ? ccy0 + (ay >= by) : ay / g.cell_h;
+            return s_thr[cy * g.cols + cx];
+        };
+        if (y0 < h) {
+            // interior of the tile: one aligned float4 per lane where the row length allows it
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (y < h && x < w) {
+                const float* row = eig + (size_t)y * w;
+                if (x + 3 < w && (w & 3) == 0) {
+                    const float4 e = *reinterpret_cast<const float4*>(row + x);
+                    v[0] = e.x; v[1] = e.y; v[2] = e.z; v[3] = e.w;
+                } else {
+                    for (int i = 0; i < 4 && x + i < w; i++) v[i] = row[x + i];
+                }
 #pragma unroll
-                for (int j = 0; j < 3; j++)
+                for (int i = 0; i < 4; i++) v[i] = (x + i < w && v[i] > thr_at(x + i, y)) ? v[i] : 0.f;
+            }
 #pragma unroll
-                    for (int i = 0; i < 3; i++) {
-                        const float e = eig[(size_t)(y + j - 1) * w + (x + i - 1)];
-                        const float v = (e > s_thr[cys[j] * g.cols + cxs[i]]) ? e : 0.f;
-                        m = (v > m) ? v : m;
-                    }
-                if (val == m) {
-                    flags |= 1u << k;
-                    vals[k] = val;
+            for (int i = 0; i < 4; i++) s_v[r + 1][4 * q + 1 + i] = v[i];
+            // ring: top and bottom rows (CW each), left and right columns (TH each)
+            if (tid < 2 * CW + 2 * TH) {
+                int cx, cy;
+                if (tid < 2 * CW) {
+                    cy = tid < CW ? 0 : CH - 1;
+                    cx = tid < CW ? tid : tid - CW;
+                } else {
+                    const int k = tid - 2 * CW;
+                    cy = 1 + (k >> 1);
+                    cx = (k & 1) ? CW - 1 : 0;
+                }
+                const int ax = x0 - 1 + cx, ay = y0 - 1 + cy;
+                float e = 0.f;
+                if (ax >= 0 && ax < w && ay >= 0 && ay < h) {
+                    e = eig[(size_t)ay * w + ax];
+                    e = (e > thr_at(ax, ay)) ? e : 0.f;
+                }
+                s_v[cy][cx] = e;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; i++) vals[sub][i] = 0.f;
+        if (y < h && x < w) {
+            // column maxima of the three rows for columns x - 1 .. x + 4
+            float cm[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const float a = s_v[r][4 * q + i], b = s_v[r + 1][4 * q + i], c = s_v[r + 2][4 * q + i];
+                const float m = a > b ? a : b;
+                cm[i] = m > c ? m : c;
+            }
+            uint32_t f4 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float val = s_v[r + 1][4 * q + 1 + i];
+                float m = cm[i] > cm[i + 1] ? cm[i] : cm[i + 1];
+                m = m > cm[i + 2] ? m : cm[i + 2];
+                const int xi = x + i;
+                if (val != 0.f && val == m && xi >= 1 && xi < w - 1 && y >= 1 && y < h - 1) {
+                    f4 |= 1u << i;
+                    vals[sub][i] = val;
                 }
             }
-        }
-    }
-    // dense priority map for the suppression kernel: ordered(value) at candidates, 0 elsewhere;
-    // every pixel is written, so the maps need no clearing between frames
-    if (cmap && x < w) {
-#pragma unroll
-        for (int k = 0; k < NMS_R; k++) {
-            const int y = blockIdx.y * NMS_TH + wave + 4 * k;
-            if (y < h) {
-                cmap[(size_t)y * w + x] = (flags & (1u << k)) ? float_to_ordered(vals[k]) : 0u;
-                state[(size_t)y * w + x] = 0u;
+            flags |= f4 << (4 * sub);
+            uint8_t* cs = cstate + (size_t)y * w + x;
+            if (x + 3 < w && ((w & 3) == 0)) {
+                *reinterpret_cast<uint32_t*>(cs) = (f4 & 1u) | ((f4 & 2u) << 7) | ((f4 & 4u) << 14) | ((f4 & 8u) << 21);
+            } else {
+                for (int i = 0; i < 4 && x + i < w; i++) cs[i] = (uint8_t)((f4 >> i) & 1u);
             }
         }
     }
-    // workgroup-aggregated append: one global atomic per 64 x 64 tile
+    // workgroup-aggregated append
+    const int lane = tid & 63, wave = tid >> 6;
     const uint32_t cnt = (uint32_t)__popc(flags);
     uint32_t incl = cnt;
 #pragma unroll
@@ -213,7 +289,7 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restric
     }
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         s_base = total ? atomicAdd(counter, total) : 0u;
     }
@@ -222,86 +298,72 @@ __global__ __launch_bounds__(256) void nms_compact_kernel(const float* __restric
     uint32_t pos = s_base + incl - cnt;
     for (int wv = 0; wv < wave; wv++) pos += s_wave[wv];
 #pragma unroll
-    for (int k = 0; k < NMS_R; k++) {
-        if (flags & (1u << k)) {
-            const int y = blockIdx.y * NMS_TH + wave + 4 * k;
-            if (pos < cap)
-                keys[pos] = ((unsigned long long)float_to_ordered(vals[k]) << 32) | (unsigned long long)(uint32_t)(y * w + x);
-            pos++;
+    for (int sub = 0; sub < NMS_SUB; sub++) {
+        const int y = (blockIdx.y * NMS_SUB + sub) * TH + r;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (flags & (1u << (4 * sub + i))) {
+                if (pos < cap)
+                    keys[pos] = ((unsigned long long)float_to_ordered(vals[sub][i]) << 32) | (unsigned long long)(uint32_t)(y * w + x + i);
+                pos++;
+            }
         }
     }
 }
 
-void launch_nms_compact(const float* eig, int w, int h, const GfttGrid& g, const uint32_t* cell_max,
-                        double quality_level, unsigned long long* keys, uint32_t cap, uint32_t* counter,
-                        uint32_t* cmap, uint32_t* state, hipStream_t s) {
-    dim3 grid((w + 63) / 64, (h + NMS_TH - 1) / NMS_TH);
-    hipLaunchKernelGGL(nms_compact_kernel, grid, dim3(256), 0, s, eig, w, h, g, cell_max, quality_level, keys, cap,
-                       counter, cmap, state);
+void launch_nms(const float* eig, int w, int h, const GfttGrid& g, const uint32_t* cell_max, double quality_level,
+                unsigned long long* keys, uint32_t cap, uint32_t* counter, uint8_t* cstate, hipStream_t s) {
+    dim3 grid((w + TW - 1) / TW, (h + NMS_SUB * TH - 1) / (NMS_SUB * TH));
+    hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, s, eig, w, h, g, cell_max, quality_level, keys, cap, counter, cstate);
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5  exact min-distance suppression on the GPU.
-// The reference's greedy loop (gftt.cc:100-164) accepts a candidate iff no ALREADY ACCEPTED candidate
-// lies within min_distance; processing order = (value desc, address desc).  Equivalently: a
-// candidate is accepted iff every higher-priority candidate within the radius is rejected -- the
-// lexicographically-first maximal independent set of the conflict graph.  Each candidate is owned by
-// one lane of a fully resident grid and re-evaluates until all its higher-priority neighbours are
-// decided; decisions are final and monotone, so asynchronous evaluation reaches exactly the
-// sequential result.  Progress: the highest-priority undecided candidate is always decidable, and a
-// lane round-robins over its candidates (never spins on one), so no cycle of waits can form.
-// States (dense u32 map, agent-scope relaxed atomics: per-XCD L2s are not coherent): 0 undecided,
-// 1 accepted, 2 rejected.
+// K5  exact min-distance suppression on the GPU, candidates in PRIORITY ORDER.
+// The reference's greedy loop (gftt.cc:100-164) accepts a candidate iff no ALREADY ACCEPTED candidate lies within
+// min_distance; processing order = (value desc, address desc) = the order of `keys` here.  Equivalently: a candidate
+// is accepted iff every higher-priority candidate within the radius is rejected -- the lexicographically-first
+// maximal independent set of the conflict graph.  Lane i owns candidate i and re-evaluates until all its
+// higher-priority neighbours are decided; decisions are final and monotone, so asynchronous evaluation reaches
+// exactly the sequential result.
+// Progress under ANY occupancy: lane i only ever waits for candidates j < i, i.e. for its own or LOWER-numbered
+// workgroups.  Workgroups are handed out in index order (per XCD), so the lowest-numbered unfinished workgroup is
+// always running and never waits on an unfinished one: no assumption that the grid is resident (round 1 sized the
+// grid to "what fits" and relied on it).  The spin bound stays as a tripwire.
+// States (one byte per pixel, agent-scope relaxed atomics: per-XCD L2s are not coherent): see the header.
+// Afterwards accepted_per_block[b] = accepted candidates of workgroup b (input of the ordered compaction).
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t ST_ACCEPTED = 1u, ST_REJECTED = 2u;
+constexpr uint8_t CS_CAND = 1, CS_ACCEPTED = 2, CS_REJECTED = 3;
+constexpr int SUP_NB = 12;  // higher-priority neighbours cached in registers
+constexpr int SUP_BLOCK = 256;
 
-// Evaluate one candidate against the current states of its higher-priority neighbours.
-// Returns 0 = still blocked, ST_ACCEPTED or ST_REJECTED.
-__device__ __forceinline__ uint32_t suppress_eval_scan(uint32_t my_val, uint32_t my_idx, int x, int y, int w, int h,
-                                                       const uint32_t* __restrict__ cmap, uint32_t* state,
-                                                       const int2* __restrict__ offsets, int n_offsets) {
-    bool blocked = false;
-    for (int o = 0; o < n_offsets; o++) {
-        const int nx = x + offsets[o].x, ny = y + offsets[o].y;
-        if (nx < 0 || nx >= w || ny < 0 || ny >= h) continue;
-        const uint32_t nidx = (uint32_t)(ny * w + nx);
-        const uint32_t nval = cmap[nidx];
-        if (nval == 0u) continue;
-        if (!(nval > my_val || (nval == my_val && nidx > my_idx))) continue;  // lower priority
-        const uint32_t st = __hip_atomic_load(&state[nidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (st == ST_ACCEPTED) return ST_REJECTED;
-        if (st == 0u) blocked = true;
-    }
-    return blocked ? 0u : ST_ACCEPTED;
-}
+__device__ __forceinline__ uint8_t cs_load(const uint8_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cs_store(uint8_t* p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-constexpr int SUP_NB = 12;  // higher-priority neighbours cached in registers by the fast path
-
-__global__ __launch_bounds__(256) void suppress_kernel(const unsigned long long* __restrict__ keys,
-                                                       const uint32_t* __restrict__ counter, uint32_t cap, int w, int h,
-                                                       const uint32_t* __restrict__ cmap, uint32_t* state,
-                                                       const int2* __restrict__ offsets, int n_offsets,
-                                                       uint32_t* __restrict__ stuck) {
-    const uint32_t n = min(*counter, cap);
-    const uint32_t T = gridDim.x * blockDim.x;
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= n) return;
-    if (n <= T) {
-        // fast path (the usual case): one candidate per lane.  Scan the neighbourhood once, remember
-        // the higher-priority candidates, then only poll their states.
-        const unsigned long long key = keys[tid];
-        const uint32_t my_val = (uint32_t)(key >> 32), my_idx = (uint32_t)key;
-        const int y = (int)(my_idx / (uint32_t)w), x = (int)(my_idx - (uint32_t)y * (uint32_t)w);
-        uint32_t nb[SUP_NB];
-        int n_nb = 0;
-        bool overflow = false;
+__global__ __launch_bounds__(SUP_BLOCK) void suppress_sorted_kernel(const unsigned long long* __restrict__ keys, uint32_t n, int w, int h,
+                                                                    const float* __restrict__ eig, uint8_t* cstate,
+                                                                    const int2* __restrict__ offsets, int n_offsets,
+                                                                    uint32_t* __restrict__ accepted_per_block,
+                                                                    uint32_t* __restrict__ stuck) {
+    const uint32_t i = blockIdx.x * SUP_BLOCK + threadIdx.x;
+    const bool live = i < n;
+    uint32_t my_val = 0, my_idx = 0;
+    uint32_t nb[SUP_NB];
+    int n_nb = 0;
+    bool overflow = false;
+    int x = 0, y = 0;
+    if (live) {
+        const unsigned long long key = keys[i];
+        my_val = (uint32_t)(key >> 32);
+        my_idx = (uint32_t)key;
+        y = (int)(my_idx / (uint32_t)w);
+        x = (int)(my_idx - (uint32_t)y * (uint32_t)w);
         for (int o = 0; o < n_offsets; o++) {
             const int nx = x + offsets[o].x, ny = y + offsets[o].y;
             if (nx < 0 || nx >= w || ny < 0 || ny >= h) continue;
             const uint32_t nidx = (uint32_t)(ny * w + nx);
-            const uint32_t nval = cmap[nidx];
-            if (nval == 0u) continue;
-            if (!(nval > my_val || (nval == my_val && nidx > my_idx))) continue;
+            if (cstate[nidx] == 0) continue;   // plain load: "is a candidate" never changes during this kernel
+            const uint32_t nval = float_to_ordered(eig[nidx]);
+            if (!(nval > my_val || (nval == my_val && nidx > my_idx))) continue;  // lower priority
             if (n_nb < SUP_NB) {
 #pragma unroll
                 for (int k = 0; k < SUP_NB; k++)
@@ -311,129 +373,136 @@ __global__ __launch_bounds__(256) void suppress_kernel(const unsigned long long*
                 overflow = true;
             }
         }
-        // NOTE on control flow: a lane must publish its decision INSIDE the loop and keep iterating
-        // (idle) until the whole wave is done.  With a per-lane `return` the store would sit in the
-        // loop's exit block, which a wave only executes after ALL its lanes left the loop -- a lane
-        // waiting for a neighbour owned by the same wave would then never see it (SIMT deadlock).
-        bool done = false;
-        for (uint32_t spin = 0;; spin++) {
-            if (!done) {
-                uint32_t decision;
-                if (overflow) {
-                    decision = suppress_eval_scan(my_val, my_idx, x, y, w, h, cmap, state, offsets, n_offsets);
-                } else {
-                    bool blocked = false, rejected = false;
+    }
+    // NOTE on control flow: a lane must publish its decision INSIDE the loop and keep iterating (idle) until the
+    // whole wave is done.  With a per-lane exit the store would sit in the loop's exit block, which a wave only
+    // executes after ALL its lanes left the loop -- a lane waiting for a neighbour owned by the same wave would then
+    // never see it (SIMT deadlock).
+    bool done = !live;
+    bool accepted = false;
+    for (uint32_t spin = 0;; spin++) {
+        if (!done) {
+            bool blocked = false, rejected = false;
+            if (overflow) {
+                for (int o = 0; o < n_offsets; o++) {
+                    const int nx = x + offsets[o].x, ny = y + offsets[o].y;
+                    if (nx < 0 || nx >= w || ny < 0 || ny >= h) continue;
+                    const uint32_t nidx = (uint32_t)(ny * w + nx);
+                    const uint8_t st = cs_load(&cstate[nidx]);
+                    if (st == 0) continue;
+                    const uint32_t nval = float_to_ordered(eig[nidx]);
+                    if (!(nval > my_val || (nval == my_val && nidx > my_idx))) continue;
+                    rejected |= (st == CS_ACCEPTED);
+                    blocked |= (st == CS_CAND);
+                }
+            } else {
 #pragma unroll
-                    for (int k = 0; k < SUP_NB; k++) {
-                        if (k < n_nb) {
-                            const uint32_t st = __hip_atomic_load(&state[nb[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            rejected |= (st == ST_ACCEPTED);
-                            blocked |= (st == 0u);
-                        }
+                for (int k = 0; k < SUP_NB; k++) {
+                    if (k < n_nb) {
+                        const uint8_t st = cs_load(&cstate[nb[k]]);
+                        rejected |= (st == CS_ACCEPTED);
+                        blocked |= (st == CS_CAND);
                     }
-                    decision = rejected ? ST_REJECTED : (blocked ? 0u : ST_ACCEPTED);
-                }
-                if (decision != 0u) {
-                    __hip_atomic_store(&state[my_idx], decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    done = true;
                 }
             }
-            if (__all(done)) break;           // wave-uniform exit
-            if (spin > (1u << 20)) {          // bounded spin: report instead of hanging the GPU
-                if (!done) atomicAdd(stuck, 1u);
-                break;
+            if (rejected || !blocked) {
+                cs_store(&cstate[my_idx], rejected ? CS_REJECTED : CS_ACCEPTED);
+                accepted = !rejected;
+                done = true;
             }
-            __builtin_amdgcn_s_sleep(1);
         }
-        return;
+        if (__all(done)) break;           // wave-uniform exit
+        if (spin > (1u << 22)) {          // tripwire: report instead of hanging the GPU
+            if (!done) atomicAdd(stuck, 1u);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
     }
-    // general path: several candidates per lane, visited round-robin (never spin on one candidate)
-    const uint32_t mine = (n - tid + T - 1) / T;   // candidates tid, tid+T, ...
-    uint32_t remaining = mine;
-    for (uint32_t spin = 0; remaining > 0; spin++) {
-        for (uint32_t j = 0; j < mine; j++) {
-            const unsigned long long key = keys[tid + (size_t)j * T];
-            const uint32_t my_val = (uint32_t)(key >> 32), my_idx = (uint32_t)key;
-            if (__hip_atomic_load(&state[my_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;
-            const int y = (int)(my_idx / (uint32_t)w), x = (int)(my_idx - (uint32_t)y * (uint32_t)w);
-            const uint32_t decision = suppress_eval_scan(my_val, my_idx, x, y, w, h, cmap, state, offsets, n_offsets);
-            if (decision != 0u) {
-                __hip_atomic_store(&state[my_idx], decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                remaining--;
-            }
-        }
-        if (remaining > 0) {
-            if (spin > (1u << 20)) {
-                atomicAdd(stuck, 1u);
-                return;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
+    const int c = __syncthreads_count(accepted);
+    if (threadIdx.x == 0) accepted_per_block[blockIdx.x] = (uint32_t)c;
+}
+
+// no suppression (min_distance < 1, gftt.cc:165-181): every candidate is accepted
+__global__ __launch_bounds__(SUP_BLOCK) void accept_all_kernel(const unsigned long long* __restrict__ keys, uint32_t n, uint8_t* cstate,
+                                                               uint32_t* __restrict__ accepted_per_block) {
+    const uint32_t i = blockIdx.x * SUP_BLOCK + threadIdx.x;
+    if (i < n) cstate[(uint32_t)keys[i]] = CS_ACCEPTED;
+    if (threadIdx.x == 0) accepted_per_block[blockIdx.x] = min((uint32_t)SUP_BLOCK, n - blockIdx.x * SUP_BLOCK);
+}
+
+// exclusive scan of the per-block counts (one workgroup) + the keypoint count (truncated to max_corners, gftt.cc:160-162)
+__global__ __launch_bounds__(1024) void accepted_scan_kernel(uint32_t* __restrict__ per_block, int nblocks, uint32_t max_corners,
+                                                             uint32_t* __restrict__ n_out) {
+    __shared__ uint32_t s_sum[1024];
+    const int per = (nblocks + 1023) / 1024;
+    const int b = threadIdx.x * per, e = min(b + per, nblocks);
+    uint32_t s = 0;
+    for (int i = b; i < e; i++) s += per_block[i];
+    s_sum[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = (threadIdx.x >= (unsigned)d) ? s_sum[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_sum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[threadIdx.x] - s;
+    for (int i = b; i < e; i++) {
+        const uint32_t c = per_block[i];
+        per_block[i] = run;
+        run += c;
+    }
+    if (threadIdx.x == 1023) {
+        const uint32_t total = s_sum[1023];
+        *n_out = (max_corners > 0 && total > max_corners) ? max_corners : total;
     }
 }
 
-// accepted candidates -> dense list (order irrelevant: sorted afterwards); grid-stride so that the
-// launch does not need the candidate count on the host
-__global__ __launch_bounds__(256) void collect_accepted_kernel(const unsigned long long* __restrict__ keys,
-                                                               const uint32_t* __restrict__ counter, uint32_t cap,
-                                                               const uint32_t* __restrict__ state, int take_all,
-                                                               unsigned long long* __restrict__ out,
-                                                               uint32_t* __restrict__ out_counter) {
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_base;
-    const uint32_t n = min(*counter, cap);
+// accepted candidates, in priority order = acceptance order of the greedy loop -> Point2f((float)x, (float)y) (gftt.cc:157)
+__global__ __launch_bounds__(SUP_BLOCK) void accepted_scatter_kernel(const unsigned long long* __restrict__ keys, uint32_t n, int w,
+                                                                     const uint8_t* __restrict__ cstate,
+                                                                     const uint32_t* __restrict__ block_offset, uint32_t max_corners,
+                                                                     float2* __restrict__ xy) {
+    __shared__ uint32_t s_wave[SUP_BLOCK / 64];
+    const uint32_t i = blockIdx.x * SUP_BLOCK + threadIdx.x;
+    uint32_t idx = 0;
+    bool keep = false;
+    if (i < n) {
+        idx = (uint32_t)keys[i];
+        keep = cstate[idx] == CS_ACCEPTED;
+    }
+    const unsigned long long ballot = __ballot(keep);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
-        const uint32_t i = base + threadIdx.x;
-        unsigned long long key = 0ull;
-        bool keep = false;
-        if (i < n) {
-            key = keys[i];
-            keep = take_all || state[(uint32_t)key] == ST_ACCEPTED;
-        }
-        const unsigned long long ballot = __ballot(keep);
-        __syncthreads();  // previous iteration's readers of s_wave / s_base are done
-        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(ballot);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-            s_base = total ? atomicAdd(out_counter, total) : 0u;
-        }
-        __syncthreads();
-        if (keep) {
-            uint32_t pos = s_base + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-            for (int wv = 0; wv < wave; wv++) pos += s_wave[wv];
-            out[pos] = key;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void keys_to_xy_kernel(const unsigned long long* __restrict__ keys, int n, int w,
-                                                         float2* __restrict__ xy) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t idx = (uint32_t)keys[i];
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(ballot);
+    __syncthreads();
+    if (!keep) return;
+    uint32_t pos = block_offset[blockIdx.x] + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+    for (int wv = 0; wv < wave; wv++) pos += s_wave[wv];
+    if (max_corners > 0 && pos >= max_corners) return;
     const uint32_t y = idx / (uint32_t)w;
-    xy[i] = make_float2((float)(idx - y * (uint32_t)w), (float)y);  // Point2f((float)x, (float)y), gftt.cc:157
+    xy[pos] = make_float2((float)(idx - y * (uint32_t)w), (float)y);
 }
 
-void launch_suppress(const unsigned long long* keys, const uint32_t* counter, uint32_t cap, int w, int h,
-                     const uint32_t* cmap, uint32_t* state, const int2* offsets, int n_offsets, uint32_t* stuck,
-                     int resident_blocks, hipStream_t s) {
-    hipLaunchKernelGGL(suppress_kernel, dim3(resident_blocks), dim3(256), 0, s, keys, counter, cap, w, h, cmap, state,
-                       offsets, n_offsets, stuck);
+int suppress_num_blocks(uint32_t n) { return (int)((n + SUP_BLOCK - 1) / SUP_BLOCK); }
+
+void launch_suppress_sorted(const unsigned long long* keys, uint32_t n, int w, int h, const float* eig, uint8_t* cstate,
+                            const int2* offsets, int n_offsets, bool suppress, uint32_t* accepted_per_block, uint32_t* stuck,
+                            hipStream_t s) {
+    const int nb = suppress_num_blocks(n);
+    if (nb == 0) return;
+    if (suppress)
+        hipLaunchKernelGGL(suppress_sorted_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n, w, h, eig, cstate, offsets, n_offsets,
+                           accepted_per_block, stuck);
+    else
+        hipLaunchKernelGGL(accept_all_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n, cstate, accepted_per_block);
 }
 
-void launch_collect_accepted(const unsigned long long* keys, const uint32_t* counter, uint32_t cap,
-                             const uint32_t* state, int take_all, unsigned long long* out, uint32_t* out_counter,
-                             hipStream_t s) {
-    hipLaunchKernelGGL(collect_accepted_kernel, dim3(1024), dim3(256), 0, s, keys, counter, cap, state, take_all, out,
-                       out_counter);
-}
-
-void launch_keys_to_xy(const unsigned long long* keys, int n, int w, float2* xy, hipStream_t s) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(keys_to_xy_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, w, xy);
+void launch_accepted_to_keypoints(const unsigned long long* keys, uint32_t n, int w, const uint8_t* cstate, uint32_t* per_block,
+                                  uint32_t max_corners, float2* xy, uint32_t* n_out, hipStream_t s) {
+    const int nb = suppress_num_blocks(n);
+    hipLaunchKernelGGL(accepted_scan_kernel, dim3(1), dim3(1024), 0, s, per_block, nb, max_corners, n_out);
+    if (nb > 0)
+        hipLaunchKernelGGL(accepted_scatter_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n, w, cstate, per_block, max_corners, xy);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -333,9 +333,10 @@ bool launch_lk(const LKParams& p, int win, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 constexpr int BIN_SHIFT = 6;
 
-__global__ __launch_bounds__(256) void bin_count_kernel(const float2* __restrict__ pts, int n, int tiles_x, int n_tiles,
+__global__ __launch_bounds__(256) void bin_count_kernel(const float2* __restrict__ pts, int n_max, const uint32_t* __restrict__ n_dev, int tiles_x, int n_tiles,
                                                         uint32_t* __restrict__ hist) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = n_dev ? min((int)*n_dev, n_max) : n_max;
     if (i >= n) return;
     const float2 p = pts[i];
     const int t = min(n_tiles - 1, max(0, ((int)p.y >> BIN_SHIFT) * tiles_x + ((int)p.x >> BIN_SHIFT)));
@@ -364,10 +365,11 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t* __restrict__ h
     }
 }
 
-__global__ __launch_bounds__(256) void bin_scatter_kernel(const float2* __restrict__ pts, int n, int tiles_x, int n_tiles,
+__global__ __launch_bounds__(256) void bin_scatter_kernel(const float2* __restrict__ pts, int n_max, const uint32_t* __restrict__ n_dev, int tiles_x, int n_tiles,
                                                           uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm,
                                                           uint32_t* __restrict__ slot_of) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = n_dev ? min((int)*n_dev, n_max) : n_max;
     if (i >= n) return;
     const float2 p = pts[i];
     const int t = min(n_tiles - 1, max(0, ((int)p.y >> BIN_SHIFT) * tiles_x + ((int)p.x >> BIN_SHIFT)));
@@ -378,14 +380,14 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const float2* __restri
 
 int bin_num_tiles(int w, int h) { return ((w + 63) >> BIN_SHIFT) * ((h + 63) >> BIN_SHIFT); }
 
-void launch_spatial_bins(const float2* pts, int n, int w, int h, uint32_t* hist, uint32_t* perm, uint32_t* slot_of,
-                         hipStream_t s) {
+void launch_spatial_bins(const float2* pts, int n, const uint32_t* n_dev, int w, int h, uint32_t* hist, uint32_t* perm,
+                         uint32_t* slot_of, hipStream_t s) {
     if (n <= 0) return;
     const int tiles_x = (w + 63) >> BIN_SHIFT, n_tiles = bin_num_tiles(w, h);
     (void)hipMemsetAsync(hist, 0, (size_t)n_tiles * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(bin_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, tiles_x, n_tiles, hist);
+    hipLaunchKernelGGL(bin_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, hist, n_tiles);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, tiles_x, n_tiles, hist, perm, slot_of);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist, perm, slot_of);
 }
 
 // ------------------------------------------------------------------------------------------------
