@@ -5,13 +5,20 @@ A "step" = one frame1 of the clip: make the new neighbour frame resident (RGB->g
 detect keypoints (GFTT), track them into its 8 neighbours (+-1,2,4,8) with pyramidal LK, filter
 status==1 and deliver the records to the host -- i.e. one iteration of the outer loop of
 GenerateOpticalFlowDatabase (reference cpp/opticalflow.cc:237-316) without the SQLite insert
-(reported separately).  Frames are resident in HBM before the timed region starts.
+(reported separately under "end_to_end").  Frames are resident in HBM before the timed region starts.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c1]
 
+What is timed: after at least 24 untimed frames (every ring slot used, clocks up; --warmup adds to that),
+EXACTLY K steps between barrier + synchronize on both sides.  A K-step region shorter than half a second
+(K = 20 at 1080p is 11 ms) is measured several times over consecutive stretches of the clip and the MEDIAN
+region is reported (`config.timed_regions`), so that a short driver run is not a cold one-off sample.
+The headline line is the 1080p configuration C2 (BASELINE.json configs[1]); the same JSON object carries
+the 4K configuration C3 under "c3" (the >= 30x target is quoted on 4K) unless --no-c3.
+
 N > 1: launched by torch.distributed.run, one rank per GPU; frames are sharded across ranks
 (contiguous ranges + 8-frame halo, no data-path collective) and the flow records are stitched with
-one RCCL all-gather at the end, inside the timed region.  scaling = "weak".
+an RCCL all-gather inside the timed region.  scaling = "weak".
 """
 from __future__ import annotations
 
@@ -21,6 +28,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -35,6 +43,12 @@ CONFIGS = {
     "c3": (3840, 2160, 4, "C3 3840x2160 300-frame clip, 4-level LK (max_level=4) + feature detect"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+# one wave64 VALU instruction occupies a SIMD for 4 cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 4
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
+CLIP_FRAMES = 300
+MIN_PREWARM = 24
+MIN_REGION_S = 0.5
+LK_KERNEL = "lk3_kernel<10>"
 
 
 def level_pixels(w, h, max_level, win=10):
@@ -87,13 +101,265 @@ def cpu_baseline(fetch_host, f1_candidates, gopt_kw, fopt_kw, target_seconds=12.
     return out
 
 
+def end_to_end(cfg, frames_dev, n_frames=60):
+    """GenerateOpticalFlowDatabase through the polychase_core module (what the Blender addon calls): frames as host
+    numpy arrays (PCIe upload inside the call), with and without the SQLite insert.  Not part of `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "polychase_amd", "core"))
+    import polychase_core as core
+
+    w, h, ml, _ = CONFIGS[cfg]
+    dev = [frames_dev[i] for i in range(n_frames)]
+    host = [f.cpu().numpy() for f in dev]
+    fo = core.OpticalFlowOptions()
+    fo.max_level = ml
+    vi = core.VideoInfo(w, h, 1, n_frames)
+    out = {"frames": n_frames, "note": "whole call incl. engine creation, clip edges and first-use allocations"}
+    with tempfile.TemporaryDirectory() as td:
+        for name, frames, db in [("device_frames_no_db_fps", dev, ""), ("host_frames_over_pcie_no_db_fps", host, ""),
+                                 ("host_frames_over_pcie_sqlite_fps", host, os.path.join(td, "a.db"))]:
+            core.generate_optical_flow_database(core.VideoInfo(w, h, 1, 12), lambda f: frames[f - 1], None, "", core.GFTTOptions(), fo)
+            t0 = time.perf_counter()
+            core.generate_optical_flow_database(vi, lambda f: frames[f - 1], None, db, core.GFTTOptions(), fo)
+            out[name] = n_frames / (time.perf_counter() - t0)
+            if db:
+                out["sqlite_bytes_per_frame"] = os.path.getsize(db) / n_frames
+    return out
+
+
+def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
+    """One configuration: returns the result object of this rank (rank 0's is printed)."""
+    import torch
+    import torch.distributed as dist
+
+    from polychase_amd import hip, synth
+    from polychase_amd.pipeline import ClipAnalyzer
+
+    w, h, max_level, label = CONFIGS[cfg]
+    clip = synth.NoiseClip(w, h, CLIP_FRAMES, device=str(dev))
+    clip_frames = [clip.frame_torch(t) for t in range(CLIP_FRAMES)]
+    torch.cuda.synchronize()
+
+    def source(fid):
+        # the clip played forwards and backwards over and over: a continuous motion for any number of frame ids
+        t = (fid + rank * 37) % (2 * CLIP_FRAMES - 2)
+        return clip_frames[t if t < CLIP_FRAMES else 2 * CLIP_FRAMES - 2 - t]
+
+    ctx = hip.Context(dev.index or 0)
+    gopt_kw, fopt_kw = {}, {"max_level": max_level}
+    prewarm = max(MIN_PREWARM, W)
+    dist_path = world > 1 or args.force_dist_path
+
+    # ---- how many K-step regions: a short probe after the pre-warm gives the step time ----
+    first_id = 1
+    an = ClipAnalyzer(ctx, w, h, first_id, 1 << 30, source, hip.gftt_options(**gopt_kw), hip.flow_options(**fopt_kw), max_jobs=3)
+
+    def barrier():
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    n_kps, n_rows = [], []
+
+    def sink(frame1, kps, detected, flows):
+        n_kps.append(len(kps))
+        n_rows.append(sum(len(v[0]) for v in flows.values()))
+
+    # the Python driver loop must not stall the GPU pipeline: a generation-2 collection pauses this process for
+    # 50-90 ms (the C++ driver of polychase_core has no such pauses)
+    gc.collect()
+    gc.disable()
+    nxt = first_id + 8
+    an.run(range(nxt, nxt + prewarm), sink)
+    nxt += prewarm
+    barrier()
+    t0 = time.perf_counter()
+    an.run(range(nxt, nxt + 8), sink, copy=False)
+    barrier()
+    est_step = (time.perf_counter() - t0) / 8
+    nxt += 8
+    regions = int(min(40, max(1, -(-MIN_REGION_S // max(K * est_step, 1e-6)))))
+    if world > 1:
+        tt = torch.tensor([regions], dtype=torch.int64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        regions = int(tt.item())
+
+    log = stitch = None
+    if dist_path:
+        # device-resident record log: the stitch all-gathers these bytes, no host copy of the payload
+        from polychase_amd import distributed as D
+        max_kp = int(1.5 * max(n_kps)) + 4096
+        log = torch.empty(D.log_capacity_bytes(K + 2, max_kp), dtype=torch.uint8, device=dev)
+        side = None
+        if world > 1:
+            try:
+                side = dist.new_group(backend="gloo")
+            except Exception as e:   # no usable interface for gloo: the sizes go over the main group instead
+                print(f"[bench] gloo side group unavailable ({e}); exchanging piece sizes over RCCL", file=sys.stderr)
+        stitch = D.ChunkedLogStitch(log, side_group=side)
+        stitch.warm_up()
+        piece_frames = max(1, K // 8)
+        stitch.reserve((K + piece_frames - 1) // piece_frames + 1, D.log_capacity_bytes(piece_frames + 1, max_kp))
+
+    region_s, lk_avg, lk_busy = [], [], []
+    lk_launches = 0
+    n_kps.clear()
+    n_rows.clear()
+    for _ in range(regions):
+        timed = range(nxt, nxt + K)
+        nxt += K
+        if dist_path:
+            an.an.set_device_log(log)   # resets the log (synchronises: outside the timed region)
+        barrier()
+        ctx.enable_timing(["lk"])   # HIP events around the dominant kernel only (2 records per step)
+        ctx.reset_timing()
+        t0 = time.perf_counter()
+        if not dist_path:
+            an.run(timed, sink, copy=False)
+        else:
+            # the same loop as ClipAnalyzer.run, plus: whenever the last frame1 of a piece has been collected (its log
+            # bytes are complete), all-gather that piece over RCCL -- the transfer runs beside the LK launches of the
+            # following frames; only the last piece is exposed (SURVEY 8(e): the one collective of the path)
+            piece = max(1, K // 8)
+            log_end = {}
+            piece_start = 0
+
+            def collect_one():
+                nonlocal piece_start
+                r = an.an.collect(False)
+                sink(*r)
+                done = r[0] - timed.start + 1
+                if done % piece == 0 or done == K:
+                    stitch.gather(piece_start, log_end[r[0]])
+                    piece_start = log_end[r[0]]
+
+            for f in timed:
+                if an.an.pending == an.max_jobs:
+                    collect_one()
+                an.submit(f)
+                log_end[f] = an.an.device_log_used
+            while an.an.pending:
+                collect_one()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        region_s.append(dt)
+        timing = ctx.timing()
+        lk_n, lk_ms = timing["lk"]
+        lk_launches += lk_n
+        lk_avg.append(lk_ms / max(1, lk_n))
+        lk_busy.append(ctx.busy_ms("lk") / max(1, lk_n))
+        ctx.enable_timing(False)
+        if dist_path:
+            # outside the timed region: every rank's shard must parse and hold exactly K records in frame order
+            an.an.set_device_log(None)
+            for r, (buf, used) in enumerate(stitch.rank_logs()):
+                recs = D.parse_device_log(buf, used)
+                assert len(recs) == K and [x[0] for x in recs] == list(range(recs[0][0], recs[0][0] + K)), "stitched log is not K consecutive frames"
+                if r == rank:
+                    assert [x[0] for x in recs] == list(timed)
+                    assert [len(x[1]) for x in recs] == n_kps[-K:] and [sum(len(v[0]) for v in x[2].values()) for x in recs] == n_rows[-K:]
+    gc.enable()
+    if dist_path:
+        del stitch, log
+    an.close()
+    order = np.argsort(region_s)
+    mid = int(order[len(order) // 2])      # the median region
+    dt = region_s[mid]
+
+    # per-class kernel breakdown from a short extra pass over the same frames (not part of `value`)
+    breakdown = None
+    if not args.no_breakdown:
+        n_extra = min(K, 20)
+        an = ClipAnalyzer(ctx, w, h, first_id, 1 << 30, source, hip.gftt_options(**gopt_kw), hip.flow_options(**fopt_kw), max_jobs=3)
+        an.run(range(first_id + 8, first_id + 8 + 20), None)
+        ctx.synchronize()
+        ctx.enable_timing(True)
+        ctx.reset_timing()
+        an.run(range(first_id + 28, first_id + 28 + n_extra), None)
+        breakdown = {k: v[1] / n_extra for k, v in ctx.timing().items()}
+        ctx.enable_timing(False)
+        an.close()
+
+    out = None
+    if rank == 0:
+        P = w * h
+        S = level_pixels(w, h, max_level)
+        lk_avg_ms, lk_busy_ms = lk_avg[mid], lk_busy[mid]
+        lk_bytes = (5 + 8) * S  # LK I-side 5S (image S + derivs 4S) + J-side S per target, K_f = 8
+        frame_bytes = 14 * P + (12 + 8) * S
+        achieved = lk_bytes / (lk_avg_ms * 1e-3) / 1e9 if lk_avg_ms > 0 else 0.0
+        fps = world * K / dt
+        # counters of the LK launch from separate rocprofv3 --pmc passes (they cannot be collected in-process)
+        traffic = valu = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "lk_hbm_traffic.json")))
+            traffic = tj[cfg]["traffic_bytes"]
+            valu = tj[cfg].get("valu_insts")
+        except Exception:
+            pass
+        out = {
+            "metric": "optical-flow frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 fixed-point + f32 2x2 solve",
+            "data": "synthetic",
+            "config": {"workload": label, "width": w, "height": h, "max_level": max_level,
+                       "window": 10, "pairs_per_frame": 8, "frames_per_gpu": K,
+                       "mean_keypoints": float(np.mean(n_kps)), "mean_flow_rows": float(np.mean(n_rows)),
+                       "parallelism": f"frame-shard x{world}" if world > 1 else "single GPU",
+                       "untimed_prewarm_steps": prewarm + 8, "timed_regions": len(region_s),
+                       "region_ms_min_median_max": [min(region_s) * 1e3, dt * 1e3, max(region_s) * 1e3]},
+            "roofline": {"bound": "hbm", "kernel": LK_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": lk_bytes, "avg_launch_ms": lk_avg_ms,
+                         "launches": lk_launches,
+                         # the contract's two bounds are "hbm" and "mfma"; what the counters say limits this gather
+                         # kernel is neither (see valu_roofline and DESIGN.md section 4)
+                         "observed_limiter": "VALU issue + dependent latency at 3 wavefronts/SIMD; HBM traffic is at the algorithmic bytes",
+                         # two launches are in flight at a time (job lanes): each one's start-to-end time exceeds
+                         # the GPU time it costs.  `achieved` uses the start-to-end time (comparable with
+                         # rocprofv3's per-dispatch durations); the per-launch share of the GPU is given beside it.
+                         "launch_overlap": lk_avg_ms / lk_busy_ms if lk_busy_ms > 0 else None,
+                         "busy_ms_per_launch": lk_busy_ms,
+                         "achieved_per_busy_time": lk_bytes / (lk_busy_ms * 1e-3) / 1e9 if lk_busy_ms > 0 else None},
+            "valu_roofline": None if not valu else {
+                "kernel": LK_KERNEL, "valu_wave_instructions_per_launch": valu,
+                "achieved": valu / (lk_busy_ms * 1e-3) / 1e9, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                "frac": valu / (lk_busy_ms * 1e-3) / 1e9 / VALU_PEAK_GINST,
+                "note": "SQ_INSTS_VALU of a separate rocprofv3 --pmc pass (profiles/) over the launch's GPU-busy time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles"},
+            "path_roofline": {"algorithmic_bytes_per_frame": frame_bytes,
+                              "achieved_GBs": frame_bytes * (K / dt) / 1e9,
+                              "frac": frame_bytes * (K / dt) / 1e9 / HBM_PEAK_GBS},
+            "kernel_ms_per_frame": breakdown,
+        }
+        if with_cpu:
+            f1s = [first_id + 8 + i for i in range(K)]
+            out["cpu_baseline"] = cpu_baseline(lambda f: source(f).cpu().numpy(), f1s, gopt_kw, fopt_kw,
+                                               target_seconds=args.cpu_seconds)
+            out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]
+        if with_e2e:
+            try:
+                out["end_to_end"] = end_to_end(cfg, clip_frames)
+            except Exception as e:   # the module is optional for the kernel benchmark
+                out["end_to_end"] = {"error": str(e)}
+    ctx.close()
+    del clip_frames, clip
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)   # > 17 + 2 ring slots: every slot has been used once
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-c3", action="store_true", help="skip the nested 4K configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true",
                     help="skip the extra per-class timing pass (profilers: only warm-up + timed launches remain)")
     ap.add_argument("--force-dist-path", action="store_true",
@@ -116,180 +382,18 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    from polychase_amd import hip, synth
-    from polychase_amd.pipeline import ClipAnalyzer
-
-    w, h, max_level, label = CONFIGS[args.config]
     K, W = args.steps, args.warmup
-    n_local = K + W + 16          # every timed frame1 is interior (8 targets)
-    first_id = 1 + rank * (K + W)  # frame ids of this rank's shard (8-frame halo on both sides)
-    clip = synth.NoiseClip(w, h, max(300, world * (K + W) + 16), device=str(dev))
-    frames = {first_id + i: clip.frame_torch(first_id - 1 + i) for i in range(n_local)}
-    torch.cuda.synchronize()
-
-    ctx = hip.Context(local_rank)
-    gopt_kw, fopt_kw = {}, {"max_level": max_level}
-    an = ClipAnalyzer(ctx, w, h, first_id, n_local, lambda fid: frames[fid], hip.gftt_options(**gopt_kw),
-                      hip.flow_options(**fopt_kw), max_jobs=3)
-
-    def barrier():
-        torch.cuda.synchronize()
-        ctx.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    f1_first = first_id + 8
-    n_kps, n_rows = [], []
-    dist_path = world > 1 or args.force_dist_path
-
-    def sink(frame1, kps, detected, flows):
-        n_kps.append(len(kps))
-        n_rows.append(sum(len(v[0]) for v in flows.values()))
-
-    # the Python driver loop must not stall the GPU pipeline: a generation-2 collection pauses this process for
-    # 50-90 ms (the C++ driver of polychase_core has no such pauses).  Collected BEFORE the warm-up so that nothing
-    # slow sits between the warm-up and the timed region: an idle GPU drops its clocks and the first launches
-    # after the barrier would run at a fraction of their speed.
-    gc.collect()
-    gc.disable()
-    an.run(range(f1_first, f1_first + W), sink)
-    log = stitch = None
-    if dist_path:
-        # device-resident record log: the stitch all-gathers these bytes, no host copy of the payload
-        from polychase_amd import distributed as D
-        # capacity per record: 1.5x the keypoints seen in the warm-up; without a warm-up the densest packing the
-        # 5-px minimum distance allows (one keypoint per ~21.6 px^2)
-        max_kp = (int(1.5 * max(n_kps)) if n_kps else w * h // 20) + 4096
-        log = torch.empty(D.log_capacity_bytes(K + 2, max_kp), dtype=torch.uint8, device=dev)
-        an.an.set_device_log(log)
-        # sizes of the log pieces are agreed on over gloo so that the exchange never waits for an RCCL transfer
-        side = None
-        if world > 1:
-            try:
-                side = dist.new_group(backend="gloo")
-            except Exception as e:   # no usable interface for gloo: the sizes go over the main group instead
-                print(f"[bench] gloo side group unavailable ({e}); exchanging piece sizes over RCCL", file=sys.stderr)
-        stitch = D.ChunkedLogStitch(log, side_group=side)
-        stitch.warm_up()
-        # receive buffers of the pieces, allocated before the timed region
-        piece_frames = max(1, K // 8)
-        stitch.reserve((K + piece_frames - 1) // piece_frames + 1, D.log_capacity_bytes(piece_frames + 1, max_kp))
-    n_kps.clear()
-    n_rows.clear()
-    barrier()
-    ctx.enable_timing(["lk"])   # HIP events around the dominant kernel only (2 records per step)
-    ctx.reset_timing()
-    t0 = time.perf_counter()
-    timed = range(f1_first + W, f1_first + W + K)
-    if not dist_path:
-        an.run(timed, sink, copy=False)
-    else:
-        # the same loop as ClipAnalyzer.run, plus: whenever the last frame1 of a piece has been collected (its log
-        # bytes are complete), all-gather that piece over RCCL -- the transfer runs beside the LK launches of the
-        # following frames; only the last piece is exposed (the one collective of the path)
-        piece = max(1, K // 8)
-        log_end = {}                      # frame1 -> log offset after its record
-        piece_start = 0
-
-        def collect_one():
-            nonlocal piece_start
-            r = an.an.collect(False)
-            sink(*r)
-            done = r[0] - timed.start + 1
-            if done % piece == 0 or done == K:
-                stitch.gather(piece_start, log_end[r[0]])
-                piece_start = log_end[r[0]]
-
-        for f in timed:
-            if an.an.pending == an.max_jobs:
-                collect_one()
-            an.submit(f)
-            log_end[f] = an.an.device_log_used
-        while an.an.pending:
-            collect_one()
-    barrier()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    timing = ctx.timing()
-    lk_busy_ms = ctx.busy_ms("lk")
-    ctx.enable_timing(False)
-    if dist_path:
-        # outside the timed region: every rank's shard must parse and hold exactly K records in frame order
-        an.an.set_device_log(None)
-        for r, (buf, used) in enumerate(stitch.rank_logs()):
-            recs = D.parse_device_log(buf, used)
-            exp0 = 1 + r * (K + W) + 8 + W
-            assert [x[0] for x in recs] == list(range(exp0, exp0 + K)), "stitched log is not the expected frame range"
-            if r == rank:
-                assert [len(x[1]) for x in recs] == n_kps and [sum(len(v[0]) for v in x[2].values()) for x in recs] == n_rows
-        del stitch, log
-    # per-class kernel breakdown from a short extra pass over the same frames (not part of `value`)
-    an.close()
-    breakdown = None
-    if not args.no_breakdown:
-        n_extra = min(K, 20)
-        an = ClipAnalyzer(ctx, w, h, first_id, n_local, lambda fid: frames[fid], hip.gftt_options(**gopt_kw),
-                          hip.flow_options(**fopt_kw), max_jobs=3)
-        an.run(range(f1_first, f1_first + 2), None)
-        ctx.synchronize()
-        ctx.enable_timing(True)
-        ctx.reset_timing()
-        an.run(range(f1_first + 2, f1_first + 2 + n_extra), None)
-        breakdown = {k: v[1] / n_extra for k, v in ctx.timing().items()}
-        ctx.enable_timing(False)
-        an.close()
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
+    single = world == 1 and not args.force_dist_path
+    out = run_config(args.config, K, W, args, rank, world, dev, with_cpu=single and not args.no_cpu_baseline,
+                     with_e2e=single and not args.no_end_to_end and args.config == "c2")
+    if args.config == "c2" and not args.no_c3:
+        # the 4K configuration rides along (fewer steps: a step is 4.5x longer); its CPU sample is shorter
+        args.cpu_seconds = min(args.cpu_seconds, 8.0)
+        c3 = run_config("c3", max(10, K // 2), W, args, rank, world, dev, with_cpu=single and not args.no_cpu_baseline, with_e2e=False)
+        if rank == 0:
+            out["c3"] = c3
     if rank == 0:
-        P = w * h
-        S = level_pixels(w, h, max_level)
-        lk_n, lk_ms = timing["lk"]
-        lk_avg_ms = lk_ms / max(1, lk_n)          # a launch's own start-to-end time (what rocprofv3 reports per dispatch)
-        lk_busy_avg_ms = lk_busy_ms / max(1, lk_n)  # the analyzer overlaps consecutive launches: GPU time per launch
-        lk_bytes = (5 + 8) * S  # LK I-side 5S (image S + derivs 4S) + J-side S per target, K_f = 8
-        frame_bytes = 14 * P + (12 + 8) * S
-        achieved = lk_bytes / (lk_avg_ms * 1e-3) / 1e9 if lk_avg_ms > 0 else 0.0
-        fps = world * K / dt
-        traffic = None   # HBM bytes per LK launch from a separate rocprofv3 --pmc pass (cannot be collected in-process)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "lk_hbm_traffic.json")))
-            traffic = tj[args.config]["traffic_bytes"]
-        except Exception:
-            pass
-        out = {
-            "metric": "optical-flow frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 fixed-point + f32 2x2 solve",
-            "data": "synthetic",
-            "config": {"workload": label, "width": w, "height": h, "max_level": max_level,
-                       "window": 10, "pairs_per_frame": 8, "frames_per_gpu": K,
-                       "mean_keypoints": float(np.mean(n_kps)), "mean_flow_rows": float(np.mean(n_rows)),
-                       "parallelism": f"frame-shard x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "lk2_kernel<10>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": lk_bytes, "avg_launch_ms": lk_avg_ms,
-                         "launches": lk_n,
-                         # two launches are in flight at a time (job lanes): each one's start-to-end time is about
-                         # twice the GPU time it costs.  `achieved` uses the start-to-end time (comparable with
-                         # rocprofv3's per-dispatch durations); the per-launch share of the GPU is given beside it.
-                         "launch_overlap": lk_ms / lk_busy_ms if lk_busy_ms > 0 else None,
-                         "busy_ms_per_launch": lk_busy_avg_ms,
-                         "achieved_per_busy_time": lk_bytes / (lk_busy_avg_ms * 1e-3) / 1e9 if lk_busy_avg_ms > 0 else None},
-            "path_roofline": {"algorithmic_bytes_per_frame": frame_bytes,
-                              "achieved_GBs": frame_bytes * (K / dt) / 1e9,
-                              "frac": frame_bytes * (K / dt) / 1e9 / HBM_PEAK_GBS},
-            "kernel_ms_per_frame": breakdown,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            f1s = [f1_first + W + i for i in range(K)]
-            out["cpu_baseline"] = cpu_baseline(lambda f: frames[f].cpu().numpy(), f1s, gopt_kw, fopt_kw,
-                                               target_seconds=args.cpu_seconds)
-            out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

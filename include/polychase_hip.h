@@ -186,11 +186,14 @@ typedef struct pc_frame_result {
     const float* flow_err;                 /* flow_errors */
 } pc_frame_result;
 
+#define PC_ANALYZER_SPARE_SLOTS 3
+#define PC_ANALYZER_LOOKAHEAD 1
 int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_options* gftt,
                        const pc_flow_options* flow, int ring_frames, int max_jobs, pc_analyzer** out);
 void pc_analyzer_destroy(pc_analyzer* a);
-/* Make `frame_id` resident (evicting the frame ring_frames + 2 ids back: the ring holds two slots more than
- * asked for, so that a put never waits for LK launches that still read older frames):
+/* Make `frame_id` resident (evicting the frame ring_frames + PC_ANALYZER_SPARE_SLOTS ids back: the ring holds three
+ * slots more than asked for, so that a put never waits for LK launches that still read older frames and the caller
+ * can run PC_ANALYZER_LOOKAHEAD = 1 frame ahead of the window frame1 - 8 .. frame1 + 8 of the current submit):
  * RGB->gray + pyramid, and, when will_detect != 0, the dense part of GoodFeaturesToTrack.
  * Replaces RequestFrame + cvtColor + GeneratePyramid (opticalflow.cc:249-263, :287-302). */
 int pc_analyzer_put_frame(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, size_t row_pitch,

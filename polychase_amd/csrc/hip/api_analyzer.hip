@@ -11,6 +11,8 @@ using namespace pc_api;
 
 namespace {
 
+constexpr int kSpareSlots = PC_ANALYZER_SPARE_SLOTS;
+
 enum DetState { DET_NONE = 0, DET_DENSE = 1, DET_ORDERED = 2, DET_DONE = 3 };   // phases A, B enqueued; C done
 
 struct Slot {
@@ -129,9 +131,11 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
     a->gopt = *gftt;
     a->fopt = *flow;
     a->grid = grid0;
-    // two extra slots: a frame can be overwritten (prep stream) while the LK launches that read its
-    // predecessors in the ring are still running, without the two streams waiting on each other
-    a->slots.resize((size_t)ring_frames + 2);
+    // spare slots: a frame can be overwritten (prep stream) while the LK launches that read its predecessors in the
+    // ring are still running, without the streams waiting on each other, and the drivers make frame1 + 9 resident
+    // one step before the first launch that reads it (PC_ANALYZER_LOOKAHEAD) so that its pyramid never sits on
+    // the critical path of that launch
+    a->slots.resize((size_t)ring_frames + kSpareSlots);
     a->jobs.resize((size_t)max_jobs);
     int rc = PC_OK;
     for (auto& s : a->slots) {
@@ -385,9 +389,13 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     PC_HIP(hipMemcpyAsync(j.h_pack.p, pack, j.pack_bytes, hipMemcpyDeviceToHost, ls));
     PC_HIP(hipEventRecord(j.done, ls));
     a->job_count++;
-    // (5) while this LK launch runs: order the keypoints of the next frame1
+    // (5) while this LK launch runs: phase B (sort, suppression, keypoints, visiting order) of the frames that become
+    // frame1 next.  Two frames ahead: beside a running LK launch phase B takes about as long as the launch itself, and
+    // the launch after next could otherwise not start under the tail of this one.
     SlowSection ss("submit/preorder");
-    return preorder_if_ready(a, frame1 + 1);
+    for (int ahead = 1; ahead <= 2; ahead++)
+        if ((rc = preorder_if_ready(a, frame1 + ahead)) != PC_OK) return rc;
+    return PC_OK;
 }
 
 int pc_analyzer_pending(const pc_analyzer* a) { return a ? (int)a->job_count : 0; }

@@ -431,16 +431,16 @@ __global__ __launch_bounds__(SUP_BLOCK) void accept_all_kernel(const unsigned lo
 }
 
 // exclusive scan of the per-block counts (one workgroup) + the keypoint count (truncated to max_corners, gftt.cc:160-162)
-__global__ __launch_bounds__(1024) void accepted_scan_kernel(uint32_t* __restrict__ per_block, int nblocks, uint32_t max_corners,
-                                                             uint32_t* __restrict__ n_out) {
-    __shared__ uint32_t s_sum[1024];
-    const int per = (nblocks + 1023) / 1024;
+__global__ __launch_bounds__(256) void accepted_scan_kernel(uint32_t* __restrict__ per_block, int nblocks, uint32_t max_corners,
+                                                            uint32_t* __restrict__ n_out) {
+    __shared__ uint32_t s_sum[256];
+    const int per = (nblocks + 255) / 256;
     const int b = threadIdx.x * per, e = min(b + per, nblocks);
     uint32_t s = 0;
     for (int i = b; i < e; i++) s += per_block[i];
     s_sum[threadIdx.x] = s;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
+    for (int d = 1; d < 256; d <<= 1) {
         const uint32_t v = (threadIdx.x >= (unsigned)d) ? s_sum[threadIdx.x - d] : 0u;
         __syncthreads();
         s_sum[threadIdx.x] += v;
@@ -452,8 +452,8 @@ __global__ __launch_bounds__(1024) void accepted_scan_kernel(uint32_t* __restric
         per_block[i] = run;
         run += c;
     }
-    if (threadIdx.x == 1023) {
-        const uint32_t total = s_sum[1023];
+    if (threadIdx.x == 255) {
+        const uint32_t total = s_sum[255];
         *n_out = (max_corners > 0 && total > max_corners) ? max_corners : total;
     }
 }
@@ -500,7 +500,7 @@ void launch_suppress_sorted(const unsigned long long* keys, uint32_t n, int w, i
 void launch_accepted_to_keypoints(const unsigned long long* keys, uint32_t n, int w, const uint8_t* cstate, uint32_t* per_block,
                                   uint32_t max_corners, float2* xy, uint32_t* n_out, hipStream_t s) {
     const int nb = suppress_num_blocks(n);
-    hipLaunchKernelGGL(accepted_scan_kernel, dim3(1), dim3(1024), 0, s, per_block, nb, max_corners, n_out);
+    hipLaunchKernelGGL(accepted_scan_kernel, dim3(1), dim3(256), 0, s, per_block, nb, max_corners, n_out);
     if (nb > 0)
         hipLaunchKernelGGL(accepted_scatter_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n, w, cstate, per_block, max_corners, xy);
 }

@@ -343,15 +343,18 @@ __global__ __launch_bounds__(256) void bin_count_kernel(const float2* __restrict
     atomicAdd(&hist[t], 1u);
 }
 
-__global__ __launch_bounds__(1024) void bin_scan_kernel(uint32_t* __restrict__ hist, int n_tiles) {
-    __shared__ uint32_t s_sum[1024];
-    const int per = (n_tiles + 1023) / 1024;
+// (256 lanes: beside a running LK launch a workgroup needs its wavefronts resident together, and 1024-lane
+// workgroups -- 4 wavefronts per SIMD -- do not fit the registers three LK wavefronts per SIMD leave over; they
+// waited for the whole LK launch to drain, measured 2 ms for a 50-us kernel)
+__global__ __launch_bounds__(256) void bin_scan_kernel(uint32_t* __restrict__ hist, int n_tiles) {
+    __shared__ uint32_t s_sum[256];
+    const int per = (n_tiles + 255) / 256;
     const int b = threadIdx.x * per, e = min(b + per, n_tiles);
     uint32_t s = 0;
     for (int i = b; i < e; i++) s += hist[i];
     s_sum[threadIdx.x] = s;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
+    for (int d = 1; d < 256; d <<= 1) {
         const uint32_t v = (threadIdx.x >= (unsigned)d) ? s_sum[threadIdx.x - d] : 0u;
         __syncthreads();
         s_sum[threadIdx.x] += v;
@@ -386,7 +389,7 @@ void launch_spatial_bins(const float2* pts, int n, const uint32_t* n_dev, int w,
     const int tiles_x = (w + 63) >> BIN_SHIFT, n_tiles = bin_num_tiles(w, h);
     (void)hipMemsetAsync(hist, 0, (size_t)n_tiles * sizeof(uint32_t), s);
     hipLaunchKernelGGL(bin_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, hist, n_tiles);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, hist, n_tiles);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist, perm, slot_of);
 }
 
@@ -397,12 +400,13 @@ void launch_spatial_bins(const float2* pts, int n, const uint32_t* n_dev, int w,
 // fast index, so the 8 lanes of a keypoint read exactly that line through the inverse permutation
 // and write one run per target in ascending keypoint order.
 // ------------------------------------------------------------------------------------------------
-constexpr int CF = 128;   // keypoints per 1024-lane workgroup
+constexpr int CF = 32;    // keypoints per 256-lane workgroup (small workgroups: see bin_scan_kernel)
+constexpr int CT = CF * kRecStride;
 int compact_num_blocks(int n) { return (n + CF - 1) / CF; }
 
 __device__ __forceinline__ unsigned long long target_lanes(int t) { return 0x0101010101010101ull << t; }
 
-__global__ __launch_bounds__(1024) void compact_count_kernel(const float4* __restrict__ rec, const uint32_t* __restrict__ slot_of,
+__global__ __launch_bounds__(CT) void compact_count_kernel(const float4* __restrict__ rec, const uint32_t* __restrict__ slot_of,
                                                              int n, int n_targets, int nblocks,
                                                              uint32_t* __restrict__ block_counts) {
     __shared__ uint32_t s_cnt[kRecStride];
@@ -431,15 +435,13 @@ __global__ __launch_bounds__(256) void compact_scan_kernel(uint32_t* __restrict_
     for (int i = b; i < e; i++) sum += block_counts[i];
     s_part[threadIdx.x] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        long long run = 0;
-        for (int i = 0; i < 256; i++) {
-            const long long v = s_part[i];
-            s_part[i] = run;
-            run += v;
-        }
+    for (int d = 1; d < 256; d <<= 1) {   // inclusive scan of the 256 partial sums
+        const long long v = (threadIdx.x >= (unsigned)d) ? s_part[threadIdx.x - d] : 0ll;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
     }
-    __syncthreads();
+    s_part[threadIdx.x] -= sum;   // exclusive (each lane touches only its own entry)
     long long run = s_part[threadIdx.x];
     for (int i = b; i < e; i++) {
         const uint32_t c = block_counts[i];
@@ -452,12 +454,12 @@ __global__ __launch_bounds__(256) void compact_scan_kernel(uint32_t* __restrict_
         for (int t = 0; t <= n_targets; t++) row_offset[t] = 0;
 }
 
-__global__ __launch_bounds__(1024) void compact_scatter_kernel(const float4* __restrict__ rec, const uint32_t* __restrict__ slot_of,
+__global__ __launch_bounds__(CT) void compact_scatter_kernel(const float4* __restrict__ rec, const uint32_t* __restrict__ slot_of,
                                                                int n, int n_targets, int nblocks,
                                                                const uint32_t* __restrict__ block_offsets,
                                                                uint32_t* __restrict__ out_idx,
                                                                float2* __restrict__ out_xy, float* __restrict__ out_err) {
-    __shared__ uint32_t s_wave[16][kRecStride];
+    __shared__ uint32_t s_wave[CT / 64][kRecStride];
     const int t = threadIdx.x & 7, i = blockIdx.x * CF + (int)(threadIdx.x >> 3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -513,10 +515,10 @@ void launch_compact(const float4* rec, const uint32_t* slot_of, int n, int n_tar
                     float* out_err, hipStream_t s) {
     const int nblocks = compact_num_blocks(n);
     if (nblocks > 0)
-        hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(1024), 0, s, rec, slot_of, n, n_targets, nblocks, block_counts);
+        hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(CT), 0, s, rec, slot_of, n, n_targets, nblocks, block_counts);
     hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(256), 0, s, block_counts, nblocks, n_targets, row_offset);
     if (nblocks > 0)
-        hipLaunchKernelGGL(compact_scatter_kernel, dim3(nblocks), dim3(1024), 0, s, rec, slot_of, n, n_targets, nblocks,
+        hipLaunchKernelGGL(compact_scatter_kernel, dim3(nblocks), dim3(CT), 0, s, rec, slot_of, n, n_targets, nblocks,
                            block_counts, out_idx, out_xy, out_err);
 }
 

@@ -238,8 +238,9 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
                 return;
             }
         }
-        // make frame1 .. frame1+8 resident; every frame is requested exactly once, in increasing order
-        const int32_t upto = std::min(frame_id1 + 8, to - 1);
+        // make frame1 .. frame1+8 resident, and one frame more (its pyramid is then ready a whole step before the first
+        // launch that reads it); every frame is requested exactly once, in increasing order
+        const int32_t upto = std::min(frame_id1 + 8 + PC_ANALYZER_LOOKAHEAD, to - 1);
         for (int32_t fid = std::max(highest_put + 1, std::max(from, frame_id1 - 8)); fid <= upto; fid++) {
             std::optional<FrameView> f = fetch(fid);
             if (!f) {

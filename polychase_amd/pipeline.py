@@ -14,6 +14,7 @@ from . import hip
 
 IMAGE_SKIPS = (-8, -4, -2, -1, 1, 2, 4, 8)  # reference cpp/opticalflow.cc:76-77
 RING = 17                                    # reference SequentialWrapper<17>, opticalflow_thread.h:34-79
+LOOKAHEAD = 1                                # PC_ANALYZER_LOOKAHEAD: frame1 + 9 becomes resident one step early
 
 
 class ClipAnalyzer:
@@ -42,7 +43,7 @@ class ClipAnalyzer:
             self.highest = fid
 
     def submit(self, frame1: int, targets: Iterable[int] | None = None):
-        self._ensure_resident(frame1 + 8, frame1)
+        self._ensure_resident(frame1 + 8 + LOOKAHEAD, frame1)
         tg = list(self.targets_of(frame1) if targets is None else targets)
         self.an.submit(frame1, tg)
 

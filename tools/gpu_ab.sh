@@ -9,7 +9,7 @@ LIBS="default $@"
 [ $# -eq 0 ] && LIBS="default $(ls polychase_amd/lib/variants 2>/dev/null | sed 's/libpolychase_hip_//; s/.so//')"
 for l in $LIBS; do
   if [ $l = default ]; then unset POLYCHASE_HIP_LIB; else export POLYCHASE_HIP_LIB=$ROOT/polychase_amd/lib/variants/libpolychase_hip_$l.so; fi
-  python bench.py --no-cpu-baseline --config $CFG 2>/dev/null > gpurun_out/ab_${CFG}_$l.json
+  python bench.py --no-cpu-baseline --no-c3 --no-end-to-end --config $CFG 2>/dev/null > gpurun_out/ab_${CFG}_$l.json
   python - "$l" "gpurun_out/ab_${CFG}_$l.json" <<'PY'
 import json, sys
 try:

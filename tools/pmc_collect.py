@@ -31,7 +31,7 @@ def main():
     for g in args.groups:
         d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", *g.split(","), "--output-format", "csv", "-d", d, "--",
-               sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--config", args.config,
+               sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-c3", "--no-end-to-end", "--config", args.config,
                "--steps", str(args.steps), "--warmup", "4"]
         r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
