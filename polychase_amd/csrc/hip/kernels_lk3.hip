@@ -54,7 +54,10 @@ struct LK3Geo {
     static constexpr int J_DW = RH * PITCH;                   // per-group J region (16-byte multiple)
     static constexpr int I_CH = (WIN + 3) / 4, I_PITCH = 4 * I_CH, I_ROWS = WIN + 1;
     static constexpr int I_DW = I_ROWS * I_PITCH;             // I window of one keypoint, same format
-    static constexpr int D_PITCH = WIN + 1, D_DW = (WIN + 1) * (WIN + 1);   // raw Scharr window
+    // raw Scharr window.  D_DW is kept EVEN: the exchange buffer behind it is read with ds_read_b64, and at an odd dword
+    // offset every one of those reads is 8-byte misaligned -- 62 LDS stall cycles each, SQ_LDS_UNALIGNED_STALL = 60 % of
+    // the LDS pipe's busy time, which itself was 82 % of the launch (rounds 1 and 2 until this was found)
+    static constexpr int D_PITCH = WIN + 1, D_DW = (((WIN + 1) * (WIN + 1)) + 1) & ~1;
     static constexpr int X_DW = 2 * NPX;                      // (bias, Dxy) exchange of one keypoint
     static constexpr int HALF_I_DW = ((I_DW + D_DW + X_DW + 3) / 4) * 4;
     static constexpr int WAVE_DW = 16 * J_DW > 2 * HALF_I_DW ? 16 * J_DW : 2 * HALF_I_DW;

@@ -115,7 +115,7 @@ struct LKGeo {
     static constexpr int J_DW = RH * PAIR_PITCH / 4 + 1;              // per-group J region (odd dword stride)
     static constexpr int I_DW = (WIN + 1) * PAIR_PITCH / 4;           // per-wave I window in pair format
     static constexpr int D_PITCH = WIN + 1;                           // dwords per Scharr window row
-    static constexpr int D_DW = (WIN + 1) * D_PITCH;                  // per-wave raw Scharr window
+    static constexpr int D_DW = (((WIN + 1) * D_PITCH) + 1) & ~1;     // per-wave raw Scharr window (even: the exchange buffer behind it must be 8-byte aligned, see kernels_lk3.hip)
     static constexpr int X_DW = NPX * 2;                              // per-wave exchange: (Ival, Dxy) per pixel
     static constexpr int WAVE_DW = ((I_DW + D_DW + X_DW + 8 * J_DW + 1) / 2) * 2;  // 8-B aligned
 };
