@@ -37,6 +37,21 @@ void pco_rgb2gray(const uint8_t* rgb, int w, int h, uint8_t* gray) {
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------------------------- */
+/* Where OpenCV's result depends on how the host executes it, the oracle has ONE canonical order (the one
+ * the GPU matches bit for bit) and, for measuring how far that is from an x86 OpenCV build, an emulation of
+ * the x86 SIMD order (pco_set_opencv_emulation; tests/test_oracle_cpu.py and DESIGN.md section 2 report the
+ * differences; tests/opencv_crosscheck.py checks both against a real cv2 where one exists):
+ *   PCO_EMU_LK_SIMD    LKTrackerInvoker, CV_SIMD128 path (video/lkpyramid.cpp, baseline SSE2/SSE3 build): the
+ *                      structure tensor and the mismatch vector are summed in fp32 -- four vector lanes over the
+ *                      first (win/8)*8 columns plus a scalar accumulator over the rest, combined at the end --
+ *                      instead of exactly in integers.  v_muladd is mul + add there (no FMA in the baseline).
+ *   PCO_EMU_SOBEL_FMA  the symmetric 3-tap column filter of Sobel (imgproc/filter.simd.hpp, dispatched to AVX2
+ *                      on any recent x86): v_muladd(S0 + S2, k1, v_muladd(S1, k0, 0)) with a fused multiply-add. */
+static int g_emulation = 0;
+void pco_set_opencv_emulation(int flags) { g_emulation = flags; }
+int pco_get_opencv_emulation(void) { return g_emulation; }
+
 /* cornerMinEigenVal (OpenCV imgproc/corner.cpp cornerEigenValsVecs + calcMinEigenVal).
  *   scale = 1 / (2^(ksize-1) * block_size * 255)            (8U input)
  *   Dx = Sobel(src, 32F, 1, 0, 3, scale): row kernel [-1,0,1] (exact), column kernel
@@ -80,8 +95,11 @@ int pco_min_eigen_val(const uint8_t* gray, int w, int h, int block_size, int ksi
     for (int y = 0; y < h; y++) {
         const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
         for (int x = 0; x < w; x++) {
-            const float dx = (rdx[(size_t)ym * w + x] + rdx[(size_t)yp * w + x]) * f1 +
-                             rdx[(size_t)y * w + x] * f0;
+            float dx;
+            if (g_emulation & PCO_EMU_SOBEL_FMA)
+                dx = fmaf(rdx[(size_t)ym * w + x] + rdx[(size_t)yp * w + x], f1, rdx[(size_t)y * w + x] * f0);
+            else
+                dx = (rdx[(size_t)ym * w + x] + rdx[(size_t)yp * w + x]) * f1 + rdx[(size_t)y * w + x] * f0;
             const float dy = rdy[(size_t)yp * w + x] - rdy[(size_t)ym * w + x];
             float* c = cov + ((size_t)y * w + x) * 3;
             c[0] = dx * dx;
@@ -477,6 +495,13 @@ static void lk_range(const pco_pyramid* P, const pco_pyramid* N, const float* pt
             int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
             int64_t iA11 = 0, iA12 = 0, iA22 = 0;
+            /* x86 SIMD order (PCO_EMU_LK_SIMD): lane j of the 4-lane fp32 accumulators takes columns x = j mod 4 of
+             * the first simd_w columns (every product is exact in fp32: |ix|, |iy| <= 4080), the scalar fp32
+             * accumulator the rest, row by row; "iA11 += buf[0] + buf[1] + buf[2] + buf[3]" at the end */
+            const int emu = g_emulation & PCO_EMU_LK_SIMD;
+            const int simd_w = (win / 8) * 8;
+            float qA11[4] = {0, 0, 0, 0}, qA12[4] = {0, 0, 0, 0}, qA22[4] = {0, 0, 0, 0};
+            float fA11 = 0.f, fA12 = 0.f, fA22 = 0.f;
             for (int y = 0; y < win; y++) {
                 const uint8_t* src = I + (ptrdiff_t)(y + ipy) * stepI + ipx;
                 const int16_t* dsrc = dI + (ptrdiff_t)(y + ipy) * dstep + ipx * 2;
@@ -496,11 +521,33 @@ static void lk_range(const pco_pyramid* P, const pco_pyramid* N, const float* pt
                     iA11 += (int64_t)ixval * ixval;
                     iA12 += (int64_t)ixval * iyval;
                     iA22 += (int64_t)iyval * iyval;
+                    if (emu) {
+                        const float fx = (float)ixval, fy = (float)iyval;
+                        if (x < simd_w) {
+                            qA22[x & 3] = fy * fy + qA22[x & 3];
+                            qA12[x & 3] = fx * fy + qA12[x & 3];
+                            qA11[x & 3] = fx * fx + qA11[x & 3];
+                        } else {
+                            fA11 += (float)(ixval * ixval);
+                            fA12 += (float)(ixval * iyval);
+                            fA22 += (float)(iyval * iyval);
+                        }
+                    }
                 }
             }
-            const float A11 = (float)iA11 * FLT_SCALE;
-            const float A12 = (float)iA12 * FLT_SCALE;
-            const float A22 = (float)iA22 * FLT_SCALE;
+            float A11, A12, A22;
+            if (emu) {
+                fA11 += qA11[0] + qA11[1] + qA11[2] + qA11[3];
+                fA12 += qA12[0] + qA12[1] + qA12[2] + qA12[3];
+                fA22 += qA22[0] + qA22[1] + qA22[2] + qA22[3];
+                A11 = fA11 * FLT_SCALE;
+                A12 = fA12 * FLT_SCALE;
+                A22 = fA22 * FLT_SCALE;
+            } else {
+                A11 = (float)iA11 * FLT_SCALE;
+                A12 = (float)iA12 * FLT_SCALE;
+                A22 = (float)iA22 * FLT_SCALE;
+            }
             float D = A11 * A22 - A12 * A12;
             const float tdiff = A11 - A22;
             const float min_eig = (A22 + A11 - sqrtf(tdiff * tdiff + 4.f * A12 * A12)) /
@@ -529,8 +576,14 @@ static void lk_range(const pco_pyramid* P, const pco_pyramid* N, const float* pt
                 iw10 = cv_round_f((1.f - a) * b * (float)(1 << W_BITS));
                 iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
                 int64_t ib1 = 0, ib2 = 0;
+                /* x86 SIMD order: per group of 8 columns the products of columns (c, c + 4) are added as int32 pairs
+                 * (v_dotprod), converted to fp32 and accumulated in lane (c & 1) * 2 of qb0 (c = 0, 1) or qb1 (c = 2, 3)
+                 * for b1, the lane after it for b2; the scalar fp32 accumulator takes the remaining columns;
+                 * "ib1 += bbuf[0] + bbuf[2]" with bbuf = qb0 + qb1 at the end */
+                float qb0[4] = {0, 0, 0, 0}, qb1[4] = {0, 0, 0, 0}, fb1 = 0.f, fb2 = 0.f;
                 for (int y = 0; y < win; y++) {
                     const uint8_t* Jp = J + (ptrdiff_t)(y + iqy) * stepJ + iqx;
+                    int dcol[16];
                     for (int x = 0; x < win; x++) {
                         const int diff = DESCALE(Jp[x] * iw00 + Jp[x + 1] * iw01 +
                                                      Jp[x + stepJ] * iw10 + Jp[x + stepJ + 1] * iw11,
@@ -538,10 +591,38 @@ static void lk_range(const pco_pyramid* P, const pco_pyramid* N, const float* pt
                                          Iwin[y * win + x];
                         ib1 += (int64_t)diff * dIwin[(y * win + x) * 2];
                         ib2 += (int64_t)diff * dIwin[(y * win + x) * 2 + 1];
+                        if (emu) {
+                            if (x < simd_w) {
+                                dcol[x & 7] = diff;
+                                if ((x & 7) == 7) {
+                                    const int16_t* d8 = dIwin + (y * win + (x - 7)) * 2;
+                                    for (int c = 0; c < 4; c++) {
+                                        const int p1 = dcol[c] * d8[2 * c] + dcol[c + 4] * d8[2 * (c + 4)];
+                                        const int p2 = dcol[c] * d8[2 * c + 1] + dcol[c + 4] * d8[2 * (c + 4) + 1];
+                                        float* q = (c < 2) ? qb0 : qb1;
+                                        q[(c & 1) * 2] += (float)p1;
+                                        q[(c & 1) * 2 + 1] += (float)p2;
+                                    }
+                                }
+                            } else {
+                                fb1 += (float)(diff * dIwin[(y * win + x) * 2]);
+                                fb2 += (float)(diff * dIwin[(y * win + x) * 2 + 1]);
+                            }
+                        }
                     }
                 }
-                const float b1 = (float)ib1 * FLT_SCALE;
-                const float b2 = (float)ib2 * FLT_SCALE;
+                float b1, b2;
+                if (emu) {
+                    float bbuf[4];
+                    for (int k = 0; k < 4; k++) bbuf[k] = qb0[k] + qb1[k];
+                    fb1 += bbuf[0] + bbuf[2];
+                    fb2 += bbuf[1] + bbuf[3];
+                    b1 = fb1 * FLT_SCALE;
+                    b2 = fb2 * FLT_SCALE;
+                } else {
+                    b1 = (float)ib1 * FLT_SCALE;
+                    b2 = (float)ib2 * FLT_SCALE;
+                }
                 const float dx = (A12 * b2 - A22 * b1) * D;
                 const float dy = (A12 * b1 - A11 * b2) * D;
                 qx += dx;

@@ -63,9 +63,30 @@ def lib(path: str | None = None):
                                    C.c_int32, C.POINTER(GfttOptions), C.POINTER(FlowOptions), C.c_int,
                                    C.c_int, _RECORD_CB, C.c_void_p]
     L.pco_analyze_clip.restype = C.c_int
+    L.pco_set_opencv_emulation.argtypes = [C.c_int]
+    L.pco_get_opencv_emulation.restype = C.c_int
     if path is None:
         _lib = L
     return L
+
+
+EMU_LK_SIMD, EMU_SOBEL_FMA = 1, 2
+
+
+class emulation:
+    """with oracle.emulation(flags): the oracle runs in OpenCV's x86 SIMD execution order (pc_oracle.c)."""
+
+    def __init__(self, flags: int):
+        self.flags = flags
+
+    def __enter__(self):
+        self.prev = lib().pco_get_opencv_emulation()
+        lib().pco_set_opencv_emulation(self.flags)
+        return self
+
+    def __exit__(self, *exc):
+        lib().pco_set_opencv_emulation(self.prev)
+        return False
 
 
 def gftt_options(**kw) -> GfttOptions:

@@ -1,0 +1,90 @@
+"""Distance between the oracle's canonical float order (what the GPU matches bit for bit) and the execution order of an
+x86 OpenCV build, which the oracle can emulate (oracle/pc_oracle.c: PCO_EMU_LK_SIMD = the 4-lane fp32 partial sums of
+LKTrackerInvoker's CV_SIMD128 path, PCO_EMU_SOBEL_FMA = the fused multiply-add of the AVX2 column filter of Sobel).
+
+Reference call sites: cv::calcOpticalFlowPyrLK at cpp/opticalflow.cc:119-125, cv::cornerMinEigenVal at
+cpp/feature_detection/gftt.cc:35.  No cv2 exists in this image (tests/opencv_crosscheck.py runs where one does and
+asserts the same bounds against the real library); these tests bound the gap the two documented deviations can open, on the
+benchmark's own clips, and print the numbers DESIGN.md section 2 quotes (pytest -s shows them).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from polychase_amd import synth
+
+# north_star: flow vectors within 1e-3 px of OpenCV.  On step edges (the checkerboard) a handful of vectors land between
+# 1e-3 and 2e-3 px: counted, bounded, and stated in DESIGN.md rather than hidden.
+TOL_PX = 1e-3
+HARD_LIMIT_PX = 5e-3
+
+
+def _lk_gap(g0, g1, kps, max_level=3):
+    p0, p1 = oracle.Pyramid(g0, max_level=max_level), oracle.Pyramid(g1, max_level=max_level)
+    fo = oracle.flow_options(max_level=max_level)
+    xc, sc, ec = oracle.lk(p0, p1, kps, fo)
+    with oracle.emulation(oracle.EMU_LK_SIMD):
+        xe, se, ee = oracle.lk(p0, p1, kps, fo)
+    both = (sc == 1) & (se == 1)
+    d = np.abs(xc - xe)[both].max(axis=1) if both.any() else np.zeros(0)
+    return {"n": len(kps), "tracked": int(both.sum()), "status_flips": int((sc != se).sum()),
+            "max_px": float(d.max()) if len(d) else 0.0, "over_tol": int((d > TOL_PX).sum()),
+            "identical": float((d == 0).mean()) if len(d) else 1.0,
+            "max_err_diff": float(np.abs(ec - ee)[both].max()) if both.any() else 0.0}
+
+
+def test_c1_checkerboard_lk_gap_to_x86_simd_order():
+    """C1 (640x480 checkerboard, step edges: window sums exceed 2^24, so fp32 partial sums round)."""
+    frames = synth.checkerboard_clip(30)
+    g = {t: oracle.rgb2gray(frames[t]) for t in (2, 6, 8, 9, 10, 11, 12, 14, 18)}
+    kps = oracle.gftt(g[10])
+    assert len(kps) >= 100
+    total_over, total, worst, differing = 0, 0, 0.0, 0
+    for t in (2, 6, 8, 9, 11, 12, 14, 18):          # the eight skips of frame 10
+        r = _lk_gap(g[10], g[t], kps)
+        print(f"C1 frame 10 -> {t}: {r}")
+        assert r["status_flips"] == 0
+        assert r["max_px"] <= HARD_LIMIT_PX
+        total_over += r["over_tol"]
+        total += r["tracked"]
+        worst = max(worst, r["max_px"])
+        differing += int(round((1.0 - r["identical"]) * r["tracked"]))
+    print(f"C1 summary: {total} vectors, {differing} differ at all, {total_over} by more than {TOL_PX} px, worst {worst:.2e} px")
+    assert differing > 0, "the emulation changed nothing: it is not exercising the fp32 partial sums"
+    assert total_over <= total * 0.005       # measured: 4 of 2400
+
+
+def test_c2_noise_clip_lk_is_identical_in_x86_simd_order():
+    """C2's band-limited texture keeps every window sum below 2^24: the fp32 lane sums of the SIMD path are exact there
+    and the canonical integer sums give the same bits -- the benchmark clips cannot show a gap on the LK side."""
+    clip = synth.NoiseClip(960, 540, 40)
+    g = {t: oracle.rgb2gray(clip.frame(t)) for t in (20, 21, 28)}
+    kps = oracle.gftt(g[20])
+    for t in (21, 28):
+        r = _lk_gap(g[20], g[t], kps)
+        print(f"C2-content 960x540 frame 20 -> {t}: {r}")
+        assert r["status_flips"] == 0 and r["max_px"] <= TOL_PX and r["over_tol"] == 0
+
+
+@pytest.mark.parametrize("name", ["c1", "c2"])
+def test_gftt_gap_to_avx2_sobel(name):
+    """The AVX2 column filter fuses one multiply-add of Dx: the min-eig map moves in its last bits, which can swap
+    neighbours in the (value, address) order of the corners but must not change WHICH corners are kept on these clips."""
+    if name == "c1":
+        gray = oracle.rgb2gray(synth.checkerboard_clip(12)[10])
+    else:
+        gray = oracle.rgb2gray(synth.NoiseClip(960, 540, 40).frame(20))
+    ec = oracle.min_eigen_val(gray)
+    kc = oracle.gftt(gray)
+    with oracle.emulation(oracle.EMU_SOBEL_FMA):
+        ee = oracle.min_eigen_val(gray)
+        ke = oracle.gftt(gray)
+    scale = float(np.abs(ec).max())
+    changed = float((ec != ee).mean())
+    max_rel = float(np.abs(ec - ee).max() / scale)
+    sc, se = set(map(tuple, kc.astype(int))), set(map(tuple, ke.astype(int)))
+    moved = int((kc != ke).any(axis=1).sum()) if len(kc) == len(ke) else -1
+    print(f"{name}: min-eig map differs at {changed * 100:.2f} % of the pixels, max |diff| / max = {max_rel:.1e}; "
+          f"{len(kc)} corners canonical / {len(ke)} emulated, {len(sc ^ se)} not common, {moved} positions of the list hold another corner")
+    assert max_rel < 1e-6
+    assert len(sc ^ se) <= max(2, len(kc) // 1000)
