@@ -86,3 +86,23 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
                                  OpticalFlowProgressCallback callback, const std::string& database_path,
                                  const GFTTOptions& detector_options = {}, const OpticalFlowOptions& flow_options = {},
                                  bool write_images = false, OpticalFlowRunStats* stats = nullptr);
+
+// ---- multi-GPU analysis (one process per GPU, frame1 ranges sharded, RCCL only for the stitch) ----------
+
+// One shard of the clip: the frame1 loop of GenerateOpticalFlowDatabase (cpp/opticalflow.cc:237-316) for
+// frame1 in [shard_begin, shard_end) only.  Frames up to 8 outside the shard are requested from the accessor as
+// tracking targets (gray + pyramid, no detection); pairs are clipped to the clip of `video_info`, so the records do not
+// depend on how the clip is cut.  Nothing is stored: every frame1's record (keypoints + the status == 1 rows of its
+// pairs) is appended on the GPU to `device_log` (HIP device memory of the GPU in use, 16-byte aligned, capacity_bytes
+// long) in the analyzer's log format (include/polychase_hip.h, pc_analyzer_set_device_log) -- the bytes the ranks
+// exchange with one all-gather.  Returns the bytes used; throws when the log is too small.
+size_t GenerateOpticalFlowRecords(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
+                                  OpticalFlowProgressCallback callback, int32_t shard_begin, int32_t shard_end,
+                                  void* device_log, size_t capacity_bytes, const GFTTOptions& detector_options = {},
+                                  const OpticalFlowOptions& flow_options = {}, OpticalFlowRunStats* stats = nullptr);
+
+// Stores a record log (host copy, e.g. one rank's part of the all-gather) in the database: per record one transaction
+// with the `keypoints` row and its `optical_flow` rows, rows that exist are kept (opticalflow.cc:168-178, :286) --
+// the statements of the single-process run in the same order, so logs written in frame order give the same file.
+void WriteOpticalFlowRecords(const std::string& database_path, const uint8_t* log, size_t bytes,
+                             OpticalFlowRunStats* stats = nullptr);

@@ -135,11 +135,18 @@ class RecordWriter {
 
 }  // namespace
 
-void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
-                                 OpticalFlowProgressCallback callback, const std::string& database_path,
-                                 const GFTTOptions& detector_options, const OpticalFlowOptions& flow_options,
-                                 bool /*write_images: debug PNG dump of the reference (:80-96) is not produced*/,
-                                 OpticalFlowRunStats* stats) {
+// A shard of the frame1 loop; the whole clip when shard == nullptr
+struct Shard {
+    int32_t begin, end;       // frame1 ids [begin, end)
+    void* device_log;         // records go here instead of a database
+    size_t capacity_bytes;
+    size_t used_bytes = 0;
+};
+
+static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
+                        OpticalFlowProgressCallback callback, const std::string& database_path,
+                        const GFTTOptions& detector_options, const OpticalFlowOptions& flow_options,
+                        OpticalFlowRunStats* stats, Shard* shard) {
     CHECK(frame_accessor);
     const double t_begin = Now();
     std::unique_ptr<Database> db;
@@ -166,6 +173,11 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
 
     const int32_t from = video_info.first_frame;
     const int32_t to = video_info.first_frame + static_cast<int32_t>(video_info.num_frames);
+    // frame1 ids of this run, and the frames it has to see (a shard: 8 more on both sides, as targets only)
+    const int32_t f1_begin = shard ? std::max(shard->begin, from) : from;
+    const int32_t f1_end = shard ? std::min(shard->end, to) : to;
+    const int32_t res_begin = shard ? std::max(from, f1_begin - 8) : from;
+    const int32_t res_end = shard ? std::min(to, f1_end + 8) : to;
 
     pc_gftt_options gopt;
     gopt.quality_level = detector_options.quality_level;
@@ -191,6 +203,8 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
     if (pc_analyzer_create(eng.ctx, static_cast<int>(video_info.width), static_cast<int>(video_info.height), &gopt,
                            &fopt, kRing, kMaxJobs, &eng.an) != PC_OK)
         ThrowHip("pc_analyzer_create");
+    if (shard && pc_analyzer_set_device_log(eng.an, shard->device_log, shard->capacity_bytes) != PC_OK)
+        ThrowHip("pc_analyzer_set_device_log");
 
     OpticalFlowRunStats local_stats;
     std::mutex db_mtx;
@@ -225,11 +239,12 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
         if (stats) *stats = local_stats;
     };
 
-    int32_t highest_put = from - 1;
+    int32_t highest_put = res_begin - 1;
     Keypoints known;
-    for (int32_t frame_id1 = from; frame_id1 < to; frame_id1++) {
+    for (int32_t frame_id1 = f1_begin; frame_id1 < f1_end; frame_id1++) {
         if (callback) {
-            const float progress = static_cast<float>(frame_id1 - from) / static_cast<float>(video_info.num_frames);
+            const float progress = shard ? static_cast<float>(frame_id1 - f1_begin) / static_cast<float>(std::max(1, f1_end - f1_begin))
+                                         : static_cast<float>(frame_id1 - from) / static_cast<float>(video_info.num_frames);
             const bool ok = callback(progress, "Processing frame " + std::to_string(frame_id1));
             if (!ok) {
                 drain();  // jobs already on the GPU are complete work: keep them
@@ -240,8 +255,8 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
         }
         // make frame1 .. frame1+8 resident, and one frame more (its pyramid is then ready a whole step before the first
         // launch that reads it); every frame is requested exactly once, in increasing order
-        const int32_t upto = std::min(frame_id1 + 8 + PC_ANALYZER_LOOKAHEAD, to - 1);
-        for (int32_t fid = std::max(highest_put + 1, std::max(from, frame_id1 - 8)); fid <= upto; fid++) {
+        const int32_t upto = std::min(frame_id1 + 8 + PC_ANALYZER_LOOKAHEAD, res_end - 1);
+        for (int32_t fid = std::max(highest_put + 1, std::max(res_begin, frame_id1 - 8)); fid <= upto; fid++) {
             std::optional<FrameView> f = fetch(fid);
             if (!f) {
                 drain();
@@ -250,7 +265,7 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
                 throw std::runtime_error(
                     "Exiting optical flow generation prematurely because some frames were not provided");
             }
-            bool will_detect = true;
+            bool will_detect = fid >= f1_begin && fid < f1_end;   // the halo of a shard is tracked into, never from
             if (db) {
                 std::lock_guard<std::mutex> lk(db_mtx);
                 will_detect = !db->KeypointsExist(fid);
@@ -289,6 +304,70 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
         if (pc_analyzer_submit(eng.an, frame_id1, targets, n_targets) != PC_OK) ThrowHip("pc_analyzer_submit");
     }
     drain();
+    if (shard && pc_analyzer_device_log_used(eng.an, &shard->used_bytes) != PC_OK) ThrowHip("pc_analyzer_device_log_used");
     finish_stats();
     if (callback) callback(1.0f, "Done");
+}
+
+void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
+                                 OpticalFlowProgressCallback callback, const std::string& database_path,
+                                 const GFTTOptions& detector_options, const OpticalFlowOptions& flow_options,
+                                 bool /*write_images: debug PNG dump of the reference (:80-96) is not produced*/,
+                                 OpticalFlowRunStats* stats) {
+    RunAnalysis(video_info, std::move(frame_accessor), std::move(callback), database_path, detector_options, flow_options, stats,
+                nullptr);
+}
+
+size_t GenerateOpticalFlowRecords(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
+                                  OpticalFlowProgressCallback callback, int32_t shard_begin, int32_t shard_end,
+                                  void* device_log, size_t capacity_bytes, const GFTTOptions& detector_options,
+                                  const OpticalFlowOptions& flow_options, OpticalFlowRunStats* stats) {
+    CHECK(device_log != nullptr);
+    CHECK(shard_begin <= shard_end);
+    Shard shard{shard_begin, shard_end, device_log, capacity_bytes};
+    RunAnalysis(video_info, std::move(frame_accessor), std::move(callback), "", detector_options, flow_options, stats, &shard);
+    return shard.used_bytes;
+}
+
+void WriteOpticalFlowRecords(const std::string& database_path, const uint8_t* log, size_t bytes, OpticalFlowRunStats* stats) {
+    CHECK(!database_path.empty());
+    Database db(database_path);
+    OpticalFlowRunStats local;
+    const double t0 = Now();
+    auto up16 = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
+    size_t o = 0;
+    while (o < bytes) {
+        // header (128 B): magic, frame1, keypoints, targets, target ids [8], rows; then the packed record:
+        // row offsets (128 B) | keypoints | src indices | tgt xy | errors, every part 16-byte aligned
+        if (o + 256 > bytes) throw std::runtime_error("truncated optical-flow record log");
+        const long long* hdr = reinterpret_cast<const long long*>(log + o);
+        if (hdr[0] != PC_LOG_MAGIC) throw std::runtime_error("corrupt optical-flow record log");
+        const int32_t frame1 = static_cast<int32_t>(hdr[1]);
+        const size_t n = static_cast<size_t>(hdr[2]), rows = static_cast<size_t>(hdr[12]);
+        const int nt = static_cast<int>(hdr[3]);
+        if (nt < 0 || nt > PC_MAX_TARGETS) throw std::runtime_error("corrupt optical-flow record log");
+        const long long* off = reinterpret_cast<const long long*>(log + o + 128);
+        const size_t o_kps = o + 256, o_idx = up16(o_kps + n * 8), o_xy = up16(o_idx + rows * 4), o_err = up16(o_xy + rows * 8);
+        const size_t end = up16(o_err + rows * 4);
+        if (end > bytes) throw std::runtime_error("truncated optical-flow record log");
+        db.Begin();
+        if (!db.KeypointsExist(frame1)) {
+            db.WriteKeypoints(frame1, reinterpret_cast<const float*>(log + o_kps), n);
+            local.keypoint_rows_written++;
+        }
+        for (int t = 0; t < nt; t++) {
+            const int32_t frame2 = static_cast<int32_t>(hdr[4 + t]);
+            if (db.ImagePairFlowExists(frame1, frame2)) continue;
+            const size_t a = static_cast<size_t>(off[t]), b = static_cast<size_t>(off[t + 1]);
+            if (b < a || b > rows) throw std::runtime_error("corrupt optical-flow record log");
+            db.WriteImagePairFlow(frame1, frame2, reinterpret_cast<const uint32_t*>(log + o_idx) + a,
+                                  reinterpret_cast<const float*>(log + o_xy) + 2 * a, reinterpret_cast<const float*>(log + o_err) + a, b - a);
+            local.flow_rows_written++;
+        }
+        db.Commit();
+        local.frames_processed++;
+        o = end;
+    }
+    local.seconds_db = local.seconds_total = Now() - t0;
+    if (stats) *stats = local;
 }

@@ -106,6 +106,44 @@ OpticalFlowRunStats GenerateOpticalFlowDatabasePy(const VideoInfo& video_info, p
     return stats;
 }
 
+// one shard of a multi-process analysis: records into a device log (a torch uint8 CUDA tensor's memory)
+py::tuple GenerateOpticalFlowRecordsPy(const VideoInfo& video_info, py::object frame_accessor, py::object callback,
+                                       int32_t shard_begin, int32_t shard_end, uintptr_t device_log, size_t capacity_bytes,
+                                       const GFTTOptions& detector_options, const OpticalFlowOptions& flow_options) {
+    std::deque<py::object> keep_alive;
+    FrameAccessorFunction accessor;
+    if (!frame_accessor.is_none())
+        accessor = [&](int32_t frame_id) -> std::optional<FrameView> {
+            py::gil_scoped_acquire gil;
+            return FrameFromPython(frame_accessor(frame_id), keep_alive);
+        };
+    OpticalFlowProgressCallback cb;
+    if (!callback.is_none())
+        cb = [&](float progress, const std::string& msg) -> bool {
+            py::gil_scoped_acquire gil;
+            return callback(progress, msg).cast<bool>();
+        };
+    OpticalFlowRunStats stats;
+    size_t used = 0;
+    {
+        py::gil_scoped_release release;
+        used = GenerateOpticalFlowRecords(video_info, accessor, cb, shard_begin, shard_end, reinterpret_cast<void*>(device_log),
+                                          capacity_bytes, detector_options, flow_options, &stats);
+    }
+    keep_alive.clear();
+    return py::make_tuple(used, stats);
+}
+
+OpticalFlowRunStats WriteOpticalFlowRecordsPy(const std::string& database_path, const U8Array& log, size_t bytes) {
+    if (bytes > static_cast<size_t>(log.size())) throw py::value_error("bytes exceeds the buffer");
+    OpticalFlowRunStats stats;
+    {
+        py::gil_scoped_release release;
+        WriteOpticalFlowRecords(database_path, log.data(), bytes, &stats);
+    }
+    return stats;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(polychase_core, m) {
@@ -224,6 +262,12 @@ PYBIND11_MODULE(polychase_core, m) {
                            static_cast<int>(u.shape(2)), static_cast<size_t>(u.shape(1) * u.shape(2)));
         });
 
+    // not in the reference: the two halves of a multi-GPU analysis (polychase_amd/analyze.py launches them, one
+    // process per GPU, and all-gathers the record logs over RCCL in between)
+    m.def("generate_optical_flow_records", &GenerateOpticalFlowRecordsPy, py::arg("video_info"), py::arg("frame_accessor_function"),
+          py::arg("callback"), py::arg("shard_begin"), py::arg("shard_end"), py::arg("device_log"), py::arg("capacity_bytes"),
+          py::arg("detector_options") = GFTTOptions{}, py::arg("flow_options") = OpticalFlowOptions{});
+    m.def("write_optical_flow_records", &WriteOpticalFlowRecordsPy, py::arg("database_path"), py::arg("log"), py::arg("bytes"));
     m.def("generate_optical_flow_database", &GenerateOpticalFlowDatabasePy, py::arg("video_info"),
           py::arg("frame_accessor_function"), py::arg("callback"), py::arg("database_path"),
           py::arg("detector_options") = GFTTOptions{}, py::arg("flow_options") = OpticalFlowOptions{},

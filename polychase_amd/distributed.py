@@ -130,8 +130,9 @@ def log_capacity_bytes(n_frames: int, max_keypoints: int, n_targets: int = 8) ->
 
 
 def all_gather_device_log(log, used: int, group=None):
-    """log: uint8 CUDA tensor, first `used` bytes valid.  Returns (gathered [world, max_used] uint8
-    on the same device, sizes list).  Collectives: all_gather of one int64, all_gather_into_tensor."""
+    """log: uint8 tensor (CUDA under RCCL; CPU under gloo in the tests), first `used` bytes valid.  Returns
+    (gathered [world, max_used] uint8 on the same device, sizes list).  Collectives: all_gather of one int64, then
+    the payload -- all_gather_into_tensor straight into the result under NCCL/RCCL."""
     import torch
     import torch.distributed as dist
 
@@ -140,12 +141,46 @@ def all_gather_device_log(log, used: int, group=None):
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([used], dtype=torch.int64, device=dev), group=group)
     sizes = [int(s.item()) for s in sizes]
-    mx = (max(sizes) + 15) // 16 * 16
-    if mx > log.numel():
-        raise RuntimeError("device log smaller than the largest shard")
+    mx = max(16, (max(sizes) + 15) // 16 * 16)
+    if mx > log.numel():     # another rank's shard is longer than this rank's whole buffer: pad a copy
+        src = torch.zeros(mx, dtype=torch.uint8, device=dev)
+        src[:used] = log[:used]
+    else:
+        src = log[:mx]       # bytes past `used` are padding, never parsed
     out = torch.empty((world, mx), dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(out.view(-1), log[:mx], group=group)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out.view(-1), src, group=group)
+    else:
+        dist.all_gather(list(out.unbind(0)), src.contiguous(), group=group)
     return out, sizes
+
+
+def pack_device_log(records) -> np.ndarray:
+    """records (frame1, kps [N,2] f32, {frame2: (idx, xy, err)}) -> the bytes pc_analyzer_set_device_log would have
+    produced for them (include/polychase_hip.h), one record after the other."""
+    up16 = lambda v: (v + 15) & ~15
+    chunks = []
+    for frame1, kps, flows in records:
+        items = sorted(flows.items())
+        kps = np.ascontiguousarray(kps, np.float32).reshape(-1, 2)
+        rows = len(kps) * len(items)
+        hdr = np.zeros(16, np.int64)
+        hdr[0], hdr[1], hdr[2], hdr[3], hdr[12] = LOG_MAGIC, frame1, len(kps), len(items), rows
+        off = np.zeros(16, np.int64)
+        idx, xy, err = np.zeros(rows, np.uint32), np.zeros((rows, 2), np.float32), np.zeros(rows, np.float32)
+        o = 0
+        for t, (f2, (i_, x_, e_)) in enumerate(items):
+            hdr[4 + t] = f2
+            m = len(i_)
+            idx[o:o + m], xy[o:o + m], err[o:o + m] = i_, np.asarray(x_, np.float32).reshape(-1, 2), e_
+            o += m
+            off[t + 1] = o
+        rec = bytearray(hdr.tobytes() + off.tobytes() + kps.tobytes())
+        for part in (idx.tobytes(), xy.tobytes(), err.tobytes()):
+            rec += b"\0" * (up16(len(rec)) - len(rec)) + part
+        rec += b"\0" * (up16(len(rec)) - len(rec))
+        chunks.append(bytes(rec))
+    return np.frombuffer(b"".join(chunks), np.uint8).copy()
 
 
 class ChunkedLogStitch:

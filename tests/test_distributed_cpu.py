@@ -154,3 +154,88 @@ def test_chunked_log_stitch_two_ranks(tmp_path, use_side):
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / f"sh{r}.npy"), h_ref)
         assert np.array_equal(np.load(tmp_path / f"sp{r}.npy"), p_ref)
+
+
+# ----------------------------------------------------------------------------------------------
+# records -> database: the product path of the multi-rank analysis (polychase_amd/analyze.py) after the GPU part.
+# Rank r holds the record log of its frame range, the logs are all-gathered (gloo here, RCCL on the GPU box), rank 0
+# stores them through polychase_core.write_optical_flow_records: the file must equal the single-rank one.
+# ----------------------------------------------------------------------------------------------
+def _core():
+    sys.path.insert(0, os.path.join(ROOT, "polychase_amd", "core"))
+    import polychase_core
+    return polychase_core
+
+
+def _db_dump(path):
+    import sqlite3
+    con = sqlite3.connect(path)
+    k = list(con.execute("select rowid, image_id, rows, keypoints from keypoints order by rowid"))
+    f = list(con.execute("select rowid, image_id_from, image_id_to, rows, src_keypoints_indices, tgt_keypoints, flow_errors "
+                         "from optical_flow order by rowid"))
+    con.close()
+    return k, f
+
+
+def _db_worker(rank, world, port, first, n, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = D.shard_range(first, n, world, rank)
+    log_np = D.pack_device_log([fake_record(f, first, n) for f in range(b, e)])
+    log = torch.from_numpy(log_np) if len(log_np) else torch.zeros(0, dtype=torch.uint8)
+    gathered, sizes = D.all_gather_device_log(log, len(log_np))
+    if rank == 0:
+        core = _core()
+        for r in range(world):
+            core.write_optical_flow_records(os.path.join(out_dir, "sharded.db"), gathered[r, :sizes[r]].numpy().copy(), sizes[r])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [21, 2])
+def test_two_ranks_write_the_single_rank_database(tmp_path, n):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    first = 3
+    mp.spawn(_db_worker, args=(2, port, first, n, str(tmp_path)), nprocs=2, join=True)
+    core = _core()
+    records = [fake_record(f, first, n) for f in range(first, first + n)]
+    # single rank, the C++ writer on one log
+    one = D.pack_device_log(records)
+    st = core.write_optical_flow_records(str(tmp_path / "single.db"), one, len(one))
+    assert st.frames_processed == n and st.keypoint_rows_written == n
+    # and the record-by-record writer over the Database class (what GenerateOpticalFlowDatabase's writer thread does)
+    db = core.Database(str(tmp_path / "python.db"))
+    D.write_records(db, records)
+    db.close()
+    ref = _db_dump(str(tmp_path / "single.db"))
+    assert len(ref[0]) == n and len(ref[1]) == sum(len(r[2]) for r in records)
+    assert _db_dump(str(tmp_path / "sharded.db")) == ref
+    assert _db_dump(str(tmp_path / "python.db")) == ref
+    # storing a log twice changes nothing (rows that exist are kept, like a resumed run)
+    core.write_optical_flow_records(str(tmp_path / "single.db"), one, len(one))
+    assert _db_dump(str(tmp_path / "single.db")) == ref
+
+
+def test_record_log_roundtrip_and_corruption():
+    records = [fake_record(f, 1, 12) for f in range(1, 13)]
+    log = D.pack_device_log(records)
+    back = D.parse_device_log(log, len(log))
+    assert [r[0] for r in back] == list(range(1, 13))
+    for (f, k, fl), (f2, k2, fl2) in zip(records, back):
+        assert np.array_equal(k, k2) and sorted(fl) == sorted(fl2)
+        for t in fl:
+            assert all(np.array_equal(a, b) for a, b in zip(fl[t], fl2[t]))
+    core = _core()
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        bad = log.copy()
+        bad[0] ^= 0xFF
+        with pytest.raises(RuntimeError):
+            core.write_optical_flow_records(os.path.join(td, "x.db"), bad, len(bad))
+        with pytest.raises(RuntimeError):
+            core.write_optical_flow_records(os.path.join(td, "y.db"), log, len(log) - 40)

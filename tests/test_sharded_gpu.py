@@ -1,0 +1,132 @@
+"""GPU: the multi-rank analysis as a product (polychase_amd/analyze.py over polychase_core.generate_optical_flow_records /
+write_optical_flow_records; SURVEY 8(e), BASELINE config C4).  One GPU is enough to check everything but the RCCL call
+itself: a shard is the same C++ driver over a frame1 range with an 8-frame halo, its records go to a device log, the logs
+are stored in frame order -- the database must not depend on how the clip is cut
+(reference: cpp/opticalflow.cc:209-321, cpp/database.cc:183-214)."""
+import os
+import sqlite3
+import sys
+
+import numpy as np
+import pytest
+
+from polychase_amd import distributed as D
+from polychase_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def core():
+    import torch  # noqa: F401
+    sys.path.insert(0, os.path.join(ROOT, "polychase_amd", "core"))
+    import polychase_core
+    return polychase_core
+
+
+def _dump(path):
+    con = sqlite3.connect(path)
+    k = list(con.execute("select rowid, image_id, rows, keypoints from keypoints order by rowid"))
+    f = list(con.execute("select rowid, image_id_from, image_id_to, rows, src_keypoints_indices, tgt_keypoints, flow_errors "
+                         "from optical_flow order by rowid"))
+    con.close()
+    return k, f
+
+
+def _shards_to_db(core, vi, frames_of, cuts, path, fopt, capacity):
+    """what `world` ranks do, one after the other on this GPU: a log per shard, stored in rank order"""
+    import torch
+    for b, e in cuts:
+        log = torch.empty(capacity, dtype=torch.uint8, device="cuda")
+        used, st = core.generate_optical_flow_records(vi, frames_of, None, b, e, log.data_ptr(), log.numel(), core.GFTTOptions(), fopt)
+        assert st.frames_processed == e - b
+        host = log[:used].cpu().numpy()
+        recs = D.parse_device_log(host, used)
+        assert [r[0] for r in recs] == list(range(b, e))
+        core.write_optical_flow_records(path, host, used)
+
+
+def test_database_does_not_depend_on_the_number_of_ranks(core, tmp_path):
+    w, h, n, first = 320, 240, 37, 5
+    clip = synth.NoiseClip(w, h, n)
+    frames = [clip.frame(t) for t in range(n)]
+    acc = lambda fid: frames[fid - first]
+    vi = core.VideoInfo(w, h, first, n)
+    fo = core.OpticalFlowOptions()
+    ref = str(tmp_path / "single.db")
+    core.generate_optical_flow_database(vi, acc, None, ref, core.GFTTOptions(), fo)
+    want = _dump(ref)
+    assert len(want[0]) == n
+    cap = D.log_capacity_bytes(n + 1, w * h // 20)
+    for world in (1, 2, 3, 8):
+        path = str(tmp_path / f"w{world}.db")
+        _shards_to_db(core, vi, acc, [D.shard_range(first, n, world, r) for r in range(world)], path, fo, cap)
+        assert _dump(path) == want, f"{world} ranks give another database"
+
+
+def test_requested_frames_of_a_shard_are_its_range_plus_the_halo(core):
+    import torch
+    w, h, n, first = 160, 120, 40, 1
+    clip = synth.NoiseClip(w, h, n)
+    asked = []
+
+    def acc(fid):
+        asked.append(fid)
+        return clip.frame(fid - first)
+
+    log = torch.empty(D.log_capacity_bytes(16, w * h // 20), dtype=torch.uint8, device="cuda")
+    used, st = core.generate_optical_flow_records(core.VideoInfo(w, h, first, n), acc, None, 14, 22, log.data_ptr(), log.numel())
+    assert asked == list(range(6, 30))          # 14 - 8 .. 21 + 8, each once, increasing
+    assert st.frames_processed == 8
+    # a log that is too small is an error, not a truncated result
+    with pytest.raises(RuntimeError, match="device log full"):
+        core.generate_optical_flow_records(core.VideoInfo(w, h, first, n), lambda f: clip.frame(f - first), None, 14, 22, log.data_ptr(), 4096)
+
+
+def test_analyze_entry_point_single_rank(core, tmp_path):
+    """polychase_amd.analyze.analyze without a process group = one rank owning the whole clip"""
+    from polychase_amd import analyze
+    w, h, n, first = 320, 240, 20, 1
+    clip = synth.NoiseClip(w, h, n, device="cuda")
+    dev_frames = [clip.frame_torch(t) for t in range(n)]
+    host_frames = [f.cpu().numpy() for f in dev_frames]
+    out = analyze.analyze(w, h, first, n, lambda fid: dev_frames[fid - first], str(tmp_path / "a.db"))
+    assert out["world"] == 1 and out["frames"] == n and out["written"]["keypoint_rows"] == n
+    core.generate_optical_flow_database(core.VideoInfo(w, h, first, n), lambda fid: host_frames[fid - first], None, str(tmp_path / "b.db"))
+    assert _dump(str(tmp_path / "a.db")) == _dump(str(tmp_path / "b.db"))
+
+
+def test_c4_rank_workload_at_4k(core, tmp_path):
+    """The per-rank workload of config C4 (3840x2160, max_level 4): a shard in the middle of a clip -- halo on both
+    sides, device log, parse, store -- against the rows the unsharded run writes for the same frames."""
+    import torch
+    w, h, n, first = 3840, 2160, 26, 1
+    clip = synth.NoiseClip(w, h, 300, device="cuda")
+    frames = [clip.frame_torch(100 + t) for t in range(n)]
+    acc = lambda fid: frames[fid - first]
+    vi = core.VideoInfo(w, h, first, n)
+    fo = core.OpticalFlowOptions()
+    fo.max_level = 4
+    ref = str(tmp_path / "single.db")
+    core.generate_optical_flow_database(vi, acc, None, ref, core.GFTTOptions(), fo)
+    b, e = 10, 16
+    log = torch.empty(D.log_capacity_bytes(e - b + 1, w * h // 40), dtype=torch.uint8, device="cuda")
+    used, st = core.generate_optical_flow_records(vi, acc, None, b, e, log.data_ptr(), log.numel(), core.GFTTOptions(), fo)
+    host = log[:used].cpu().numpy()
+    recs = D.parse_device_log(host, used)
+    assert [r[0] for r in recs] == list(range(b, e))
+    assert all(len(r[2]) == 8 for r in recs)              # interior frames: all eight pairs, into the halo too
+    assert min(len(r[1]) for r in recs) > 100_000         # a 4K frame of this clip has ~160 k keypoints
+    core.write_optical_flow_records(str(tmp_path / "shard.db"), host, used)
+    con = sqlite3.connect(ref)
+    want_k = list(con.execute("select image_id, rows, keypoints from keypoints where image_id >= ? and image_id < ? order by image_id", (b, e)))
+    want_f = list(con.execute("select image_id_from, image_id_to, rows, src_keypoints_indices, tgt_keypoints, flow_errors from optical_flow "
+                              "where image_id_from >= ? and image_id_from < ? order by image_id_from, rowid", (b, e)))
+    con.close()
+    con = sqlite3.connect(str(tmp_path / "shard.db"))
+    got_k = list(con.execute("select image_id, rows, keypoints from keypoints order by image_id"))
+    got_f = list(con.execute("select image_id_from, image_id_to, rows, src_keypoints_indices, tgt_keypoints, flow_errors from optical_flow "
+                             "order by image_id_from, rowid"))
+    con.close()
+    assert got_k == want_k and got_f == want_f
