@@ -90,6 +90,12 @@ int pc_context_reset_timing(pc_context* ctx);
  * [5] error pass, [6] wavefront life time, [7] wavefronts, [8] wavefront-iterations, [9] region stagings. */
 #define PC_LK_PROFILE_SLOTS 16
 int pc_debug_lk_profile(pc_context* ctx, unsigned long long* out /* [PC_LK_PROFILE_SLOTS] */);
+/* Diagnostics of the device-resident PnP solver: ONE damped 9x9 system through the in-kernel float32 Cholesky
+ * factorisation and solve that pc_pnp_solve uses (row-major a81, only the lower triangle is read; l81 receives the
+ * factor, x9 the solution of L L^T x = b; *positive_definite = 0 and x9 = 0 when the factorisation fails).  Exists so
+ * that the reference's known-answer test (cpp/examples/levmarq_ill_conditioned_float32_issue.cpp:16-63) runs on the
+ * device copy of the solver, not only on the host one. */
+int pc_debug_llt9(pc_context* ctx, const float* a81, const float* b9, float* l81, float* x9, int* positive_definite);
 #define PC_K_GRAY 0
 #define PC_K_PYRAMID 1
 #define PC_K_MINEIG 2

@@ -624,6 +624,25 @@ int pc_pnp_total_cost(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_
 }
 
 
+int pc_debug_llt9(pc_context* ctx, const float* a81, const float* b9, float* l81, float* x9, int* positive_definite) {
+    if (!ctx || !a81 || !b9 || !l81 || !x9 || !positive_definite) return fail(PC_E_INVALID, "null argument");
+    PC_HIP(hipSetDevice(ctx->device));
+    float* d = nullptr;
+    PC_HIP(hipMalloc(reinterpret_cast<void**>(&d), (81 + 9 + 81 + 9 + 1) * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d, a81, 81 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + 81, b9, 9 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        pc::launch_llt9_debug(d, d + 81, d + 90, d + 171, reinterpret_cast<int*>(d + 180), ctx->stream);
+        e = hipMemcpyAsync(l81, d + 90, 81 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(x9, d + 171, 9 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(positive_definite, d + 180, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(PC_E_HIP, "pc_debug_llt9: %s", hipGetErrorString(e));
+    return PC_OK;
+}
+
 // =============================================================================================
 // refiner path
 // =============================================================================================

@@ -161,6 +161,10 @@ void launch_pnp_cost(const float* X, const float* x, const float* w, int n, cons
                      float* partials, float* out4, hipStream_t s);
 
 
+// lm_cholesky9 + lm_cholesky9_solve (pnp_lm.hpp) of one system on the device; all pointers device memory
+void launch_llt9_debug(const float* a81, const float* b9, float* l81, float* x9, int* ok, hipStream_t s);
+
+
 // ---- kernels_refiner.hip ----
 struct RefineCamera {   // one frame of the trajectory
     float R[9];

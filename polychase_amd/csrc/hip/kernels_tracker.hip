@@ -515,4 +515,22 @@ void launch_pnp_cost(const float* X, const float* x, const float* w, int n, cons
     hipLaunchKernelGGL(pnp_finalize_kernel, dim3(1), dim3(1024), 0, s, partials, nb, 4, out4);
 }
 
+// The damped 9x9 solve of the device-resident LM on its own (pc_debug_llt9: the reference's float32 known-answer test,
+// cpp/examples/levmarq_ill_conditioned_float32_issue.cpp, is run on THIS copy of the factorisation too)
+__global__ void llt9_debug_kernel(const float* __restrict__ a81, const float* __restrict__ b9, float* __restrict__ l81,
+                                  float* __restrict__ x9, int* __restrict__ ok) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float a[81], x[9];
+    for (int i = 0; i < 81; i++) a[i] = a81[i];
+    const bool good = lm_cholesky9(a);
+    for (int i = 0; i < 9; i++) x[i] = 0.f;
+    if (good) lm_cholesky9_solve(a, b9, x);
+    for (int i = 0; i < 81; i++) l81[i] = a[i];
+    for (int i = 0; i < 9; i++) x9[i] = x[i];
+    *ok = good ? 1 : 0;
+}
+void launch_llt9_debug(const float* a81, const float* b9, float* l81, float* x9, int* ok, hipStream_t s) {
+    hipLaunchKernelGGL(llt9_debug_kernel, dim3(1), dim3(64), 0, s, a81, b9, l81, x9, ok);
+}
+
 }  // namespace pc

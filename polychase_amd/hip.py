@@ -21,7 +21,7 @@ SYMBOLS = [
     "pc_gftt_default_options", "pc_flow_default_options", "pc_last_error", "pc_version",
     "pc_context_create", "pc_context_destroy", "pc_context_synchronize", "pc_context_stream",
     "pc_context_enable_timing", "pc_context_get_timing", "pc_context_get_busy_time", "pc_context_reset_timing",
-    "pc_debug_lk_profile",
+    "pc_debug_lk_profile", "pc_debug_llt9",
     "pc_frame_create", "pc_frame_destroy", "pc_frame_set_rgb", "pc_frame_set_rgb_f32", "pc_frame_set_gray",
     "pc_host_buffer_alloc", "pc_host_buffer_free",
     "pc_frame_num_levels", "pc_frame_level_size", "pc_frame_download_gray", "pc_frame_download_level",
@@ -104,6 +104,7 @@ def load():
     L.pc_context_get_busy_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.pc_context_reset_timing.argtypes = [vp]
     L.pc_debug_lk_profile.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    L.pc_debug_llt9.argtypes = [vp, vp, vp, vp, vp, ip]
     L.pc_frame_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.pc_frame_destroy.argtypes = [vp]
     L.pc_frame_destroy.restype = None
@@ -210,6 +211,14 @@ class Context:
         out = (C.c_ulonglong * 16)()
         _check(load().pc_debug_lk_profile(self._h, out))
         return list(out)
+
+    def llt9(self, a: np.ndarray, b: np.ndarray):
+        """the device solver's 9x9 float32 Cholesky + solve -> (L, x, positive_definite)"""
+        a = np.ascontiguousarray(a, np.float32).reshape(9, 9)
+        b = np.ascontiguousarray(b, np.float32).reshape(9)
+        l, x, ok = np.zeros((9, 9), np.float32), np.zeros(9, np.float32), C.c_int()
+        _check(load().pc_debug_llt9(self._h, a.ctypes.data, b.ctypes.data, l.ctypes.data, x.ctypes.data, C.byref(ok)))
+        return l, x, bool(ok.value)
 
     def busy_ms(self, kernel_class: str) -> float:
         """wall time during which at least one launch of the class was executing (launches may overlap)"""

@@ -11,7 +11,8 @@
 
     python tests/c5_endtoend.py [--width 1920 --height 1080 --frames 300 --oracle-frames 6 --out gpurun_out/c5.json]
 
-Test infrastructure (it uses the oracle as the checker); the miniature of this run is
+Test infrastructure (it uses the oracle as the checker); tests/test_c5_gpu.py runs it at 1920x1080 with 40 frames
+inside `pytest -m gpu` and asserts the pose tolerances; the miniature is
 tests/test_tracker_gpu.py::test_c5_end_to_end_rendered_plane.
 """
 import argparse
@@ -30,7 +31,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
-def main() -> int:
+def main(argv=None) -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -38,7 +39,7 @@ def main() -> int:
     ap.add_argument("--oracle-frames", type=int, default=6, help="frames solved by the CPU reference as well")
     ap.add_argument("--refine-iterations", type=int, default=30)
     ap.add_argument("--out", default=None)
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
 
     import torch
     import torch.nn.functional as Fn

@@ -1,0 +1,35 @@
+"""GPU: BASELINE config C5 at its real frame size -- 1920x1080 frames RENDERED from a textured plane under a known camera
+path -> generate_optical_flow_database (GFTT + pyramidal LK, SQLite) -> track_sequence (ray casting + PnP,
+cpp/tracker.cc:36-131) -> refine_trajectory (cpp/refiner.cc) -- with 40 frames instead of 300 so that it fits the
+test run.  Pose error against the ground truth and, for the first frames, against the CPU reference of the tracking
+step (oracle/pnp_oracle.py, float64) on the same database: rotation <= 1e-4 rad, translation <= 1e-4 * |t|
+(the tolerance BASELINE.json's north_star states for PnP poses).  tests/c5_endtoend.py is the runner (300 frames
+stand-alone: profiles/r01_c5_endtoend.json)."""
+import json
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_c5_1080p_analysis_tracking_refinement(tmp_path):
+    sys.path.insert(0, HERE)
+    import c5_endtoend
+    out_path = str(tmp_path / "c5.json")
+    assert c5_endtoend.main(["--width", "1920", "--height", "1080", "--frames", "40", "--oracle-frames", "3",
+                             "--refine-iterations", "15", "--out", out_path]) == 0
+    r = json.load(open(out_path))
+    print(json.dumps(r, indent=1))
+    tr = r["tracking"]
+    assert min(tr["keypoints_per_frame"]) > 20_000                      # full-size frames: tens of thousands of keypoints
+    assert tr["min_inlier_ratio"] >= 0.8       # the 40-frame path moves 7.5x faster than the 300-frame one: some tracks leave the plane
+    assert tr["vs_truth"]["rotation_rad_max"] <= 1e-3 and tr["vs_truth"]["translation_max"] <= 6e-3   # dead reckoning over 40 frames
+    ref = tr["vs_cpu_reference"]
+    assert ref["frames"] == 3
+    assert ref["rotation_rad_max"] <= 1e-4 and ref["translation_rel_max"] <= 1e-4
+    rf = r["refinement"]
+    assert rf["cost"][1] <= rf["cost"][0]
+    assert rf["vs_truth"]["rotation_rad_max"] <= 1e-3 and rf["vs_truth"]["translation_max"] <= 6e-3

@@ -65,6 +65,42 @@ def test_4k_keypoint_properties(setup):
     assert np.array_equal(a.keypoints(), kps)
 
 
+def test_4k_keypoints_equal_the_oracle_full_frame(setup):
+    """GoodFeaturesToTrack on the whole 3840x2160 frame (cpp/feature_detection/gftt.cc:14-192): the min-eig map, the
+    candidate count and the keypoints -- value AND acceptance order -- against the oracle's full-frame run (seconds
+    on the CPU; a crop would not be comparable because the per-cell thresholds depend on the full frame)."""
+    ctx, clip, _, (f0, _), (a, _) = setup
+    g = oracle.rgb2gray(f0.cpu().numpy())
+    okps, _, ocand = oracle.gftt(g, want_eig=True)      # (the map gftt returns is already thresholded in place, gftt.cc:64-65)
+    assert np.array_equal(a.min_eig().view(np.uint32), oracle.min_eigen_val(g).view(np.uint32))
+    assert a.num_candidates == ocand
+    kps = a.keypoints()
+    assert len(kps) == len(okps) and np.array_equal(kps, okps)
+
+
+def test_4k_detection_under_saturated_lk_lanes(setup):
+    """Suppression must make progress whatever else occupies the GPU: 4K detection (sorted candidates, a lane only waits
+    on lower-numbered workgroups) runs on the preparation stream of the pipelined analyzer while both LK lanes are kept
+    busy with 4K launches; every frame's keypoints must equal the stand-alone detection of the same frame, and no
+    lane may hit the spin bound (that is an error of the call)."""
+    from polychase_amd.pipeline import ClipAnalyzer
+    ctx, clip, _, _, (a, _) = setup
+    n = 22
+    frames = {i + 1: clip.frame_torch(i % 30) for i in range(n)}
+    got = {}
+    an = ClipAnalyzer(ctx, W, H, 1, n, lambda fid: frames[fid], hip.gftt_options(), hip.flow_options(max_level=ML), max_jobs=3)
+    an.run(range(1, n + 1), lambda f1, k, det, flows: got.__setitem__(f1, k.copy()))
+    an.close()
+    assert sorted(got) == list(range(1, n + 1))
+    for fid in (1, 9, 10, 17, 22):
+        a.set_rgb(frames[fid])
+        a.detect()
+        assert np.array_equal(got[fid], a.keypoints()), f"frame {fid}: keypoints under load differ from the stand-alone run"
+    _, _, _, (f0, _), _ = setup
+    a.set_rgb(f0)      # the fixture's frame, for the tests below
+    a.detect()
+
+
 def test_4k_lk_subset_bit_exact_and_truth(setup):
     ctx, clip, (t0, t1), (f0, f1), (a, b) = setup
     kps = a.keypoints()

@@ -508,3 +508,37 @@ def test_bvh_ray_casting_equals_exhaustive_sweep(core, kind, n_tris):
                     continue
                 assert ha.primitive_id == hb.primitive_id and ha.t == hb.t
                 assert np.array_equal(ha.barycentric_coordinate, hb.barycentric_coordinate) and np.array_equal(ha.pos, hb.pos)
+
+
+def test_llt9_known_answer_on_the_device_solver(core):
+    """The reference's float32 LLT known-answer case (cpp/examples/levmarq_ill_conditioned_float32_issue.cpp:16-63,
+    tests/golden/llt9_ill_conditioned.json) through the factorisation the device-resident LM actually uses
+    (lm_cholesky9 in csrc/hip/pnp_lm.hpp, via pc_debug_llt9) -- the CPU test runs the same case on the host copy
+    (tests/test_tracker_cpu.py); both must be at least as accurate as the numbers the reference prints, and equal."""
+    import json
+    from polychase_amd import hip
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "llt9_ill_conditioned.json")))
+    A = np.zeros((9, 9), np.float32)
+    for i, r in enumerate(d["jtj_lower_rows"]):
+        A[i, :len(r)] = r
+    b = np.array(d["jtr"], np.float32)
+    Ad = A.copy()
+    Ad[np.diag_indices(9)] += np.float32(d["lambda"])
+    sym = lambda M: np.tril(M) + np.tril(M, -1).T
+    ctx = hip.Context(0)
+    L, x, ok = ctx.llt9(Ad, b)
+    assert ok
+    step = -x
+    residual = np.linalg.norm(sym(Ad) @ step + b)
+    assert residual <= d["reference_float32_residual_norm"]
+    exact = -np.linalg.solve(sym(Ad).astype(np.float64), b.astype(np.float64))
+    exp_exact = exact @ (2 * b + sym(A).astype(np.float64) @ exact)
+    exp_dev = float(step @ (2 * b + sym(A) @ step))
+    assert exp_exact < 0
+    assert abs(exp_dev - exp_exact) <= abs(d["reference_float32_expected_cost_change"] - exp_exact)
+    # the host copy (linalg.h CholeskyLower<9>) takes the same steps: same bits
+    assert np.array_equal(x, core._llt9_solve(Ad, b))
+    # a matrix that is not positive definite is reported, not factorised
+    _, x0, ok0 = ctx.llt9(-np.eye(9, dtype=np.float32), b)
+    assert not ok0 and not x0.any()
+    ctx.close()
