@@ -17,3 +17,8 @@ pc_context* SharedGpuContext() {
     }
     return ctx;
 }
+
+std::recursive_mutex& SharedGpuMutex() {
+    static std::recursive_mutex mtx;
+    return mtx;
+}

@@ -49,6 +49,7 @@ void SolvePnPIterative(const float* object_points, const float* image_points, co
     CHECK_GE(n, static_cast<size_t>(3));  // solvers.cc:54-55
     const int lt = static_cast<int>(opts.bundle_opts.loss_type);
     if (lt < 0 || lt > 2) throw std::runtime_error("Unknown loss type: " + std::to_string(lt));
+    GpuSection section;
     GpuProblem gp{SharedGpuContext()};
     {
         StageClock::Scope sc("pnp/create+upload");
@@ -67,6 +68,7 @@ void SolvePnPIterativeOnGpu(pc_pnp_problem* problem, size_t n, const PnPOptions&
     const bool opt_f = opts.optimize_focal_length && n > 3;
     const bool opt_pp = opts.optimize_principal_point && n > 3;
     const CameraIntrinsics::Bounds bounds = result.camera.intrinsics.GetBounds();
+    GpuSection section;
     struct {
         pc_context* ctx;
         pc_pnp_problem* prob;

@@ -7,15 +7,20 @@
 AcceleratedMesh::AcceleratedMesh(std::vector<float> vertices, std::vector<uint32_t> triangles,
                                  std::vector<uint32_t> masked_triangles)
     : mesh_(std::move(vertices), std::move(triangles), std::move(masked_triangles)) {
+    GpuSection section;
     pc_context* ctx = SharedGpuContext();
     if (pc_mesh_create(ctx, mesh_.vertices.data(), static_cast<int>(mesh_.NumVertices()), mesh_.triangles.data(),
                        static_cast<int>(mesh_.NumTriangles()), &gpu_) != PC_OK)
         throw std::runtime_error(std::string("pc_mesh_create: ") + pc_last_error());
 }
 
-AcceleratedMesh::~AcceleratedMesh() { pc_mesh_destroy(gpu_); }
+AcceleratedMesh::~AcceleratedMesh() {
+    GpuSection section;
+    pc_mesh_destroy(gpu_);
+}
 
 void AcceleratedMesh::SyncMask() const {
+    GpuSection section;
     if (pc_mesh_set_mask(SharedGpuContext(), gpu_, mesh_.masked_triangles.data(),
                          static_cast<int>(mesh_.masked_triangles.size())) != PC_OK)
         throw std::runtime_error(std::string("pc_mesh_set_mask: ") + pc_last_error());
@@ -40,6 +45,7 @@ void AcceleratedMesh::RayCastPixels(const SceneTransformations& st, const float*
                                     std::vector<std::optional<RayHit>>& hits, bool exhaustive) const {
     hits.assign(n, std::nullopt);
     if (n == 0) return;
+    GpuSection section;   // also guards the mutable host scratch below (hit_, pos_, uvt_, prim_)
     pc_context* ctx = SharedGpuContext();
     pc_ray_camera cam;
     MakeRayCamera(st, &cam);

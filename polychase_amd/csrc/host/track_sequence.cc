@@ -160,11 +160,15 @@ struct Scratch {
     Keypoints targets;
 
     Scratch() : ctx(SharedGpuContext()) {
+        GpuSection section;
         if (pc_corr_set_create(ctx, &set) != PC_OK) throw std::runtime_error(std::string("pc_corr_set_create: ") + pc_last_error());
     }
     Scratch(const Scratch&) = delete;
     Scratch& operator=(const Scratch&) = delete;
-    ~Scratch() { pc_corr_set_destroy(set); }
+    ~Scratch() {
+        GpuSection section;
+        pc_corr_set_destroy(set);
+    }
 
     const Keypoints& KeypointsOf(const Database& db, int32_t frame, FlowPrefetcher::Batch* batch) {
         CachedKeypoints* slot = &cache[0];
@@ -265,6 +269,9 @@ int GatherCorrespondences(const Database& db, const CameraTrajectory& traj, cons
 std::optional<PnPResult> SolveFrame(const Database& db, const CameraTrajectory& traj, const Mat4f& model_matrix,
                                     int32_t frame, const AcceleratedMesh& mesh, const PnPOptions& pnp_opts, Scratch& s,
                                     FlowPrefetcher::Batch* batch) {
+    // the GPU part of one frame -- correspondences appended, counted, solved, read back -- is one section on the shared
+    // context; between frames other threads (ray_cast from Python, a refinement) get their turn
+    GpuSection section;
     const int n = GatherCorrespondences(db, traj, model_matrix, frame, mesh, s, batch);
     if (n < 3) return std::nullopt;  // :95-97
     PnPResult result;
@@ -287,6 +294,7 @@ std::optional<PnPResult> SolveFrame(const Database& db, const CameraTrajectory& 
 void FrameCorrespondences(const Database& database, const CameraTrajectory& camera_traj, const Mat4f& model_matrix,
                           int32_t frame, const AcceleratedMesh& accel_mesh, std::vector<float>& world_points,
                           std::vector<float>& image_points) {
+    GpuSection section;
     Scratch scratch;
     const int n = GatherCorrespondences(database, camera_traj, model_matrix, frame, accel_mesh, scratch);
     world_points.assign(3 * static_cast<size_t>(n), 0.f);

@@ -248,7 +248,10 @@ double Norm(const std::vector<double>& v) {
 
 struct GpuRefineProblem {
     pc_refine_problem* p = nullptr;
-    ~GpuRefineProblem() { pc_refine_problem_destroy(p); }
+    ~GpuRefineProblem() {
+        GpuSection section;
+        pc_refine_problem_destroy(p);
+    }
 };
 
 void PackCameras(const CameraTrajectory& traj, std::vector<pc_refine_camera>& out) {
@@ -320,6 +323,7 @@ class RefineSession {
         desc.optimize_focal_length = opt_f ? 1 : 0;
         desc.optimize_principal_point = opt_pp ? 1 : 0;
         // Evaluate ray casts with check_mask = true (refiner.cc:335): send the current mask bits
+        GpuSection section;   // mask upload + problem upload: one section on the shared context (gpu_context.h)
         if (pc_mesh_set_mask(ctx_, mesh.Gpu(), mesh.Inner().masked_triangles.data(),
                              static_cast<int>(mesh.Inner().masked_triangles.size())) != PC_OK)
             ThrowHip("pc_mesh_set_mask");
@@ -349,6 +353,7 @@ class RefineSession {
         PackCameras(traj, cams_);
         double cost = 0.0;
         StageClock::Scope sc("refine/cost sweep");
+        GpuSection section;
         if (pc_refine_total_cost(ctx_, gpu_.p, cams_.data(), loss_type_, opts_.loss_scale, &cost) != PC_OK)
             ThrowHip("pc_refine_total_cost");
         return cost;
@@ -358,9 +363,12 @@ class RefineSession {
     void BuildNormalEquations(const CameraTrajectory& traj) {
         PackCameras(traj, cams_);
         StageClock::Scope sc("refine/normal equations (sweep + host assembly)");
-        if (pc_refine_normal_equations(ctx_, gpu_.p, cams_.data(), loss_type_, opts_.loss_scale, edge_blocks_.data(), nullptr) !=
-            PC_OK)
-            ThrowHip("pc_refine_normal_equations");
+        {
+            GpuSection section;
+            if (pc_refine_normal_equations(ctx_, gpu_.p, cams_.data(), loss_type_, opts_.loss_scale, edge_blocks_.data(), nullptr) !=
+                PC_OK)
+                ThrowHip("pc_refine_normal_equations");
+        }
         JtJ.SetZero();
         std::fill(Jtr.begin(), Jtr.end(), 0.0);
         const int B = block_, pair = 2 * B, tri = pair * (pair + 1) / 2;

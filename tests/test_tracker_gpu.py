@@ -542,3 +542,48 @@ def test_llt9_known_answer_on_the_device_solver(core):
     _, x0, ok0 = ctx.llt9(-np.eye(9, dtype=np.float32), b)
     assert not ok0 and not x0.any()
     ctx.close()
+
+
+def test_ray_cast_from_python_while_a_tracker_thread_runs(core, tmp_path):
+    """The reference's Embree ray_cast is thread safe, so the addon may cast rays (pin mode, mask painting) while a
+    TrackerThread works.  Here both go through one shared GPU context: the host sections that use it are serialised
+    (csrc/host/gpu_context.h).  Hammer ray_cast from this thread while tracking runs on the worker; the poses must equal
+    those of an undisturbed run and every ray cast must give the undisturbed answer."""
+    import time
+    verts, tris = grid_mesh()
+    model = np.eye(4, dtype=np.float32)
+    path = str(tmp_path / "flow.db")
+    n_frames = 16
+    _build_flow_db(core, path, verts, tris, model, n_frames, n_kp=2000)
+    R0, t0 = true_pose(1)
+    st = core.SceneTransformations(model, view4(R0, t0), intr(core))
+    mesh = core.AcceleratedMesh(verts, tris)
+    quiet = {}
+    core.track_sequence(path, 1, n_frames, st, mesh, lambda r: quiet.__setitem__(r.frame, (np.array(r.pose.q), np.array(r.pose.t))) or True,
+                        False, False, core.BundleOptions())
+    px = [np.array([W * (0.2 + 0.6 * k / 9), H * (0.3 + 0.4 * ((k * 7) % 10) / 9)], np.float32) for k in range(10)]
+    want = [core.ray_cast(mesh, st, p, False) for p in px]
+    assert any(h is not None for h in want)
+    th = core.TrackerThread(path, 1, n_frames, st, mesh, False, False, core.BundleOptions())
+    got, casts, t_start = {}, 0, time.time()
+    done = False
+    while not done and time.time() - t_start < 120:
+        for p, w_ in zip(px, want):                     # ray casts between (and during) the worker's frames
+            h = core.ray_cast(mesh, st, p, False)
+            assert (h is None) == (w_ is None)
+            if h is not None:
+                assert h.primitive_id == w_.primitive_id and np.array_equal(np.array(h.pos), np.array(w_.pos))
+            casts += 1
+        while True:
+            m = th.try_pop()
+            if m is None:
+                break
+            if m is True:
+                done = True
+                break
+            assert not isinstance(m, core.CppException), m.what() if isinstance(m, core.CppException) else ""
+            got[m.frame] = (np.array(m.pose.q), np.array(m.pose.t))
+    th.join()
+    assert done and sorted(got) == sorted(quiet) and casts >= 10
+    for f in quiet:
+        assert np.array_equal(got[f][0], quiet[f][0]) and np.array_equal(got[f][1], quiet[f][1]), f
