@@ -208,6 +208,10 @@ int pc_analyzer_put_frame(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, 
 int pc_analyzer_put_frame_f32(pc_analyzer* a, int32_t frame_id, const float* rgb, size_t row_pitch, int channels,
                               int on_device, int will_detect);
 int pc_analyzer_has_frame(const pc_analyzer* a, int32_t frame_id);
+/* 1 when the pixels handed to pc_analyzer_put_frame for `frame_id` are no longer read (its gray conversion has
+ * finished, or the frame has left the ring), 0 while the GPU may still read them.  Device / pinned sources are read
+ * asynchronously: the caller keeps such a buffer alive, and unmodified, until this returns 1. */
+int pc_analyzer_frame_ingested(const pc_analyzer* a, int32_t frame_id);
 /* Keypoints already stored in the database for this frame (resume, opticalflow.cc:168-178). */
 int pc_analyzer_set_keypoints(pc_analyzer* a, int32_t frame_id, const float* xy, int n);
 /* Enqueue one iteration of the outer loop (opticalflow.cc:259-309) for frame1 and the given

@@ -259,6 +259,13 @@ int pc_analyzer_has_frame(const pc_analyzer* a, int32_t frame_id) {
     return find_slot(const_cast<pc_analyzer*>(a), frame_id) != nullptr;
 }
 
+int pc_analyzer_frame_ingested(const pc_analyzer* a, int32_t frame_id) {
+    if (!a) return 1;
+    Slot* s = find_slot(const_cast<pc_analyzer*>(a), frame_id);
+    if (!s || !s->img_ready) return 1;   // evicted: whatever read it was ordered before the eviction
+    return hipEventQuery(s->img_ready) == hipSuccess ? 1 : 0;
+}
+
 int pc_analyzer_set_keypoints(pc_analyzer* a, int32_t frame_id, const float* xy, int n) {
     if (!a || n < 0 || (!xy && n > 0)) return fail(PC_E_INVALID, "bad argument");
     Slot* s = find_slot(a, frame_id);

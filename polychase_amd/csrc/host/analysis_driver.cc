@@ -79,6 +79,7 @@ class RecordWriter {
     double seconds() const { return seconds_; }
 
    private:
+    struct WriterStopped {};
     void Rethrow() {
         if (error_) std::rethrow_exception(error_);
     }
@@ -92,10 +93,16 @@ class RecordWriter {
                 r = queue_.front();
                 busy_ = true;
             }
+            bool in_transaction = false;
             try {
                 const double t0 = Now();
                 std::lock_guard<std::mutex> dblk(*db_mtx_);
+                {
+                    std::lock_guard<std::mutex> lk(mtx_);
+                    if (error_) throw WriterStopped{};   // an earlier record failed: nothing more is written
+                }
                 db_->Begin();
+                in_transaction = true;
                 if (r.keypoints_detected && !db_->KeypointsExist(r.frame1)) {
                     db_->WriteKeypoints(r.frame1, r.keypoints_xy, static_cast<size_t>(r.n_keypoints));
                     stats_->keypoint_rows_written++;
@@ -107,10 +114,19 @@ class RecordWriter {
                     stats_->flow_rows_written++;
                 }
                 db_->Commit();
+                in_transaction = false;
                 seconds_ += Now() - t0;
+            } catch (const WriterStopped&) {
             } catch (...) {
+                if (in_transaction) {
+                    try {
+                        std::lock_guard<std::mutex> dblk(*db_mtx_);
+                        db_->Rollback();   // or every later Begin fails with "cannot start a transaction within a transaction"
+                    } catch (...) {
+                    }
+                }
                 std::lock_guard<std::mutex> lk(mtx_);
-                error_ = std::current_exception();
+                if (!error_) error_ = std::current_exception();   // the first error is the cause; later ones are its echo
             }
             {
                 std::lock_guard<std::mutex> lk(mtx_);
@@ -196,6 +212,9 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
     fopt.term_epsilon = flow_options.term_epsilon;
     fopt.min_eigen_threshold = flow_options.min_eigen_threshold;
 
+    // owners of frames the GPU may still be reading; declared BEFORE the engine, i.e. destroyed AFTER it: on every way
+    // out (exceptions included) the analyzer has synchronised its streams before a buffer goes back to the pool
+    std::deque<std::pair<int32_t, std::shared_ptr<void>>> frames_in_flight;
     Engine eng;
     int device = 0;
     if (const char* env = std::getenv("POLYCHASE_DEVICE")) device = std::atoi(env);
@@ -239,6 +258,19 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
         if (stats) *stats = local_stats;
     };
 
+    // A frame handed over as device / pinned memory is read by the GPU after put_frame has returned: its owner is kept
+    // until the analyzer reports the pixels consumed (not "eight newer frames later", which a GPU busy with other work
+    // -- Blender rendering on the same device -- could outlast)
+    auto release_ingested = [&](bool wait) {
+        while (!frames_in_flight.empty()) {
+            if (!pc_analyzer_frame_ingested(eng.an, frames_in_flight.front().first)) {
+                if (!wait) break;
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+                continue;
+            }
+            frames_in_flight.pop_front();
+        }
+    };
     int32_t highest_put = res_begin - 1;
     Keypoints known;
     for (int32_t frame_id1 = f1_begin; frame_id1 < f1_end; frame_id1++) {
@@ -276,6 +308,8 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
                                                 f->on_device ? 1 : 0, will_detect ? 1 : 0)
                     : pc_analyzer_put_frame(eng.an, fid, f->data, f->row_pitch, f->on_device ? 1 : 0, will_detect ? 1 : 0);
             if (put_rc != PC_OK) ThrowHip("pc_analyzer_put_frame");
+            if (f->on_device && f->owner) frames_in_flight.emplace_back(fid, std::move(f->owner));
+            release_ingested(frames_in_flight.size() > 24);   // bounded: the pool behind the owners is finite
             highest_put = fid;
         }
         // ReadOrGenerateKeypoints (:168-178)

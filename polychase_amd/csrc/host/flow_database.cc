@@ -118,6 +118,9 @@ void Database::Open(const std::string& path) {
     path_ = path;
     // NOMUTEX like the reference: callers serialise access (one writer thread here)
     SQL_OK(sqlite3_open_v2(path.c_str(), &db_, SQLITE_OPEN_READWRITE | SQLITE_OPEN_CREATE | SQLITE_OPEN_NOMUTEX, nullptr));
+    // another connection may be in the middle of a commit (the analysis bulk-loads under a rollback journal, so a reader
+    // that opens the file meanwhile meets a locked database): wait instead of failing with SQLITE_BUSY
+    sqlite3_busy_timeout(db_, 10000);
     // Opt-in, not in the reference: POLYCHASE_DB_PAGE_SIZE=32768 creates NEW databases with larger pages (the blobs of
     // one frame are ~5 MB: with 4 KiB pages most of the insert time goes into overflow-page chains; 32 KiB pages
     // measured 1.7x faster).  The page size is a property of the file -- the reference reads and appends to such a
@@ -168,6 +171,7 @@ std::string Database::SetJournalMode(const char* mode) {
 
 void Database::Begin() { Exec("BEGIN", __LINE__); }
 void Database::Commit() { Exec("COMMIT", __LINE__); }
+void Database::Rollback() { Exec("ROLLBACK", __LINE__); }
 
 // ---- generic helpers -------------------------------------------------------------------------
 bool Database::HasRow(Statement s, int32_t key_a, const int32_t* key_b) const {

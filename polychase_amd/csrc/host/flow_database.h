@@ -76,6 +76,7 @@ class Database {
     // Not in the reference: explicit transactions, so one frame's rows go in as one batch.
     void Begin();
     void Commit();
+    void Rollback();
     // Not in the reference: `PRAGMA journal_mode=<mode>`; returns the mode now in effect (lower case).  The analysis
     // driver loads its rows under a rollback journal ("truncate") and puts the file back into WAL mode -- what the
     // reference's Open() sets (cpp/database.cc:88-92) -- when it is done: with 5 MB of blobs per frame, WAL mode

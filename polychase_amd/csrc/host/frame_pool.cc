@@ -9,7 +9,9 @@
 
 namespace {
 
-constexpr size_t kMinIdle = 8;   // released buffers that must queue up before the oldest one is reused
+// A buffer is released by its owner only after the GPU has consumed it (analysis_driver.cc keeps the owner until
+// pc_analyzer_frame_ingested), so reuse is safe at once; a few idle buffers are kept so that acquire rarely allocates
+constexpr size_t kMinIdle = 2;   // released buffers that queue up before the oldest one is reused
 constexpr size_t kMaxIdle = 24;  // beyond this the oldest idle buffers are freed
 
 struct Pool {

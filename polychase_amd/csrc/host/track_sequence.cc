@@ -183,6 +183,7 @@ struct Scratch {
             slot->keypoints.swap(batch->keypoints);   // read ahead by the prefetcher
             batch->has_keypoints = false;
         } else {
+            slot->keypoints.clear();   // a recycled slot: a frame without a keypoints row must not inherit the old ones
             db.ReadKeypoints(frame, slot->keypoints);
         }
         slot->frame = frame;

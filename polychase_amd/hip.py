@@ -29,7 +29,7 @@ SYMBOLS = [
     "pc_frame_num_keypoints", "pc_frame_download_keypoints", "pc_frame_set_keypoints",
     "pc_lk_track", "pc_lk_track_filtered",
     "pc_analyzer_create", "pc_analyzer_destroy", "pc_analyzer_put_frame", "pc_analyzer_put_frame_f32",
-    "pc_analyzer_has_frame",
+    "pc_analyzer_has_frame", "pc_analyzer_frame_ingested",
     "pc_analyzer_set_keypoints", "pc_analyzer_submit", "pc_analyzer_pending", "pc_analyzer_collect",
     "pc_analyzer_set_device_log", "pc_analyzer_device_log_used",
     "pc_mesh_create", "pc_mesh_set_mask", "pc_mesh_destroy", "pc_raycast_pixels", "pc_raycast_pixels_sweep",
@@ -131,6 +131,7 @@ def load():
     L.pc_analyzer_put_frame.argtypes = [vp, C.c_int32, vp, C.c_size_t, C.c_int, C.c_int]
     L.pc_analyzer_put_frame_f32.argtypes = [vp, C.c_int32, vp, C.c_size_t, C.c_int, C.c_int, C.c_int]
     L.pc_analyzer_has_frame.argtypes = [vp, C.c_int32]
+    L.pc_analyzer_frame_ingested.argtypes = [vp, C.c_int32]
     L.pc_analyzer_set_keypoints.argtypes = [vp, C.c_int32, vp, C.c_int]
     L.pc_analyzer_submit.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.c_int]
     L.pc_analyzer_pending.argtypes = [vp]
