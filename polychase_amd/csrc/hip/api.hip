@@ -132,9 +132,9 @@ int validate_gftt(const pc_gftt_options* opt, int w, int h, pc::GfttGrid* g) {
 
 // Phase A of GoodFeaturesToTrack (see DetectScratch), asynchronous: min-eig map + per-cell max (gftt.cc:35,:61-63),
 // threshold + NMS -> candidates (gftt.cc:64-86).  The candidate count is copied to pinned memory; `ev` fires after.
-int detect_phase_a(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const pc_gftt_options& opt,
-                   DetectScratch& d) {
-    const int w = f->w, h = f->h;
+// every buffer a detection of a w x h frame needs (the analyzer calls this per slot at creation: an allocation inside the
+// running pipeline synchronises the device)
+int detect_reserve(pc_context* ctx, int w, int h, DetectScratch& d) {
     const size_t npx = (size_t)w * h;
     PC_HIP(d.eig.ensure(npx));
     PC_HIP(d.cstate.ensure(npx + 16));
@@ -145,6 +145,15 @@ int detect_phase_a(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const
     PC_HIP(d.h_counters.ensure(2 * kCounterCells));
     if (!d.ev) PC_HIP(hipEventCreateWithFlags(&d.ev, hipEventDisableTiming));
     if (!d.ev_b) PC_HIP(hipEventCreateWithFlags(&d.ev_b, hipEventDisableTiming));
+    (void)ctx;
+    return PC_OK;
+}
+
+int detect_phase_a(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const pc_gftt_options& opt,
+                   DetectScratch& d) {
+    const int w = f->w, h = f->h;
+    const size_t npx = (size_t)w * h;
+    if (int rrc = detect_reserve(ctx, w, h, d)) return rrc;
     const bool suppress = opt.min_distance >= 1;
     if (suppress && ctx->sup_min_distance != opt.min_distance) {
         const std::vector<int2> offs = suppression_offsets(opt.min_distance);

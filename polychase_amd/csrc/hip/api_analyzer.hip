@@ -149,6 +149,7 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
             break;
         }
         s.frame->perm_cap = kp0;
+        if ((rc = detect_reserve(ctx, width, height, s.scratch)) != PC_OK) break;
         if (hipEventCreateWithFlags(&s.img_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.kps_ready, hipEventDisableTiming) != hipSuccess) {
             rc = fail(PC_E_HIP, "hipEventCreate failed");
@@ -165,6 +166,14 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
         for (auto& lane : a->lk_done)
             for (hipEvent_t& e : lane)
                 if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = fail(PC_E_HIP, "hipEventCreate failed");
+    if (rc == PC_OK) {
+        // scratch shared by the slots (stream-ordered on the preparation stream): the radix sort's and the binning's
+        size_t temp_bytes = 0;
+        const uint32_t npx = (uint32_t)((size_t)width * height);
+        if (pc::sort_keys_desc(nullptr, temp_bytes, a->slots[0].scratch.keys.p, a->slots[0].scratch.keys_sorted.p, npx / 8 + 1024, ctx->prep_stream) != hipSuccess ||
+            ctx->sort_temp.ensure(temp_bytes) != hipSuccess || ctx->prep_hist.ensure((size_t)pc::bin_num_tiles(width, height) + 1) != hipSuccess)
+            rc = fail(PC_E_HIP, "allocation failed");
+    }
     if (rc == PC_OK) {
         // Warm the runtime's copy engines: it picks a free SDMA engine per copy and creates an engine's queue the first
         // time it is used (5-8 ms inside some hipMemcpyAsync, observed twice or three times in the first few dozen
