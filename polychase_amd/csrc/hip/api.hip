@@ -112,7 +112,14 @@ void build_pyramid(pc_context* c, pc_frame* f, int first) {
     }
 }
 
-static constexpr int kCounterCells = 4;  // counters[0..3] = candidates, accepted, stuck, pad; then cell max keys
+// DetectScratch::counters layout
+static constexpr int kCounterCells = 8;            // header words
+static constexpr int kCntCand = 0, kCntKps = 1, kCntStuck = 2, kCntOverflow = 3, kCntSortParams = 4;
+static constexpr int kCellMaxAt = kCounterCells;
+static constexpr int kHistAt = kCellMaxAt + pc::kMaxGridCells;
+static constexpr int kCursorAt = kHistAt + pc::kSortBuckets;
+static constexpr int kCountersWords = kCursorAt + pc::kSortBuckets;
+static constexpr uint32_t kOverflowSort = 1u, kOverflowKeypoints = 2u;   // bits of counters[kCntOverflow]
 
 int validate_gftt(const pc_gftt_options* opt, int w, int h, pc::GfttGrid* g) {
     // CHECKs of gftt.cc:18-19
@@ -136,103 +143,154 @@ int validate_gftt(const pc_gftt_options* opt, int w, int h, pc::GfttGrid* g) {
 // running pipeline synchronises the device)
 int detect_reserve(pc_context* ctx, int w, int h, DetectScratch& d) {
     const size_t npx = (size_t)w * h;
+    // 3x3 local maxima: at most one per 2x2 block unless the response has plateaus; more than that takes the slow path
+    const size_t cand_cap = std::min(npx, npx / 4 + 65536);
     PC_HIP(d.eig.ensure(npx));
     PC_HIP(d.cstate.ensure(npx + 16));
-    PC_HIP(d.keys.ensure(npx));
-    PC_HIP(d.keys_sorted.ensure(npx));
-    PC_HIP(d.counters.ensure(kCounterCells + pc::kMaxGridCells));
-    PC_HIP(d.per_block.ensure((size_t)pc::suppress_num_blocks((uint32_t)npx) + 1));
-    PC_HIP(d.h_counters.ensure(2 * kCounterCells));
-    if (!d.ev) PC_HIP(hipEventCreateWithFlags(&d.ev, hipEventDisableTiming));
+    PC_HIP(d.keys.ensure(cand_cap));
+    PC_HIP(d.keys_bucketed.ensure(cand_cap));
+    PC_HIP(d.keys_sorted.ensure(cand_cap));
+    d.cand_cap = (uint32_t)std::min<size_t>(d.keys.cap, std::min(d.keys_bucketed.cap, d.keys_sorted.cap));
+    PC_HIP(d.counters.ensure(kCountersWords));
+    PC_HIP(d.bucket_offsets.ensure(pc::kSortBuckets + 1));
+    PC_HIP(d.per_block.ensure((size_t)pc::suppress_num_blocks(d.cand_cap) + 1));
+    PC_HIP(d.h_counters.ensure(kCounterCells));
     if (!d.ev_b) PC_HIP(hipEventCreateWithFlags(&d.ev_b, hipEventDisableTiming));
     (void)ctx;
     return PC_OK;
 }
 
-int detect_phase_a(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const pc_gftt_options& opt,
-                   DetectScratch& d) {
+static int upload_suppression_offsets(pc_context* ctx, const pc_gftt_options& opt) {
+    if (!(opt.min_distance >= 1) || ctx->sup_min_distance == opt.min_distance) return PC_OK;
+    const std::vector<int2> offs = suppression_offsets(opt.min_distance);
+    PC_HIP(ctx->sup_offsets.ensure(offs.size() + 1));
+    PC_HIP(hipStreamSynchronize(ctx->work));  // a queued suppression may still read the old table
+    PC_HIP(hipMemcpy(ctx->sup_offsets.p, offs.data(), offs.size() * sizeof(int2), hipMemcpyHostToDevice));
+    ctx->n_sup_offsets = (int)offs.size();
+    ctx->sup_min_distance = opt.min_distance;
+    return PC_OK;
+}
+
+static int ensure_perm_capacity(pc_frame* f, int n) {
+    if (f->perm_cap >= n) return PC_OK;
+    if (f->d_perm) PC_HIP(hipFree(f->d_perm));
+    f->d_perm = nullptr;
+    f->perm_cap = 0;
+    const int want = std::max(n + n / 2, 1024);
+    PC_HIP(hipMalloc(&f->d_perm, (size_t)want * 2 * sizeof(uint32_t)));   // order + inverse
+    f->perm_cap = want;
+    return PC_OK;
+}
+
+// GoodFeaturesToTrack, enqueued in one go on the current work stream (see DetectScratch): min-eig map + per-cell max
+// (gftt.cc:35,:61-63), threshold + NMS -> candidates (gftt.cc:64-86), their sort (gftt.cc:98), the suppression in that
+// order (gftt.cc:100-164), the accepted corners -> keypoints truncated to max_corners (gftt.cc:157-162), the LK visiting
+// order.  Every count stays on the device; the counters are copied to pinned memory and `ev_b` fires after.
+int detect_enqueue(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const pc_gftt_options& opt, DetectScratch& d,
+                   DevBuf<uint32_t>& hist, bool full_launch) {
     const int w = f->w, h = f->h;
-    const size_t npx = (size_t)w * h;
-    if (int rrc = detect_reserve(ctx, w, h, d)) return rrc;
-    const bool suppress = opt.min_distance >= 1;
-    if (suppress && ctx->sup_min_distance != opt.min_distance) {
-        const std::vector<int2> offs = suppression_offsets(opt.min_distance);
-        PC_HIP(ctx->sup_offsets.ensure(offs.size() + 1));
-        PC_HIP(hipStreamSynchronize(ctx->work));  // a queued suppression may still read the old table
-        PC_HIP(hipMemcpy(ctx->sup_offsets.p, offs.data(), offs.size() * sizeof(int2), hipMemcpyHostToDevice));
-        ctx->n_sup_offsets = (int)offs.size();
-        ctx->sup_min_distance = opt.min_distance;
-    }
-    PC_HIP(hipMemsetAsync(d.counters.p, 0, (kCounterCells + pc::kMaxGridCells) * sizeof(uint32_t), ctx->work));
-    uint32_t* cell_max = d.counters.p + kCounterCells;
+    int rc = detect_reserve(ctx, w, h, d);
+    if (rc != PC_OK) return rc;
+    if ((rc = upload_suppression_offsets(ctx, opt)) != PC_OK) return rc;
+    if (f->kp_cap < 4096 && (rc = ensure_kp_capacity(f, 4096)) != PC_OK) return rc;
+    if ((rc = ensure_perm_capacity(f, f->kp_cap)) != PC_OK) return rc;
+    PC_HIP(hist.ensure((size_t)pc::bin_num_tiles(w, h) + 1));
+    uint32_t* const cnt = d.counters.p;
+    PC_HIP(hipMemsetAsync(cnt, 0, kCountersWords * sizeof(uint32_t), ctx->work));
     {
         ScopedTimer t(ctx, PC_K_MINEIG);
-        pc::launch_min_eig(f->levels[0], d.eig.p, grid, cell_max, ctx->work);
+        pc::launch_min_eig(f->levels[0], d.eig.p, grid, cnt + kCellMaxAt, ctx->work);
     }
     {
         ScopedTimer t(ctx, PC_K_NMS);
-        pc::launch_nms(d.eig.p, w, h, grid, cell_max, opt.quality_level, d.keys.p, (uint32_t)npx, d.counters.p, d.cstate.p, ctx->work);
+        pc::launch_nms(d.eig.p, w, h, grid, cnt + kCellMaxAt, opt.quality_level, d.keys.p, d.cand_cap, cnt + kCntCand, d.cstate.p,
+                       cnt + kCntSortParams, cnt + kHistAt, ctx->work);
     }
-    PC_HIP(hipMemcpyAsync(d.h_counters.p, d.counters.p, kCounterCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
-    PC_HIP(hipEventRecord(d.ev, ctx->work));
+    // launches sized for the expected number of candidates (workgroups that find nothing to do still queue for a slot
+    // beside the LK wavefronts), the buffers for the capacity
+    const uint32_t n_launch = (ctx->cand_hint > 0 && !full_launch) ? std::min(ctx->cand_hint, d.cand_cap) : d.cand_cap;
+    {
+        ScopedTimer t(ctx, PC_K_SORT);
+        pc::launch_bucket_sort(d.keys.p, d.cand_cap, n_launch, cnt + kCntCand, cnt + kCntSortParams, cnt + kHistAt, d.bucket_offsets.p,
+                               cnt + kCursorAt, d.keys_bucketed.p, d.keys_sorted.p, cnt + kCntOverflow, ctx->work);
+    }
+    // keypoints beyond the frame's buffer are not written; the count then exceeds the capacity and the slow path redoes it
+    const uint32_t limit = opt.max_corners > 0 ? std::min<uint32_t>((uint32_t)opt.max_corners, (uint32_t)f->kp_cap) : (uint32_t)f->kp_cap;
+    {
+        ScopedTimer t(ctx, PC_K_SUPPRESS);
+        pc::launch_suppress_sorted(d.keys_sorted.p, n_launch, cnt + kCntCand, w, h, d.eig.p, d.cstate.p, ctx->sup_offsets.p,
+                                   ctx->n_sup_offsets, opt.min_distance >= 1, d.per_block.p, cnt + kCntStuck, ctx->work);
+        pc::launch_accepted_to_keypoints(d.keys_sorted.p, n_launch, cnt + kCntCand, w, h, d.cstate.p, d.per_block.p, limit, f->d_kps,
+                                         cnt + kCntKps, hist.p, cnt + kCntOverflow, ctx->work);
+    }
+    pc::launch_spatial_bins_counted(f->d_kps, (int)std::min<uint32_t>(limit, n_launch), cnt + kCntKps, w, h, hist.p, f->d_perm,
+                                    f->d_perm + f->perm_cap, ctx->work);
+    PC_HIP(hipMemcpyAsync(d.h_counters.p, cnt, kCounterCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
+    PC_HIP(hipEventRecord(d.ev_b, ctx->work));
     f->n_kps = -1;
     f->n_cands = -1;
     f->perm_valid = false;
     return PC_OK;
 }
 
-// Phase B: waits (on the host) for the candidate count, then enqueues the candidate sort (value desc, address desc ==
-// the processing order of the greedy loop, gftt.cc:98), the suppression in that order (gftt.cc:100-164), the ordered
-// compaction of the accepted corners into keypoints (truncated to max_corners, gftt.cc:157-162) and their LK visiting
-// order.  The keypoint count is copied to pinned memory; `ev_b` fires after.
-int detect_phase_b(pc_context* ctx, pc_frame* f, const pc_gftt_options& opt, DetectScratch& d, DevBuf<uint32_t>& hist) {
-    PC_HIP(hipEventSynchronize(d.ev));
-    const uint32_t npx = (uint32_t)((size_t)f->w * f->h);
-    const uint32_t n_cand = std::min(d.h_counters.p[0], npx);
-    d.n_cand = n_cand;
+// The slow path, synchronous, for frames the fast path cannot hold (more candidates than one per 2x2 block -- plateaus of
+// the response --, a value bucket beyond its LDS buffer, more keypoints than the frame's buffer): candidate and
+// keypoint counts on the host, rocPRIM sort, buffers grown to what the frame needs.
+static int detect_slow_path(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const pc_gftt_options& opt, DetectScratch& d,
+                            DevBuf<uint32_t>& hist) {
+    const int w = f->w, h = f->h;
+    const uint32_t npx = (uint32_t)((size_t)w * h);
+    PC_HIP(hipStreamSynchronize(ctx->work));
+    PC_HIP(d.keys.ensure(npx));
+    PC_HIP(d.keys_sorted.ensure(npx));
+    PC_HIP(d.per_block.ensure((size_t)pc::suppress_num_blocks(npx) + 1));
+    uint32_t* const cnt = d.counters.p;
+    PC_HIP(hipMemsetAsync(cnt, 0, kCountersWords * sizeof(uint32_t), ctx->work));
+    pc::launch_min_eig(f->levels[0], d.eig.p, grid, cnt + kCellMaxAt, ctx->work);
+    pc::launch_nms(d.eig.p, w, h, grid, cnt + kCellMaxAt, opt.quality_level, d.keys.p, npx, cnt + kCntCand, d.cstate.p,
+                   cnt + kCntSortParams, cnt + kHistAt, ctx->work);
+    PC_HIP(hipMemcpyAsync(d.h_counters.p, cnt, kCounterCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
+    PC_HIP(hipStreamSynchronize(ctx->work));
+    const uint32_t n_cand = std::min(d.h_counters.p[kCntCand], npx);
     f->n_cands = (int)n_cand;
-    f->perm_valid = false;
-    if (n_cand > 0) {
-        size_t temp_bytes = 0;
-        PC_HIP(pc::sort_keys_desc(nullptr, temp_bytes, d.keys.p, d.keys_sorted.p, n_cand, ctx->work));
-        PC_HIP(ctx->sort_temp.ensure(temp_bytes));
-        {
-            ScopedTimer t(ctx, PC_K_SORT);
-            PC_HIP(pc::sort_keys_desc(ctx->sort_temp.p, temp_bytes, d.keys.p, d.keys_sorted.p, n_cand, ctx->work));
-        }
-        // every candidate may become a keypoint
-        const int cap = opt.max_corners > 0 ? (int)std::min<uint32_t>(n_cand, (uint32_t)opt.max_corners) : (int)n_cand;
-        int rc = ensure_kp_capacity(f, cap);
-        if (rc != PC_OK) return rc;
-        if (f->perm_cap < cap) {
-            if (f->d_perm) PC_HIP(hipFree(f->d_perm));
-            f->d_perm = nullptr;
-            f->perm_cap = 0;
-            const int want = std::max(cap + cap / 2, 1024);
-            PC_HIP(hipMalloc(&f->d_perm, (size_t)want * 2 * sizeof(uint32_t)));   // order + inverse
-            f->perm_cap = want;
-        }
-        {
-            ScopedTimer t(ctx, PC_K_SUPPRESS);
-            pc::launch_suppress_sorted(d.keys_sorted.p, n_cand, f->w, f->h, d.eig.p, d.cstate.p, ctx->sup_offsets.p, ctx->n_sup_offsets,
-                                       opt.min_distance >= 1, d.per_block.p, d.counters.p + 2, ctx->work);
-            pc::launch_accepted_to_keypoints(d.keys_sorted.p, n_cand, f->w, d.cstate.p, d.per_block.p, (uint32_t)std::max(opt.max_corners, 0),
-                                             f->d_kps, d.counters.p + 1, ctx->work);
-        }
-        PC_HIP(hist.ensure((size_t)pc::bin_num_tiles(f->w, f->h) + 1));
-        pc::launch_spatial_bins(f->d_kps, cap, d.counters.p + 1, f->w, f->h, hist.p, f->d_perm, f->d_perm + f->perm_cap, ctx->work);
-    }
-    PC_HIP(hipMemcpyAsync(d.h_counters.p + kCounterCells, d.counters.p, kCounterCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
-    PC_HIP(hipEventRecord(d.ev_b, ctx->work));
+    f->n_kps = 0;
+    if (n_cand == 0) return PC_OK;
+    size_t temp_bytes = 0;
+    PC_HIP(pc::sort_keys_desc(nullptr, temp_bytes, d.keys.p, d.keys_sorted.p, n_cand, ctx->work));
+    PC_HIP(ctx->sort_temp.ensure(temp_bytes));
+    PC_HIP(pc::sort_keys_desc(ctx->sort_temp.p, temp_bytes, d.keys.p, d.keys_sorted.p, n_cand, ctx->work));
+    const int cap = opt.max_corners > 0 ? (int)std::min<uint32_t>(n_cand, (uint32_t)opt.max_corners) : (int)n_cand;
+    int rc = ensure_kp_capacity(f, cap);
+    if (rc != PC_OK) return rc;
+    if ((rc = ensure_perm_capacity(f, f->kp_cap)) != PC_OK) return rc;
+    PC_HIP(hist.ensure((size_t)pc::bin_num_tiles(w, h) + 1));
+    pc::launch_suppress_sorted(d.keys_sorted.p, n_cand, nullptr, w, h, d.eig.p, d.cstate.p, ctx->sup_offsets.p, ctx->n_sup_offsets,
+                               opt.min_distance >= 1, d.per_block.p, cnt + kCntStuck, ctx->work);
+    pc::launch_accepted_to_keypoints(d.keys_sorted.p, n_cand, nullptr, w, h, d.cstate.p, d.per_block.p, (uint32_t)std::max(opt.max_corners, 0),
+                                     f->d_kps, cnt + kCntKps, hist.p, nullptr, ctx->work);
+    pc::launch_spatial_bins_counted(f->d_kps, cap, cnt + kCntKps, w, h, hist.p, f->d_perm, f->d_perm + f->perm_cap, ctx->work);
+    PC_HIP(hipMemcpyAsync(d.h_counters.p, cnt, kCounterCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
+    PC_HIP(hipStreamSynchronize(ctx->work));
+    if (d.h_counters.p[kCntStuck] != 0) return fail(PC_E_HIP, "suppression kernel did not converge (%u lanes gave up)", d.h_counters.p[kCntStuck]);
+    f->n_kps = (int)std::min<uint32_t>(d.h_counters.p[kCntKps], (uint32_t)cap);
+    f->perm_valid = f->n_kps > 0;
     return PC_OK;
 }
 
-// Phase C: the keypoint count reaches the host
-int detect_phase_c(pc_context* ctx, pc_frame* f, DetectScratch& d) {
+// The keypoint count reaches the host (waits for ev_b); frames beyond the fast path's bounds are redone on the slow path
+int detect_finish(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const pc_gftt_options& opt, DetectScratch& d,
+                  DevBuf<uint32_t>& hist) {
     PC_HIP(hipEventSynchronize(d.ev_b));
-    const uint32_t* hc = d.h_counters.p + kCounterCells;
-    if (hc[2] != 0) return fail(PC_E_HIP, "suppression kernel did not converge (%u lanes gave up)", hc[2]);
-    f->n_kps = d.n_cand > 0 ? (int)std::min(hc[1], d.n_cand) : 0;
+    const uint32_t* hc = d.h_counters.p;
+    const bool too_many_candidates = hc[kCntCand] > d.cand_cap;
+    const bool too_many_keypoints = hc[kCntKps] >= (uint32_t)f->kp_cap && !(opt.max_corners > 0 && opt.max_corners <= f->kp_cap);
+    static const bool force_slow = getenv("POLYCHASE_GFTT_SLOW_PATH") != nullptr;   // tests: the slow path must give the same keypoints
+    ctx->cand_hint = std::max<uint32_t>(4096u, hc[kCntCand] + hc[kCntCand] / 4);
+    if (too_many_candidates || too_many_keypoints || hc[kCntOverflow] != 0 || force_slow)
+        return detect_slow_path(ctx, f, grid, opt, d, hist);
+    if (hc[kCntStuck] != 0) return fail(PC_E_HIP, "suppression kernel did not converge (%u lanes gave up)", hc[kCntStuck]);
+    f->n_cands = (int)hc[kCntCand];
+    f->n_kps = (int)hc[kCntKps];
     f->perm_valid = f->n_kps > 0;
     return PC_OK;
 }
@@ -704,10 +762,9 @@ int pc_frame_detect(pc_context* ctx, pc_frame* f, const pc_gftt_options* opt) {
     PC_HIP(hipSetDevice(ctx->device));
     if (int jrc = join_prep(ctx)) return jrc;
     if (!ctx->detect) ctx->detect = new DetectScratch();
-    if ((rc = detect_phase_a(ctx, f, g, *opt, *ctx->detect)) != PC_OK) return rc;
+    if ((rc = detect_enqueue(ctx, f, g, *opt, *ctx->detect, ctx->lk_hist, /*full_launch=*/true)) != PC_OK) return rc;
     ctx->eig_owner = f;
-    if ((rc = detect_phase_b(ctx, f, *opt, *ctx->detect, ctx->lk_hist)) != PC_OK) return rc;
-    if ((rc = detect_phase_c(ctx, f, *ctx->detect)) != PC_OK) return rc;
+    if ((rc = detect_finish(ctx, f, g, *opt, *ctx->detect, ctx->lk_hist)) != PC_OK) return rc;
     PC_HIP(hipStreamSynchronize(ctx->stream));
     return PC_OK;
 }

@@ -13,7 +13,7 @@ namespace {
 
 constexpr int kSpareSlots = PC_ANALYZER_SPARE_SLOTS;
 
-enum DetState { DET_NONE = 0, DET_DENSE = 1, DET_ORDERED = 2, DET_DONE = 3 };   // phases A, B enqueued; C done
+enum DetState { DET_NONE = 0, DET_ENQUEUED = 2, DET_DONE = 3 };   // detection enqueued / keypoint count on the host
 
 struct Slot {
     pc_frame* frame = nullptr;
@@ -68,43 +68,31 @@ Slot* find_slot(pc_analyzer* a, int32_t frame_id) {
     return (s.valid && s.frame_id == frame_id) ? &s : nullptr;
 }
 
-// All three run on the prep stream (the callers hold a PrepScope).
+// detection of the slot's frame, enqueued on the prep stream in one go; `kps_ready` fires when keypoints and visiting
+// order are complete
 int detect_dense(pc_analyzer* a, Slot& s) {
-    int rc = detect_phase_a(a->ctx, s.frame, a->grid, a->gopt, s.scratch);
-    if (rc == PC_OK) s.det = DET_DENSE;
-    return rc;
-}
-
-// phase B (sort, suppression in priority order, keypoints, visiting order) once the candidate count is on the host
-int detect_order(pc_analyzer* a, Slot& s) {
-    int rc;
-    if (s.det == DET_NONE && (rc = detect_dense(a, s)) != PC_OK) return rc;
-    if ((rc = detect_phase_b(a->ctx, s.frame, a->gopt, s.scratch, a->ctx->prep_hist)) != PC_OK) return rc;
+    PrepScope prep(a->ctx);
+    int rc = detect_enqueue(a->ctx, s.frame, a->grid, a->gopt, s.scratch, a->ctx->prep_hist);
+    if (rc != PC_OK) return rc;
     PC_HIP(hipEventRecord(s.kps_ready, a->ctx->prep_stream));
-    s.det = DET_ORDERED;
+    s.det = DET_ENQUEUED;
     s.supplied = false;
     return PC_OK;
 }
 
-int detect_finish(pc_analyzer* a, Slot& s) {
+// the keypoint count on the host (waits for the detection; a frame beyond the fast path's bounds is redone synchronously)
+int detect_finish_slot(pc_analyzer* a, Slot& s) {
     int rc;
-    if (s.det < DET_ORDERED) {
+    if (s.det == DET_NONE && (rc = detect_dense(a, s)) != PC_OK) return rc;
+    {
         PrepScope prep(a->ctx);
-        if ((rc = detect_order(a, s)) != PC_OK) return rc;
+        const int before = s.frame->n_kps;
+        if ((rc = detect_finish(a->ctx, s.frame, a->grid, a->gopt, s.scratch, a->ctx->prep_hist)) != PC_OK) return rc;
+        (void)before;
+        PC_HIP(hipEventRecord(s.kps_ready, a->ctx->prep_stream));   // the slow path may have redone the keypoints
     }
-    if ((rc = detect_phase_c(a->ctx, s.frame, s.scratch)) != PC_OK) return rc;
     s.det = DET_DONE;
     return PC_OK;
-}
-
-// Phase B of the frame that will most likely be the next frame1, if its dense phase has already delivered its
-// candidate count: keeps sort + suppression + binning off the LK lanes' critical path.
-int preorder_if_ready(pc_analyzer* a, int32_t frame_id) {
-    Slot* s = find_slot(a, frame_id);
-    if (!s || s->det != DET_DENSE || !s->scratch.ev) return PC_OK;
-    if (hipEventQuery(s->scratch.ev) != hipSuccess) return PC_OK;
-    PrepScope prep(a->ctx);
-    return detect_order(a, *s);
 }
 
 }  // namespace
@@ -167,12 +155,8 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
             for (hipEvent_t& e : lane)
                 if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = fail(PC_E_HIP, "hipEventCreate failed");
     if (rc == PC_OK) {
-        // scratch shared by the slots (stream-ordered on the preparation stream): the radix sort's and the binning's
-        size_t temp_bytes = 0;
-        const uint32_t npx = (uint32_t)((size_t)width * height);
-        if (pc::sort_keys_desc(nullptr, temp_bytes, a->slots[0].scratch.keys.p, a->slots[0].scratch.keys_sorted.p, npx / 8 + 1024, ctx->prep_stream) != hipSuccess ||
-            ctx->sort_temp.ensure(temp_bytes) != hipSuccess || ctx->prep_hist.ensure((size_t)pc::bin_num_tiles(width, height) + 1) != hipSuccess)
-            rc = fail(PC_E_HIP, "allocation failed");
+        // scratch shared by the slots (stream-ordered on the preparation stream): the binning histogram
+        if (ctx->prep_hist.ensure((size_t)pc::bin_num_tiles(width, height) + 1) != hipSuccess) rc = fail(PC_E_HIP, "allocation failed");
     }
     if (rc == PC_OK) {
         // Warm the runtime's copy engines: it picks a free SDMA engine per copy and creates an engine's queue the first
@@ -317,7 +301,7 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     bool detected = false;
     if (s1->det != DET_DONE) {
         SlowSection ss("submit/detect_finish");
-        if ((rc = detect_finish(a, *s1)) != PC_OK) return rc;
+        if ((rc = detect_finish_slot(a, *s1)) != PC_OK) return rc;
         detected = true;
     } else {
         detected = !s1->supplied;
@@ -405,12 +389,6 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     PC_HIP(hipMemcpyAsync(j.h_pack.p, pack, j.pack_bytes, hipMemcpyDeviceToHost, ls));
     PC_HIP(hipEventRecord(j.done, ls));
     a->job_count++;
-    // (5) while this LK launch runs: phase B (sort, suppression, keypoints, visiting order) of the frames that become
-    // frame1 next.  Two frames ahead: beside a running LK launch phase B takes about as long as the launch itself, and
-    // the launch after next could otherwise not start under the tail of this one.
-    SlowSection ss("submit/preorder");
-    for (int ahead = 1; ahead <= 2; ahead++)
-        if ((rc = preorder_if_ready(a, frame1 + ahead)) != PC_OK) return rc;
     return PC_OK;
 }
 

@@ -62,11 +62,12 @@ struct SlowSection {
 int collect_timing(pc_context* c);
 int ensure_kp_capacity(pc_frame* f, int n);
 int validate_gftt(const pc_gftt_options* opt, int w, int h, pc::GfttGrid* g);
-// the three phases of GoodFeaturesToTrack (internal.hpp DetectScratch); A and B enqueue on the current work stream
+// GoodFeaturesToTrack (internal.hpp DetectScratch): everything enqueued on the current work stream / the count on the host
 int detect_reserve(pc_context* ctx, int w, int h, DetectScratch& d);
-int detect_phase_a(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const pc_gftt_options& opt, DetectScratch& d);
-int detect_phase_b(pc_context* ctx, pc_frame* f, const pc_gftt_options& opt, DetectScratch& d, DevBuf<uint32_t>& hist);
-int detect_phase_c(pc_context* ctx, pc_frame* f, DetectScratch& d);
+int detect_enqueue(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const pc_gftt_options& opt, DetectScratch& d,
+                   DevBuf<uint32_t>& hist, bool full_launch = false);
+int detect_finish(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const pc_gftt_options& opt, DetectScratch& d,
+                  DevBuf<uint32_t>& hist);
 // orders `stream` behind everything queued on the side streams so far
 int join_prep(pc_context* ctx);
 int order_keypoints_spatially(pc_context* ctx, pc_frame* f, DevBuf<uint32_t>& hist);

@@ -101,32 +101,35 @@ using pc::PinBuf;
 using pc::TimedRange;
 using pc::fail;
 
-// Per-detection buffers of one frame.  Detection is three-phase and host-free between the phases:
-//   A (dense)    min-eig map + per-cell max, threshold + NMS -> candidate keys + state bytes; the candidate count goes
-//                to pinned memory (ev_a)
-//   B (ordering) needs that count on the host: sort the candidates, greedy suppression in priority order, ordered
-//                compaction -> keypoints, LK visiting order; the keypoint count goes to pinned memory (ev_b)
-//   C            the host reads the keypoint count
+// Per-detection buffers of one frame.  Detection is enqueued in one go, without the host in the loop:
+//   min-eig map + per-cell max, threshold + NMS -> candidate keys + state bytes + per-bucket counts, bucket sort of the
+//   candidates (counts stay on the device), greedy suppression in priority order, ordered compaction -> keypoints, LK
+//   visiting order; the counters go to pinned memory (ev_b).  detect_finish() then reads the keypoint count -- and
+//   redoes the frame on the slow path (candidate count on the host, rocPRIM sort) if a fast-path bound was exceeded.
 struct DetectScratch {
-    DevBuf<unsigned long long> keys, keys_sorted;
+    DevBuf<unsigned long long> keys, keys_bucketed, keys_sorted;
     DevBuf<float> eig;                     // min-eig map (K2 -> K3, K5)
     DevBuf<uint8_t> cstate;                // 0 no candidate / 1 candidate / 2 accepted / 3 rejected
-    DevBuf<uint32_t> counters;             // [0] candidates, [1] keypoints, [2] stuck lanes, [3] pad, [4..] cell max
+    // [0] candidates, [1] keypoints, [2] stuck lanes, [3] fast-path overflow bits, [4] sort range hi, [5] sort shift, [6..7] pad,
+    // [8 ..] cell max [kMaxGridCells], bucket counts [kSortBuckets], bucket cursors [kSortBuckets]
+    DevBuf<uint32_t> counters;
+    DevBuf<uint32_t> bucket_offsets;       // [kSortBuckets + 1]
     DevBuf<uint32_t> per_block;            // accepted candidates per suppression workgroup -> their exclusive scan
-    PinBuf<uint32_t> h_counters;           // [0..3] after phase A, [4..7] after phase B
-    hipEvent_t ev = nullptr, ev_b = nullptr;
-    uint32_t n_cand = 0;
+    PinBuf<uint32_t> h_counters;           // counters[0..7] after the detection
+    hipEvent_t ev_b = nullptr;
+    uint32_t cand_cap = 0;                 // candidates the fast path holds
     void release() {
         keys.release();
+        keys_bucketed.release();
         keys_sorted.release();
         eig.release();
         cstate.release();
         counters.release();
+        bucket_offsets.release();
         per_block.release();
         h_counters.release();
-        if (ev) (void)hipEventDestroy(ev);
         if (ev_b) (void)hipEventDestroy(ev_b);
-        ev = ev_b = nullptr;
+        ev_b = nullptr;
     }
 };
 
@@ -153,6 +156,9 @@ struct pc_context {
     DevBuf<int2> sup_offsets;              // suppression neighbourhood for sup_min_distance
     double sup_min_distance = -1.0;
     int n_sup_offsets = 0;
+    // candidates of the latest finished detection + 25 %: the detections enqueued next size their launches for that many
+    // (the count itself stays on the device; a frame with more is redone with launches for the full capacity)
+    uint32_t cand_hint = 0;
     struct DetectScratch* detect = nullptr;  // scratch of the stage-level pc_frame_detect
     DevBuf<uint8_t> sort_temp;
     const pc_frame* eig_owner = nullptr;

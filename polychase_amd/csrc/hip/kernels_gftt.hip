@@ -12,6 +12,7 @@
 // candidate state (0 no candidate, 1 candidate, 2 accepted, 3 rejected; written by K3, updated by K5).  Round 1 had
 // two more dword maps (priority + decision, 8 bytes per pixel written per frame); a neighbour's priority is now
 // read from the min-eig map itself.
+#include <algorithm>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -173,21 +174,57 @@ void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* ce
 // ------------------------------------------------------------------------------------------------
 constexpr int NMS_SUB = 4;   // 64 x 16 tiles per workgroup
 
+// Bucket of a candidate for the sort (K4): the ordered-uint image of a float is monotone and piecewise linear in
+// log(value), so equal slices of it hold similar numbers of corner responses (measured on the benchmark clips with
+// 8192 buckets: at most 62 candidates per bucket at 1080p, 222 at 4K).  Bucket 0 holds the LARGEST values.
+struct SortRange {
+    uint32_t hi, shift;
+};
+__host__ __device__ __forceinline__ SortRange make_sort_range(uint32_t lo, uint32_t hi) {
+    SortRange r;
+    r.hi = hi;
+    r.shift = 0;
+    const uint32_t span = hi > lo ? hi - lo : 0u;
+    while ((span >> r.shift) >= (uint32_t)kSortBuckets) r.shift++;
+    return r;
+}
+__device__ __forceinline__ uint32_t bucket_of(uint32_t ord, const SortRange& r) {
+    const uint32_t d = r.hi > ord ? r.hi - ord : 0u;
+    const uint32_t b = d >> r.shift;
+    return b < (uint32_t)kSortBuckets ? b : (uint32_t)kSortBuckets - 1u;
+}
+
 __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ eig, int w, int h, GfttGrid g,
                                                   const uint32_t* __restrict__ cell_max, double quality_level,
                                                   unsigned long long* __restrict__ keys, uint32_t cap,
-                                                  uint32_t* __restrict__ counter, uint8_t* __restrict__ cstate) {
+                                                  uint32_t* __restrict__ counter, uint8_t* __restrict__ cstate,
+                                                  uint32_t* __restrict__ sort_params, uint32_t* __restrict__ hist) {
     __shared__ float s_thr[kMaxGridCells];
+    __shared__ uint32_t s_hi, s_lo;
     __shared__ float s_v[CH][CW + 2];
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TW;
     const int ncells = g.rows * g.cols;
+    if (tid == 0) {
+        s_hi = 0u;
+        s_lo = 0xffffffffu;
+    }
+    __syncthreads();
     for (int i = tid; i < ncells; i += 256) {
         // cv::threshold on CV_32F compares with (float)(maxVal * quality_level), maxVal a double
         const float mx = ordered_to_float(cell_max[i]);
         s_thr[i] = (float)((double)mx * quality_level);
+        // value range of the candidates (bucket sort, see bucket_of): above the smallest threshold, up to the largest maximum
+        atomicMax(&s_hi, cell_max[i]);
+        atomicMin(&s_lo, float_to_ordered(s_thr[i] > 0.f ? s_thr[i] : 0.f));
+    }
+    __syncthreads();
+    const SortRange range = make_sort_range(s_lo, s_hi);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        sort_params[0] = range.hi;
+        sort_params[1] = range.shift;
     }
     const int r = tid >> 4, q = tid & 15;
     const int x = x0 + 4 * q;
@@ -303,8 +340,11 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ eig,
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if (flags & (1u << (4 * sub + i))) {
-                if (pos < cap)
-                    keys[pos] = ((unsigned long long)float_to_ordered(vals[sub][i]) << 32) | (unsigned long long)(uint32_t)(y * w + x + i);
+                const uint32_t ord = float_to_ordered(vals[sub][i]);
+                if (pos < cap) {
+                    keys[pos] = ((unsigned long long)ord << 32) | (unsigned long long)(uint32_t)(y * w + x + i);
+                    atomicAdd(&hist[bucket_of(ord, range)], 1u);
+                }
                 pos++;
             }
         }
@@ -312,9 +352,100 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ eig,
 }
 
 void launch_nms(const float* eig, int w, int h, const GfttGrid& g, const uint32_t* cell_max, double quality_level,
-                unsigned long long* keys, uint32_t cap, uint32_t* counter, uint8_t* cstate, hipStream_t s) {
+                unsigned long long* keys, uint32_t cap, uint32_t* counter, uint8_t* cstate, uint32_t* sort_params, uint32_t* hist,
+                hipStream_t s) {
     dim3 grid((w + TW - 1) / TW, (h + NMS_SUB * TH - 1) / (NMS_SUB * TH));
-    hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, s, eig, w, h, g, cell_max, quality_level, keys, cap, counter, cstate);
+    hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, s, eig, w, h, g, cell_max, quality_level, keys, cap, counter, cstate,
+                       sort_params, hist);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4  sort of the candidates, descending (value, address) = the processing order of the greedy loop (gftt.cc:7-12, :98),
+// without the candidate count on the host: K3 has counted the candidates per value bucket; here an exclusive scan of
+// the 8192 counts, a scatter into bucket order and a rank sort inside every bucket (one wavefront per bucket, keys in
+// LDS).  Three launches; rocPRIM's sort of the same keys is 9 (1080p) to 18 (4K) launches and needs the count on the
+// host, which tied the ordering phase of detection to a host round trip.  A bucket with more keys than fit its LDS
+// buffer raises the overflow flag: the caller then sorts with rocPRIM (sort_keys_desc).
+// ------------------------------------------------------------------------------------------------
+constexpr int kBucketLds = 512;    // keys a bucket may hold on the fast path (4 KB of LDS; measured maximum 222 at 4K)
+
+__global__ __launch_bounds__(256) void bucket_scan_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ offsets) {
+    __shared__ uint32_t s_sum[256];
+    constexpr int per = kSortBuckets / 256;
+    const int b = threadIdx.x * per;
+    uint32_t s = 0;
+    for (int i = 0; i < per; i++) s += hist[b + i];
+    s_sum[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t v = (threadIdx.x >= (unsigned)d) ? s_sum[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_sum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[threadIdx.x] - s;
+    for (int i = 0; i < per; i++) {
+        const uint32_t c = hist[b + i];
+        offsets[b + i] = run;
+        run += c;
+    }
+    if (threadIdx.x == 255) offsets[kSortBuckets] = run;
+}
+
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(const unsigned long long* __restrict__ keys, uint32_t cap,
+                                                             const uint32_t* __restrict__ counter, const uint32_t* __restrict__ sort_params,
+                                                             const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+                                                             unsigned long long* __restrict__ out) {
+    const uint32_t n = min(*counter, cap);
+    SortRange range;
+    range.hi = sort_params[0];
+    range.shift = sort_params[1];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned long long key = keys[i];
+        const uint32_t b = bucket_of((uint32_t)(key >> 32), range);
+        out[offsets[b] + atomicAdd(&cursor[b], 1u)] = key;
+    }
+}
+
+constexpr int kBucketsPerWave = 4;
+
+// one wavefront per workgroup (small workgroups with 4 KB of LDS find room beside the LK wavefronts, which hold 120 of a
+// CU's 160 KB), four consecutive buckets each, one after the other in the same LDS buffer
+__global__ __launch_bounds__(64) void bucket_sort_kernel(const unsigned long long* __restrict__ in, const uint32_t* __restrict__ offsets,
+                                                         unsigned long long* __restrict__ out, uint32_t* __restrict__ overflow) {
+    __shared__ unsigned long long s_keys[kBucketLds];
+    const int lane = threadIdx.x;
+    const int b0 = blockIdx.x * kBucketsPerWave;
+    if (offsets[b0] == offsets[min(b0 + kBucketsPerWave, kSortBuckets)]) return;   // nothing in these buckets
+    for (int b = b0; b < b0 + kBucketsPerWave && b < kSortBuckets; b++) {
+        const uint32_t base = offsets[b], n = offsets[b + 1] - base;
+        if (n == 0) continue;
+        if (n > (uint32_t)kBucketLds) {
+            // beyond the fast path: the caller redoes the frame; the kernels queued behind this one still run, so they
+            // must find VALID keys (copied unsorted), not whatever the buffer held before
+            if (lane == 0) atomicOr(overflow, 1u);
+            for (uint32_t i = lane; i < n; i += 64) out[base + i] = in[base + i];
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous bucket's readers are done (one wavefront: program order)
+        for (uint32_t i = lane; i < n; i += 64) s_keys[i] = in[base + i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t i = lane; i < n; i += 64) {
+            const unsigned long long mine = s_keys[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; j++) rank += s_keys[j] > mine ? 1u : 0u;   // keys are distinct (the address part)
+            out[base + rank] = mine;
+        }
+    }
+}
+
+void launch_bucket_sort(const unsigned long long* keys, uint32_t cap, uint32_t n_launch, const uint32_t* counter, const uint32_t* sort_params,
+                        const uint32_t* hist, uint32_t* offsets, uint32_t* cursor, unsigned long long* scratch, unsigned long long* out,
+                        uint32_t* overflow, hipStream_t s) {
+    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(256), 0, s, hist, offsets);
+    const unsigned blocks = std::max(1u, std::min<unsigned>(1024u, (n_launch + 255u) / 256u));
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(blocks), dim3(256), 0, s, keys, cap, counter, sort_params, offsets, cursor, scratch);
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3(kSortBuckets / kBucketsPerWave), dim3(64), 0, s, scratch, offsets, out, overflow);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -339,11 +470,13 @@ constexpr int SUP_BLOCK = 256;
 __device__ __forceinline__ uint8_t cs_load(const uint8_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void cs_store(uint8_t* p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(SUP_BLOCK) void suppress_sorted_kernel(const unsigned long long* __restrict__ keys, uint32_t n, int w, int h,
+__global__ __launch_bounds__(SUP_BLOCK) void suppress_sorted_kernel(const unsigned long long* __restrict__ keys, uint32_t n_max,
+                                                                    const uint32_t* __restrict__ n_dev, int w, int h,
                                                                     const float* __restrict__ eig, uint8_t* cstate,
                                                                     const int2* __restrict__ offsets, int n_offsets,
                                                                     uint32_t* __restrict__ accepted_per_block,
                                                                     uint32_t* __restrict__ stuck) {
+    const uint32_t n = n_dev ? min(*n_dev, n_max) : n_max;   // the launch covers n_max; workgroups past the count leave at once
     const uint32_t i = blockIdx.x * SUP_BLOCK + threadIdx.x;
     const bool live = i < n;
     uint32_t my_val = 0, my_idx = 0;
@@ -423,17 +556,27 @@ __global__ __launch_bounds__(SUP_BLOCK) void suppress_sorted_kernel(const unsign
 }
 
 // no suppression (min_distance < 1, gftt.cc:165-181): every candidate is accepted
-__global__ __launch_bounds__(SUP_BLOCK) void accept_all_kernel(const unsigned long long* __restrict__ keys, uint32_t n, uint8_t* cstate,
+__global__ __launch_bounds__(SUP_BLOCK) void accept_all_kernel(const unsigned long long* __restrict__ keys, uint32_t n_max,
+                                                               const uint32_t* __restrict__ n_dev, uint8_t* cstate,
                                                                uint32_t* __restrict__ accepted_per_block) {
+    const uint32_t n = n_dev ? min(*n_dev, n_max) : n_max;
     const uint32_t i = blockIdx.x * SUP_BLOCK + threadIdx.x;
     if (i < n) cstate[(uint32_t)keys[i]] = CS_ACCEPTED;
-    if (threadIdx.x == 0) accepted_per_block[blockIdx.x] = min((uint32_t)SUP_BLOCK, n - blockIdx.x * SUP_BLOCK);
+    const uint32_t first = blockIdx.x * SUP_BLOCK;
+    if (threadIdx.x == 0) accepted_per_block[blockIdx.x] = first < n ? min((uint32_t)SUP_BLOCK, n - first) : 0u;
 }
 
 // exclusive scan of the per-block counts (one workgroup) + the keypoint count (truncated to max_corners, gftt.cc:160-162)
 __global__ __launch_bounds__(256) void accepted_scan_kernel(uint32_t* __restrict__ per_block, int nblocks, uint32_t max_corners,
-                                                            uint32_t* __restrict__ n_out) {
+                                                            uint32_t* __restrict__ n_out, uint32_t* __restrict__ bin_hist, int n_tiles,
+                                                            uint32_t n_max, const uint32_t* __restrict__ n_dev,
+                                                            uint32_t* __restrict__ overflow) {
     __shared__ uint32_t s_sum[256];
+    // the launches of this detection cover n_max candidates (sized from the previous frames' counts): more than that
+    // were not all processed -- flag it, the caller redoes the frame
+    if (threadIdx.x == 0 && n_dev && overflow && *n_dev > n_max) atomicOr(overflow, 4u);
+    if (bin_hist)   // the histogram the scatter kernel counts the keypoints' tiles into (LK visiting order)
+        for (int i = threadIdx.x; i < n_tiles; i += 256) bin_hist[i] = 0u;
     const int per = (nblocks + 255) / 256;
     const int b = threadIdx.x * per, e = min(b + per, nblocks);
     uint32_t s = 0;
@@ -459,11 +602,14 @@ __global__ __launch_bounds__(256) void accepted_scan_kernel(uint32_t* __restrict
 }
 
 // accepted candidates, in priority order = acceptance order of the greedy loop -> Point2f((float)x, (float)y) (gftt.cc:157)
-__global__ __launch_bounds__(SUP_BLOCK) void accepted_scatter_kernel(const unsigned long long* __restrict__ keys, uint32_t n, int w,
+__global__ __launch_bounds__(SUP_BLOCK) void accepted_scatter_kernel(const unsigned long long* __restrict__ keys, uint32_t n_max,
+                                                                     const uint32_t* __restrict__ n_dev, int w,
                                                                      const uint8_t* __restrict__ cstate,
                                                                      const uint32_t* __restrict__ block_offset, uint32_t max_corners,
-                                                                     float2* __restrict__ xy) {
+                                                                     float2* __restrict__ xy, uint32_t* __restrict__ bin_hist, int tiles_x,
+                                                                     int n_tiles) {
     __shared__ uint32_t s_wave[SUP_BLOCK / 64];
+    const uint32_t n = n_dev ? min(*n_dev, n_max) : n_max;
     const uint32_t i = blockIdx.x * SUP_BLOCK + threadIdx.x;
     uint32_t idx = 0;
     bool keep = false;
@@ -479,34 +625,39 @@ __global__ __launch_bounds__(SUP_BLOCK) void accepted_scatter_kernel(const unsig
     uint32_t pos = block_offset[blockIdx.x] + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
     for (int wv = 0; wv < wave; wv++) pos += s_wave[wv];
     if (max_corners > 0 && pos >= max_corners) return;
-    const uint32_t y = idx / (uint32_t)w;
-    xy[pos] = make_float2((float)(idx - y * (uint32_t)w), (float)y);
+    const uint32_t y = idx / (uint32_t)w, x = idx - y * (uint32_t)w;
+    xy[pos] = make_float2((float)x, (float)y);
+    if (bin_hist) atomicAdd(&bin_hist[min(n_tiles - 1, (int)((y >> 6) * tiles_x + (x >> 6)))], 1u);   // = bin_count_kernel
 }
 
 int suppress_num_blocks(uint32_t n) { return (int)((n + SUP_BLOCK - 1) / SUP_BLOCK); }
 
-void launch_suppress_sorted(const unsigned long long* keys, uint32_t n, int w, int h, const float* eig, uint8_t* cstate,
-                            const int2* offsets, int n_offsets, bool suppress, uint32_t* accepted_per_block, uint32_t* stuck,
-                            hipStream_t s) {
-    const int nb = suppress_num_blocks(n);
+void launch_suppress_sorted(const unsigned long long* keys, uint32_t n_max, const uint32_t* n_dev, int w, int h, const float* eig,
+                            uint8_t* cstate, const int2* offsets, int n_offsets, bool suppress, uint32_t* accepted_per_block,
+                            uint32_t* stuck, hipStream_t s) {
+    const int nb = suppress_num_blocks(n_max);
     if (nb == 0) return;
     if (suppress)
-        hipLaunchKernelGGL(suppress_sorted_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n, w, h, eig, cstate, offsets, n_offsets,
-                           accepted_per_block, stuck);
+        hipLaunchKernelGGL(suppress_sorted_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, w, h, eig, cstate, offsets,
+                           n_offsets, accepted_per_block, stuck);
     else
-        hipLaunchKernelGGL(accept_all_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n, cstate, accepted_per_block);
+        hipLaunchKernelGGL(accept_all_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, cstate, accepted_per_block);
 }
 
-void launch_accepted_to_keypoints(const unsigned long long* keys, uint32_t n, int w, const uint8_t* cstate, uint32_t* per_block,
-                                  uint32_t max_corners, float2* xy, uint32_t* n_out, hipStream_t s) {
-    const int nb = suppress_num_blocks(n);
-    hipLaunchKernelGGL(accepted_scan_kernel, dim3(1), dim3(256), 0, s, per_block, nb, max_corners, n_out);
+void launch_accepted_to_keypoints(const unsigned long long* keys, uint32_t n_max, const uint32_t* n_dev, int w, int h,
+                                  const uint8_t* cstate, uint32_t* per_block, uint32_t max_corners, float2* xy, uint32_t* n_out,
+                                  uint32_t* bin_hist, uint32_t* overflow, hipStream_t s) {
+    const int nb = suppress_num_blocks(n_max);
+    const int tiles_x = (w + 63) >> 6, n_tiles = bin_hist ? bin_num_tiles(w, h) : 0;
+    hipLaunchKernelGGL(accepted_scan_kernel, dim3(1), dim3(256), 0, s, per_block, nb, max_corners, n_out, bin_hist, n_tiles, n_max, n_dev,
+                       overflow);
     if (nb > 0)
-        hipLaunchKernelGGL(accepted_scatter_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n, w, cstate, per_block, max_corners, xy);
+        hipLaunchKernelGGL(accepted_scatter_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, w, cstate, per_block,
+                           max_corners, xy, bin_hist, tiles_x, n_tiles);
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4  descending 64-bit radix sort (value desc, linear index desc).
+// K4 (fallback)  descending 64-bit radix sort (value desc, linear index desc) with the count on the host.
 // ------------------------------------------------------------------------------------------------
 hipError_t sort_keys_desc(void* temp, size_t& temp_bytes, unsigned long long* keys_in,
                           unsigned long long* keys_out, uint32_t n, hipStream_t s) {

@@ -393,6 +393,14 @@ void launch_spatial_bins(const float2* pts, int n, const uint32_t* n_dev, int w,
     hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist, perm, slot_of);
 }
 
+void launch_spatial_bins_counted(const float2* pts, int n, const uint32_t* n_dev, int w, int h, uint32_t* hist, uint32_t* perm,
+                                 uint32_t* slot_of, hipStream_t s) {
+    if (n <= 0) return;
+    const int tiles_x = (w + 63) >> BIN_SHIFT, n_tiles = bin_num_tiles(w, h);
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, hist, n_tiles);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist, perm, slot_of);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Ordered compaction of status == 1 rows (opticalflow.cc:130-147): count per block of 128 keypoints,
 // exclusive scan of the block counts (one small workgroup), scatter.  The LK kernel leaves its records

@@ -5,10 +5,13 @@ Float stages: the min-eig map and the LK outputs are ALSO required to be bit-exa
 FMA contraction and accumulate LK sums exactly); the stated tolerance of the north star (1e-3 px) is
 asserted separately so that a future relaxation cannot silently exceed it.
 """
+import os
 import numpy as np
 import pytest
 
 import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from polychase_amd import hip, synth
 
 pytestmark = pytest.mark.gpu
@@ -442,3 +445,46 @@ def test_hip_path_against_committed_golden_vectors(ctx):
         assert np.array_equal(err[k - 1][m].view(np.uint32), G[f"lk_err_{k}"][m].view(np.uint32))
     for x in fr:
         x.close()
+
+
+def test_detection_slow_path_and_launch_hint(ctx):
+    """Detection keeps every count on the device and sizes its launches from the previous frames' candidate counts; a
+    frame beyond those bounds is redone on the slow path (counts on the host, rocPRIM sort).  (a) The forced slow path
+    (POLYCHASE_GFTT_SLOW_PATH, read once per process: a subprocess) gives the keypoints of the fast path; (b) a clip
+    whose textured area -- and candidate count -- jumps by more than 5x in the middle comes out of the pipelined analyzer with the
+    keypoints of the stand-alone detection of every frame."""
+    import subprocess
+    import sys
+    from polychase_amd.pipeline import ClipAnalyzer
+    w, h = 480, 360
+    clip = synth.NoiseClip(w, h, 24)
+    frames = []
+    for t in range(24):
+        f = clip.frame(t)
+        if t < 12:      # first half: texture only in one corner, the rest flat -> a fraction of the candidates
+            g = np.full_like(f, 128)
+            g[:96, :96] = f[:96, :96]
+            f = g
+        frames.append(np.ascontiguousarray(f))
+    want = {}
+    fr = hip.Frame(ctx, w, h)
+    for t in range(24):
+        fr.set_rgb(frames[t])
+        fr.detect()
+        want[t + 1] = fr.keypoints()
+        assert np.array_equal(want[t + 1], oracle.gftt(oracle.rgb2gray(frames[t])))
+    fr.close()
+    assert len(want[20]) > 5 * len(want[5])
+    got = {}
+    an = ClipAnalyzer(ctx, w, h, 1, 24, lambda fid: frames[fid - 1])
+    an.run(range(1, 25), lambda f1, k, det, flows: got.__setitem__(f1, k.copy()))
+    an.close()
+    for f1 in range(1, 25):
+        assert np.array_equal(got[f1], want[f1]), f1
+    # (a) the slow path in a fresh process
+    np.save("/tmp/_pc_slow_in.npy", frames[18])
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from polychase_amd import hip; c = hip.Context(0); "
+            "f = hip.Frame(c, %d, %d); f.set_rgb(np.load('/tmp/_pc_slow_in.npy')); f.detect(); np.save('/tmp/_pc_slow_out.npy', f.keypoints())"
+            % (ROOT, w, h))
+    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, POLYCHASE_GFTT_SLOW_PATH="1"))
+    assert np.array_equal(np.load("/tmp/_pc_slow_out.npy"), want[19])
