@@ -18,7 +18,7 @@ namespace pc_api {
 
 int collect_timing(pc_context* c) {
     if (c->ranges.empty()) return PC_OK;
-    PC_HIP(hipStreamSynchronize(c->prep_stream));
+    PC_HIP(c->sync_side_streams());
     PC_HIP(hipStreamSynchronize(c->stream));
     PC_HIP(hipStreamSynchronize(c->stream_b));
     // launches of one class may overlap (the analyzer's two job lanes): besides the sum of the durations keep the
@@ -113,8 +113,10 @@ void build_pyramid(pc_context* c, pc_frame* f, int first) {
 }
 
 // DetectScratch::counters layout
-static constexpr int kCounterCells = 8;            // header words
+static constexpr int kCounterCells = 16;           // header words; the first kHostCells reach the host
+static constexpr int kHostCells = 8;
 static constexpr int kCntCand = 0, kCntKps = 1, kCntStuck = 2, kCntOverflow = 3, kCntSortParams = 4;
+static constexpr int kCntTickets = 8;              // [8] NMS, [9] suppression, [10] compaction (pc::last_workgroup)
 static constexpr int kCellMaxAt = kCounterCells;
 static constexpr int kHistAt = kCellMaxAt + pc::kMaxGridCells;
 static constexpr int kCursorAt = kHistAt + pc::kSortBuckets;
@@ -154,7 +156,7 @@ int detect_reserve(pc_context* ctx, int w, int h, DetectScratch& d) {
     PC_HIP(d.counters.ensure(kCountersWords));
     PC_HIP(d.bucket_offsets.ensure(pc::kSortBuckets + 1));
     PC_HIP(d.per_block.ensure((size_t)pc::suppress_num_blocks(d.cand_cap) + 1));
-    PC_HIP(d.h_counters.ensure(kCounterCells));
+    PC_HIP(d.h_counters.ensure(kHostCells));
     if (!d.ev_b) PC_HIP(hipEventCreateWithFlags(&d.ev_b, hipEventDisableTiming));
     (void)ctx;
     return PC_OK;
@@ -196,7 +198,9 @@ int detect_enqueue(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const
     if ((rc = ensure_perm_capacity(f, f->kp_cap)) != PC_OK) return rc;
     PC_HIP(hist.ensure((size_t)pc::bin_num_tiles(w, h) + 1));
     uint32_t* const cnt = d.counters.p;
-    PC_HIP(hipMemsetAsync(cnt, 0, kCountersWords * sizeof(uint32_t), ctx->work));
+    // the analyzer has the level-0 kernel of the frame zero the counters (detect_clear_list): one command less in the chain
+    if (!d.cleared) PC_HIP(hipMemsetAsync(cnt, 0, kCountersWords * sizeof(uint32_t), ctx->work));
+    d.cleared = false;
     {
         ScopedTimer t(ctx, PC_K_MINEIG);
         pc::launch_min_eig(f->levels[0], d.eig.p, grid, cnt + kCellMaxAt, ctx->work);
@@ -204,28 +208,27 @@ int detect_enqueue(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const
     {
         ScopedTimer t(ctx, PC_K_NMS);
         pc::launch_nms(d.eig.p, w, h, grid, cnt + kCellMaxAt, opt.quality_level, d.keys.p, d.cand_cap, cnt + kCntCand, d.cstate.p,
-                       cnt + kCntSortParams, cnt + kHistAt, ctx->work);
+                       cnt + kCntSortParams, cnt + kHistAt, cnt + kCntTickets, d.bucket_offsets.p, hist.p, ctx->work);
     }
     // launches sized for the expected number of candidates (workgroups that find nothing to do still queue for a slot
     // beside the LK wavefronts), the buffers for the capacity
     const uint32_t n_launch = (ctx->cand_hint > 0 && !full_launch) ? std::min(ctx->cand_hint, d.cand_cap) : d.cand_cap;
     {
         ScopedTimer t(ctx, PC_K_SORT);
-        pc::launch_bucket_sort(d.keys.p, d.cand_cap, n_launch, cnt + kCntCand, cnt + kCntSortParams, cnt + kHistAt, d.bucket_offsets.p,
+        pc::launch_bucket_sort(d.keys.p, d.cand_cap, n_launch, cnt + kCntCand, cnt + kCntSortParams, d.bucket_offsets.p,
                                cnt + kCursorAt, d.keys_bucketed.p, d.keys_sorted.p, cnt + kCntOverflow, ctx->work);
     }
     // keypoints beyond the frame's buffer are not written; the count then exceeds the capacity and the slow path redoes it
     const uint32_t limit = opt.max_corners > 0 ? std::min<uint32_t>((uint32_t)opt.max_corners, (uint32_t)f->kp_cap) : (uint32_t)f->kp_cap;
     {
         ScopedTimer t(ctx, PC_K_SUPPRESS);
-        pc::launch_suppress_sorted(d.keys_sorted.p, n_launch, cnt + kCntCand, w, h, d.eig.p, d.cstate.p, ctx->sup_offsets.p,
-                                   ctx->n_sup_offsets, opt.min_distance >= 1, d.per_block.p, cnt + kCntStuck, ctx->work);
-        pc::launch_accepted_to_keypoints(d.keys_sorted.p, n_launch, cnt + kCntCand, w, h, d.cstate.p, d.per_block.p, limit, f->d_kps,
-                                         cnt + kCntKps, hist.p, cnt + kCntOverflow, ctx->work);
+        pc::launch_suppress_and_compact(d.keys_sorted.p, n_launch, cnt + kCntCand, w, h, d.eig.p, d.cstate.p, ctx->sup_offsets.p,
+                                        ctx->n_sup_offsets, opt.min_distance >= 1, d.per_block.p, cnt + kCntStuck, limit, f->d_kps,
+                                        cnt + kCntKps, hist.p, cnt + kCntOverflow, cnt + kCntTickets + 1, ctx->work);
     }
+    // the visiting order; the same launch stores the counters in pinned host memory (no copy command behind it)
     pc::launch_spatial_bins_counted(f->d_kps, (int)std::min<uint32_t>(limit, n_launch), cnt + kCntKps, w, h, hist.p, f->d_perm,
-                                    f->d_perm + f->perm_cap, ctx->work);
-    PC_HIP(hipMemcpyAsync(d.h_counters.p, cnt, kCounterCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
+                                    f->d_perm + f->perm_cap, cnt, d.h_counters.p, kHostCells, ctx->work);
     PC_HIP(hipEventRecord(d.ev_b, ctx->work));
     f->n_kps = -1;
     f->n_cands = -1;
@@ -244,12 +247,14 @@ static int detect_slow_path(pc_context* ctx, pc_frame* f, const pc::GfttGrid& gr
     PC_HIP(d.keys.ensure(npx));
     PC_HIP(d.keys_sorted.ensure(npx));
     PC_HIP(d.per_block.ensure((size_t)pc::suppress_num_blocks(npx) + 1));
+    PC_HIP(hist.ensure((size_t)pc::bin_num_tiles(w, h) + 1));
     uint32_t* const cnt = d.counters.p;
+    d.cleared = false;
     PC_HIP(hipMemsetAsync(cnt, 0, kCountersWords * sizeof(uint32_t), ctx->work));
     pc::launch_min_eig(f->levels[0], d.eig.p, grid, cnt + kCellMaxAt, ctx->work);
     pc::launch_nms(d.eig.p, w, h, grid, cnt + kCellMaxAt, opt.quality_level, d.keys.p, npx, cnt + kCntCand, d.cstate.p,
-                   cnt + kCntSortParams, cnt + kHistAt, ctx->work);
-    PC_HIP(hipMemcpyAsync(d.h_counters.p, cnt, kCounterCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
+                   cnt + kCntSortParams, cnt + kHistAt, cnt + kCntTickets, d.bucket_offsets.p, hist.p, ctx->work);
+    PC_HIP(hipMemcpyAsync(d.h_counters.p, cnt, kHostCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
     PC_HIP(hipStreamSynchronize(ctx->work));
     const uint32_t n_cand = std::min(d.h_counters.p[kCntCand], npx);
     f->n_cands = (int)n_cand;
@@ -263,13 +268,12 @@ static int detect_slow_path(pc_context* ctx, pc_frame* f, const pc::GfttGrid& gr
     int rc = ensure_kp_capacity(f, cap);
     if (rc != PC_OK) return rc;
     if ((rc = ensure_perm_capacity(f, f->kp_cap)) != PC_OK) return rc;
-    PC_HIP(hist.ensure((size_t)pc::bin_num_tiles(w, h) + 1));
-    pc::launch_suppress_sorted(d.keys_sorted.p, n_cand, nullptr, w, h, d.eig.p, d.cstate.p, ctx->sup_offsets.p, ctx->n_sup_offsets,
-                               opt.min_distance >= 1, d.per_block.p, cnt + kCntStuck, ctx->work);
-    pc::launch_accepted_to_keypoints(d.keys_sorted.p, n_cand, nullptr, w, h, d.cstate.p, d.per_block.p, (uint32_t)std::max(opt.max_corners, 0),
-                                     f->d_kps, cnt + kCntKps, hist.p, nullptr, ctx->work);
-    pc::launch_spatial_bins_counted(f->d_kps, cap, cnt + kCntKps, w, h, hist.p, f->d_perm, f->d_perm + f->perm_cap, ctx->work);
-    PC_HIP(hipMemcpyAsync(d.h_counters.p, cnt, kCounterCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
+    pc::launch_suppress_and_compact(d.keys_sorted.p, n_cand, nullptr, w, h, d.eig.p, d.cstate.p, ctx->sup_offsets.p, ctx->n_sup_offsets,
+                                    opt.min_distance >= 1, d.per_block.p, cnt + kCntStuck, (uint32_t)std::max(opt.max_corners, 0), f->d_kps,
+                                    cnt + kCntKps, hist.p, nullptr, cnt + kCntTickets + 1, ctx->work);
+    pc::launch_spatial_bins_counted(f->d_kps, cap, cnt + kCntKps, w, h, hist.p, f->d_perm, f->d_perm + f->perm_cap, nullptr, nullptr, 0,
+                                    ctx->work);
+    PC_HIP(hipMemcpyAsync(d.h_counters.p, cnt, kHostCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
     PC_HIP(hipStreamSynchronize(ctx->work));
     if (d.h_counters.p[kCntStuck] != 0) return fail(PC_E_HIP, "suppression kernel did not converge (%u lanes gave up)", d.h_counters.p[kCntStuck]);
     f->n_kps = (int)std::min<uint32_t>(d.h_counters.p[kCntKps], (uint32_t)cap);
@@ -299,10 +303,12 @@ int detect_finish(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const 
 // order `stream` after it.
 int join_prep(pc_context* ctx) {
     if (!ctx->prep_dirty) return PC_OK;
-    PC_HIP(hipEventRecord(ctx->prep_fence, ctx->prep_stream));
-    PC_HIP(hipStreamWaitEvent(ctx->stream, ctx->prep_fence, 0));
-    PC_HIP(hipEventRecord(ctx->prep_fence, ctx->stream_b));
-    PC_HIP(hipStreamWaitEvent(ctx->stream, ctx->prep_fence, 0));
+    hipStream_t const side[4] = {ctx->prep_stream, ctx->stream_b, ctx->detect_stream[0], ctx->detect_stream[1]};
+    for (hipStream_t s : side) {
+        if (!s) continue;
+        PC_HIP(hipEventRecord(ctx->prep_fence, s));
+        PC_HIP(hipStreamWaitEvent(ctx->stream, ctx->prep_fence, 0));
+    }
     ctx->prep_dirty = false;
     return PC_OK;
 }
@@ -441,6 +447,11 @@ int pc_context_create(int device_index, pc_context** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->prep_fence, hipEventDisableTiming);
+    {
+        const char* v = getenv("POLYCHASE_DETECT_STREAMS");
+        c->n_detect = v ? std::max(0, std::min(2, atoi(v))) : 0;
+        for (int k = 0; k < c->n_detect && e == hipSuccess; k++) e = hipStreamCreateWithFlags(&c->detect_stream[k], hipStreamNonBlocking);
+    }
     c->work = c->stream;
     if (e != hipSuccess) {
         delete c;
@@ -453,7 +464,7 @@ int pc_context_create(int device_index, pc_context** out) {
 void pc_context_destroy(pc_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
+    if (c->prep_stream) (void)c->sync_side_streams();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& r : c->ranges) {
         (void)hipEventDestroy(r.a);
@@ -478,7 +489,6 @@ void pc_context_destroy(pc_context* c) {
     c->lk_perm.release();
     c->lk_prof.release();
     c->lk_hist.release();
-    c->prep_hist.release();
     c->lk_row_offset.release();
     c->h_row_offset.release();
     for (auto& b : c->lk_pack) b.release();
@@ -487,6 +497,8 @@ void pc_context_destroy(pc_context* c) {
         (void)hipStreamDestroy(c->stream_b);
     }
     if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
+    for (hipStream_t s : c->detect_stream)
+        if (s) (void)hipStreamDestroy(s);
     if (c->prep_fence) (void)hipEventDestroy(c->prep_fence);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -494,7 +506,7 @@ void pc_context_destroy(pc_context* c) {
 
 int pc_context_synchronize(pc_context* c) {
     if (!c) return fail(PC_E_INVALID, "null context");
-    PC_HIP(hipStreamSynchronize(c->prep_stream));
+    PC_HIP(c->sync_side_streams());
     PC_HIP(hipStreamSynchronize(c->stream));
     PC_HIP(hipStreamSynchronize(c->stream_b));
     c->prep_dirty = false;
@@ -623,7 +635,7 @@ void pc_frame_destroy(pc_frame* f) {
     if (!f) return;
     if (f->ctx) {
         (void)hipSetDevice(f->ctx->device);
-        (void)hipStreamSynchronize(f->ctx->prep_stream);
+        (void)f->ctx->sync_side_streams();
         (void)hipStreamSynchronize(f->ctx->stream);
         (void)hipStreamSynchronize(f->ctx->stream_b);
         if (f->ctx->eig_owner == f) f->ctx->eig_owner = nullptr;
@@ -637,8 +649,10 @@ void pc_frame_destroy(pc_frame* f) {
 }  // extern "C"
 
 // channels: 1 / 3 = u8 gray / RGB; elem_size 4 = float32 RGB(A) with `channels` floats per pixel
+int pc_api::detect_counter_words() { return kCountersWords; }
+
 int pc_api::set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t row_pitch, int on_device, int channels,
-                      int elem_size) {
+                      int elem_size, uint32_t* clear, int clear_words) {
     if (!ctx || !f || !src) return fail(PC_E_INVALID, "null argument");
     if (f->ctx != ctx) return fail(PC_E_INVALID, "frame belongs to another context");
     if (elem_size == 4 && channels != 3 && channels != 4) return fail(PC_E_INVALID, "float frames need 3 or 4 channels, got %d", channels);
@@ -667,12 +681,15 @@ int pc_api::set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t r
         in.src_pitch = d_pitch;
         in.channels = channels;
         in.aligned = ((reinterpret_cast<uintptr_t>(d_src) | d_pitch) & 3) == 0;
+        in.clear = clear;
+        in.clear_words = clear ? clear_words : 0;
         {
             ScopedTimer t(ctx, PC_K_PYRAMID);
             pc::launch_level(in, f->levels[0], f->win, ctx->work);
         }
         build_pyramid(ctx, f, 1);
     } else {
+        if (clear) PC_HIP(hipMemsetAsync(clear, 0, (size_t)clear_words * sizeof(uint32_t), ctx->work));
         {
             ScopedTimer t(ctx, PC_K_GRAY);
             if (elem_size == 4) pc::launch_rgbf32_to_gray(reinterpret_cast<const float*>(d_src), d_pitch, channels, f->levels[0], ctx->work);

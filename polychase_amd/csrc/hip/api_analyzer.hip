@@ -71,10 +71,12 @@ Slot* find_slot(pc_analyzer* a, int32_t frame_id) {
 // detection of the slot's frame, enqueued on the prep stream in one go; `kps_ready` fires when keypoints and visiting
 // order are complete
 int detect_dense(pc_analyzer* a, Slot& s) {
-    PrepScope prep(a->ctx);
-    int rc = detect_enqueue(a->ctx, s.frame, a->grid, a->gopt, s.scratch, a->ctx->prep_hist);
+    hipStream_t const ds = a->ctx->detect_stream_for(s.frame_id);
+    PrepScope prep(a->ctx, ds);
+    if (ds != a->ctx->prep_stream) PC_HIP(hipStreamWaitEvent(ds, s.img_ready, 0));
+    int rc = detect_enqueue(a->ctx, s.frame, a->grid, a->gopt, s.scratch, s.scratch.bin_hist);
     if (rc != PC_OK) return rc;
-    PC_HIP(hipEventRecord(s.kps_ready, a->ctx->prep_stream));
+    PC_HIP(hipEventRecord(s.kps_ready, ds));
     s.det = DET_ENQUEUED;
     s.supplied = false;
     return PC_OK;
@@ -85,11 +87,10 @@ int detect_finish_slot(pc_analyzer* a, Slot& s) {
     int rc;
     if (s.det == DET_NONE && (rc = detect_dense(a, s)) != PC_OK) return rc;
     {
-        PrepScope prep(a->ctx);
-        const int before = s.frame->n_kps;
-        if ((rc = detect_finish(a->ctx, s.frame, a->grid, a->gopt, s.scratch, a->ctx->prep_hist)) != PC_OK) return rc;
-        (void)before;
-        PC_HIP(hipEventRecord(s.kps_ready, a->ctx->prep_stream));   // the slow path may have redone the keypoints
+        hipStream_t const ds = a->ctx->detect_stream_for(s.frame_id);
+        PrepScope prep(a->ctx, ds);
+        if ((rc = detect_finish(a->ctx, s.frame, a->grid, a->gopt, s.scratch, s.scratch.bin_hist)) != PC_OK) return rc;
+        PC_HIP(hipEventRecord(s.kps_ready, ds));   // the slow path may have redone the keypoints
     }
     s.det = DET_DONE;
     return PC_OK;
@@ -138,6 +139,10 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
         }
         s.frame->perm_cap = kp0;
         if ((rc = detect_reserve(ctx, width, height, s.scratch)) != PC_OK) break;
+        if (s.scratch.bin_hist.ensure((size_t)pc::bin_num_tiles(width, height) + 1) != hipSuccess) {
+            rc = fail(PC_E_HIP, "allocation failed");
+            break;
+        }
         if (hipEventCreateWithFlags(&s.img_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.kps_ready, hipEventDisableTiming) != hipSuccess) {
             rc = fail(PC_E_HIP, "hipEventCreate failed");
@@ -154,10 +159,6 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
         for (auto& lane : a->lk_done)
             for (hipEvent_t& e : lane)
                 if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = fail(PC_E_HIP, "hipEventCreate failed");
-    if (rc == PC_OK) {
-        // scratch shared by the slots (stream-ordered on the preparation stream): the binning histogram
-        if (ctx->prep_hist.ensure((size_t)pc::bin_num_tiles(width, height) + 1) != hipSuccess) rc = fail(PC_E_HIP, "allocation failed");
-    }
     if (rc == PC_OK) {
         // Warm the runtime's copy engines: it picks a free SDMA engine per copy and creates an engine's queue the first
         // time it is used (5-8 ms inside some hipMemcpyAsync, observed twice or three times in the first few dozen
@@ -191,7 +192,7 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
 void pc_analyzer_destroy(pc_analyzer* a) {
     if (!a) return;
     (void)hipSetDevice(a->ctx->device);
-    (void)hipStreamSynchronize(a->ctx->prep_stream);
+    (void)a->ctx->sync_side_streams();
     (void)hipStreamSynchronize(a->ctx->stream);
     (void)hipStreamSynchronize(a->ctx->stream_b);
     for (auto& s : a->slots) {
@@ -223,7 +224,13 @@ static int analyzer_put(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, si
         if (e) PC_HIP(hipStreamWaitEvent(a->ctx->prep_stream, e, 0));
         e = nullptr;
     }
-    int rc = set_image(a->ctx, s.frame, rgb, row_pitch, on_device, channels, elem_size);
+    // ... and so may the detection of a frame that was never submitted as frame1
+    if (s.valid && s.det == DET_ENQUEUED && a->ctx->n_detect > 0) PC_HIP(hipStreamWaitEvent(a->ctx->prep_stream, s.kps_ready, 0));
+    // the detection that follows expects its counters zeroed: the frame's first kernel does it on the way
+    const bool clear_here = will_detect && a->ctx->n_detect == 0;
+    int rc = set_image(a->ctx, s.frame, rgb, row_pitch, on_device, channels, elem_size, clear_here ? s.scratch.counters.p : nullptr,
+                       detect_counter_words());
+    s.scratch.cleared = rc == PC_OK && clear_here;
     if (rc != PC_OK) {
         s.valid = false;
         return rc;
@@ -267,14 +274,17 @@ int pc_analyzer_set_keypoints(pc_analyzer* a, int32_t frame_id, const float* xy,
     if (rc != PC_OK) return rc;
     if (n > 0) {
         // resume path (keypoints from the database): pageable source, so the copy is synchronous
-        PC_HIP(hipMemcpyAsync(s->frame->d_kps, xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, a->ctx->prep_stream));
-        PC_HIP(hipStreamSynchronize(a->ctx->prep_stream));
+        hipStream_t const ds = a->ctx->detect_stream_for(frame_id);
+        PC_HIP(hipStreamSynchronize(ds));   // a detection of this frame in flight would write the same buffer
+        PC_HIP(hipMemcpyAsync(s->frame->d_kps, xy, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, ds));
+        PC_HIP(hipStreamSynchronize(ds));
     }
     s->frame->n_kps = n;
     {
-        PrepScope prep(a->ctx);
-        if ((rc = order_keypoints_spatially(a->ctx, s->frame, a->ctx->prep_hist)) != PC_OK) return rc;
-        PC_HIP(hipEventRecord(s->kps_ready, a->ctx->prep_stream));
+        hipStream_t const ds = a->ctx->detect_stream_for(frame_id);
+        PrepScope prep(a->ctx, ds);
+        if ((rc = order_keypoints_spatially(a->ctx, s->frame, s->scratch.bin_hist)) != PC_OK) return rc;
+        PC_HIP(hipEventRecord(s->kps_ready, ds));
     }
     s->det = DET_DONE;
     s->supplied = true;
@@ -397,7 +407,7 @@ int pc_analyzer_pending(const pc_analyzer* a) { return a ? (int)a->job_count : 0
 int pc_analyzer_set_device_log(pc_analyzer* a, void* d_log, size_t capacity_bytes) {
     if (!a) return fail(PC_E_INVALID, "null analyzer");
     if (d_log && (reinterpret_cast<uintptr_t>(d_log) & 15)) return fail(PC_E_INVALID, "device log must be 16-byte aligned");
-    PC_HIP(hipStreamSynchronize(a->ctx->prep_stream));
+    PC_HIP(a->ctx->sync_side_streams());
     PC_HIP(hipStreamSynchronize(a->ctx->stream));
     PC_HIP(hipStreamSynchronize(a->ctx->stream_b));
     a->d_log = static_cast<uint8_t*>(d_log);
@@ -422,6 +432,7 @@ int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out) {
     (void)hipStreamQuery(a->ctx->stream);
     (void)hipStreamQuery(a->ctx->stream_b);
     (void)hipStreamQuery(a->ctx->prep_stream);
+    for (int k = 0; k < a->ctx->n_detect; k++) (void)hipStreamQuery(a->ctx->detect_stream[k]);
     out->frame1 = j.frame1;
     out->n_keypoints = j.n_kps;
     out->keypoints_detected = j.detected ? 1 : 0;

@@ -40,8 +40,8 @@ struct ScopedTimer {
 // image / detection helpers enqueue on prep_stream while one of these is alive
 struct PrepScope {
     pc_context* c;
-    explicit PrepScope(pc_context* ctx) : c(ctx) {
-        c->work = c->prep_stream;
+    explicit PrepScope(pc_context* ctx, hipStream_t s = nullptr) : c(ctx) {
+        c->work = s ? s : c->prep_stream;
         c->prep_dirty = true;
     }
     ~PrepScope() { c->work = c->stream; }
@@ -77,6 +77,9 @@ int check_lk_args(pc_context* ctx, const pc_frame* frame1, const pc_frame* const
 int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targets, int n_targets, const pc_flow_options* opt,
            int set = 0);
 // gray (+ pyramid) of a frame from u8 gray / u8 RGB / float32 RGB(A) pixels, host or device, on the work stream
-int set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t row_pitch, int on_device, int channels, int elem_size = 1);
+// `clear` (may be null): clear_words words zeroed in front of the frame's kernels (by the level-0 kernel where there is one)
+int set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t row_pitch, int on_device, int channels, int elem_size = 1,
+              uint32_t* clear = nullptr, int clear_words = 0);
+int detect_counter_words();   // words of DetectScratch::counters a detection expects zeroed
 
 }  // namespace pc_api

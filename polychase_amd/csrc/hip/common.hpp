@@ -52,4 +52,88 @@ __host__ __device__ __forceinline__ float ordered_to_float(uint32_t k) {
 
 #define PC_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
+#ifdef __HIPCC__
+// "The last workgroup finishes the job": true in the workgroup that arrives last (of `total`) at `*ticket` (zero before
+// the launch).  Every lane of every workgroup must call it.  What it buys: a dependent single-workgroup step (a scan of
+// per-workgroup counts) runs in the tail of the kernel that produced its input instead of as a launch of its own --
+// beside a running LK launch every dependent launch of the frame-preparation chain costs ~12 us whatever it computes
+// (DESIGN.md section 3).
+// NO RELEASE FENCE: the XCDs' L2s are not coherent with one another, so an agent-scope release is an L2 write-back --
+// in every workgroup of the launch (measured with a fence pair: the NMS kernel 3x slower, and the LK launch that shares
+// those L2s 17 % slower).  Instead the data that crosses workgroups here must be written with agent-scope ATOMICS
+// (atomicAdd, pc::publish): those go past the L2 to the coherent level by themselves.  Each lane waits until the memory
+// system has acknowledged its own operations (s_waitcnt), the barrier collects the workgroup, then one lane takes the
+// ticket.  The last workgroup alone pays one acquire (an L2 invalidate of its XCD) and may then read with plain loads.
+__device__ __forceinline__ void publish(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool last_workgroup(uint32_t* ticket, uint32_t total) {
+    __shared__ uint32_t s_is_last;
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0);     // vmcnt = lgkmcnt = 0: this lane's stores and atomics are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) s_is_last = (atomicAdd(ticket, 1u) == total - 1u) ? 1u : 0u;
+    __syncthreads();
+    const bool last = s_is_last != 0u;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    return last;
+}
+
+// Exclusive scan of in[0..n) into out[0..n) (may alias) by one 256-lane workgroup; returns the total (in every lane).
+__device__ __forceinline__ uint32_t scan_exclusive_256(const uint32_t* in, uint32_t* out, int n, uint32_t* s_sum /* [256] */) {
+    const int tid = (int)threadIdx.x;
+    const int per = (n + 255) / 256;
+    const int b = tid * per, e = min(b + per, n);
+    uint32_t s = 0;
+    for (int i = b; i < e; i++) s += in[i];
+    __syncthreads();
+    s_sum[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t v = (tid >= d) ? s_sum[tid - d] : 0u;
+        __syncthreads();
+        s_sum[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[tid] - s;
+    for (int i = b; i < e; i++) {
+        const uint32_t c = in[i];
+        out[i] = run;
+        run += c;
+    }
+    return s_sum[255];
+}
+// the same for n = 256 * PER words, PER a multiple of 4: every lane's loads are in flight together
+template <int PER>
+__device__ __forceinline__ uint32_t scan_exclusive_256_fixed(const uint32_t* in, uint32_t* out, uint32_t* s_sum /* [256] */) {
+    static_assert(PER % 4 == 0, "whole uint4s");
+    const int tid = (int)threadIdx.x;
+    uint4 v[PER / 4];
+#pragma unroll
+    for (int k = 0; k < PER / 4; k++) v[k] = reinterpret_cast<const uint4*>(in + tid * PER)[k];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < PER / 4; k++) s += v[k].x + v[k].y + v[k].z + v[k].w;
+    __syncthreads();
+    s_sum[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t t = (tid >= d) ? s_sum[tid - d] : 0u;
+        __syncthreads();
+        s_sum[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = s_sum[tid] - s;
+#pragma unroll
+    for (int k = 0; k < PER / 4; k++) {
+        uint4 o;
+        o.x = run; run += v[k].x;
+        o.y = run; run += v[k].y;
+        o.z = run; run += v[k].z;
+        o.w = run; run += v[k].w;
+        reinterpret_cast<uint4*>(out + tid * PER)[k] = o;
+    }
+    return s_sum[255];
+}
+#endif
+
 }  // namespace pc

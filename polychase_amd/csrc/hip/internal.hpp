@@ -115,9 +115,11 @@ struct DetectScratch {
     DevBuf<uint32_t> counters;
     DevBuf<uint32_t> bucket_offsets;       // [kSortBuckets + 1]
     DevBuf<uint32_t> per_block;            // accepted candidates per suppression workgroup -> their exclusive scan
+    DevBuf<uint32_t> bin_hist;             // keypoints per 64x64 tile (the analyzer's detections; stage-level calls use the context's)
     PinBuf<uint32_t> h_counters;           // counters[0..7] after the detection
     hipEvent_t ev_b = nullptr;
     uint32_t cand_cap = 0;                 // candidates the fast path holds
+    bool cleared = false;                  // `counters` were zeroed in front of the coming detection (by the frame's level-0 kernel)
     void release() {
         keys.release();
         keys_bucketed.release();
@@ -127,6 +129,7 @@ struct DetectScratch {
         counters.release();
         bucket_offsets.release();
         per_block.release();
+        bin_hist.release();
         h_counters.release();
         if (ev_b) (void)hipEventDestroy(ev_b);
         ev_b = nullptr;
@@ -147,6 +150,20 @@ struct pc_context {
     // stream so that it overlaps the LK launch of the previous frame1 on `stream`.  `work` is the stream
     // the image / detection helpers enqueue on: `stream` by default, `prep_stream` inside the analyzer.
     hipStream_t prep_stream = nullptr;
+    // Detection of a resident frame is needed only when the frame becomes frame1, nine steps after it was put, while its
+    // pyramid is read by the very next launch: the analyzer enqueues detections on their own streams (frames alternate
+    // over n_detect of them) so that the image path never queues behind a suppression kernel and the latency-bound
+    // detection kernels of neighbouring frames overlap.  n_detect = 0: detection follows the image path on prep_stream.
+    hipStream_t detect_stream[2] = {nullptr, nullptr};
+    int n_detect = 0;
+    hipStream_t detect_stream_for(int32_t frame_id) const {
+        return n_detect > 0 ? detect_stream[(unsigned)frame_id % (unsigned)n_detect] : prep_stream;
+    }
+    hipError_t sync_side_streams() const {
+        hipError_t e = hipStreamSynchronize(prep_stream);
+        for (int k = 0; k < n_detect && e == hipSuccess; k++) e = hipStreamSynchronize(detect_stream[k]);
+        return e;
+    }
     hipStream_t work = nullptr;
     hipEvent_t prep_fence = nullptr;     // orders `stream` after everything queued on prep_stream so far
     bool prep_dirty = false;
@@ -169,7 +186,7 @@ struct pc_context {
     DevBuf<float2> lk_cxy;
     DevBuf<uint8_t> lk_ustatus;            // pc_lk_track: unpacked status
     DevBuf<float> lk_cerr;
-    DevBuf<uint32_t> lk_cidx, lk_block_counts[2], lk_perm, lk_hist, prep_hist;
+    DevBuf<uint32_t> lk_cidx, lk_block_counts[2], lk_perm, lk_hist;
     DevBuf<unsigned long long> lk_prof;    // pc_debug_lk_profile: 16 words per wavefront of the latest launch
     size_t lk_prof_rows = 0;
     DevBuf<long long> lk_row_offset;

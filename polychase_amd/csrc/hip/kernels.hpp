@@ -33,6 +33,8 @@ struct LevelSource {
     int channels;         // floats per pixel (SRC_RGBF32)
     int aligned;          // src and src_pitch are multiples of 4: the u8 sources are read as dwords
     Level parent;         // SRC_PYR
+    uint32_t* clear;      // clear_words words zeroed by the launch (the detection's counters: saves the fill command
+    int clear_words;      // in front of the detection chain), or null
 };
 // requires out.w > win + 1 and out.h > win + 1 (single reflection in the padding); smaller levels take the unfused kernels
 void launch_level(const LevelSource& in, const Level& out, int win, hipStream_t s);
@@ -49,33 +51,34 @@ void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* ce
 // K3: per-cell THRESH_TOZERO + 3x3 dilate + strict-interior local maxima -> 64-bit keys
 // (ordered(value) << 32 | y*w+x) appended to `keys` (capacity `cap`), count in *counter; cstate (w*h bytes): 1 at
 // candidates, 0 elsewhere, every pixel written; sort_params[2] / hist[kSortBuckets]: value range and per-bucket counts
-// of the candidates for launch_bucket_sort (hist zeroed by the caller).
+// of the candidates for launch_bucket_sort (hist zeroed by the caller).  The workgroup that finishes last scans the
+// bucket counts into bucket_offsets[kSortBuckets + 1] (`ticket`: one zeroed word); bin_hist (may be null):
+// bin_num_tiles(w, h) words zeroed here for launch_suppress_and_compact.
 constexpr int kSortBuckets = 8192;
 void launch_nms(const float* eig, int w, int h, const GfttGrid& g, const uint32_t* cell_max, double quality_level,
                 unsigned long long* keys, uint32_t cap, uint32_t* counter, uint8_t* cstate, uint32_t* sort_params, uint32_t* hist,
-                hipStream_t s);
+                uint32_t* ticket, uint32_t* bucket_offsets, uint32_t* bin_hist, hipStream_t s);
 // K4: the candidates in descending (value, address) order -> out; no count on the host (scan of the bucket counts,
 // scatter into bucket order via `scratch`, rank sort per bucket).  offsets[kSortBuckets + 1], cursor[kSortBuckets]
 // (zeroed by the caller); n_launch sizes the scatter's grid (it walks all candidates whatever the grid);
 // *overflow |= 1 when a bucket exceeds the fast path (then: sort_keys_desc).
 void launch_bucket_sort(const unsigned long long* keys, uint32_t cap, uint32_t n_launch, const uint32_t* counter, const uint32_t* sort_params,
-                        const uint32_t* hist, uint32_t* offsets, uint32_t* cursor, unsigned long long* scratch, unsigned long long* out,
+                        const uint32_t* offsets, uint32_t* cursor, unsigned long long* scratch, unsigned long long* out,
                         uint32_t* overflow, hipStream_t s);
-// K5: exact greedy min-distance suppression (gftt.cc:100-164) over the candidates SORTED by priority (keys descending):
-// cstate becomes 2 (accepted) / 3 (rejected) at every candidate; accepted_per_block[suppress_num_blocks(n_max)] receives
-// the accepted count of each workgroup.  The number of candidates is min(*n_dev, n_max) (n_dev may be null); the launch
-// covers n_max.  suppress == false: min_distance < 1, everything is accepted (gftt.cc:165-181).  *stuck != 0 afterwards
-// means the spin bound hit.
+// K5: exact greedy min-distance suppression (gftt.cc:100-164) over the candidates SORTED by priority (keys descending),
+// then the accepted ones in priority order -> float2 keypoints (truncated to max_corners if > 0).  TWO launches:
+//   suppression: cstate becomes 2 (accepted) / 3 (rejected) at every candidate; its last workgroup scans the accepted
+//     counts of the workgroups (per_block: suppress_num_blocks(n_max) + 1 words of scratch) and writes *n_out;
+//   compaction: keypoints written; with bin_hist (bin_num_tiles(w, h) zeroed words, see launch_nms) it counts the
+//     keypoints per 64x64 tile and its last workgroup scans the counts (= the input of launch_spatial_bins_counted).
+// The number of candidates is min(*n_dev, n_max) (n_dev may be null); the launches cover n_max; *overflow |= 4 when
+// *n_dev exceeds n_max.  suppress == false: min_distance < 1, everything is accepted (gftt.cc:165-181).  *stuck != 0
+// afterwards means the spin bound hit.  tickets: two zeroed words.
 int suppress_num_blocks(uint32_t n);
-void launch_suppress_sorted(const unsigned long long* keys, uint32_t n_max, const uint32_t* n_dev, int w, int h, const float* eig,
-                            uint8_t* cstate, const int2* offsets, int n_offsets, bool suppress, uint32_t* accepted_per_block,
-                            uint32_t* stuck, hipStream_t s);
-// accepted candidates in priority order -> float2 keypoints (truncated to max_corners if > 0); *n_out = their number;
-// bin_hist (may be null): bin_num_tiles(w, h) words that receive the keypoints' 64x64-tile histogram (zeroed here);
-// *overflow |= 4 when *n_dev exceeds n_max (the launches did not cover every candidate)
-void launch_accepted_to_keypoints(const unsigned long long* keys, uint32_t n_max, const uint32_t* n_dev, int w, int h,
-                                  const uint8_t* cstate, uint32_t* per_block, uint32_t max_corners, float2* xy, uint32_t* n_out,
-                                  uint32_t* bin_hist, uint32_t* overflow, hipStream_t s);
+void launch_suppress_and_compact(const unsigned long long* keys, uint32_t n_max, const uint32_t* n_dev, int w, int h, const float* eig,
+                                 uint8_t* cstate, const int2* offsets, int n_offsets, bool suppress, uint32_t* per_block,
+                                 uint32_t* stuck, uint32_t max_corners, float2* xy, uint32_t* n_out, uint32_t* bin_hist,
+                                 uint32_t* overflow, uint32_t* tickets, hipStream_t s);
 // K4 fallback: descending radix sort of the candidate keys (rocPRIM), count on the host.  temp may be null to query bytes.
 hipError_t sort_keys_desc(void* temp, size_t& temp_bytes, unsigned long long* keys_in,
                           unsigned long long* keys_out, uint32_t n, hipStream_t s);
@@ -115,9 +118,11 @@ int bin_num_tiles(int w, int h);
 // is read from device memory (<= n, which then only sizes the launch).
 void launch_spatial_bins(const float2* pts, int n, const uint32_t* n_dev, int w, int h, uint32_t* hist, uint32_t* perm,
                          uint32_t* slot_of, hipStream_t s);
-// the same when `hist` already holds the tile histogram (launch_accepted_to_keypoints): scan + scatter only
+// the same when `hist` already holds the tiles' first positions (launch_suppress_and_compact): the scatter only.
+// copy_words > 0: the launch also copies copy_src[0 .. copy_words) to copy_dst (device-visible host memory: the
+// detection's counters reach the host without a copy command behind the kernel).
 void launch_spatial_bins_counted(const float2* pts, int n, const uint32_t* n_dev, int w, int h, uint32_t* hist, uint32_t* perm,
-                                 uint32_t* slot_of, hipStream_t s);
+                                 uint32_t* slot_of, const uint32_t* copy_src, uint32_t* copy_dst, int copy_words, hipStream_t s);
 
 // Ordered compaction of status==1 rows per target (opticalflow.cc:130-147).
 // rec / slot_of: the LK kernel's raw records (visiting order) and the inverse visiting order.

@@ -198,7 +198,9 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ eig,
                                                   const uint32_t* __restrict__ cell_max, double quality_level,
                                                   unsigned long long* __restrict__ keys, uint32_t cap,
                                                   uint32_t* __restrict__ counter, uint8_t* __restrict__ cstate,
-                                                  uint32_t* __restrict__ sort_params, uint32_t* __restrict__ hist) {
+                                                  uint32_t* __restrict__ sort_params, uint32_t* __restrict__ hist,
+                                                  uint32_t* __restrict__ ticket, uint32_t* __restrict__ bucket_offsets,
+                                                  uint32_t* __restrict__ bin_hist, int n_tiles) {
     __shared__ float s_thr[kMaxGridCells];
     __shared__ uint32_t s_hi, s_lo;
     __shared__ float s_v[CH][CW + 2];
@@ -222,9 +224,14 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ eig,
     }
     __syncthreads();
     const SortRange range = make_sort_range(s_lo, s_hi);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-        sort_params[0] = range.hi;
-        sort_params[1] = range.shift;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (tid == 0) {
+            sort_params[0] = range.hi;
+            sort_params[1] = range.shift;
+        }
+        // the tile histogram the compaction counts the keypoints into (LK visiting order)
+        if (bin_hist)
+            for (int i = tid; i < n_tiles; i += 256) bin_hist[i] = 0u;
     }
     const int r = tid >> 4, q = tid & 15;
     const int x = x0 + 4 * q;
@@ -331,32 +338,39 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ eig,
         s_base = total ? atomicAdd(counter, total) : 0u;
     }
     __syncthreads();
-    if (cnt == 0) return;
-    uint32_t pos = s_base + incl - cnt;
-    for (int wv = 0; wv < wave; wv++) pos += s_wave[wv];
+    if (cnt != 0) {
+        uint32_t pos = s_base + incl - cnt;
+        for (int wv = 0; wv < wave; wv++) pos += s_wave[wv];
 #pragma unroll
-    for (int sub = 0; sub < NMS_SUB; sub++) {
-        const int y = (blockIdx.y * NMS_SUB + sub) * TH + r;
+        for (int sub = 0; sub < NMS_SUB; sub++) {
+            const int y = (blockIdx.y * NMS_SUB + sub) * TH + r;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (flags & (1u << (4 * sub + i))) {
-                const uint32_t ord = float_to_ordered(vals[sub][i]);
-                if (pos < cap) {
-                    keys[pos] = ((unsigned long long)ord << 32) | (unsigned long long)(uint32_t)(y * w + x + i);
-                    atomicAdd(&hist[bucket_of(ord, range)], 1u);
+            for (int i = 0; i < 4; i++) {
+                if (flags & (1u << (4 * sub + i))) {
+                    const uint32_t ord = float_to_ordered(vals[sub][i]);
+                    if (pos < cap) {
+                        keys[pos] = ((unsigned long long)ord << 32) | (unsigned long long)(uint32_t)(y * w + x + i);
+                        atomicAdd(&hist[bucket_of(ord, range)], 1u);
+                    }
+                    pos++;
                 }
-                pos++;
             }
         }
+    }
+    // K4, first step: the workgroup that finishes last turns the bucket counts into bucket offsets (descending value)
+    if (ticket && last_workgroup(ticket, gridDim.x * gridDim.y)) {
+        __shared__ uint32_t s_scan[256];
+        const uint32_t total = scan_exclusive_256_fixed<kSortBuckets / 256>(hist, bucket_offsets, s_scan);
+        if (tid == 0) bucket_offsets[kSortBuckets] = total;
     }
 }
 
 void launch_nms(const float* eig, int w, int h, const GfttGrid& g, const uint32_t* cell_max, double quality_level,
                 unsigned long long* keys, uint32_t cap, uint32_t* counter, uint8_t* cstate, uint32_t* sort_params, uint32_t* hist,
-                hipStream_t s) {
+                uint32_t* ticket, uint32_t* bucket_offsets, uint32_t* bin_hist, hipStream_t s) {
     dim3 grid((w + TW - 1) / TW, (h + NMS_SUB * TH - 1) / (NMS_SUB * TH));
     hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, s, eig, w, h, g, cell_max, quality_level, keys, cap, counter, cstate,
-                       sort_params, hist);
+                       sort_params, hist, ticket, bucket_offsets, bin_hist, bin_hist ? bin_num_tiles(w, h) : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -368,29 +382,6 @@ void launch_nms(const float* eig, int w, int h, const GfttGrid& g, const uint32_
 // buffer raises the overflow flag: the caller then sorts with rocPRIM (sort_keys_desc).
 // ------------------------------------------------------------------------------------------------
 constexpr int kBucketLds = 512;    // keys a bucket may hold on the fast path (4 KB of LDS; measured maximum 222 at 4K)
-
-__global__ __launch_bounds__(256) void bucket_scan_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ offsets) {
-    __shared__ uint32_t s_sum[256];
-    constexpr int per = kSortBuckets / 256;
-    const int b = threadIdx.x * per;
-    uint32_t s = 0;
-    for (int i = 0; i < per; i++) s += hist[b + i];
-    s_sum[threadIdx.x] = s;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const uint32_t v = (threadIdx.x >= (unsigned)d) ? s_sum[threadIdx.x - d] : 0u;
-        __syncthreads();
-        s_sum[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = s_sum[threadIdx.x] - s;
-    for (int i = 0; i < per; i++) {
-        const uint32_t c = hist[b + i];
-        offsets[b + i] = run;
-        run += c;
-    }
-    if (threadIdx.x == 255) offsets[kSortBuckets] = run;
-}
 
 __global__ __launch_bounds__(256) void bucket_scatter_kernel(const unsigned long long* __restrict__ keys, uint32_t cap,
                                                              const uint32_t* __restrict__ counter, const uint32_t* __restrict__ sort_params,
@@ -440,9 +431,8 @@ __global__ __launch_bounds__(64) void bucket_sort_kernel(const unsigned long lon
 }
 
 void launch_bucket_sort(const unsigned long long* keys, uint32_t cap, uint32_t n_launch, const uint32_t* counter, const uint32_t* sort_params,
-                        const uint32_t* hist, uint32_t* offsets, uint32_t* cursor, unsigned long long* scratch, unsigned long long* out,
+                        const uint32_t* offsets, uint32_t* cursor, unsigned long long* scratch, unsigned long long* out,
                         uint32_t* overflow, hipStream_t s) {
-    hipLaunchKernelGGL(bucket_scan_kernel, dim3(1), dim3(256), 0, s, hist, offsets);
     const unsigned blocks = std::max(1u, std::min<unsigned>(1024u, (n_launch + 255u) / 256u));
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(blocks), dim3(256), 0, s, keys, cap, counter, sort_params, offsets, cursor, scratch);
     hipLaunchKernelGGL(bucket_sort_kernel, dim3(kSortBuckets / kBucketsPerWave), dim3(64), 0, s, scratch, offsets, out, overflow);
@@ -463,6 +453,25 @@ void launch_bucket_sort(const unsigned long long* keys, uint32_t cap, uint32_t n
 // States (one byte per pixel, agent-scope relaxed atomics: per-XCD L2s are not coherent): see the header.
 // Afterwards accepted_per_block[b] = accepted candidates of workgroup b (input of the ordered compaction).
 // ------------------------------------------------------------------------------------------------
+// The tail of the suppression kernel: its last workgroup turns the per-workgroup counts of accepted candidates into
+// their exclusive scan (input of the ordered compaction) and leaves the keypoint count (truncated to max_corners,
+// gftt.cc:160-162) on the device.
+struct AcceptedScan {
+    uint32_t* ticket;       // zero before the launch
+    uint32_t* n_out;        // keypoint count
+    uint32_t* overflow;     // fast path: bit 4 = more candidates than the launches of this detection cover
+    uint32_t max_corners;
+};
+__device__ __forceinline__ void finish_accepted_scan(uint32_t* per_block, const AcceptedScan& fin, uint32_t n_max, const uint32_t* n_dev) {
+    if (!last_workgroup(fin.ticket, gridDim.x)) return;
+    __shared__ uint32_t s_scan[256];
+    // the launches of this detection cover n_max candidates (sized from the previous frames' counts): more than that
+    // were not all processed -- flag it, the caller redoes the frame
+    if (threadIdx.x == 0 && n_dev && fin.overflow && *n_dev > n_max) atomicOr(fin.overflow, 4u);
+    const uint32_t total = scan_exclusive_256(per_block, per_block, (int)gridDim.x, s_scan);
+    if (threadIdx.x == 0) *fin.n_out = (fin.max_corners > 0 && total > fin.max_corners) ? fin.max_corners : total;
+}
+
 constexpr uint8_t CS_CAND = 1, CS_ACCEPTED = 2, CS_REJECTED = 3;
 constexpr int SUP_NB = 12;  // higher-priority neighbours cached in registers
 constexpr int SUP_BLOCK = 256;
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(SUP_BLOCK) void suppress_sorted_kernel(const unsign
                                                                     const float* __restrict__ eig, uint8_t* cstate,
                                                                     const int2* __restrict__ offsets, int n_offsets,
                                                                     uint32_t* __restrict__ accepted_per_block,
-                                                                    uint32_t* __restrict__ stuck) {
+                                                                    uint32_t* __restrict__ stuck, AcceptedScan fin) {
     const uint32_t n = n_dev ? min(*n_dev, n_max) : n_max;   // the launch covers n_max; workgroups past the count leave at once
     const uint32_t i = blockIdx.x * SUP_BLOCK + threadIdx.x;
     const bool live = i < n;
@@ -552,53 +561,20 @@ __global__ __launch_bounds__(SUP_BLOCK) void suppress_sorted_kernel(const unsign
         __builtin_amdgcn_s_sleep(1);
     }
     const int c = __syncthreads_count(accepted);
-    if (threadIdx.x == 0) accepted_per_block[blockIdx.x] = (uint32_t)c;
+    if (threadIdx.x == 0) publish(&accepted_per_block[blockIdx.x], (uint32_t)c);
+    finish_accepted_scan(accepted_per_block, fin, n_max, n_dev);
 }
 
 // no suppression (min_distance < 1, gftt.cc:165-181): every candidate is accepted
 __global__ __launch_bounds__(SUP_BLOCK) void accept_all_kernel(const unsigned long long* __restrict__ keys, uint32_t n_max,
                                                                const uint32_t* __restrict__ n_dev, uint8_t* cstate,
-                                                               uint32_t* __restrict__ accepted_per_block) {
+                                                               uint32_t* __restrict__ accepted_per_block, AcceptedScan fin) {
     const uint32_t n = n_dev ? min(*n_dev, n_max) : n_max;
     const uint32_t i = blockIdx.x * SUP_BLOCK + threadIdx.x;
     if (i < n) cstate[(uint32_t)keys[i]] = CS_ACCEPTED;
     const uint32_t first = blockIdx.x * SUP_BLOCK;
-    if (threadIdx.x == 0) accepted_per_block[blockIdx.x] = first < n ? min((uint32_t)SUP_BLOCK, n - first) : 0u;
-}
-
-// exclusive scan of the per-block counts (one workgroup) + the keypoint count (truncated to max_corners, gftt.cc:160-162)
-__global__ __launch_bounds__(256) void accepted_scan_kernel(uint32_t* __restrict__ per_block, int nblocks, uint32_t max_corners,
-                                                            uint32_t* __restrict__ n_out, uint32_t* __restrict__ bin_hist, int n_tiles,
-                                                            uint32_t n_max, const uint32_t* __restrict__ n_dev,
-                                                            uint32_t* __restrict__ overflow) {
-    __shared__ uint32_t s_sum[256];
-    // the launches of this detection cover n_max candidates (sized from the previous frames' counts): more than that
-    // were not all processed -- flag it, the caller redoes the frame
-    if (threadIdx.x == 0 && n_dev && overflow && *n_dev > n_max) atomicOr(overflow, 4u);
-    if (bin_hist)   // the histogram the scatter kernel counts the keypoints' tiles into (LK visiting order)
-        for (int i = threadIdx.x; i < n_tiles; i += 256) bin_hist[i] = 0u;
-    const int per = (nblocks + 255) / 256;
-    const int b = threadIdx.x * per, e = min(b + per, nblocks);
-    uint32_t s = 0;
-    for (int i = b; i < e; i++) s += per_block[i];
-    s_sum[threadIdx.x] = s;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const uint32_t v = (threadIdx.x >= (unsigned)d) ? s_sum[threadIdx.x - d] : 0u;
-        __syncthreads();
-        s_sum[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = s_sum[threadIdx.x] - s;
-    for (int i = b; i < e; i++) {
-        const uint32_t c = per_block[i];
-        per_block[i] = run;
-        run += c;
-    }
-    if (threadIdx.x == 255) {
-        const uint32_t total = s_sum[255];
-        *n_out = (max_corners > 0 && total > max_corners) ? max_corners : total;
-    }
+    if (threadIdx.x == 0) publish(&accepted_per_block[blockIdx.x], first < n ? min((uint32_t)SUP_BLOCK, n - first) : 0u);
+    finish_accepted_scan(accepted_per_block, fin, n_max, n_dev);
 }
 
 // accepted candidates, in priority order = acceptance order of the greedy loop -> Point2f((float)x, (float)y) (gftt.cc:157)
@@ -607,7 +583,7 @@ __global__ __launch_bounds__(SUP_BLOCK) void accepted_scatter_kernel(const unsig
                                                                      const uint8_t* __restrict__ cstate,
                                                                      const uint32_t* __restrict__ block_offset, uint32_t max_corners,
                                                                      float2* __restrict__ xy, uint32_t* __restrict__ bin_hist, int tiles_x,
-                                                                     int n_tiles) {
+                                                                     int n_tiles, uint32_t* __restrict__ ticket) {
     __shared__ uint32_t s_wave[SUP_BLOCK / 64];
     const uint32_t n = n_dev ? min(*n_dev, n_max) : n_max;
     const uint32_t i = blockIdx.x * SUP_BLOCK + threadIdx.x;
@@ -621,39 +597,43 @@ __global__ __launch_bounds__(SUP_BLOCK) void accepted_scatter_kernel(const unsig
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) s_wave[wave] = (uint32_t)__popcll(ballot);
     __syncthreads();
-    if (!keep) return;
-    uint32_t pos = block_offset[blockIdx.x] + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-    for (int wv = 0; wv < wave; wv++) pos += s_wave[wv];
-    if (max_corners > 0 && pos >= max_corners) return;
-    const uint32_t y = idx / (uint32_t)w, x = idx - y * (uint32_t)w;
-    xy[pos] = make_float2((float)x, (float)y);
-    if (bin_hist) atomicAdd(&bin_hist[min(n_tiles - 1, (int)((y >> 6) * tiles_x + (x >> 6)))], 1u);   // = bin_count_kernel
+    if (keep) {
+        uint32_t pos = block_offset[blockIdx.x] + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+        for (int wv = 0; wv < wave; wv++) pos += s_wave[wv];
+        if (!(max_corners > 0 && pos >= max_corners)) {
+            const uint32_t y = idx / (uint32_t)w, x = idx - y * (uint32_t)w;
+            xy[pos] = make_float2((float)x, (float)y);
+            if (bin_hist) atomicAdd(&bin_hist[min(n_tiles - 1, (int)((y >> 6) * tiles_x + (x >> 6)))], 1u);   // = bin_count_kernel
+        }
+    }
+    // the last workgroup turns the tile counts into the tiles' first positions in the LK visiting order (= bin_scan_kernel)
+    if (bin_hist && ticket && last_workgroup(ticket, gridDim.x)) {
+        __shared__ uint32_t s_scan[256];
+        (void)scan_exclusive_256(bin_hist, bin_hist, n_tiles, s_scan);
+    }
 }
 
 int suppress_num_blocks(uint32_t n) { return (int)((n + SUP_BLOCK - 1) / SUP_BLOCK); }
 
-void launch_suppress_sorted(const unsigned long long* keys, uint32_t n_max, const uint32_t* n_dev, int w, int h, const float* eig,
-                            uint8_t* cstate, const int2* offsets, int n_offsets, bool suppress, uint32_t* accepted_per_block,
-                            uint32_t* stuck, hipStream_t s) {
+// Suppression + ordered compaction: TWO launches.  `tickets` = two zeroed words (one per launch, see last_workgroup);
+// `n_out` receives the keypoint count, per_block is scratch [suppress_num_blocks(n_max) + 1].  With `bin_hist` (zeroed,
+// bin_num_tiles words) the compaction also leaves the tiles' first positions of the LK visiting order there.
+void launch_suppress_and_compact(const unsigned long long* keys, uint32_t n_max, const uint32_t* n_dev, int w, int h, const float* eig,
+                                 uint8_t* cstate, const int2* offsets, int n_offsets, bool suppress, uint32_t* per_block,
+                                 uint32_t* stuck, uint32_t max_corners, float2* xy, uint32_t* n_out, uint32_t* bin_hist,
+                                 uint32_t* overflow, uint32_t* tickets, hipStream_t s) {
+    uint32_t* const accepted_per_block = per_block;
     const int nb = suppress_num_blocks(n_max);
     if (nb == 0) return;
+    const AcceptedScan fin{tickets, n_out, overflow, max_corners};
     if (suppress)
         hipLaunchKernelGGL(suppress_sorted_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, w, h, eig, cstate, offsets,
-                           n_offsets, accepted_per_block, stuck);
+                           n_offsets, accepted_per_block, stuck, fin);
     else
-        hipLaunchKernelGGL(accept_all_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, cstate, accepted_per_block);
-}
-
-void launch_accepted_to_keypoints(const unsigned long long* keys, uint32_t n_max, const uint32_t* n_dev, int w, int h,
-                                  const uint8_t* cstate, uint32_t* per_block, uint32_t max_corners, float2* xy, uint32_t* n_out,
-                                  uint32_t* bin_hist, uint32_t* overflow, hipStream_t s) {
-    const int nb = suppress_num_blocks(n_max);
+        hipLaunchKernelGGL(accept_all_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, cstate, accepted_per_block, fin);
     const int tiles_x = (w + 63) >> 6, n_tiles = bin_hist ? bin_num_tiles(w, h) : 0;
-    hipLaunchKernelGGL(accepted_scan_kernel, dim3(1), dim3(256), 0, s, per_block, nb, max_corners, n_out, bin_hist, n_tiles, n_max, n_dev,
-                       overflow);
-    if (nb > 0)
-        hipLaunchKernelGGL(accepted_scatter_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, w, cstate, per_block,
-                           max_corners, xy, bin_hist, tiles_x, n_tiles);
+    hipLaunchKernelGGL(accepted_scatter_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, w, cstate, per_block, max_corners, xy,
+                       bin_hist, tiles_x, n_tiles, tickets + 1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -370,8 +370,10 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(uint32_t* __restrict__ hi
 
 __global__ __launch_bounds__(256) void bin_scatter_kernel(const float2* __restrict__ pts, int n_max, const uint32_t* __restrict__ n_dev, int tiles_x, int n_tiles,
                                                           uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm,
-                                                          uint32_t* __restrict__ slot_of) {
+                                                          uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ copy_src,
+                                                          uint32_t* __restrict__ copy_dst, int copy_words) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && (int)threadIdx.x < copy_words) copy_dst[threadIdx.x] = copy_src[threadIdx.x];
     const int n = n_dev ? min((int)*n_dev, n_max) : n_max;
     if (i >= n) return;
     const float2 p = pts[i];
@@ -390,15 +392,15 @@ void launch_spatial_bins(const float2* pts, int n, const uint32_t* n_dev, int w,
     (void)hipMemsetAsync(hist, 0, (size_t)n_tiles * sizeof(uint32_t), s);
     hipLaunchKernelGGL(bin_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist);
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, hist, n_tiles);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist, perm, slot_of);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist, perm, slot_of,
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, 0);
 }
 
 void launch_spatial_bins_counted(const float2* pts, int n, const uint32_t* n_dev, int w, int h, uint32_t* hist, uint32_t* perm,
-                                 uint32_t* slot_of, hipStream_t s) {
-    if (n <= 0) return;
+                                 uint32_t* slot_of, const uint32_t* copy_src, uint32_t* copy_dst, int copy_words, hipStream_t s) {
     const int tiles_x = (w + 63) >> BIN_SHIFT, n_tiles = bin_num_tiles(w, h);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, hist, n_tiles);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist, perm, slot_of);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((std::max(n, 1) + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist, perm,
+                       slot_of, copy_src, copy_dst, copy_words);
 }
 
 // ------------------------------------------------------------------------------------------------

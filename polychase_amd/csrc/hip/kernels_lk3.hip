@@ -28,6 +28,12 @@ namespace pc {
 #ifndef PC_LK3_ATTR
 #define PC_LK3_ATTR
 #endif
+// PC_LK3_PAIRS=1: the b-vector accumulation takes the pixels of two runs at a time: (hi16 R_a, hi16 R_b) packed by one
+// v_perm_b32, then b1 += R_a * ix_a + R_b * ix_b as ONE v_dot2_i32_i16 (and one for b2) -- 3 instructions per two
+// pixels where the v_mad_i32_i16 form takes 4.
+#ifndef PC_LK3_PAIRS
+#define PC_LK3_PAIRS 0
+#endif
 #ifndef PC_LK3_WAVES
 #define PC_LK3_WAVES 1   // wavefronts per workgroup
 #endif
@@ -324,6 +330,18 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                     Bias[c * WIN + r] = (int)v.x;
                     Dxy[c * WIN + r] = (int)v.y;
                 }
+#if PC_LK3_PAIRS
+            // rows r and H1 + r of a chain (the same step of its two runs) share their registers: slot r holds
+            // (ix_a, ix_b), slot H1 + r holds (iy_a, iy_b); an odd window's middle row keeps the (ix, iy) form
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int r = 0; r < WIN - (WIN + 1) / 2; r++) {
+                    const uint32_t a = (uint32_t)Dxy[c * WIN + r], b = (uint32_t)Dxy[c * WIN + (WIN + 1) / 2 + r];
+                    Dxy[c * WIN + r] = (int)__builtin_amdgcn_perm(b, a, 0x05040100u);
+                    Dxy[c * WIN + (WIN + 1) / 2 + r] = (int)__builtin_amdgcn_perm(b, a, 0x07060302u);
+                }
+#endif
 #pragma unroll
             for (int e = 0; e < KE; e++) {
                 uint2 v = make_uint2(0u, 0u);
@@ -420,6 +438,37 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
+#if PC_LK3_PAIRS
+                    if (st < H2) {
+                        uint32_t Rp[NCH > 0 ? NCH : 1];
+#pragma unroll
+                        for (int c = 0; c < NCH; c++) Rp[c] = __builtin_amdgcn_perm((uint32_t)R[2 * c + 1], (uint32_t)R[2 * c], 0x07060302u);
+#pragma unroll
+                        for (int c = 0; c < NCH; c++) {
+                            if (c & 1) {
+                                tb1 = sdot2(Rp[c], (uint32_t)Dxy[c * WIN + st], tb1);
+                                tb2 = sdot2(Rp[c], (uint32_t)Dxy[c * WIN + H1 + st], tb2);
+                            } else {
+                                sb1 = sdot2(Rp[c], (uint32_t)Dxy[c * WIN + st], sb1);
+                                sb2 = sdot2(Rp[c], (uint32_t)Dxy[c * WIN + H1 + st], sb2);
+                            }
+                        }
+                    } else {   // an odd window's middle row: the upper runs only
+#pragma unroll
+                        for (int c = 0; c < NCH; c++) {
+                            if (st < H1) {
+                                sb1 = mad16_hl(R[2 * c], (uint32_t)Dxy[c * WIN + st], sb1);
+                                sb2 = mad16_hh(R[2 * c], (uint32_t)Dxy[c * WIN + st], sb2);
+                            }
+                        }
+                    }
+                    if constexpr (NR > NRC) {
+                        if (st < KE) {
+                            tb1 = mad16_hl(R[NRC], (uint32_t)Dxy[KM + st], tb1);
+                            tb2 = mad16_hh(R[NRC], (uint32_t)Dxy[KM + st], tb2);
+                        }
+                    }
+#else
 #pragma unroll
                     for (int u = 0; u < NR; u++) {
                         const int len = u < NRC ? ((u & 1) ? H2 : H1) : KE;
@@ -435,6 +484,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                             }
                         }
                     }
+#endif
 #pragma unroll
                     for (int u = 0; u < NR; u++) bot[u] = nxt[u];
                     __builtin_amdgcn_sched_barrier(0);

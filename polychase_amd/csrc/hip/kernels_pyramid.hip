@@ -70,6 +70,10 @@ __global__ __launch_bounds__(256) void level_kernel(const LevelSource in, const 
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int w = out.w, h = out.h;
+    if (in.clear) {
+        const int stride = (int)(gridDim.x * gridDim.y) * 256;
+        for (int i = (int)(blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < in.clear_words; i += stride) in.clear[i] = 0u;
+    }
 
     // ---- phase A: every in-image pixel of [x0 - 1, x0 + TW] x [y0 - 1, y0 + TH] into s_c ----
     if constexpr (SRC == SRC_PYR) {
