@@ -32,7 +32,13 @@ namespace pc {
 // v_perm_b32, then b1 += R_a * ix_a + R_b * ix_b as ONE v_dot2_i32_i16 (and one for b2) -- 3 instructions per two
 // pixels where the v_mad_i32_i16 form takes 4.
 #ifndef PC_LK3_PAIRS
-#define PC_LK3_PAIRS 0
+#define PC_LK3_PAIRS 1
+#endif
+// PC_LK3_TRIM=1: the per-iteration arithmetic around the pixel loop with fewer instructions (same values bit for bit):
+// weights rounded by the 1.5 * 2^23 addition and packed with v_perm_b32 (packed_weights), the fractional parts from
+// the floor values, image / region tests as unsigned compares, the oscillation test in fp32.
+#ifndef PC_LK3_TRIM
+#define PC_LK3_TRIM 1
 #endif
 #ifndef PC_LK3_WAVES
 #define PC_LK3_WAVES 1   // wavefronts per workgroup
@@ -84,8 +90,18 @@ struct RowRegs {
 #pragma unroll
         for (int c = 0; c < CHN; c++) {
             const uint32_t a = v.d[2 * c], b = v.d[2 * c + 1], e = v.d[2 * c + 2];
+#if PC_LK3_TRIM
+            // ds_write2_b32 stores two ARBITRARY registers to two dwords; the 16-byte store the compiler forms wants
+            // four consecutive registers and pays a v_mov for each loaded dword (LDS operations of a wavefront
+            // complete in order, so the compiler's lgkmcnt waits stay sufficient with these in the queue)
+            const uint32_t p1 = __builtin_amdgcn_alignbit(b, a, 16), p3 = __builtin_amdgcn_alignbit(e, b, 16);
+            const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(dst);
+            asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(addr), "v"(a), "v"(p1), "n"(4 * c), "n"(4 * c + 1) : "memory");
+            asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(addr), "v"(b), "v"(p3), "n"(4 * c + 2), "n"(4 * c + 3) : "memory");
+#else
             *reinterpret_cast<uint4*>(dst + 4 * c) =
                 make_uint4(a, __builtin_amdgcn_alignbit(b, a, 16), b, __builtin_amdgcn_alignbit(e, b, 16));
+#endif
         }
     }
 };
@@ -94,6 +110,23 @@ struct RowRegs {
 __device__ __forceinline__ int interp_r(uint32_t top, uint32_t bot, const Weights& w, int bias) {
     const int t = __builtin_amdgcn_sdot2(__builtin_bit_cast(pc_short2, top), __builtin_bit_cast(pc_short2, w.r0), bias, true);
     return sdot2(bot, w.r1, t);
+}
+// bilinear_weights(a, b).r0 / .r1 in 14 instructions instead of 25.  cvRound(x) for 0 <= x < 2^22 is the low mantissa
+// bits of fl(x + 1.5 * 2^23) (the addition rounds to nearest even at unit granularity); scaling one factor by 2^14 before
+// the product instead of the product after it is exact, so the products round identically; the 16-bit halves are picked
+// out of the sums' bit patterns with v_perm_b32 and w11 = 2^14 - w00 - w01 - w10 is formed on those patterns.
+__device__ __forceinline__ Weights packed_weights(float a, float b) {
+    constexpr float S = (float)(1 << W_BITS), M = 12582912.f;
+    constexpr uint32_t MB = 0x4B400000u;   // bits of M
+    const float na = 1.f - a, nbs = (1.f - b) * S, bs = b * S;
+    const uint32_t t00 = __float_as_uint(na * nbs + M), t01 = __float_as_uint(a * nbs + M), t10 = __float_as_uint(na * bs + M);
+    const uint32_t w11 = ((1u << W_BITS) + 3u * MB) - (t00 + t01 + t10);
+    Weights w;
+    w.w00 = w.w01 = w.w10 = w.w11 = 0;
+    w.neg11 = false;
+    w.r0 = __builtin_amdgcn_perm(t01, t00, 0x05040100u);
+    w.r1 = __builtin_amdgcn_perm(w11, t10, 0x05040100u);
+    return w;
 }
 __device__ __forceinline__ int bias_of(int ival) { return (1 << 15) - (ival << 16); }
 // acc + hi16(a) * (int16)b.lo / b.hi
@@ -114,6 +147,14 @@ __device__ __forceinline__ int half_sum3_i32(int v) {
 }
 __device__ __forceinline__ float half_exact_sum3(int partial) {
     return exact_sum_to_float(half_sum3_i32(partial >> 16), half_sum3_i32(partial & 0xffff));
+}
+// the same when the total is known to fit int32 (NPX * 4080^2 < 2^31): one reduction, one conversion -- one rounding
+__device__ __forceinline__ float half_exact_sum3_small(int partial) { return (float)half_sum3_i32(partial); }
+// v_dot2_i32_i16 with a zero accumulator (the compiler's form is a v_mov 0 and the accumulating VOP2 encoding)
+__device__ __forceinline__ int sdot2_zero(uint32_t a, uint32_t b) {
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
 }
 // sum over a 4-lane group as ONE rounding of the exact integer
 template <int K>
@@ -232,7 +273,11 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         const Level L = p.src[level];
         const uint16_t* __restrict__ J16 = p.tgt16[tgt][level];
         const int pitch = L.pitch;
+#if PC_LK3_TRIM
+        const float lscale = __uint_as_float((uint32_t)(127 - level) << 23);   // 2^-level, the value of 1.f / (1 << level)
+#else
         const float lscale = 1.f / (float)(1 << level);
+#endif
         float px = pt.x * lscale, py = pt.y * lscale;
         float qx, qy;
         if (level == p.max_level) {
@@ -254,7 +299,11 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
             status = false;
             err = 0.f;
         }
+#if PC_LK3_TRIM
+        const Weights wI = packed_weights(px - (float)ipx, py - (float)ipy);
+#else
         const Weights wI = bilinear_weights(px - (float)ipx, py - (float)ipy);
+#endif
         const uint32_t wrow0 = wI.r0, wrow1 = wI.r1;
 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous level's J regions are dead
@@ -297,9 +346,16 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
             }
         }
         // per-lane partials fit int32; the half's totals are reduced as exact (hi, lo) halves
+#if PC_LK3_TRIM
+        static_assert((long long)NPX * 4080 * 4080 < (1ll << 31), "structure tensor sums fit int32");
+        const float A11 = half_exact_sum3_small(sA11) * FLT_SCALE;
+        const float A12 = half_exact_sum3_small(sA12) * FLT_SCALE;
+        const float A22 = half_exact_sum3_small(sA22) * FLT_SCALE;
+#else
         const float A11 = half_exact_sum3(sA11) * FLT_SCALE;
         const float A12 = half_exact_sum3(sA12) * FLT_SCALE;
         const float A22 = half_exact_sum3(sA22) * FLT_SCALE;
+#endif
         float D = A11 * A22 - A12 * A12;
         const float tdiff = A11 - A22;
         const float min_eig = (A22 + A11 - sqrtf(tdiff * tdiff + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
@@ -367,6 +423,30 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         bool staged = false;
         for (int j = 0; j < p.max_iters; j++) {
             PC_PROF_COUNT(8);
+#if PC_LK3_TRIM
+            const float fqx = floorf(qx), fqy = floorf(qy);
+            const int iqx = (int)fqx, iqy = (int)fqy;
+            if ((unsigned)(iqx + WIN) >= (unsigned)(L.w + WIN) || (unsigned)(iqy + WIN) >= (unsigned)(L.h + WIN)) {
+                if (level == 0) status = false;
+                break;
+            }
+            int ox = iqx - rx0, oy = iqy - ry0;
+            if (!staged || (unsigned)ox > (unsigned)(2 * G::MX) || (unsigned)oy > (unsigned)(2 * G::MY)) {
+                rx0 = iqx - G::MX;
+                ry0 = iqy - G::MY;
+                ox = G::MX;
+                oy = G::MY;
+                PC_PROF(4);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                stage_region<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                staged = true;
+                PC_PROF_COUNT(9);
+                PC_PROF(3);
+            }
+            const Weights wJ = packed_weights(qx - fqx, qy - fqy);   // (float)iqx == fqx
+            const uint32_t* jq = jbuf + __mul24(oy, G::PITCH) + ox;
+#else
             const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
             if (iqx < -WIN || iqx >= L.w || iqy < -WIN || iqy >= L.h) {
                 if (level == 0) status = false;
@@ -385,6 +465,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
             }
             const Weights wJ = bilinear_weights(qx - (float)iqx, qy - (float)iqy);
             const uint32_t* jq = jbuf + (iqy - ry0) * G::PITCH + (iqx - rx0);
+#endif
             int sb1 = 0, sb2 = 0;  // per-lane partials: <= K * 8160 * 4080
             // A pixel is a dependent chain dot2 -> dot2 -> mad with wait states after each dot product; walked one
             // pixel after the other that chain, not instruction issue, sets the pace (lk2 and a first version of this
@@ -445,7 +526,10 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                         for (int c = 0; c < NCH; c++) Rp[c] = __builtin_amdgcn_perm((uint32_t)R[2 * c + 1], (uint32_t)R[2 * c], 0x07060302u);
 #pragma unroll
                         for (int c = 0; c < NCH; c++) {
-                            if (c & 1) {
+                            if (PC_LK3_TRIM && st == 0 && c < 2) {   // the first term of an accumulator
+                                (c ? tb1 : sb1) = sdot2_zero(Rp[c], (uint32_t)Dxy[c * WIN + st]);
+                                (c ? tb2 : sb2) = sdot2_zero(Rp[c], (uint32_t)Dxy[c * WIN + H1 + st]);
+                            } else if (c & 1) {
                                 tb1 = sdot2(Rp[c], (uint32_t)Dxy[c * WIN + st], tb1);
                                 tb2 = sdot2(Rp[c], (uint32_t)Dxy[c * WIN + H1 + st], tb2);
                             } else {
@@ -514,7 +598,12 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
             nx = qx + half_win;
             ny = qy + half_win;
             if ((double)dx * (double)dx + (double)dy * (double)dy <= p.eps_sq) break;
+#if PC_LK3_TRIM
+            // |float| < 0.01 (a double) <=> |float| <= 0.01f: 0.01f = 0x1.47ae14p-7 is the largest float below 0.01
+            if (j > 0 && fabsf(dx + pdx) <= 0x1.47ae14p-7f && fabsf(dy + pdy) <= 0x1.47ae14p-7f) {
+#else
             if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+#endif
                 nx -= dx * 0.5f;
                 ny -= dy * 0.5f;
                 break;
@@ -540,7 +629,11 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 staged = true;
             }
+#if PC_LK3_TRIM
+            const Weights wE = packed_weights(ex - (float)iex, ey - (float)iey);
+#else
             const Weights wE = bilinear_weights(ex - (float)iex, ey - (float)iey);
+#endif
             const uint32_t* jq = jbuf + (iey - ry0) * G::PITCH + (iex - rx0);
             int se = 0;
 #pragma unroll
