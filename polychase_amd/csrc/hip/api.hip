@@ -20,7 +20,6 @@ int collect_timing(pc_context* c) {
     if (c->ranges.empty()) return PC_OK;
     PC_HIP(c->sync_side_streams());
     PC_HIP(hipStreamSynchronize(c->stream));
-    PC_HIP(hipStreamSynchronize(c->stream_b));
     // launches of one class may overlap (the analyzer's two job lanes): besides the sum of the durations keep the
     // length of the union of the intervals, placed on one time axis relative to the first range's start event
     std::vector<std::pair<float, float>> spans[PC_K_COUNT];
@@ -283,15 +282,18 @@ static int detect_slow_path(pc_context* ctx, pc_frame* f, const pc::GfttGrid& gr
 
 // The keypoint count reaches the host (waits for ev_b); frames beyond the fast path's bounds are redone on the slow path
 int detect_finish(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const pc_gftt_options& opt, DetectScratch& d,
-                  DevBuf<uint32_t>& hist) {
+                  DevBuf<uint32_t>& hist, bool* redone) {
+    if (redone) *redone = false;
     PC_HIP(hipEventSynchronize(d.ev_b));
     const uint32_t* hc = d.h_counters.p;
     const bool too_many_candidates = hc[kCntCand] > d.cand_cap;
     const bool too_many_keypoints = hc[kCntKps] >= (uint32_t)f->kp_cap && !(opt.max_corners > 0 && opt.max_corners <= f->kp_cap);
     static const bool force_slow = getenv("POLYCHASE_GFTT_SLOW_PATH") != nullptr;   // tests: the slow path must give the same keypoints
     ctx->cand_hint = std::max<uint32_t>(4096u, hc[kCntCand] + hc[kCntCand] / 4);
-    if (too_many_candidates || too_many_keypoints || hc[kCntOverflow] != 0 || force_slow)
+    if (too_many_candidates || too_many_keypoints || hc[kCntOverflow] != 0 || force_slow) {
+        if (redone) *redone = true;
         return detect_slow_path(ctx, f, grid, opt, d, hist);
+    }
     if (hc[kCntStuck] != 0) return fail(PC_E_HIP, "suppression kernel did not converge (%u lanes gave up)", hc[kCntStuck]);
     f->n_cands = (int)hc[kCntCand];
     f->n_kps = (int)hc[kCntKps];
@@ -392,6 +394,9 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
     p.min_eig_thr = (float)opt->min_eigen_threshold;
     p.out_rec = ctx->lk_rec[set].p;
     p.prof = nullptr;
+    p.gate = ctx->lk_gate_next ? ctx->lk_gate.p : nullptr;
+    p.gate_value = ctx->lk_gate_next;
+    ctx->lk_gate_next = 0;
     if (pc::lk_profile_enabled()) {   // diagnostics build: 16 words per wavefront, the latest launch only
         ctx->lk_prof_rows = (size_t)n / 2 + 1;
         PC_HIP(ctx->lk_prof.ensure(ctx->lk_prof_rows * PC_LK_PROFILE_SLOTS));
@@ -444,13 +449,28 @@ int pc_context_create(int device_index, pc_context** out) {
     if (!c) return fail(PC_E_INVALID, "out of host memory");
     c->device = device_index;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    {
+        const char* g = getenv("POLYCHASE_LK_GATE");
+        c->lk_gate_on = !(g && atoi(g) == 0);
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->prep_fence, hipEventDisableTiming);
     {
         const char* v = getenv("POLYCHASE_DETECT_STREAMS");
         c->n_detect = v ? std::max(0, std::min(2, atoi(v))) : 0;
-        for (int k = 0; k < c->n_detect && e == hipSuccess; k++) e = hipStreamCreateWithFlags(&c->detect_stream[k], hipStreamNonBlocking);
+        // POLYCHASE_DETECT_CUMASK=1 (experiment): created with a (full) CU mask a stream owns its hardware queue instead of
+        // sharing one of the runtime's pool of GPU_MAX_HW_QUEUES (4)
+        const bool masked = getenv("POLYCHASE_DETECT_CUMASK") != nullptr;
+        for (int k = 0; k < c->n_detect && e == hipSuccess; k++) {
+            if (masked) {
+                uint32_t mask[8];
+                for (uint32_t& m : mask) m = 0xffffffffu;
+                e = hipExtStreamCreateWithCUMask(&c->detect_stream[k], 8, mask);
+            } else {
+                e = hipStreamCreateWithFlags(&c->detect_stream[k], hipStreamNonBlocking);
+            }
+        }
     }
     c->work = c->stream;
     if (e != hipSuccess) {
@@ -488,6 +508,7 @@ void pc_context_destroy(pc_context* c) {
     for (auto& b : c->lk_block_counts) b.release();
     c->lk_perm.release();
     c->lk_prof.release();
+    c->lk_gate.release();
     c->lk_hist.release();
     c->lk_row_offset.release();
     c->h_row_offset.release();
@@ -508,7 +529,6 @@ int pc_context_synchronize(pc_context* c) {
     if (!c) return fail(PC_E_INVALID, "null context");
     PC_HIP(c->sync_side_streams());
     PC_HIP(hipStreamSynchronize(c->stream));
-    PC_HIP(hipStreamSynchronize(c->stream_b));
     c->prep_dirty = false;
     return PC_OK;
 }
@@ -544,7 +564,6 @@ int pc_debug_lk_profile(pc_context* c, unsigned long long* out) {
     for (int k = 0; k < PC_LK_PROFILE_SLOTS; k++) out[k] = 0;
     if (!c->lk_prof.p || c->lk_prof_rows == 0) return PC_OK;
     PC_HIP(hipStreamSynchronize(c->stream));
-    PC_HIP(hipStreamSynchronize(c->stream_b));
     std::vector<unsigned long long> h(c->lk_prof_rows * PC_LK_PROFILE_SLOTS);
     PC_HIP(hipMemcpy(h.data(), c->lk_prof.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (size_t r = 0; r < c->lk_prof_rows; r++)
@@ -637,7 +656,6 @@ void pc_frame_destroy(pc_frame* f) {
         (void)hipSetDevice(f->ctx->device);
         (void)f->ctx->sync_side_streams();
         (void)hipStreamSynchronize(f->ctx->stream);
-        (void)hipStreamSynchronize(f->ctx->stream_b);
         if (f->ctx->eig_owner == f) f->ctx->eig_owner = nullptr;
     }
     if (f->slab) (void)hipFree(f->slab);

@@ -55,6 +55,7 @@ struct pc_analyzer {
     // lane's stream order puts behind the remembered one -- waiting for it is still correct.
     static constexpr int kLaneEvents = 16;
     hipEvent_t lk_done[2][kLaneEvents] = {};
+    bool gate_armed = false;             // a gated launch is ahead: the next one waits for its "all dispatched" signal
     uint8_t* d_log = nullptr;            // optional device-resident record log
     size_t log_cap = 0, log_used = 0;
     std::vector<PinBuf<long long>> log_hdr;  // one pinned header per job slot
@@ -89,8 +90,12 @@ int detect_finish_slot(pc_analyzer* a, Slot& s) {
     {
         hipStream_t const ds = a->ctx->detect_stream_for(s.frame_id);
         PrepScope prep(a->ctx, ds);
-        if ((rc = detect_finish(a->ctx, s.frame, a->grid, a->gopt, s.scratch, s.scratch.bin_hist)) != PC_OK) return rc;
-        PC_HIP(hipEventRecord(s.kps_ready, ds));   // the slow path may have redone the keypoints
+        bool redone = false;
+        if ((rc = detect_finish(a->ctx, s.frame, a->grid, a->gopt, s.scratch, s.scratch.bin_hist, &redone)) != PC_OK) return rc;
+        // Only then: recorded unconditionally the event would sit behind the detection of the frame that was made
+        // resident a moment ago, and the LK launch of THIS frame1 would wait for it (rounds 1-2 did exactly that: the
+        // "preparation chain" that bounded the step was this false dependency)
+        if (redone) PC_HIP(hipEventRecord(s.kps_ready, ds));
     }
     s.det = DET_DONE;
     return PC_OK;
@@ -194,7 +199,6 @@ void pc_analyzer_destroy(pc_analyzer* a) {
     (void)hipSetDevice(a->ctx->device);
     (void)a->ctx->sync_side_streams();
     (void)hipStreamSynchronize(a->ctx->stream);
-    (void)hipStreamSynchronize(a->ctx->stream_b);
     for (auto& s : a->slots) {
         if (s.frame) pc_frame_destroy(s.frame);
         if (s.img_ready) (void)hipEventDestroy(s.img_ready);
@@ -353,6 +357,18 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     if (n_targets > 0) {
         if (a->fopt.window_size != s1->frame->win) return fail(PC_E_INVALID, "window size mismatch");
         SlowSection ss("submit/run_lk");
+        if (ctx->lk_gate_on && n > 0) {
+            // two job lanes: this launch starts when the one before it (other lane) has handed out its last workgroup --
+            // it fills that launch's tail and does not compete with its body
+            if (!ctx->lk_gate.p) {
+                PC_HIP(ctx->lk_gate.ensure(16));
+                PC_HIP(hipMemset(ctx->lk_gate.p, 0, 16 * sizeof(uint32_t)));
+            }
+            if (a->gate_armed) pc::launch_lk_gate(ctx->lk_gate.p, ctx->lk_gate_seq, ls);
+            ctx->lk_gate_next = ++ctx->lk_gate_seq;
+            if (ctx->lk_gate_next == 0) ctx->lk_gate_next = ++ctx->lk_gate_seq;
+            a->gate_armed = true;
+        }
         if ((rc = run_lk(ctx, s1->frame, tg, n_targets, &a->fopt, lane)) != PC_OK) return rc;
     }
     SlowSection ss_post("submit/post enqueue");
@@ -409,7 +425,6 @@ int pc_analyzer_set_device_log(pc_analyzer* a, void* d_log, size_t capacity_byte
     if (d_log && (reinterpret_cast<uintptr_t>(d_log) & 15)) return fail(PC_E_INVALID, "device log must be 16-byte aligned");
     PC_HIP(a->ctx->sync_side_streams());
     PC_HIP(hipStreamSynchronize(a->ctx->stream));
-    PC_HIP(hipStreamSynchronize(a->ctx->stream_b));
     a->d_log = static_cast<uint8_t*>(d_log);
     a->log_cap = d_log ? capacity_bytes : 0;
     a->log_used = 0;
@@ -430,7 +445,7 @@ int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out) {
     // let the runtime retire the finished commands of the other streams now, a few at a time: left alone it does
     // so in one batch of several milliseconds every couple of hundred frames, inside some later launch
     (void)hipStreamQuery(a->ctx->stream);
-    (void)hipStreamQuery(a->ctx->stream_b);
+    if (a->ctx->stream_b) (void)hipStreamQuery(a->ctx->stream_b);
     (void)hipStreamQuery(a->ctx->prep_stream);
     for (int k = 0; k < a->ctx->n_detect; k++) (void)hipStreamQuery(a->ctx->detect_stream[k]);
     out->frame1 = j.frame1;

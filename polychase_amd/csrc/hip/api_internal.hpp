@@ -66,8 +66,9 @@ int validate_gftt(const pc_gftt_options* opt, int w, int h, pc::GfttGrid* g);
 int detect_reserve(pc_context* ctx, int w, int h, DetectScratch& d);
 int detect_enqueue(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const pc_gftt_options& opt, DetectScratch& d,
                    DevBuf<uint32_t>& hist, bool full_launch = false);
+// *redone (may be null): the frame took the slow path, its keypoints were written again just now
 int detect_finish(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const pc_gftt_options& opt, DetectScratch& d,
-                  DevBuf<uint32_t>& hist);
+                  DevBuf<uint32_t>& hist, bool* redone = nullptr);
 // orders `stream` behind everything queued on the side streams so far
 int join_prep(pc_context* ctx);
 int order_keypoints_spatially(pc_context* ctx, pc_frame* f, DevBuf<uint32_t>& hist);

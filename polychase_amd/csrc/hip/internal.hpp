@@ -161,6 +161,7 @@ struct pc_context {
     }
     hipError_t sync_side_streams() const {
         hipError_t e = hipStreamSynchronize(prep_stream);
+        if (stream_b && e == hipSuccess) e = hipStreamSynchronize(stream_b);
         for (int k = 0; k < n_detect && e == hipSuccess; k++) e = hipStreamSynchronize(detect_stream[k]);
         return e;
     }
@@ -187,6 +188,10 @@ struct pc_context {
     DevBuf<uint8_t> lk_ustatus;            // pc_lk_track: unpacked status
     DevBuf<float> lk_cerr;
     DevBuf<uint32_t> lk_cidx, lk_block_counts[2], lk_perm, lk_hist;
+    DevBuf<uint32_t> lk_gate;              // LKParams::gate of the analyzer's launches (one word)
+    uint32_t lk_gate_seq = 0;              // value the latest gated launch stores
+    uint32_t lk_gate_next = 0;             // run_lk: value for the coming launch (0: not gated)
+    bool lk_gate_on = true;                // POLYCHASE_LK_GATE=0 switches the gate off
     DevBuf<unsigned long long> lk_prof;    // pc_debug_lk_profile: 16 words per wavefront of the latest launch
     size_t lk_prof_rows = 0;
     DevBuf<long long> lk_row_offset;

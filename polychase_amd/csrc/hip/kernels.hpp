@@ -102,7 +102,18 @@ struct LKParams {
     // 8/4/1-byte stores through the permutation: 8x write amplification, profiles/lk_hbm_traffic.json of round 1).
     float4* out_rec;
     unsigned long long* prof; // per-phase cycle sums (PC_LK_PROFILE builds), or null
+    // "every workgroup of this launch has been handed out": the workgroup with the highest index stores gate_value here
+    // when it starts (workgroups are dispatched in index order).  launch_lk_gate makes a stream wait for it, so that
+    // the next launch fills the tail of this one -- and no more than the tail.  May be null.
+    uint32_t* gate;
+    uint32_t gate_value;
 };
+// the stream waits (one idle wavefront) until *gate has reached `value` (wrap-around compare)
+void launch_lk_gate(const uint32_t* gate, uint32_t value, hipStream_t s);
+__device__ __forceinline__ void lk_signal_dispatched(const LKParams& p) {
+    if (p.gate && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        __hip_atomic_store(p.gate, p.gate_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 constexpr int kRecStride = 8;   // records per slot (= PC_MAX_TARGETS)
 // K8-K10: pyramidal LK, one 16-lane DPP row per (keypoint, target).  Returns false if the window
 // size is unsupported.

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
     // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only).  Keypoints are visited in
     // spatially binned order (p.perm) and each XCD gets one contiguous eighth of that order, so the
     // windows a private L2 sees belong to one image region.
+    lk_signal_dispatched(p);
     const int lb = (int)(blockIdx.x & 7u) * p.blocks_per_xcd + (int)(blockIdx.x >> 3);
     const int slot = lb * 4 + wave;
     if ((int)(blockIdx.x >> 3) >= p.blocks_per_xcd || slot >= p.n) return;  // whole waves exit together
@@ -381,6 +382,19 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const float2* __restri
     const uint32_t pos = atomicAdd(&cursor[t], 1u);
     perm[pos] = (uint32_t)i;
     slot_of[i] = pos;
+}
+
+// One wavefront that idles until the launch ahead (on another stream) has handed out all its workgroups.
+__global__ __launch_bounds__(64) void lk_gate_kernel(const uint32_t* gate, uint32_t value) {
+    if (threadIdx.x != 0) return;
+    for (uint32_t spin = 0; spin < (1u << 24); spin++) {   // ~ seconds: a tripwire, the launch ahead is already queued
+        const uint32_t v = __hip_atomic_load(const_cast<uint32_t*>(gate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int32_t)(v - value) >= 0) return;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+void launch_lk_gate(const uint32_t* gate, uint32_t value, hipStream_t s) {
+    hipLaunchKernelGGL(lk_gate_kernel, dim3(1), dim3(64), 0, s, gate, value);
 }
 
 int bin_num_tiles(int w, int h) { return ((w + 63) >> BIN_SHIFT) * ((h + 63) >> BIN_SHIFT); }

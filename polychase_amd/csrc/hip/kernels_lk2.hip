@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64 * PC_LK2_WAVES) void lk2_kernel(const LKParams p
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, l32 = lane & 31, grp = (lane >> 2) & 7, lg = lane & 3;
     // Workgroup b runs on XCD b % 8; each XCD takes one contiguous eighth of the (spatially binned) keypoint order
+    lk_signal_dispatched(p);
     const int lb = (int)(blockIdx.x & 7u) * p.blocks_per_xcd + (int)(blockIdx.x >> 3);
     const int first = (lb * PC_LK2_WAVES + wave) * 2;  // first of this wave's two keypoint slots
     if ((int)(blockIdx.x >> 3) >= p.blocks_per_xcd || first >= p.n) return;   // whole waves exit together
