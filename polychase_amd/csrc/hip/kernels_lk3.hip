@@ -40,6 +40,9 @@ namespace pc {
 #ifndef PC_LK3_TRIM
 #define PC_LK3_TRIM 1
 #endif
+#ifndef PC_LK3_PREFETCH
+#define PC_LK3_PREFETCH 1   // LDS reads of the pixel loop one step ahead of the arithmetic
+#endif
 #ifndef PC_LK3_WAVES
 #define PC_LK3_WAVES 1   // wavefronts per workgroup
 #endif
@@ -174,15 +177,27 @@ __device__ __forceinline__ float group4_exact_sum3(int partial) {
 }
 
 // Stage the J region of one group: rows lg, lg + 4, ... (a lane past the last row repeats it).  PC_LK3_STAGE_ROWS rows
-// of a lane are in flight at a time (7 VGPRs each for the 10-px window): all four would cost one memory latency per
-// region instead of two, but also push the kernel past 144 VGPRs, and three such wavefronts per SIMD then leave no
-// room in the register file for the preparation kernels that run beside LK.
+// of a lane are in flight at a time (7 VGPRs each for the 10-px window): all four cost one memory latency per region.
+// (Affordable since the lane-derived addresses stopped being hoisted across the iteration loop: the 10-px kernel needs
+// 121 VGPRs with four rows in flight, it needed 142 with one.)
 #ifndef PC_LK3_STAGE_ROWS
-#define PC_LK3_STAGE_ROWS 1
+#define PC_LK3_STAGE_ROWS 4
+#endif
+// Occupancy cap.  121 registers would let four wavefronts share a SIMD (15 per CU, then LDS-bound): 3 % faster alone,
+// but those 15 hold 153 of the CU's 160 KB of LDS and the frame-preparation kernels (16 KB tiles) starve beside them --
+// at 4K the min-eig kernel took 0.83 ms instead of 0.33 and the pipeline dropped from 640 to 557 fps.  A wavefront that
+// ALLOCATES 136 registers leaves room for three per SIMD, and with them 104 VGPRs per lane and 37 KB of LDS per CU to
+// whatever runs beside LK.  The clobber below is the whole mechanism.
+#ifndef PC_LK3_MIN_VGPR
+#define PC_LK3_MIN_VGPR "v135"
 #endif
 template <int WIN>
 __device__ __forceinline__ void stage_region(const uint16_t* __restrict__ J16, int pitch, int rx0, int ry0, uint32_t* jbuf, int lg) {
     using G = LK3Geo<WIN>;
+    // The row offsets (lg + 4k) * pitch are loop invariants of the iteration loop this is called from; hoisted out of
+    // it they sit in 8 VGPRs (64-bit each) across the kernel's most register-hungry stretch.  Staging is rare:
+    // recompute them here (the empty asm hides the invariance from the optimiser).
+    asm volatile("" : "+v"(lg));
     constexpr int TRIPS = (G::RH + G::GL - 1) / G::GL;
     constexpr int B = TRIPS < PC_LK3_STAGE_ROWS ? TRIPS : PC_LK3_STAGE_ROWS;
     const uint16_t* const base = J16 + (ptrdiff_t)(ry0 * pitch) + rx0;
@@ -224,6 +239,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
     const int half = lane >> 5, l32 = lane & 31, grp = (lane >> 2) & 7, lg = lane & 3;
     // Workgroup b runs on XCD b % 8; each XCD takes one contiguous eighth of the (spatially binned) keypoint order
     lk_signal_dispatched(p);
+    asm volatile("; occupancy cap" ::: PC_LK3_MIN_VGPR);
     const int lb = (int)(blockIdx.x & 7u) * p.blocks_per_xcd + (int)(blockIdx.x >> 3);
     const int first = (lb * PC_LK3_WAVES + wave) * 2;  // first of this wave's two keypoint slots
     if ((int)(blockIdx.x >> 3) >= p.blocks_per_xcd || first >= p.n) return;   // whole waves exit together
@@ -307,16 +323,32 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
 #endif
         const uint32_t wrow0 = wI.r0, wrow1 = wI.r1;
 
+        // Lane-derived LDS addresses of the I side and the pick-up are invariants of this level loop; hoisted out of it
+        // they would occupy ~20 VGPRs across the iteration loop below, the kernel's most register-hungry stretch.  An
+        // opaque copy of the lane index makes them per-level values that die before that loop (a handful of extra
+        // integer instructions per level).
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int l32_o = lane_o & 31, lg_o = lane_o & 3;
+        uint32_t* const ibuf_o = wbase + (lane_o >> 5) * G::HALF_I_DW;
+        int32_t* const dbuf_o = reinterpret_cast<int32_t*>(ibuf_o + G::I_DW);
+        uint32_t* const xbuf_o = ibuf_o + G::I_DW + G::D_DW;
+        int e_q0_o = 0;
+        if constexpr (KE > 0 && G::RUNS) {
+            const int e0 = lg_o * KE;
+            const int len = max(0, min(KE, G::NEXTRA - e0));
+            e_q0_o = (len > 0 ? e0 % WIN : 0) * WIN + G::WM + (len > 0 ? e0 / WIN : 0);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous level's J regions are dead
         if (i_in) {
             DerivWindow<WIN, 32> dw;
-            dw.load(L.der + (ptrdiff_t)(ipy * pitch + ipx), pitch, l32);
+            dw.load(L.der + (ptrdiff_t)(ipy * pitch + ipx), pitch, l32_o);
             // I window: lane r < WIN + 1 stages row r (the other lanes repeat the last row)
             RowRegs<G::I_CH> row;
-            const int r = min(l32, G::I_ROWS - 1);
+            const int r = min(l32_o, G::I_ROWS - 1);
             row.load(L.img16 + (ptrdiff_t)((ipy + r) * pitch) + ipx);
-            row.store(ibuf + r * G::I_PITCH);
-            dw.store(dbuf, l32);
+            row.store(ibuf_o + r * G::I_PITCH);
+            dw.store(dbuf_o, l32_o);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         PC_PROF(0);
@@ -324,12 +356,12 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         if (i_in) {
 #pragma unroll
             for (int m = 0; m < KW; m++) {
-                const int q = l32 + 32 * m;
+                const int q = l32_o + 32 * m;
                 if (q < NPX) {
                     const int y = q / WIN, x = q - y * WIN;
-                    const uint32_t* qp = ibuf + y * G::I_PITCH + x;
+                    const uint32_t* qp = ibuf_o + y * G::I_PITCH + x;
                     const int ival = interp_r(qp[0], qp[G::I_PITCH], wI, 1 << 15) >> 16;
-                    const uint32_t* d = reinterpret_cast<const uint32_t*>(dbuf) + y * G::D_PITCH + x;
+                    const uint32_t* d = reinterpret_cast<const uint32_t*>(dbuf_o) + y * G::D_PITCH + x;
                     const uint32_t d00 = d[0], d01 = d[1], d10 = d[G::D_PITCH], d11 = d[G::D_PITCH + 1];
                     // (dx00, dx01), (dx10, dx11), (dy00, dy01), (dy10, dy11)
                     const uint32_t dx0 = __builtin_amdgcn_perm(d01, d00, 0x05040100u);
@@ -338,8 +370,8 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                     const uint32_t dy1 = __builtin_amdgcn_perm(d11, d10, 0x07060302u);
                     const int ix = sdot2(dx1, wrow1, sdot2(dx0, wrow0, 1 << (W_BITS - 1))) >> W_BITS;
                     const int iy = sdot2(dy1, wrow1, sdot2(dy0, wrow0, 1 << (W_BITS - 1))) >> W_BITS;
-                    xbuf[2 * q] = (uint32_t)bias_of(ival);
-                    xbuf[2 * q + 1] = (uint32_t)(ix & 0xffff) | ((uint32_t)iy << 16);
+                    xbuf_o[2 * q] = (uint32_t)bias_of(ival);
+                    xbuf_o[2 * q + 1] = (uint32_t)(ix & 0xffff) | ((uint32_t)iy << 16);
                     sA11 += __mul24(ix, ix);   // |ix|, |iy| <= 4080
                     sA12 += __mul24(ix, iy);
                     sA22 += __mul24(iy, iy);
@@ -383,7 +415,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
             for (int c = 0; c < NCH; c++)
 #pragma unroll
                 for (int r = 0; r < WIN; r++) {
-                    const uint2 v = *reinterpret_cast<const uint2*>(xbuf + 2 * (r * WIN + lg + GL * c));
+                    const uint2 v = *reinterpret_cast<const uint2*>(xbuf_o + 2 * (r * WIN + lg_o + GL * c));
                     Bias[c * WIN + r] = (int)v.x;
                     Dxy[c * WIN + r] = (int)v.y;
                 }
@@ -403,9 +435,9 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
             for (int e = 0; e < KE; e++) {
                 uint2 v = make_uint2(0u, 0u);
                 if constexpr (G::RUNS) {
-                    if (e < e_len) v = *reinterpret_cast<const uint2*>(xbuf + 2 * (e_q0 + e * WIN));
+                    if (e < e_len) v = *reinterpret_cast<const uint2*>(xbuf_o + 2 * (e_q0_o + e * WIN));
                 } else {
-                    if (qE[e] >= 0) v = *reinterpret_cast<const uint2*>(xbuf + 2 * qE[e]);
+                    if (qE[e] >= 0) v = *reinterpret_cast<const uint2*>(xbuf_o + 2 * qE[e]);
                 }
                 Bias[KM + e] = (int)v.x;
                 Dxy[KM + e] = (int)v.y;
@@ -500,7 +532,11 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
 #pragma unroll
                     for (int u = 0; u < NR; u++) {
                         const int len = u < NRC ? ((u & 1) ? H2 : H1) : KE;
+#if PC_LK3_PREFETCH
                         if (st + 1 < len) nxt[u] = rb[u][(st + 2) * G::PITCH];
+#else
+                        if (st > 0 && st < len) bot[u] = rb[u][(st + 1) * G::PITCH];
+#endif
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -570,8 +606,10 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                         }
                     }
 #endif
+#if PC_LK3_PREFETCH
 #pragma unroll
                     for (int u = 0; u < NR; u++) bot[u] = nxt[u];
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 sb1 += tb1;   // integer sums: any order gives the same bits

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--config", default="c2")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc.json"))
+    ap.add_argument("--by-kernel", action="store_true", help="per kernel name: counters summed over the run / frames (all kernels)")
     ap.add_argument("groups", nargs="+")
     args = ap.parse_args()
     env = dict(os.environ, TMPDIR="/tmp")
@@ -39,6 +40,19 @@ def main():
             print(f"[{g}] no counter file; rocprofv3 said:\n{r.stdout[-1500:]}", file=sys.stderr)
             continue
         sums, disp = {}, set()
+        if args.by_kernel:
+            per = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    name = row.get("Kernel_Name", "").split("(")[0][:48]
+                    d2 = per.setdefault(name, {"_n": set()})
+                    d2["_n"].add((f, row["Dispatch_Id"]))
+                    d2[row["Counter_Name"]] = d2.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            for name, d2 in per.items():
+                r = result.setdefault(name, {})
+                r["dispatches"] = len(d2.pop("_n"))
+                r.update(d2)
+            continue
         for f in files:
             for row in csv.DictReader(open(f)):
                 if args.kernel not in row.get("Kernel_Name", ""):
