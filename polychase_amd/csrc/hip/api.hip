@@ -115,11 +115,16 @@ void build_pyramid(pc_context* c, pc_frame* f, int first) {
 static constexpr int kCounterCells = 16;           // header words; the first kHostCells reach the host
 static constexpr int kHostCells = 8;
 static constexpr int kCntCand = 0, kCntKps = 1, kCntStuck = 2, kCntOverflow = 3, kCntSortParams = 4;
-static constexpr int kCntTickets = 8;              // [8] NMS, [9] suppression, [10] compaction (pc::last_workgroup)
 static constexpr int kCellMaxAt = kCounterCells;
 static constexpr int kHistAt = kCellMaxAt + pc::kMaxGridCells;
 static constexpr int kCursorAt = kHistAt + pc::kSortBuckets;
-static constexpr int kCountersWords = kCursorAt + pc::kSortBuckets;
+static constexpr int kTicketsAt = kCursorAt + pc::kSortBuckets;   // three ticket arrays (pc::last_workgroup): NMS, suppression, compaction
+// workgroups of the largest launch that takes tickets: the suppression over the candidate buffer's capacity (which a
+// larger frame seen earlier may have left bigger than this frame needs) or, on the slow path, over every pixel
+static uint32_t ticket_stride(int w, int h, uint32_t cand_cap) {
+    const uint32_t npx = (uint32_t)((size_t)w * h);
+    return pc::last_workgroup_words((uint32_t)pc::suppress_num_blocks(std::max(npx, cand_cap)) + 1u) + 3u;
+}
 static constexpr uint32_t kOverflowSort = 1u, kOverflowKeypoints = 2u;   // bits of counters[kCntOverflow]
 
 int validate_gftt(const pc_gftt_options* opt, int w, int h, pc::GfttGrid* g) {
@@ -152,7 +157,9 @@ int detect_reserve(pc_context* ctx, int w, int h, DetectScratch& d) {
     PC_HIP(d.keys_bucketed.ensure(cand_cap));
     PC_HIP(d.keys_sorted.ensure(cand_cap));
     d.cand_cap = (uint32_t)std::min<size_t>(d.keys.cap, std::min(d.keys_bucketed.cap, d.keys_sorted.cap));
-    PC_HIP(d.counters.ensure(kCountersWords));
+    d.ticket_stride = ticket_stride(w, h, d.cand_cap);
+    d.counter_words = kTicketsAt + 3 * (int)d.ticket_stride;
+    PC_HIP(d.counters.ensure((size_t)d.counter_words));
     PC_HIP(d.bucket_offsets.ensure(pc::kSortBuckets + 1));
     PC_HIP(d.per_block.ensure((size_t)pc::suppress_num_blocks(d.cand_cap) + 1));
     PC_HIP(d.h_counters.ensure(kHostCells));
@@ -198,7 +205,8 @@ int detect_enqueue(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const
     PC_HIP(hist.ensure((size_t)pc::bin_num_tiles(w, h) + 1));
     uint32_t* const cnt = d.counters.p;
     // the analyzer has the level-0 kernel of the frame zero the counters (detect_clear_list): one command less in the chain
-    if (!d.cleared) PC_HIP(hipMemsetAsync(cnt, 0, kCountersWords * sizeof(uint32_t), ctx->work));
+    if (!d.cleared) PC_HIP(hipMemsetAsync(cnt, 0, (size_t)d.counter_words * sizeof(uint32_t), ctx->work));
+    uint32_t* const tickets = cnt + kTicketsAt;
     d.cleared = false;
     {
         ScopedTimer t(ctx, PC_K_MINEIG);
@@ -207,7 +215,7 @@ int detect_enqueue(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const
     {
         ScopedTimer t(ctx, PC_K_NMS);
         pc::launch_nms(d.eig.p, w, h, grid, cnt + kCellMaxAt, opt.quality_level, d.keys.p, d.cand_cap, cnt + kCntCand, d.cstate.p,
-                       cnt + kCntSortParams, cnt + kHistAt, cnt + kCntTickets, d.bucket_offsets.p, hist.p, ctx->work);
+                       cnt + kCntSortParams, cnt + kHistAt, tickets, d.bucket_offsets.p, hist.p, ctx->work);
     }
     // launches sized for the expected number of candidates (workgroups that find nothing to do still queue for a slot
     // beside the LK wavefronts), the buffers for the capacity
@@ -223,7 +231,7 @@ int detect_enqueue(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const
         ScopedTimer t(ctx, PC_K_SUPPRESS);
         pc::launch_suppress_and_compact(d.keys_sorted.p, n_launch, cnt + kCntCand, w, h, d.eig.p, d.cstate.p, ctx->sup_offsets.p,
                                         ctx->n_sup_offsets, opt.min_distance >= 1, d.per_block.p, cnt + kCntStuck, limit, f->d_kps,
-                                        cnt + kCntKps, hist.p, cnt + kCntOverflow, cnt + kCntTickets + 1, ctx->work);
+                                        cnt + kCntKps, hist.p, cnt + kCntOverflow, tickets + d.ticket_stride, d.ticket_stride, ctx->work);
     }
     // the visiting order; the same launch stores the counters in pinned host memory (no copy command behind it)
     pc::launch_spatial_bins_counted(f->d_kps, (int)std::min<uint32_t>(limit, n_launch), cnt + kCntKps, w, h, hist.p, f->d_perm,
@@ -249,10 +257,11 @@ static int detect_slow_path(pc_context* ctx, pc_frame* f, const pc::GfttGrid& gr
     PC_HIP(hist.ensure((size_t)pc::bin_num_tiles(w, h) + 1));
     uint32_t* const cnt = d.counters.p;
     d.cleared = false;
-    PC_HIP(hipMemsetAsync(cnt, 0, kCountersWords * sizeof(uint32_t), ctx->work));
+    PC_HIP(hipMemsetAsync(cnt, 0, (size_t)d.counter_words * sizeof(uint32_t), ctx->work));
+    uint32_t* const tickets = cnt + kTicketsAt;
     pc::launch_min_eig(f->levels[0], d.eig.p, grid, cnt + kCellMaxAt, ctx->work);
     pc::launch_nms(d.eig.p, w, h, grid, cnt + kCellMaxAt, opt.quality_level, d.keys.p, npx, cnt + kCntCand, d.cstate.p,
-                   cnt + kCntSortParams, cnt + kHistAt, cnt + kCntTickets, d.bucket_offsets.p, hist.p, ctx->work);
+                   cnt + kCntSortParams, cnt + kHistAt, tickets, d.bucket_offsets.p, hist.p, ctx->work);
     PC_HIP(hipMemcpyAsync(d.h_counters.p, cnt, kHostCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
     PC_HIP(hipStreamSynchronize(ctx->work));
     const uint32_t n_cand = std::min(d.h_counters.p[kCntCand], npx);
@@ -269,7 +278,7 @@ static int detect_slow_path(pc_context* ctx, pc_frame* f, const pc::GfttGrid& gr
     if ((rc = ensure_perm_capacity(f, f->kp_cap)) != PC_OK) return rc;
     pc::launch_suppress_and_compact(d.keys_sorted.p, n_cand, nullptr, w, h, d.eig.p, d.cstate.p, ctx->sup_offsets.p, ctx->n_sup_offsets,
                                     opt.min_distance >= 1, d.per_block.p, cnt + kCntStuck, (uint32_t)std::max(opt.max_corners, 0), f->d_kps,
-                                    cnt + kCntKps, hist.p, nullptr, cnt + kCntTickets + 1, ctx->work);
+                                    cnt + kCntKps, hist.p, nullptr, tickets + d.ticket_stride, d.ticket_stride, ctx->work);
     pc::launch_spatial_bins_counted(f->d_kps, cap, cnt + kCntKps, w, h, hist.p, f->d_perm, f->d_perm + f->perm_cap, nullptr, nullptr, 0,
                                     ctx->work);
     PC_HIP(hipMemcpyAsync(d.h_counters.p, cnt, kHostCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
@@ -667,7 +676,7 @@ void pc_frame_destroy(pc_frame* f) {
 }  // extern "C"
 
 // channels: 1 / 3 = u8 gray / RGB; elem_size 4 = float32 RGB(A) with `channels` floats per pixel
-int pc_api::detect_counter_words() { return kCountersWords; }
+int pc_api::detect_counter_words(const DetectScratch& d) { return d.counter_words; }
 
 int pc_api::set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t row_pitch, int on_device, int channels,
                       int elem_size, uint32_t* clear, int clear_words) {

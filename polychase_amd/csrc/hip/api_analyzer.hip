@@ -233,7 +233,7 @@ static int analyzer_put(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, si
     // the detection that follows expects its counters zeroed: the frame's first kernel does it on the way
     const bool clear_here = will_detect && a->ctx->n_detect == 0;
     int rc = set_image(a->ctx, s.frame, rgb, row_pitch, on_device, channels, elem_size, clear_here ? s.scratch.counters.p : nullptr,
-                       detect_counter_words());
+                       detect_counter_words(s.scratch));
     s.scratch.cleared = rc == PC_OK && clear_here;
     if (rc != PC_OK) {
         s.valid = false;

@@ -81,6 +81,6 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
 // `clear` (may be null): clear_words words zeroed in front of the frame's kernels (by the level-0 kernel where there is one)
 int set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t row_pitch, int on_device, int channels, int elem_size = 1,
               uint32_t* clear = nullptr, int clear_words = 0);
-int detect_counter_words();   // words of DetectScratch::counters a detection expects zeroed
+int detect_counter_words(const DetectScratch& d);   // words of DetectScratch::counters a detection expects zeroed
 
 }  // namespace pc_api

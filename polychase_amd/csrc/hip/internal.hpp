@@ -119,6 +119,8 @@ struct DetectScratch {
     PinBuf<uint32_t> h_counters;           // counters[0..7] after the detection
     hipEvent_t ev_b = nullptr;
     uint32_t cand_cap = 0;                 // candidates the fast path holds
+    int counter_words = 0;                 // words of `counters` (header, cell maxima, bucket counts + cursors, tickets)
+    uint32_t ticket_stride = 0;            // words between the three ticket arrays at the end of `counters`
     bool cleared = false;                  // `counters` were zeroed in front of the coming detection (by the frame's level-0 kernel)
     void release() {
         keys.release();

@@ -52,7 +52,7 @@ void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* ce
 // (ordered(value) << 32 | y*w+x) appended to `keys` (capacity `cap`), count in *counter; cstate (w*h bytes): 1 at
 // candidates, 0 elsewhere, every pixel written; sort_params[2] / hist[kSortBuckets]: value range and per-bucket counts
 // of the candidates for launch_bucket_sort (hist zeroed by the caller).  The workgroup that finishes last scans the
-// bucket counts into bucket_offsets[kSortBuckets + 1] (`ticket`: one zeroed word); bin_hist (may be null):
+// bucket counts into bucket_offsets[kSortBuckets + 1] (`ticket`: pc::last_workgroup_words(workgroups) zeroed words); bin_hist (may be null):
 // bin_num_tiles(w, h) words zeroed here for launch_suppress_and_compact.
 constexpr int kSortBuckets = 8192;
 void launch_nms(const float* eig, int w, int h, const GfttGrid& g, const uint32_t* cell_max, double quality_level,
@@ -73,12 +73,12 @@ void launch_bucket_sort(const unsigned long long* keys, uint32_t cap, uint32_t n
 //     keypoints per 64x64 tile and its last workgroup scans the counts (= the input of launch_spatial_bins_counted).
 // The number of candidates is min(*n_dev, n_max) (n_dev may be null); the launches cover n_max; *overflow |= 4 when
 // *n_dev exceeds n_max.  suppress == false: min_distance < 1, everything is accepted (gftt.cc:165-181).  *stuck != 0
-// afterwards means the spin bound hit.  tickets: two zeroed words.
+// afterwards means the spin bound hit.  tickets: two zeroed arrays (pc::last_workgroup_words of the workgroup count), ticket_stride apart.
 int suppress_num_blocks(uint32_t n);
 void launch_suppress_and_compact(const unsigned long long* keys, uint32_t n_max, const uint32_t* n_dev, int w, int h, const float* eig,
                                  uint8_t* cstate, const int2* offsets, int n_offsets, bool suppress, uint32_t* per_block,
                                  uint32_t* stuck, uint32_t max_corners, float2* xy, uint32_t* n_out, uint32_t* bin_hist,
-                                 uint32_t* overflow, uint32_t* tickets, hipStream_t s);
+                                 uint32_t* overflow, uint32_t* tickets, uint32_t ticket_stride, hipStream_t s);
 // K4 fallback: descending radix sort of the candidate keys (rocPRIM), count on the host.  temp may be null to query bytes.
 hipError_t sort_keys_desc(void* temp, size_t& temp_bytes, unsigned long long* keys_in,
                           unsigned long long* keys_out, uint32_t n, hipStream_t s);

@@ -615,13 +615,14 @@ __global__ __launch_bounds__(SUP_BLOCK) void accepted_scatter_kernel(const unsig
 
 int suppress_num_blocks(uint32_t n) { return (int)((n + SUP_BLOCK - 1) / SUP_BLOCK); }
 
-// Suppression + ordered compaction: TWO launches.  `tickets` = two zeroed words (one per launch, see last_workgroup);
+// Suppression + ordered compaction: TWO launches.  `tickets` = two zeroed arrays of last_workgroup_words(blocks) words,
+// ticket_stride words apart (one per launch, see last_workgroup);
 // `n_out` receives the keypoint count, per_block is scratch [suppress_num_blocks(n_max) + 1].  With `bin_hist` (zeroed,
 // bin_num_tiles words) the compaction also leaves the tiles' first positions of the LK visiting order there.
 void launch_suppress_and_compact(const unsigned long long* keys, uint32_t n_max, const uint32_t* n_dev, int w, int h, const float* eig,
                                  uint8_t* cstate, const int2* offsets, int n_offsets, bool suppress, uint32_t* per_block,
                                  uint32_t* stuck, uint32_t max_corners, float2* xy, uint32_t* n_out, uint32_t* bin_hist,
-                                 uint32_t* overflow, uint32_t* tickets, hipStream_t s) {
+                                 uint32_t* overflow, uint32_t* tickets, uint32_t ticket_stride, hipStream_t s) {
     uint32_t* const accepted_per_block = per_block;
     const int nb = suppress_num_blocks(n_max);
     if (nb == 0) return;
@@ -633,7 +634,7 @@ void launch_suppress_and_compact(const unsigned long long* keys, uint32_t n_max,
         hipLaunchKernelGGL(accept_all_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, cstate, accepted_per_block, fin);
     const int tiles_x = (w + 63) >> 6, n_tiles = bin_hist ? bin_num_tiles(w, h) : 0;
     hipLaunchKernelGGL(accepted_scatter_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, w, cstate, per_block, max_corners, xy,
-                       bin_hist, tiles_x, n_tiles, tickets + 1);
+                       bin_hist, tiles_x, n_tiles, tickets + ticket_stride);
 }
 
 // ------------------------------------------------------------------------------------------------
