@@ -175,6 +175,18 @@ static int upload_suppression_offsets(pc_context* ctx, const pc_gftt_options& op
     PC_HIP(hipStreamSynchronize(ctx->work));  // a queued suppression may still read the old table
     PC_HIP(hipMemcpy(ctx->sup_offsets.p, offs.data(), offs.size() * sizeof(int2), hipMemcpyHostToDevice));
     ctx->n_sup_offsets = (int)offs.size();
+    // the same neighbourhood as half-widths per row (the set is symmetric and contiguous in dx for every dy)
+    int R = 0;
+    for (const int2& o : offs) R = std::max(R, std::max(std::abs(o.x), std::abs(o.y)));
+    std::vector<int> hw((size_t)2 * R + 1, -1);
+    for (const int2& o : offs) hw[(size_t)(o.y + R)] = std::max(hw[(size_t)(o.y + R)], std::abs(o.x));
+    hw[(size_t)R] = std::max(hw[(size_t)R], 0);   // the centre row always holds the candidate itself
+    size_t covered = 0;
+    for (int v : hw) covered += v >= 0 ? (size_t)(2 * v + 1) : 0;
+    if (covered != offs.size() + 1) return fail(PC_E_INVALID, "suppression neighbourhood is not row-contiguous");
+    PC_HIP(ctx->sup_rows.ensure(hw.size()));
+    PC_HIP(hipMemcpy(ctx->sup_rows.p, hw.data(), hw.size() * sizeof(int), hipMemcpyHostToDevice));
+    ctx->sup_R = R;
     ctx->sup_min_distance = opt.min_distance;
     return PC_OK;
 }
@@ -230,7 +242,8 @@ int detect_enqueue(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const
     {
         ScopedTimer t(ctx, PC_K_SUPPRESS);
         pc::launch_suppress_and_compact(d.keys_sorted.p, n_launch, cnt + kCntCand, w, h, d.eig.p, d.cstate.p, ctx->sup_offsets.p,
-                                        ctx->n_sup_offsets, opt.min_distance >= 1, d.per_block.p, cnt + kCntStuck, limit, f->d_kps,
+                                        ctx->n_sup_offsets, ctx->sup_rows.p, ctx->sup_R, opt.min_distance >= 1, d.per_block.p,
+                                        cnt + kCntStuck, limit, f->d_kps,
                                         cnt + kCntKps, hist.p, cnt + kCntOverflow, tickets + d.ticket_stride, d.ticket_stride, ctx->work);
     }
     // the visiting order; the same launch stores the counters in pinned host memory (no copy command behind it)
@@ -277,7 +290,7 @@ static int detect_slow_path(pc_context* ctx, pc_frame* f, const pc::GfttGrid& gr
     if (rc != PC_OK) return rc;
     if ((rc = ensure_perm_capacity(f, f->kp_cap)) != PC_OK) return rc;
     pc::launch_suppress_and_compact(d.keys_sorted.p, n_cand, nullptr, w, h, d.eig.p, d.cstate.p, ctx->sup_offsets.p, ctx->n_sup_offsets,
-                                    opt.min_distance >= 1, d.per_block.p, cnt + kCntStuck, (uint32_t)std::max(opt.max_corners, 0), f->d_kps,
+                                    ctx->sup_rows.p, ctx->sup_R, opt.min_distance >= 1, d.per_block.p, cnt + kCntStuck, (uint32_t)std::max(opt.max_corners, 0), f->d_kps,
                                     cnt + kCntKps, hist.p, nullptr, tickets + d.ticket_stride, d.ticket_stride, ctx->work);
     pc::launch_spatial_bins_counted(f->d_kps, cap, cnt + kCntKps, w, h, hist.p, f->d_perm, f->d_perm + f->perm_cap, nullptr, nullptr, 0,
                                     ctx->work);
@@ -502,6 +515,7 @@ void pc_context_destroy(pc_context* c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     c->staging.release();
     c->sup_offsets.release();
+    c->sup_rows.release();
     if (c->detect) {
         c->detect->release();
         delete c->detect;

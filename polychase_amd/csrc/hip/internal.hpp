@@ -174,6 +174,8 @@ struct pc_context {
     DevBuf<uint8_t> staging;
     // GFTT scratch
     DevBuf<int2> sup_offsets;              // suppression neighbourhood for sup_min_distance
+    DevBuf<int> sup_rows;                  // the same as half-widths per row, [2 * sup_R + 1]
+    int sup_R = 0;
     double sup_min_distance = -1.0;
     int n_sup_offsets = 0;
     // candidates of the latest finished detection + 25 %: the detections enqueued next size their launches for that many

@@ -65,6 +65,8 @@ void launch_nms(const float* eig, int w, int h, const GfttGrid& g, const uint32_
 void launch_bucket_sort(const unsigned long long* keys, uint32_t cap, uint32_t n_launch, const uint32_t* counter, const uint32_t* sort_params,
                         const uint32_t* offsets, uint32_t* cursor, unsigned long long* scratch, unsigned long long* out,
                         uint32_t* overflow, hipStream_t s);
+// offsets[n_offsets]: the (dx, dy) of the suppression neighbourhood; row_hw[2 R + 1]: the same set as half-widths per row
+// (row dy holds |dx| <= row_hw[dy + R], -1: none), the form the kernel walks.
 // K5: exact greedy min-distance suppression (gftt.cc:100-164) over the candidates SORTED by priority (keys descending),
 // then the accepted ones in priority order -> float2 keypoints (truncated to max_corners if > 0).  TWO launches:
 //   suppression: cstate becomes 2 (accepted) / 3 (rejected) at every candidate; its last workgroup scans the accepted
@@ -76,7 +78,8 @@ void launch_bucket_sort(const unsigned long long* keys, uint32_t cap, uint32_t n
 // afterwards means the spin bound hit.  tickets: two zeroed arrays (pc::last_workgroup_words of the workgroup count), ticket_stride apart.
 int suppress_num_blocks(uint32_t n);
 void launch_suppress_and_compact(const unsigned long long* keys, uint32_t n_max, const uint32_t* n_dev, int w, int h, const float* eig,
-                                 uint8_t* cstate, const int2* offsets, int n_offsets, bool suppress, uint32_t* per_block,
+                                 uint8_t* cstate, const int2* offsets, int n_offsets, const int* row_hw, int R, bool suppress,
+                                 uint32_t* per_block,
                                  uint32_t* stuck, uint32_t max_corners, float2* xy, uint32_t* n_out, uint32_t* bin_hist,
                                  uint32_t* overflow, uint32_t* tickets, uint32_t ticket_stride, hipStream_t s);
 // K4 fallback: descending radix sort of the candidate keys (rocPRIM), count on the host.  temp may be null to query bytes.

@@ -483,6 +483,7 @@ __global__ __launch_bounds__(SUP_BLOCK) void suppress_sorted_kernel(const unsign
                                                                     const uint32_t* __restrict__ n_dev, int w, int h,
                                                                     const float* __restrict__ eig, uint8_t* cstate,
                                                                     const int2* __restrict__ offsets, int n_offsets,
+                                                                    const int* __restrict__ row_hw, int R,
                                                                     uint32_t* __restrict__ accepted_per_block,
                                                                     uint32_t* __restrict__ stuck, AcceptedScan fin) {
     const uint32_t n = n_dev ? min(*n_dev, n_max) : n_max;   // the launch covers n_max; workgroups past the count leave at once
@@ -499,20 +500,35 @@ __global__ __launch_bounds__(SUP_BLOCK) void suppress_sorted_kernel(const unsign
         my_idx = (uint32_t)key;
         y = (int)(my_idx / (uint32_t)w);
         x = (int)(my_idx - (uint32_t)y * (uint32_t)w);
-        for (int o = 0; o < n_offsets; o++) {
-            const int nx = x + offsets[o].x, ny = y + offsets[o].y;
-            if (nx < 0 || nx >= w || ny < 0 || ny >= h) continue;
-            const uint32_t nidx = (uint32_t)(ny * w + nx);
-            if (cstate[nidx] == 0) continue;   // plain load: "is a candidate" never changes during this kernel
-            const uint32_t nval = float_to_ordered(eig[nidx]);
-            if (!(nval > my_val || (nval == my_val && nidx > my_idx))) continue;  // lower priority
-            if (n_nb < SUP_NB) {
+        // The neighbourhood (the offsets table: dx^2 + dy^2 < min_distance^2) row by row: row dy spans |dx| <= row_hw[dy + R].
+        // Its state bytes are read as aligned dwords -- ~40 independent loads per lane for min_distance 5 where the
+        // offset-by-offset walk made 80 byte loads, each behind a branch.  Plain loads: "is a candidate" (non-zero) never
+        // changes during this kernel, and a byte that changes 1 -> 2 / 3 under the load stays non-zero.
+        for (int dy = -R; dy <= R; dy++) {
+            const int ny = y + dy, hw = row_hw[dy + R];
+            if (ny < 0 || ny >= h || hw < 0) continue;
+            const uint32_t lin0 = (uint32_t)(ny * w + max(x - hw, 0)), lin1 = (uint32_t)(ny * w + min(x + hw, w - 1));
+            for (uint32_t a = lin0 & ~3u; a <= lin1; a += 4u) {
+                uint32_t v = *reinterpret_cast<const uint32_t*>(cstate + a);
+                // bytes of this dword outside [lin0, lin1]
+                if (a < lin0) v &= 0xffffffffu << (8u * (lin0 - a));
+                if (a + 3u > lin1) v &= 0xffffffffu >> (8u * (a + 3u - lin1));
+                while (v) {
+                    const uint32_t b = (uint32_t)(__ffs((int)v) - 1) >> 3;
+                    v &= ~(0xffu << (8u * b));
+                    const uint32_t nidx = a + b;
+                    if (nidx == my_idx) continue;
+                    const uint32_t nval = float_to_ordered(eig[nidx]);
+                    if (!(nval > my_val || (nval == my_val && nidx > my_idx))) continue;  // lower priority
+                    if (n_nb < SUP_NB) {
 #pragma unroll
-                for (int k = 0; k < SUP_NB; k++)
-                    if (k == n_nb) nb[k] = nidx;
-                n_nb++;
-            } else {
-                overflow = true;
+                        for (int k = 0; k < SUP_NB; k++)
+                            if (k == n_nb) nb[k] = nidx;
+                        n_nb++;
+                    } else {
+                        overflow = true;
+                    }
+                }
             }
         }
     }
@@ -620,7 +636,8 @@ int suppress_num_blocks(uint32_t n) { return (int)((n + SUP_BLOCK - 1) / SUP_BLO
 // `n_out` receives the keypoint count, per_block is scratch [suppress_num_blocks(n_max) + 1].  With `bin_hist` (zeroed,
 // bin_num_tiles words) the compaction also leaves the tiles' first positions of the LK visiting order there.
 void launch_suppress_and_compact(const unsigned long long* keys, uint32_t n_max, const uint32_t* n_dev, int w, int h, const float* eig,
-                                 uint8_t* cstate, const int2* offsets, int n_offsets, bool suppress, uint32_t* per_block,
+                                 uint8_t* cstate, const int2* offsets, int n_offsets, const int* row_hw, int R, bool suppress,
+                                 uint32_t* per_block,
                                  uint32_t* stuck, uint32_t max_corners, float2* xy, uint32_t* n_out, uint32_t* bin_hist,
                                  uint32_t* overflow, uint32_t* tickets, uint32_t ticket_stride, hipStream_t s) {
     uint32_t* const accepted_per_block = per_block;
@@ -629,7 +646,7 @@ void launch_suppress_and_compact(const unsigned long long* keys, uint32_t n_max,
     const AcceptedScan fin{tickets, n_out, overflow, max_corners};
     if (suppress)
         hipLaunchKernelGGL(suppress_sorted_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, w, h, eig, cstate, offsets,
-                           n_offsets, accepted_per_block, stuck, fin);
+                           n_offsets, row_hw, R, accepted_per_block, stuck, fin);
     else
         hipLaunchKernelGGL(accept_all_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, cstate, accepted_per_block, fin);
     const int tiles_x = (w + 63) >> 6, n_tiles = bin_hist ? bin_num_tiles(w, h) : 0;
