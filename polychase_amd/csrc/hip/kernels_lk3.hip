@@ -398,6 +398,12 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
             lvl_ok = false;
         }
         D = 1.f / D;
+#if PC_LK3_TRIM
+        // b = sum * 2^-20 enters the solve only through products that are then multiplied by D: the power of two commutes
+        // with every rounding on the way (nothing gets near the denormals), so it is applied to D once per level instead
+        // of to both sums in every iteration
+        D *= FLT_SCALE;
+#endif
         lvl_ok = lvl_ok && tgt_active;   // idle groups only help with the I side
 
         // every group picks up the pixels it owns
@@ -442,6 +448,17 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 Bias[KM + e] = (int)v.x;
                 Dxy[KM + e] = (int)v.y;
             }
+#if PC_LK3_PAIRS
+            if constexpr (KE > 1 && G::RUNS) {
+                // the run of the remaining columns: pixels 2m and 2m + 1 share slots 2m (ix pair) and 2m + 1 (iy pair)
+#pragma unroll
+                for (int e = 0; e + 1 < KE; e += 2) {
+                    const uint32_t a = (uint32_t)Dxy[KM + e], b = (uint32_t)Dxy[KM + e + 1];
+                    Dxy[KM + e] = (int)__builtin_amdgcn_perm(b, a, 0x05040100u);
+                    Dxy[KM + e + 1] = (int)__builtin_amdgcn_perm(b, a, 0x07060302u);
+                }
+            }
+#endif
         }
         // the J regions alias the I-side buffers of BOTH halves: no group may stage before every group has read
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -513,6 +530,8 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 uint32_t top[NR > 0 ? NR : 1];
                 const uint32_t* rb[NR > 0 ? NR : 1];
                 int tb1 = 0, tb2 = 0;
+                int r_even = 0;   // PC_LK3_PAIRS: the extra run's result of the even step, waiting for its partner
+                (void)r_even;
 #pragma unroll
                 for (int u = 0; u < NRC; u++) {
                     rb[u] = jq + lg + GL * (u >> 1) + ((u & 1) ? H1 * G::PITCH : 0);
@@ -584,9 +603,18 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                         }
                     }
                     if constexpr (NR > NRC) {
+                        // the run of the remaining columns: its pixels of steps 2m and 2m + 1 as a pair as well
                         if (st < KE) {
-                            tb1 = mad16_hl(R[NRC], (uint32_t)Dxy[KM + st], tb1);
-                            tb2 = mad16_hh(R[NRC], (uint32_t)Dxy[KM + st], tb2);
+                            if ((st & 1) == 0 && st + 1 < KE) {
+                                r_even = R[NRC];
+                            } else if (st & 1) {
+                                const uint32_t rp = __builtin_amdgcn_perm((uint32_t)R[NRC], (uint32_t)r_even, 0x07060302u);
+                                tb1 = sdot2(rp, (uint32_t)Dxy[KM + st - 1], tb1);
+                                tb2 = sdot2(rp, (uint32_t)Dxy[KM + st], tb2);
+                            } else {
+                                tb1 = mad16_hl(R[NRC], (uint32_t)Dxy[KM + st], tb1);
+                                tb2 = mad16_hh(R[NRC], (uint32_t)Dxy[KM + st], tb2);
+                            }
                         }
                     }
 #else
@@ -628,8 +656,13 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                     sb2 = mad16_hh(R[e], (uint32_t)Dxy[KM + e], sb2);
                 }
             }
+#if PC_LK3_TRIM
+            const float b1 = group4_exact_sum3<K>(sb1);
+            const float b2 = group4_exact_sum3<K>(sb2);
+#else
             const float b1 = group4_exact_sum3<K>(sb1) * FLT_SCALE;
             const float b2 = group4_exact_sum3<K>(sb2) * FLT_SCALE;
+#endif
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             qx += dx;
