@@ -1,0 +1,47 @@
+"""GPU: every execution-strategy knob of the library must leave the flow database unchanged.
+
+The knobs select kernels (LK variants 1/2/3, fused / unfused pyramid), the detection path (device-count bucket sort / the
+synchronous slow path with the rocPRIM sort) and the stream layout of the analyzer (gate between the job lanes, detection
+on its own stream(s)).  They are read when the library or a context is created, so each variant runs in its own process
+(tests/_analyze_hash.py: polychase_core.generate_optical_flow_database on a 26-frame clip -> sha256 of all rows)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+VARIANTS = [
+    {"POLYCHASE_LK_GATE": "0"},
+    {"POLYCHASE_DETECT_STREAMS": "1"},
+    {"POLYCHASE_DETECT_STREAMS": "2", "GPU_MAX_HW_QUEUES": "8"},
+    {"POLYCHASE_GFTT_SLOW_PATH": "1"},
+    {"POLYCHASE_LK_VARIANT": "2"},
+    {"POLYCHASE_LK_VARIANT": "1"},
+    {"POLYCHASE_PYRAMID_VARIANT": "1"},
+]
+
+
+def _hash(extra_env, size=(416, 304, 26)):
+    env = dict(os.environ)
+    for k in ("POLYCHASE_LK_GATE", "POLYCHASE_DETECT_STREAMS", "POLYCHASE_GFTT_SLOW_PATH", "POLYCHASE_LK_VARIANT",
+              "POLYCHASE_PYRAMID_VARIANT", "GPU_MAX_HW_QUEUES"):
+        env.pop(k, None)
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_analyze_hash.py"), *map(str, size)], env=env, text=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("HASH ")]
+    assert r.returncode == 0 and lines, f"variant {extra_env} failed:\n{r.stdout[-2000:]}\n{r.stderr[-3000:]}"
+    return lines[-1].split()[1]
+
+
+@pytest.fixture(scope="module")
+def reference_hash():
+    return _hash({})
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
+def test_knob_does_not_change_the_database(reference_hash, variant):
+    assert _hash(variant) == reference_hash
