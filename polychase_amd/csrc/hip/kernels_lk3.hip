@@ -240,6 +240,8 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
     // Workgroup b runs on XCD b % 8; each XCD takes one contiguous eighth of the (spatially binned) keypoint order
     lk_signal_dispatched(p);
     asm volatile("; occupancy cap" ::: PC_LK3_MIN_VGPR);
+    // (dealing the order to the XCDs in tile-sized chunks instead of contiguous eighths was tried: 2-6 % slower, the
+    // launch's tail is not an imbalance between XCDs)
     const int lb = (int)(blockIdx.x & 7u) * p.blocks_per_xcd + (int)(blockIdx.x >> 3);
     const int first = (lb * PC_LK3_WAVES + wave) * 2;  // first of this wave's two keypoint slots
     if ((int)(blockIdx.x >> 3) >= p.blocks_per_xcd || first >= p.n) return;   // whole waves exit together
@@ -381,9 +383,16 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         // per-lane partials fit int32; the half's totals are reduced as exact (hi, lo) halves
 #if PC_LK3_TRIM
         static_assert((long long)NPX * 4080 * 4080 < (1ll << 31), "structure tensor sums fit int32");
-        const float A11 = half_exact_sum3_small(sA11) * FLT_SCALE;
+        const int S11 = half_sum3_i32(sA11), S22 = half_sum3_i32(sA22);
+        const float A11 = (float)S11 * FLT_SCALE;
         const float A12 = half_exact_sum3_small(sA12) * FLT_SCALE;
-        const float A22 = half_exact_sum3_small(sA22) * FLT_SCALE;
+        const float A22 = (float)S22 * FLT_SCALE;
+        // |sum over any subset of the window of diff * ix| <= sqrt(NPX) * 8160 * sqrt(S11) (Cauchy-Schwarz, |diff| <= 8160):
+        // below 2^31 the b-vector's sums over the four lanes of a group can be formed in int32 (then ONE conversion, the
+        // same single rounding as the fp64 route).  True for every keypoint of the benchmark clips; a window full of
+        // 0 / 255 edges (S = 100 * 4080^2) takes the fp64 route.  Wavefront-uniform: both keypoints must qualify.
+        constexpr long long kSmallS = (1ll << 62) / ((long long)NPX * 8160 * 8160);
+        const bool int_sums = __all((!i_in) || ((long long)S11 < kSmallS && (long long)S22 < kSmallS));
 #else
         const float A11 = half_exact_sum3(sA11) * FLT_SCALE;
         const float A12 = half_exact_sum3(sA12) * FLT_SCALE;
@@ -657,8 +666,17 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 }
             }
 #if PC_LK3_TRIM
-            const float b1 = group4_exact_sum3<K>(sb1);
-            const float b2 = group4_exact_sum3<K>(sb2);
+            float b1, b2;
+            if (int_sums) {
+                int t1 = sb1 + dpp_i32<0xB1>(sb1), t2 = sb2 + dpp_i32<0xB1>(sb2);
+                t1 += dpp_i32<0x4E>(t1);
+                t2 += dpp_i32<0x4E>(t2);
+                b1 = (float)t1;
+                b2 = (float)t2;
+            } else {
+                b1 = group4_exact_sum3<K>(sb1);
+                b2 = group4_exact_sum3<K>(sb2);
+            }
 #else
             const float b1 = group4_exact_sum3<K>(sb1) * FLT_SCALE;
             const float b2 = group4_exact_sum3<K>(sb2) * FLT_SCALE;
