@@ -111,6 +111,12 @@ int pc_debug_llt9(pc_context* ctx, const float* a81, const float* b9, float* l81
  * and OpticalFlowCache (:18-37). */
 int pc_frame_create(pc_context* ctx, int width, int height, int window_size, int max_level,
                     pc_frame** out);
+/* Values of the `on_device` argument of the pc_frame_set_* / pc_analyzer_put_frame* calls:
+ * 0 = pageable host memory (copied synchronously: the caller may reuse it when the call returns), 1 = memory the GPU can
+ * read (device memory, or pc_host_buffer_alloc memory read over PCIe by the kernels), PC_FRAME_PINNED_HOST = page-locked
+ * host memory (pc_host_buffer_alloc) that the caller leaves untouched until the frame has been consumed
+ * (pc_analyzer_frame_ingested; for pc_frame_set_*: the next synchronising call): fetched by the copy engine, no wait. */
+#define PC_FRAME_PINNED_HOST 2
 void pc_frame_destroy(pc_frame* f);
 
 /* cv::cvtColor(COLOR_RGB2GRAY) (opticalflow.cc:259,:298) + cv::buildOpticalFlowPyramid

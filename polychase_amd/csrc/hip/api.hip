@@ -707,7 +707,16 @@ int pc_api::set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t r
     }
     const uint8_t* d_src = src;
     size_t d_pitch = row_pitch;
-    if (!on_device) {
+    if (on_device == PC_FRAME_PINNED_HOST) {
+        // page-locked host memory the caller leaves alone until the frame has been consumed: one DMA transfer into the
+        // staging buffer, stream-ordered, no wait.  (The kernels can also read such memory themselves -- on_device = 1 --
+        // but then a level-0 kernel holds its CUs for as long as PCIe takes: 33 MB of float pixels at 17 GB/s against
+        // 50 GB/s for the copy engine.)
+        const size_t bytes = row_pitch * (size_t)f->h;
+        PC_HIP(ctx->staging.ensure(bytes));
+        PC_HIP(hipMemcpyAsync(ctx->staging.p, src, bytes, hipMemcpyHostToDevice, ctx->work));
+        d_src = ctx->staging.p;
+    } else if (!on_device) {
         d_pitch = align_up(row_bytes, 16);
         PC_HIP(ctx->staging.ensure(d_pitch * f->h));
         // the previous frame's kernels may still read the staging buffer: ordered on the same stream

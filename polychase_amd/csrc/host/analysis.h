@@ -58,6 +58,7 @@ struct FrameView {
                            // converted on the GPU like the addon's `(image * 255).astype(np.uint8)`
     size_t row_pitch = 0;  // bytes between rows
     bool on_device = false;
+    bool pinned_host = false;   // with on_device: `data` is page-locked host memory (frame_pool.h) -> PC_FRAME_PINNED_HOST
     std::shared_ptr<void> owner;
 };
 

@@ -302,11 +302,13 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
                 std::lock_guard<std::mutex> lk(db_mtx);
                 will_detect = !db->KeypointsExist(fid);
             }
+            static const bool ingest_dma = !(std::getenv("POLYCHASE_INGEST_DMA") && std::atoi(std::getenv("POLYCHASE_INGEST_DMA")) == 0);
+            const int where = !f->on_device ? 0 : (f->pinned_host && f->owner && ingest_dma ? PC_FRAME_PINNED_HOST : 1);
             const int put_rc =
                 f->elem_size == 4
                     ? pc_analyzer_put_frame_f32(eng.an, fid, reinterpret_cast<const float*>(f->data), f->row_pitch, f->channels,
-                                                f->on_device ? 1 : 0, will_detect ? 1 : 0)
-                    : pc_analyzer_put_frame(eng.an, fid, f->data, f->row_pitch, f->on_device ? 1 : 0, will_detect ? 1 : 0);
+                                                where, will_detect ? 1 : 0)
+                    : pc_analyzer_put_frame(eng.an, fid, f->data, f->row_pitch, where, will_detect ? 1 : 0);
             if (put_rc != PC_OK) ThrowHip("pc_analyzer_put_frame");
             if (f->on_device && f->owner) frames_in_flight.emplace_back(fid, std::move(f->owner));
             release_ingested(frames_in_flight.size() > 24);   // bounded: the pool behind the owners is finite

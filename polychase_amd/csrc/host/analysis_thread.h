@@ -73,6 +73,7 @@ class OpticalFlowThread : public Worker<OpticalFlowThreadMessage> {
         view.elem_size = elem_size;
         view.row_pitch = row_bytes;
         view.on_device = true;   // device-accessible (pinned) host memory
+        view.pinned_host = true;
         view.owner = std::move(pixels);
         {
             std::lock_guard<std::mutex> lk(frame_mtx_);

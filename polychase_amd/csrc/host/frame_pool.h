@@ -12,3 +12,8 @@
 
 // Pinned buffer of at least `bytes`; returned to the pool when the last reference goes away.
 std::shared_ptr<void> AcquirePinnedFrameBuffer(size_t bytes);
+
+// memcpy for frames: large copies are cut into pieces for a few persistent worker threads.  One core copies ~8 GB/s into
+// pinned memory -- 0.8 ms for a 1080p uint8 frame, 4 ms for Blender's float32 RGBA pixels (33 MB), i.e. 250 frames/s
+// before the GPU has seen anything; the PCIe link behind it takes 50 GB/s.
+void CopyFrameBytes(void* dst, const void* src, size_t bytes);

@@ -52,9 +52,13 @@ std::optional<FrameView> FrameFromPython(const py::object& obj, std::deque<py::o
         F32Array fa = F32Array::ensure(obj);
         if (!fa || fa.ndim() != 3) throw py::value_error("float frame must have shape (H, W, 3|4)");
         std::shared_ptr<void> buf = AcquirePinnedFrameBuffer(static_cast<size_t>(fa.size()) * sizeof(float));
-        std::memcpy(buf.get(), fa.data(), static_cast<size_t>(fa.size()) * sizeof(float));
+        {
+            py::gil_scoped_release nogil;   // `fa` keeps the array alive
+            CopyFrameBytes(buf.get(), fa.data(), static_cast<size_t>(fa.size()) * sizeof(float));
+        }
         FrameView v;
-        v.on_device = true;   // pinned host memory, read by the GPU directly (frame_pool.h)
+        v.on_device = true;   // pinned host memory (frame_pool.h)
+        v.pinned_host = true;
         v.data = static_cast<const uint8_t*>(buf.get());
         v.rows = static_cast<int>(fa.shape(0));
         v.cols = static_cast<int>(fa.shape(1));
@@ -67,9 +71,13 @@ std::optional<FrameView> FrameFromPython(const py::object& obj, std::deque<py::o
     U8Array a = U8Array::ensure(obj);
     if (!a || a.ndim() != 3) throw py::value_error("frame must be a uint8 array of shape (H, W, 3)");
     std::shared_ptr<void> buf = AcquirePinnedFrameBuffer(static_cast<size_t>(a.size()));
-    std::memcpy(buf.get(), a.data(), static_cast<size_t>(a.size()));
+    {
+        py::gil_scoped_release nogil;   // `a` keeps the array alive
+        CopyFrameBytes(buf.get(), a.data(), static_cast<size_t>(a.size()));
+    }
     FrameView v;
-    v.on_device = true;   // pinned host memory, read by the GPU directly (frame_pool.h)
+    v.on_device = true;   // pinned host memory (frame_pool.h)
+    v.pinned_host = true;
     v.data = static_cast<const uint8_t*>(buf.get());
     v.rows = static_cast<int>(a.shape(0));
     v.cols = static_cast<int>(a.shape(1));
