@@ -121,13 +121,14 @@ void Database::Open(const std::string& path) {
     // another connection may be in the middle of a commit (the analysis bulk-loads under a rollback journal, so a reader
     // that opens the file meanwhile meets a locked database): wait instead of failing with SQLITE_BUSY
     sqlite3_busy_timeout(db_, 10000);
-    // Opt-in, not in the reference: POLYCHASE_DB_PAGE_SIZE=32768 creates NEW databases with larger pages (the blobs of
-    // one frame are ~5 MB: with 4 KiB pages most of the insert time goes into overflow-page chains; 32 KiB pages
-    // measured 1.7x faster).  The page size is a property of the file -- the reference reads and appends to such a
-    // database unchanged, and an existing database keeps the size it was created with.  Default: SQLite's, like
-    // the reference.
-    if (const char* ps = std::getenv("POLYCHASE_DB_PAGE_SIZE")) {
-        const int v = std::atoi(ps);
+    // Not in the reference: NEW databases are created with 64 KiB pages (the blobs of one frame are ~5 MB: with SQLite's
+    // default of 4 KiB most of the insert time goes into overflow-page chains; C2 with the insert in the loop: 425 -> 890
+    // frames/s).  The page size is a property of the file -- the reference reads and appends to such a database
+    // unchanged, and an existing database keeps the size it was created with.  POLYCHASE_DB_PAGE_SIZE=4096 gives the
+    // reference's (SQLite's) default.
+    {
+        int v = 65536;
+        if (const char* ps = std::getenv("POLYCHASE_DB_PAGE_SIZE")) v = std::atoi(ps);
         if (v >= 512 && v <= 65536 && (v & (v - 1)) == 0) Exec(("PRAGMA page_size=" + std::to_string(v)).c_str(), __LINE__);
     }
     for (const char* pragma : kPragmas) Exec(pragma, __LINE__);

@@ -108,9 +108,10 @@ def test_no_gpu_means_loud_failure(core, tmp_path):
         core.generate_optical_flow_database(vi, lambda fid: np.zeros((48, 64, 3), np.uint8), None, str(tmp_path / "x.db"))
 
 
-def test_optional_page_size_keeps_the_database_interchangeable(core, tmp_path, monkeypatch):
-    """POLYCHASE_DB_PAGE_SIZE (opt-in, 2x faster inserts): a plain SQLite property of NEW files; same schema and rows,
-    an existing database keeps its page size, nonsense values are ignored."""
+def test_page_size_keeps_the_database_interchangeable(core, tmp_path, monkeypatch):
+    """New databases get 64-KiB pages (2x faster inserts), POLYCHASE_DB_PAGE_SIZE chooses another size (4096 = the
+    reference's): a plain SQLite property of NEW files; same schema and rows, an existing database keeps its page size,
+    nonsense values leave SQLite's default."""
     kp = np.arange(20, dtype=np.float32).reshape(10, 2)
     idx = np.arange(5, dtype=np.uint32)
 
@@ -128,19 +129,23 @@ def test_optional_page_size_keeps_the_database_interchangeable(core, tmp_path, m
         con.close()
         return v, schema, rows
 
-    a, b, c = (str(tmp_path / n) for n in ("default.db", "big.db", "bogus.db"))
+    monkeypatch.delenv("POLYCHASE_DB_PAGE_SIZE", raising=False)
+    a, b, c, d = (str(tmp_path / n) for n in ("default.db", "reference.db", "bogus.db", "mid.db"))
     fill(a)
-    monkeypatch.setenv("POLYCHASE_DB_PAGE_SIZE", "32768")
+    monkeypatch.setenv("POLYCHASE_DB_PAGE_SIZE", "4096")
     fill(b)
     db = core.Database(a)                      # re-opening an existing file does not change it
     db.close()
     monkeypatch.setenv("POLYCHASE_DB_PAGE_SIZE", "12345")
     fill(c)
+    monkeypatch.setenv("POLYCHASE_DB_PAGE_SIZE", "32768")
+    fill(d)
     pa, sa, ra = page_size(a)
     pb, sb, rb = page_size(b)
     pc_, sc, rc = page_size(c)
-    assert pa == 4096 and pb == 32768 and pc_ == 4096
-    assert sa == sb == sc and ra == rb == rc
+    pd, sd, rd = page_size(d)
+    assert pa == 65536 and pb == 4096 and pc_ == 4096 and pd == 32768
+    assert sa == sb == sc == sd and ra == rb == rc == rd
 
 
 def test_bulk_load_journal_mode_round_trip(core, tmp_path):
