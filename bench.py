@@ -210,6 +210,7 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
         nxt += K
         if dist_path:
             an.an.set_device_log(log)   # resets the log (synchronises: outside the timed region)
+            stitch.reset()              # ... and the pieces gathered in the previous region
         barrier()
         ctx.enable_timing(["lk"])   # HIP events around the dominant kernel only (2 records per step)
         ctx.reset_timing()

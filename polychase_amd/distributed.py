@@ -210,7 +210,14 @@ class ChunkedLogStitch:
         if self.world == 1:
             return
         mx = max(16, (int(max_piece_bytes) + 15) // 16 * 16)
-        self._pool = [torch.empty(self.world * mx, dtype=torch.uint8, device=self.log.device) for _ in range(n_pieces)]
+        self._reserved = [torch.empty(self.world * mx, dtype=torch.uint8, device=self.log.device) for _ in range(n_pieces)]
+        self._pool = list(self._reserved)
+
+    def reset(self):
+        """Forget the pieces gathered so far (the log is about to be reused from offset 0) and take their receive
+        buffers back into the pool."""
+        self.pieces = []
+        self._pool = list(getattr(self, "_reserved", []))
 
     def warm_up(self):
         """One tiny exchange per group before anything is timed: the first collective of a communicator sets up its

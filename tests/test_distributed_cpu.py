@@ -124,12 +124,15 @@ def _stitch_worker(rank, world, port, first, n, out_dir, use_side):
     st.reserve(2, 1 << 15)                                         # two pooled receive buffers, the rest allocated on demand
     per = 3                                                        # frames per piece (the last piece is ragged)
     n_pieces = (max(D.shard_range(first, n, world, r)[1] - D.shard_range(first, n, world, r)[0] for r in range(world)) + per - 1) // per
-    for c in range(n_pieces):                                      # every rank issues the same number of collectives
-        lo, hi = min(c * per, e - b), min((c + 1) * per, e - b)
-        st.gather(bounds[lo], bounds[hi])
-    recs = []
-    for buf, used in st.rank_logs():
-        recs += D.parse_device_log(buf, used)
+    for region in range(2):                                        # bench.py reuses the log and the stitch for every timed region
+        st.reset()
+        for c in range(n_pieces):                                  # every rank issues the same number of collectives
+            lo, hi = min(c * per, e - b), min((c + 1) * per, e - b)
+            st.gather(bounds[lo], bounds[hi])
+        recs = []
+        for buf, used in st.rank_logs():
+            recs += D.parse_device_log(buf, used)
+        assert len(recs) == n, f"region {region}: {len(recs)} records, expected {n}"
     h, p = D.pack_records(sorted(recs, key=lambda r: r[0]))
     np.save(os.path.join(out_dir, f"sh{rank}.npy"), h)
     np.save(os.path.join(out_dir, f"sp{rank}.npy"), p)
