@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict_
     const int x = x0 + tx;
     const int cell_x0 = x0 / g.cell_w, cell_y0 = y0 / g.cell_h;
     const bool small_cells = (g.cell_w < TW) || (g.cell_h < TH);
+    const int cell_bx = (cell_x0 + 1) * g.cell_w, cell_by = (cell_y0 + 1) * g.cell_h;   // block-uniform
     double hxx[6], hxy[6], hyy[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -142,11 +143,13 @@ __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict_
             const float e = (a + c) - sqrtf(t * t + b * b);
             eig[(size_t)y * w + x] = e;
             const uint32_t key = float_to_ordered(e);
-            const int cx = x / g.cell_w, cy = y / g.cell_h;
             if (small_cells) {
+                const int cx = x / g.cell_w, cy = y / g.cell_h;
                 atomicMax(&cell_max[cy * g.cols + cx], key);
             } else {
-                atomicMax(&s_max[(cy - cell_y0) * 2 + (cx - cell_x0)], key);
+                // a tile spans at most two cells per axis: the cell of a pixel is a comparison with the next cell
+                // boundary, not a division (5 per lane before)
+                atomicMax(&s_max[(y >= cell_by ? 2 : 0) + (x >= cell_bx ? 1 : 0)], key);
             }
         }
     }
