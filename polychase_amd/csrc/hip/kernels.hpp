@@ -100,6 +100,9 @@ struct LKParams {
     int max_iters;
     double eps_sq;
     float min_eig_thr;
+    // lk3: the smallest float x with fl(x / (2 win^2)) >= min_eig_thr (filled in by launch_lk3; NaN: not available).
+    // fl(x / c) is monotone in x, so "fl(x / c) < thr" is "x < this" -- the per-level IEEE division becomes a compare.
+    float min_eig_num_thr;
     // Raw result records in VISITING order: out_rec[slot * 8 + target] = (next.x, next.y, err, bits(status)); slot s
     // tracks keypoint perm[s].  A wavefront's 16 results are 256 contiguous bytes (they used to be 48 scattered
     // 8/4/1-byte stores through the permutation: 8x write amplification, profiles/lk_hbm_traffic.json of round 1).

@@ -21,6 +21,9 @@
 //     wavefront, so the 12 wavefronts of a CU (3 per SIMD at this register count) fit the 160 KB of LDS.
 //   * The uint16 planes carry two addressable slack rows above and below the padded image: a region never needs
 //     address clamping, there is ONE staging path.
+#include <cmath>
+#include <limits>
+
 #include "lk_common.hpp"
 
 namespace pc {
@@ -400,9 +403,12 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
 #endif
         float D = A11 * A22 - A12 * A12;
         const float tdiff = A11 - A22;
-        const float min_eig = (A22 + A11 - sqrtf(tdiff * tdiff + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+        const float min_eig_num = A22 + A11 - sqrtf(tdiff * tdiff + 4.f * A12 * A12);
+        // min_eig = min_eig_num / (2 WIN^2) < thr, without the division (LKParams::min_eig_num_thr)
+        const bool weak = (p.min_eig_num_thr == p.min_eig_num_thr) ? (min_eig_num < p.min_eig_num_thr)
+                                                                    : (min_eig_num / (float)(2 * WIN * WIN) < p.min_eig_thr);
         bool lvl_ok = i_in;
-        if (i_in && (min_eig < p.min_eig_thr || D < 1.1920928955078125e-07f /* FLT_EPSILON */)) {
+        if (i_in && (weak || D < 1.1920928955078125e-07f /* FLT_EPSILON */)) {
             if (level == 0) status = false;
             lvl_ok = false;
         }
@@ -777,9 +783,26 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         p.out_rec[(size_t)slot * kRecStride + tgt] = make_float4(nx, ny, status ? err : 0.f, __uint_as_float(status ? 1u : 0u));
 }
 
+// smallest float x with fl(x / c) >= thr (c > 0, thr finite and positive); NaN if the search does not settle
+static float division_threshold(float thr, float c) {
+    if (!(thr > 0.f) || !std::isfinite(thr)) return std::numeric_limits<float>::quiet_NaN();
+    float x = thr * c;
+    if (!std::isfinite(x)) return std::numeric_limits<float>::quiet_NaN();
+    for (int i = 0; i < 64 && !(x / c >= thr); i++) x = std::nextafterf(x, std::numeric_limits<float>::infinity());
+    for (int i = 0; i < 64; i++) {
+        const float y = std::nextafterf(x, -std::numeric_limits<float>::infinity());
+        if (!(y / c >= thr)) break;
+        x = y;
+    }
+    const float below = std::nextafterf(x, -std::numeric_limits<float>::infinity());
+    if (!(x / c >= thr) || (below / c >= thr)) return std::numeric_limits<float>::quiet_NaN();
+    return x;
+}
+
 template <int WIN>
 static void launch_lk3_t(const LKParams& p0, hipStream_t s) {
     LKParams p = p0;
+    p.min_eig_num_thr = division_threshold(p.min_eig_thr, (float)(2 * WIN * WIN));
     const int per_block = 2 * PC_LK3_WAVES;   // two keypoints per wavefront
     const int blocks = (p.n + per_block - 1) / per_block;
     if (blocks == 0) return;
