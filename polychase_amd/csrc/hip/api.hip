@@ -532,6 +532,7 @@ void pc_context_destroy(pc_context* c) {
     c->lk_perm.release();
     c->lk_prof.release();
     c->lk_gate.release();
+    c->lk_gate_timed_out.release();
     c->lk_hist.release();
     c->lk_row_offset.release();
     c->h_row_offset.release();

@@ -363,8 +363,16 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
             if (!ctx->lk_gate.p) {
                 PC_HIP(ctx->lk_gate.ensure(16));
                 PC_HIP(hipMemset(ctx->lk_gate.p, 0, 16 * sizeof(uint32_t)));
+                PC_HIP(ctx->lk_gate_timed_out.ensure(1));
+                ctx->lk_gate_timed_out.p[0] = 0u;
             }
-            if (a->gate_armed) pc::launch_lk_gate(ctx->lk_gate.p, ctx->lk_gate_seq, ls);
+            if (*static_cast<volatile uint32_t*>(ctx->lk_gate_timed_out.p) != 0u) {
+                // a gate kernel waited in vain: the lanes' streams share a hardware queue, the launch it waited for was
+                // queued BEHIND it.  No more gates in this context.
+                ctx->lk_gate_on = false;
+                if (pc::trace_allocations()) fprintf(stderr, "[polychase_hip] LK gate timed out (streams share a hardware queue): gate switched off\n");
+            }
+            if (a->gate_armed && ctx->lk_gate_on) pc::launch_lk_gate(ctx->lk_gate.p, ctx->lk_gate_seq, ctx->lk_gate_timed_out.p, ls);
             ctx->lk_gate_next = ++ctx->lk_gate_seq;
             if (ctx->lk_gate_next == 0) ctx->lk_gate_next = ++ctx->lk_gate_seq;
             a->gate_armed = true;

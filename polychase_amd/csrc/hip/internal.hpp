@@ -193,6 +193,7 @@ struct pc_context {
     DevBuf<float> lk_cerr;
     DevBuf<uint32_t> lk_cidx, lk_block_counts[2], lk_perm, lk_hist;
     DevBuf<uint32_t> lk_gate;              // LKParams::gate of the analyzer's launches (one word)
+    PinBuf<uint32_t> lk_gate_timed_out;    // raised by a gate kernel that gave up (its stream shares a hardware queue with the other lane)
     uint32_t lk_gate_seq = 0;              // value the latest gated launch stores
     uint32_t lk_gate_next = 0;             // run_lk: value for the coming launch (0: not gated)
     bool lk_gate_on = true;                // POLYCHASE_LK_GATE=0 switches the gate off

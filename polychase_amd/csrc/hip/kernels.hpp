@@ -114,8 +114,9 @@ struct LKParams {
     uint32_t* gate;
     uint32_t gate_value;
 };
-// the stream waits (one idle wavefront) until *gate has reached `value` (wrap-around compare)
-void launch_lk_gate(const uint32_t* gate, uint32_t value, hipStream_t s);
+// the stream waits (one idle wavefront) until *gate has reached `value` (wrap-around compare); gives up after ~50 ms
+// and stores 1 to *timed_out (device-visible host memory, may be null)
+void launch_lk_gate(const uint32_t* gate, uint32_t value, uint32_t* timed_out, hipStream_t s);
 __device__ __forceinline__ void lk_signal_dispatched(const LKParams& p) {
     if (p.gate && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
         __hip_atomic_store(p.gate, p.gate_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -385,16 +385,20 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const float2* __restri
 }
 
 // One wavefront that idles until the launch ahead (on another stream) has handed out all its workgroups.
-__global__ __launch_bounds__(64) void lk_gate_kernel(const uint32_t* gate, uint32_t value) {
+// The launch ahead was enqueued first and normally runs already.  If the two streams share a hardware queue, though (the
+// process holds more HIP streams than the runtime has queues), this kernel sits in FRONT of the launch it waits for: after
+// ~50 ms it gives up and raises *timed_out (pinned host memory) -- the analyzer then stops using the gate.
+__global__ __launch_bounds__(64) void lk_gate_kernel(const uint32_t* gate, uint32_t value, uint32_t* timed_out) {
     if (threadIdx.x != 0) return;
-    for (uint32_t spin = 0; spin < (1u << 24); spin++) {   // ~ seconds: a tripwire, the launch ahead is already queued
+    for (uint32_t spin = 0; spin < 25000u; spin++) {
         const uint32_t v = __hip_atomic_load(const_cast<uint32_t*>(gate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int32_t)(v - value) >= 0) return;
-        __builtin_amdgcn_s_sleep(32);
+        __builtin_amdgcn_s_sleep(64);
     }
+    if (timed_out) __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-void launch_lk_gate(const uint32_t* gate, uint32_t value, hipStream_t s) {
-    hipLaunchKernelGGL(lk_gate_kernel, dim3(1), dim3(64), 0, s, gate, value);
+void launch_lk_gate(const uint32_t* gate, uint32_t value, uint32_t* timed_out, hipStream_t s) {
+    hipLaunchKernelGGL(lk_gate_kernel, dim3(1), dim3(64), 0, s, gate, value, timed_out);
 }
 
 int bin_num_tiles(int w, int h) { return ((w + 63) >> BIN_SHIFT) * ((h + 63) >> BIN_SHIFT); }
