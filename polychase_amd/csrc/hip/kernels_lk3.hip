@@ -203,7 +203,7 @@ __device__ __forceinline__ void stage_region(const uint16_t* __restrict__ J16, i
     asm volatile("" : "+v"(lg));
     constexpr int TRIPS = (G::RH + G::GL - 1) / G::GL;
     constexpr int B = TRIPS < PC_LK3_STAGE_ROWS ? TRIPS : PC_LK3_STAGE_ROWS;
-    const uint16_t* const base = J16 + (ptrdiff_t)(ry0 * pitch) + rx0;
+    const uint16_t* const base = J16 + (ptrdiff_t)__mul24(ry0, pitch) + rx0;   // |ry0|, pitch < 2^23: the 24-bit multiply is full rate
 #pragma unroll
     for (int k0 = 0; k0 < TRIPS; k0 += B) {
         RowRegs<G::CH> rows[B];
@@ -213,7 +213,7 @@ __device__ __forceinline__ void stage_region(const uint16_t* __restrict__ J16, i
             if (k < TRIPS) {
                 int r = lg + G::GL * k;
                 if (G::GL * (k + 1) > G::RH) r = min(r, G::RH - 1);
-                rows[b].load(base + (ptrdiff_t)(r * pitch));
+                rows[b].load(base + (ptrdiff_t)__mul24(r, pitch));
             }
         }
 #pragma unroll
@@ -347,11 +347,11 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous level's J regions are dead
         if (i_in) {
             DerivWindow<WIN, 32> dw;
-            dw.load(L.der + (ptrdiff_t)(ipy * pitch + ipx), pitch, l32_o);
+            dw.load(L.der + (ptrdiff_t)(__mul24(ipy, pitch) + ipx), pitch, l32_o);
             // I window: lane r < WIN + 1 stages row r (the other lanes repeat the last row)
             RowRegs<G::I_CH> row;
             const int r = min(l32_o, G::I_ROWS - 1);
-            row.load(L.img16 + (ptrdiff_t)((ipy + r) * pitch) + ipx);
+            row.load(L.img16 + (ptrdiff_t)__mul24(ipy + r, pitch) + ipx);
             row.store(ibuf_o + r * G::I_PITCH);
             dw.store(dbuf_o, l32_o);
         }
