@@ -5,7 +5,7 @@ The oracle records the iterations it ran per (keypoint, level) (pco_set_lk_iter_
 the script then replays the GPU kernel's wavefront mapping (2 keypoints x 8 targets per wavefront, a level costs the
 maximum over its 16 pairs) and alternatives.  The numbers behind DESIGN.md section 4 "What is left".
 
-    python tools/lk_divergence.py [--width 1920 --height 1080 --frame 100]
+    python tests/studies/lk_divergence.py [--width 1920 --height 1080 --frame 100]
 """
 import argparse
 import ctypes as C
@@ -14,7 +14,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

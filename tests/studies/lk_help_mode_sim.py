@@ -6,11 +6,12 @@ an issued iteration costs O + P instructions (O = everything around the pixel lo
 8 / k pairs of each half-wave are still active, k groups could share a pair: P / k, plus E instructions of exchange per
 iteration and S per change of mode.  The numbers behind DESIGN.md section 4 "What is left" (a).
 
-    python tools/lk_help_mode_sim.py
+    python tests/studies/lk_help_mode_sim.py
 """
 import sys, os, ctypes as C
 import numpy as np
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import oracle
 from polychase_amd import synth
 W,H,F=1280,720,100
