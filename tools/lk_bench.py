@@ -7,9 +7,9 @@ C ABI, then `pc_lk_track` is repeated: the LK class is timed with HIP events by 
 the average launch time and a checksum of the raw outputs (equal checksums <=> bit-identical
 results, the way kernel variants are compared: POLYCHASE_HIP_LIB selects the library).
 
-    python tools/lk_bench.py [--config c2|c3] [--reps 20] [--check 2000]
+    python tools/lk_bench.py [--config c2|c3] [--reps 20]
 
---check N: additionally compare the first N keypoints x 2 targets with the CPU oracle (bit-exact).
+(Parity against the CPU oracle is the test suite's business: tests/test_gpu_parity.py, tests/test_fullsize_gpu.py.)
 """
 from __future__ import annotations
 
@@ -33,7 +33,6 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--frame", type=int, default=100)
-    ap.add_argument("--check", type=int, default=0)
     ap.add_argument("--window", type=int, default=10)
     args = ap.parse_args()
 
@@ -85,21 +84,6 @@ def main():
         names = ["i_stage", "i_eval", "pickup", "j_stage", "iterate", "err", "life", "waves", "wave_iters", "stagings"]
         w = max(1, prof[7])
         out["profile_cycles_per_wave"] = {n: round(v / w, 1) for n, v in zip(names, prof)}
-    if args.check:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle  # checker only
-        m = min(args.check, n)
-        kps = f1.keypoints()
-        g0 = f1.gray()
-        p0 = oracle.Pyramid(g0, win=args.window, max_level=max_level)
-        ofl = oracle.flow_options(max_level=max_level, window_size=args.window)
-        bad = 0
-        for t in (0, 4):
-            p1 = oracle.Pyramid(targets[t].gray(), win=args.window, max_level=max_level)
-            oxy, ost, oerr = oracle.lk(p0, p1, kps[:m], ofl)
-            bad += int((ost != st[t][:m]).sum()) + int((oxy != xy[t][:m]).any(axis=1).sum()) + int((oerr != err[t][:m]).sum())
-        out["oracle_mismatches"] = bad
-        out["oracle_checked"] = 2 * m
     print(json.dumps(out), flush=True)
     for f in frames.values():
         f.close()
