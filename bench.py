@@ -378,10 +378,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # the container hostname may not resolve
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # testing aid (tests/test_bench_gpu.py): several ranks on ONE GPU over gloo -- the N > 1 control flow of this script
+    # without an N-GPU node.  RCCL wants one GPU per rank, so the real thing stays the default.
+    share_gpu = os.environ.get("POLYCHASE_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     K, W = args.steps, args.warmup
     single = world == 1 and not args.force_dist_path
