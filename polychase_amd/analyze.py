@@ -115,12 +115,20 @@ def main(argv=None) -> int:
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # testing aid (tests/test_sharded_gpu.py): all ranks on GPU 0 over gloo -- the launcher end to end without an N-GPU node
+    share_gpu = os.environ.get("POLYCHASE_ANALYZE_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     core = _core()
     fopt = core.OpticalFlowOptions()
     if args.npy:

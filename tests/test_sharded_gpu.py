@@ -130,3 +130,23 @@ def test_c4_rank_workload_at_4k(core, tmp_path):
                              "order by image_id_from, rowid"))
     con.close()
     assert got_k == want_k and got_f == want_f
+
+
+def test_launcher_with_two_ranks_on_one_gpu(tmp_path):
+    """polychase_amd.analyze as a user launches it (torch.distributed.run, two processes): both ranks on GPU 0 over gloo
+    (POLYCHASE_ANALYZE_SHARE_GPU=1) -- shard ranges, device logs, the all-gather, rank 0's store -- against the same
+    command with one process."""
+    import subprocess
+
+    def run(nproc, db, port):
+        env = dict(os.environ, POLYCHASE_ANALYZE_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "-m", "polychase_amd.analyze", "--synthetic", "c1", "--frames", "23", "--database", db]
+        r = subprocess.run(cmd, text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+
+    one, two = str(tmp_path / "one.db"), str(tmp_path / "two.db")
+    run(1, one, 29551)
+    run(2, two, 29552)
+    a, b = _dump(one), _dump(two)
+    assert len(a[0]) == 23 and a == b
