@@ -16,9 +16,11 @@ region is reported (`config.timed_regions`), so that a short driver run is not a
 The headline line is the 1080p configuration C2 (BASELINE.json configs[1]); the same JSON object carries
 the 4K configuration C3 under "c3" (the >= 30x target is quoted on 4K) unless --no-c3.
 
-N > 1: launched by torch.distributed.run, one rank per GPU; frames are sharded across ranks
-(contiguous ranges + 8-frame halo, no data-path collective) and the flow records are stitched with
-an RCCL all-gather inside the timed region.  scaling = "weak".
+N > 1: `python bench.py --gpus N ...` launches N ranks by itself (it re-executes through torch.distributed.run on
+127.0.0.1 and fails if the node has fewer than N GPUs); started under torch.distributed.run / torchrun it joins that job
+instead (WORLD_SIZE must equal --gpus).  One rank per GPU; every rank analyses its own contiguous range of frame ids
+(rank r: ids from 1 + r * RANK_ID_STRIDE, no data-path collective) and the flow records are stitched over RCCL inside the
+timed region, in pieces that overlap the analysis.  scaling = "weak".
 """
 from __future__ import annotations
 
@@ -49,6 +51,7 @@ CLIP_FRAMES = 300
 MIN_PREWARM = 24
 MIN_REGION_S = 0.5
 LK_KERNEL = "lk3_kernel<10>"
+RANK_ID_STRIDE = 1 << 20   # rank r owns frame ids 1 + r * stride ...: disjoint, ordered shards like analyze.py's
 
 
 def level_pixels(w, h, max_level, win=10):
@@ -141,7 +144,8 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
 
     def source(fid):
         # the clip played forwards and backwards over and over: a continuous motion for any number of frame ids
-        t = (fid + rank * 37) % (2 * CLIP_FRAMES - 2)
+        # (ranks start at different phases of it: fid carries the rank's id offset)
+        t = (fid % RANK_ID_STRIDE + (fid // RANK_ID_STRIDE) * 37) % (2 * CLIP_FRAMES - 2)
         return clip_frames[t if t < CLIP_FRAMES else 2 * CLIP_FRAMES - 2 - t]
 
     ctx = hip.Context(dev.index or 0)
@@ -150,7 +154,7 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
     dist_path = world > 1 or args.force_dist_path
 
     # ---- how many K-step regions: a short probe after the pre-warm gives the step time ----
-    first_id = 1
+    first_id = 1 + rank * RANK_ID_STRIDE
     an = ClipAnalyzer(ctx, w, h, first_id, 1 << 30, source, hip.gftt_options(**gopt_kw), hip.flow_options(**fopt_kw), max_jobs=3)
 
     def barrier():
@@ -260,6 +264,8 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
             for r, (buf, used) in enumerate(stitch.rank_logs()):
                 recs = D.parse_device_log(buf, used)
                 assert len(recs) == K and [x[0] for x in recs] == list(range(recs[0][0], recs[0][0] + K)), "stitched log is not K consecutive frames"
+                # the shards are disjoint and in rank order: rank r's ids are this rank's ids shifted by (r - rank) strides
+                assert recs[0][0] == timed.start + (r - rank) * RANK_ID_STRIDE, "stitched shards are not the ranks' disjoint id ranges"
                 if r == rank:
                     assert [x[0] for x in recs] == list(timed)
                     assert [len(x[1]) for x in recs] == n_kps[-K:] and [sum(len(v[0]) for v in x[2].values()) for x in recs] == n_rows[-K:]
@@ -352,6 +358,29 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
     return out
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run N ranks of this command through torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1) and return its exit code.  The sharded loop being launched is the
+    reference's frame loop, cpp/opticalflow.cc:209-321, on N disjoint frame ranges."""
+    import socket
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if os.environ.get("POLYCHASE_BENCH_SHARE_GPU") != "1" and have < n:
+        print(f"bench.py: --gpus {n} needs {n} GPUs, this node has {have} "
+              "(POLYCHASE_BENCH_SHARE_GPU=1 puts all ranks on GPU 0 over gloo: a testing aid, not a measurement)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -368,11 +397,15 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))     # N ranks of this very command; rank 0 of them prints the JSON line
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus):
+        sys.exit(f"bench.py: --gpus {args.gpus} but the job has WORLD_SIZE={world}: refusing to report a mislabelled number")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -36,3 +36,32 @@ def test_two_ranks_on_one_gpu_over_gloo():
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 16 and out["scaling"] == "weak" and out["value"] > 0
+
+
+def test_gpus_flag_launches_the_ranks_itself():
+    """`python3 bench.py --gpus 2 --steps 16 --warmup 4` -- the form the driver uses, no torchrun around it: bench.py
+    re-executes itself through torch.distributed.run with two ranks (on this one-GPU box both on GPU 0 over gloo, the
+    SHARE_GPU testing aid) and exactly one JSON line with n_gpus == 2 comes out (round 2 parsed --gpus and ignored it)."""
+    env = dict(os.environ, POLYCHASE_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "4",
+                        "--config", "c1", "--no-c3", "--no-breakdown"],
+                       text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 16 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["parallelism"] == "frame-shard x2"
+
+
+def test_gpus_flag_fails_loudly_without_enough_gpus():
+    """Without the testing aid a one-GPU box must refuse --gpus 2 instead of measuring one GPU and labelling it two."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "POLYCHASE_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "needs 2 GPUs" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
