@@ -237,6 +237,16 @@ int pc_analyzer_pending(const pc_analyzer* a);
 #define PC_LOG_MAGIC 0x50434c4f47303031ll /* "PCLOG001" */
 int pc_analyzer_set_device_log(pc_analyzer* a, void* d_log, size_t capacity_bytes);
 int pc_analyzer_device_log_used(const pc_analyzer* a, size_t* bytes);
+/* The jobs submitted from now on append to another buffer, from its offset 0, without waiting for anything (set_device_log
+ * synchronises the streams): the multi-GPU driver hands the log over piece by piece while the analysis keeps running
+ * (analysis_driver.cc, polychase_amd/analyze.py -- the store of cpp/opticalflow.cc:149-151 overlapped with the analysis).
+ * The bytes of the previous buffer are complete once the last job submitted into it has been collected.
+ * A job whose record does not fit is refused by pc_analyzer_submit with PC_E_CAPACITY BEFORE anything of it is enqueued:
+ * the caller can redirect the log and submit the same frame1 again. */
+int pc_analyzer_redirect_device_log(pc_analyzer* a, void* d_log, size_t capacity_bytes);
+/* enabled = 0: the records of the following jobs are not downloaded to pinned host memory (a rank whose records leave
+ * through the device log only); pc_analyzer_collect then returns counts and NULL array pointers.  Default 1. */
+int pc_analyzer_set_host_records(pc_analyzer* a, int enabled);
 /* Wait for the oldest submitted job.  Pointers stay valid until the job slot is reused, i.e. for
  * the next max_jobs-1 submits. */
 int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out);

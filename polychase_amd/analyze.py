@@ -1,15 +1,19 @@
 """Multi-GPU "Analyze Video": GenerateOpticalFlowDatabase (reference cpp/opticalflow.cc:209-321) with the frame1 loop
 sharded over the GPUs of one node, one process per GPU (BASELINE.json config C4).
 
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \\
-        -m polychase_amd.analyze --synthetic c3 --frames 2400 --database /tmp/clip.db
-
 Every rank runs the SAME host code as the single-GPU path -- polychase_core's C++ driver over the C ABI -- on its
-contiguous range of frame1 ids (polychase_core.generate_optical_flow_records: the frames up to 8 outside the range are
-ingested as tracking targets only, no detection) and appends the records to a log in its GPU's memory.  There is no
-collective on the data path.  The one exchange is the stitch: an all-gather of the logs over RCCL (torch.distributed,
-backend "nccl"), after which rank 0 stores them through polychase_core.write_optical_flow_records in frame order -- the
-statements of the single-process run in the same order, so the SQLite file does not depend on the number of ranks.
+contiguous range of frame1 ids (the frames up to 8 outside the range are ingested as tracking targets only, no
+detection).  There is no collective on the data path.  Rank 0, which owns the SQLite file, stores its shard as it goes;
+the other ranks append their records to a log in GPU memory that is handed over in pieces of a few frames while the
+analysis continues: the pieces travel to rank 0 over RCCL (torch.distributed, backend "nccl": device-to-device send /
+recv over xGMI) in frame order and are stored through polychase_core.write_optical_flow_records as they arrive -- the
+statements of the single-process run in the same order, so the SQLite file does not depend on the number of ranks, and
+no rank ever holds more than a few pieces.  (Only rank 0 reads the records, so this is a gather; bench.py times the
+all-gather variant of the same pieces, distributed.ChunkedLogStitch.)
+
+    python -m polychase_amd.analyze --gpus 8 --synthetic c3 --frames 2400 --database /tmp/clip.db
+
+launches the eight ranks itself (the same through torch.distributed.run / torchrun works too).
 
 `analyze()` is the library entry point (frames from any accessor, like generate_optical_flow_database); the command
 line reads a synthetic clip (--synthetic c1|c2|c3) or an .npy stack of RGB frames.
@@ -37,17 +41,39 @@ def _core():
 
 def log_capacity(n_frames: int, width: int, height: int, n_targets: int = 8, keypoints_per_frame: int | None = None) -> int:
     """Bytes of device log for `n_frames` frame1 records.  Default estimate: one keypoint per 40 pixels (the 5-px minimum
-    distance of the detector yields ~1 per 51 px on a fully textured frame), which `analyze` doubles once if a shard
-    turns out denser."""
+    distance of the detector yields ~1 per 51 px on a fully textured frame: 162 k at 3840 x 2160, i.e. 22 MB per frame
+    with its 8 flows).  A piece that fills up early simply ends early (analysis_driver.cc), so the estimate only sets
+    how many frames a piece usually holds."""
     kp = keypoints_per_frame or (width * height // 40 + 4096)
     return D.log_capacity_bytes(n_frames, kp, n_targets)
 
 
+def _control_group(group):
+    """CPU-tensor group for credits and headers: the main group when it is gloo already, else a gloo group over the same
+    ranks.  Its waits can be long (a rank waits for its turn while rank 0 stores the ranks before it)."""
+    import datetime
+
+    import torch.distributed as dist
+
+    if dist.get_backend(group) == "gloo":
+        return group
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    ranks = dist.get_process_group_ranks(group) if group is not None else None
+    return dist.new_group(ranks=ranks, backend="gloo", timeout=datetime.timedelta(hours=24))
+
+
 def analyze(width: int, height: int, first_frame: int, num_frames: int, frame_accessor, database_path: str,
-            detector_options=None, flow_options=None, callback=None, group=None, device=None):
+            detector_options=None, flow_options=None, callback=None, group=None, device=None, piece_frames: int = 16,
+            keypoints_per_frame: int | None = None):
     """Analyze frames first_frame .. first_frame + num_frames - 1 with all ranks of `group` (default: the world; one rank
     when torch.distributed is not initialised) and store the flow database at `database_path` (written by rank 0).
     frame_accessor(frame_id) -> H x W x 3 uint8 (numpy, or a torch tensor on this rank's GPU), or float32 H x W x 3|4.
+
+    Rank 0 runs its own shard straight into the database (the single-GPU path: inserts overlap the analysis); every other
+    rank analyses its shard into a two-part device log and hands the log over in pieces of `piece_frames` frames, which
+    travel to rank 0 over RCCL in frame order (distributed.OrderedPieceGather) and are stored as they arrive.  GPU and
+    host memory are bounded by the pieces in flight, whatever the length of the clip.  An existing database must hold
+    the same analysis (write_optical_flow_records refuses other keypoints).
     Returns a dict of per-phase seconds and counts (on every rank)."""
     import torch
     import torch.distributed as dist
@@ -63,41 +89,85 @@ def analyze(width: int, height: int, first_frame: int, num_frames: int, frame_ac
     gopt = detector_options or core.GFTTOptions()
     fopt = flow_options or core.OpticalFlowOptions()
     t0 = time.perf_counter()
-    cap = log_capacity(end - begin + 1, width, height)
-    used, stats = 0, None
-    for attempt in range(3):
-        log = torch.empty(cap, dtype=torch.uint8, device=dev)
-        try:
-            used, stats = core.generate_optical_flow_records(vi, frame_accessor, callback, begin, end, log.data_ptr(), log.numel(), gopt, fopt)
-            break
-        except RuntimeError as e:
-            if "device log full" not in str(e) or attempt == 2:
-                raise
-            del log
-            cap *= 2      # a denser clip than the estimate: once more with twice the room
-    t1 = time.perf_counter()
-    # ---- the stitch: the one collective of the path ----
-    if world > 1:
-        gathered, sizes = D.all_gather_device_log(log, used, group)
-        torch.cuda.synchronize(dev)
-    else:
-        gathered, sizes = log[:used][None], [used]
-    t2 = time.perf_counter()
-    written = None
+    out = {"rank": rank, "world": world, "shard": [begin, end], "frames": end - begin}
+    if world == 1:
+        st = core.generate_optical_flow_shard(vi, frame_accessor, callback, database_path, begin, end, detector_options=gopt,
+                                              flow_options=fopt)["stats"]
+        t1 = time.perf_counter()
+        out.update(seconds_analysis=t1 - t0, seconds_stitch=0.0, seconds_database=st.seconds_db, seconds_total=t1 - t0, log_bytes=0,
+                   frames_processed=st.frames_processed, cancelled=False,
+                   written={"keypoint_rows": st.keypoint_rows_written, "flow_rows": st.flow_rows_written})
+        return out
+
+    ctl = _control_group(group)
+    gather = D.OrderedPieceGather(group, ctl, device=dev)
+    cancelled = False
     if rank == 0:
-        rows_kp = rows_flow = 0
-        for r in range(world):      # ranks own increasing frame ranges: rank order is frame order
-            host = gathered[r, :sizes[r]].cpu().numpy()
-            st = core.write_optical_flow_records(database_path, host, int(sizes[r]))
-            rows_kp += st.keypoint_rows_written
-            rows_flow += st.flow_rows_written
-        written = {"keypoint_rows": rows_kp, "flow_rows": rows_flow}
-    if world > 1:
-        dist.barrier(group)
-    t3 = time.perf_counter()
-    return {"rank": rank, "world": world, "shard": [begin, end], "frames": end - begin, "log_bytes": int(used),
-            "seconds_analysis": t1 - t0, "seconds_stitch": t2 - t1, "seconds_database": t3 - t2, "written": written,
-            "frames_processed": stats.frames_processed if stats else 0}
+        # the receiver asks rank 1 for its first piece at once; what arrives waits (bounded) until this shard is stored
+        gather.start()
+        res = core.generate_optical_flow_shard(vi, frame_accessor, callback, database_path, begin, end, detector_options=gopt,
+                                               flow_options=fopt)
+        st = res["stats"]
+        cancelled = bool(res["cancelled"])
+        t1 = time.perf_counter()
+        rows_kp, rows_flow, db_s = st.keypoint_rows_written, st.flow_rows_written, st.seconds_db
+        writer = core.OpticalFlowRecordWriter(database_path)
+        for _r, _first, _frames, host in gather.pieces():      # frame order: all of rank 1, then rank 2, ...
+            ws = writer.write(host, len(host))
+            rows_kp += ws.keypoint_rows_written
+            rows_flow += ws.flow_rows_written
+            db_s += ws.seconds_db
+        writer.close()
+        t2 = time.perf_counter()
+        out.update(seconds_analysis=t1 - t0, seconds_stitch=0.0, seconds_database=db_s, log_bytes=int(gather.bytes_moved),
+                   frames_processed=st.frames_processed, written={"keypoint_rows": rows_kp, "flow_rows": rows_flow})
+    else:
+        part = log_capacity(piece_frames + 1, width, height, keypoints_per_frame=keypoints_per_frame)
+        part = (part + 15) // 16 * 16
+        log = torch.empty(2 * part, dtype=torch.uint8, device=dev)
+
+        def on_piece(piece, offset, nbytes, first, n_frames):
+            gather.put(log[offset:offset + nbytes], first, n_frames)
+
+        ok = False
+        try:
+            res = core.generate_optical_flow_shard(vi, frame_accessor, callback, "", begin, end, log.data_ptr(), log.numel(), 2,
+                                                   piece_frames, on_piece, False, gopt, fopt)
+            ok = True
+        finally:
+            gather.finish(failed=not ok)
+        st = res["stats"]
+        cancelled = bool(res["cancelled"])
+        t1 = t2 = time.perf_counter()
+        out.update(seconds_analysis=t1 - t0 - gather.seconds_blocked, seconds_stitch=gather.seconds_blocked, seconds_database=0.0,
+                   log_bytes=int(gather.bytes_moved), frames_processed=st.frames_processed, written=None, pieces=int(res["pieces"]))
+    # a rank whose progress callback cancelled leaves a hole in the clip: every rank reports it
+    flag = torch.tensor([1 if cancelled else 0], dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ctl)
+    out["cancelled"] = bool(flag.item())
+    out["seconds_total"] = time.perf_counter() - t0
+    return out
+
+
+def _self_launch(n: int, argv) -> int:
+    """`python -m polychase_amd.analyze --gpus N ...`: N ranks of this command through torch.distributed.run, one per GPU."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if os.environ.get("POLYCHASE_ANALYZE_SHARE_GPU") != "1" and have < n:
+        print(f"polychase_amd.analyze: --gpus {n} needs {n} GPUs, this node has {have}", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "polychase_amd.analyze", *argv]
+    return subprocess.call(cmd, env=env, cwd=os.path.dirname(_HERE))
 
 
 def main(argv=None) -> int:
@@ -108,7 +178,14 @@ def main(argv=None) -> int:
     ap.add_argument("--first-frame", type=int, default=1)
     ap.add_argument("--max-level", type=int, default=None)
     ap.add_argument("--database", required=True)
+    ap.add_argument("--piece-frames", type=int, default=16, help="frames per piece of the record log handed to rank 0")
+    ap.add_argument("--gpus", type=int, default=0, help="launch this many ranks (one per GPU) of this command")
     args = ap.parse_args(argv)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _self_launch(args.gpus, sys.argv[1:] if argv is None else list(argv))
+    if args.gpus > 1 and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"polychase_amd.analyze: --gpus {args.gpus} but the job has WORLD_SIZE={os.environ['WORLD_SIZE']}")
 
     import torch
     import torch.distributed as dist
@@ -153,7 +230,8 @@ def main(argv=None) -> int:
         os.remove(args.database)
     if world > 1:
         dist.barrier()
-    out = analyze(w, h, args.first_frame, n, accessor, args.database, core.GFTTOptions(), fopt, device=dev)
+    out = analyze(w, h, args.first_frame, n, accessor, args.database, core.GFTTOptions(), fopt, device=dev,
+                  piece_frames=args.piece_frames)
     import json
     print(json.dumps(out), flush=True)
     if world > 1:

@@ -713,8 +713,9 @@ int pc_api::set_image(pc_context* ctx, pc_frame* f, const uint8_t* src, size_t r
         // staging buffer, stream-ordered, no wait.  (The kernels can also read such memory themselves -- on_device = 1 --
         // but then a level-0 kernel holds its CUs for as long as PCIe takes: 33 MB of float pixels at 17 GB/s against
         // 50 GB/s for the copy engine.)
-        const size_t bytes = row_pitch * (size_t)f->h;
-        PC_HIP(ctx->staging.ensure(bytes));
+        // rows 0 .. h-2 with their pitch, the last row without: a caller's buffer need not extend to a full last pitch
+        const size_t bytes = f->h > 0 ? row_pitch * (size_t)(f->h - 1) + row_bytes : 0;
+        PC_HIP(ctx->staging.ensure(row_pitch * (size_t)f->h));
         PC_HIP(hipMemcpyAsync(ctx->staging.p, src, bytes, hipMemcpyHostToDevice, ctx->work));
         d_src = ctx->staging.p;
     } else if (!on_device) {
@@ -923,17 +924,17 @@ int pc_lk_track_filtered(pc_context* ctx, const pc_frame* frame1, const pc_frame
     if (rc != PC_OK) return rc;
     const int n = frame1->n_kps;
     const size_t rows = (size_t)n * n_targets;
-    const int nblocks = pc::compact_num_blocks(n);
     PC_HIP(ctx->lk_cxy.ensure(rows + 1));
     PC_HIP(ctx->lk_cerr.ensure(rows + 1));
     PC_HIP(ctx->lk_cidx.ensure(rows + 1));
-    PC_HIP(ctx->lk_block_counts[0].ensure((size_t)nblocks * n_targets + 1));
+    const size_t scratch_cap_before = ctx->lk_block_counts[0].cap;   // a reallocation changes the capacity (the address may repeat)
+    PC_HIP(ctx->lk_block_counts[0].ensure(pc::compact_scratch_words(n, n_targets)));
     PC_HIP(ctx->lk_row_offset.ensure(PC_MAX_TARGETS + 1));
     PC_HIP(ctx->h_row_offset.ensure(PC_MAX_TARGETS + 1));
     {
         ScopedTimer t(ctx, PC_K_COMPACT);
         pc::launch_compact(ctx->lk_rec[0].p, ctx->lk_slot_of[0], n, n_targets, ctx->lk_block_counts[0].p,
-                           ctx->lk_row_offset.p, ctx->lk_cidx.p, ctx->lk_cxy.p, ctx->lk_cerr.p, ctx->stream);
+                           ctx->lk_block_counts[0].cap != scratch_cap_before, ctx->lk_row_offset.p, ctx->lk_cidx.p, ctx->lk_cxy.p, ctx->lk_cerr.p, ctx->stream);
     }
     PC_HIP(hipMemcpyAsync(ctx->h_row_offset.p, ctx->lk_row_offset.p, (size_t)(n_targets + 1) * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     PC_HIP(hipStreamSynchronize(ctx->stream));

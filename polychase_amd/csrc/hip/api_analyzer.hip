@@ -35,7 +35,49 @@ struct Job {
     int32_t targets[PC_MAX_TARGETS];
     PinBuf<uint8_t> h_pack;   // the job's records, same layout as pc_context::lk_pack
     size_t o_kps = 0, o_idx = 0, o_xy = 0, o_err = 0, pack_bytes = 0;
+    bool host_records = true;       // the whole pack was downloaded (else its 128-byte header only)
     hipEvent_t done = nullptr;      // records of this job are in pinned memory (the job's lane)
+};
+
+// Issue priority of the helper kernels this analyzer enqueues (common.hpp: helper_priority), from what it observes.
+// The preparation stream is a FIFO: pyramid of frame f+9, then its detection.  When that chain falls behind the LK
+// launches -- the pyramid of the SECOND newest frame is not complete when a job is collected, i.e. less than one frame of
+// slack is left before a launch has to wait for it -- the helpers get the high priority; when no lag has been seen for
+// kCalm collects in a row (and it takes kLagsToRaise lags among 16 collects to raise it) they go back to filling the slots LK leaves (the better mode whenever they keep up).
+// POLYCHASE_HELPER_PRIO=0 / 1 pins the priority, "auto" (default) is this controller.
+struct HelperPriorityControl {
+    static constexpr int kCalm = 48;        // collects without a lag before the priority is dropped again
+    static constexpr int kLagsToRaise = 3;  // ... of the last 16 collects (one late pyramid at a clip's start is no trend)
+    int mode = -1;          // -1 auto, 0 / 1 pinned
+    int hi = 0;
+    int calm = 0;
+    uint32_t window = 0;    // the last 16 observations, newest in bit 0
+    uint64_t lag_seen = 0, switched_on = 0;
+    void init() {
+        const char* v = getenv("POLYCHASE_HELPER_PRIO");
+        mode = (v && (v[0] == '0' || v[0] == '1') && v[1] == 0) ? v[0] - '0' : -1;
+        hi = mode == 1 ? 1 : 0;
+    }
+    void observe(bool lagging) {
+        if (mode >= 0) return;
+        window = ((window << 1) | (lagging ? 1u : 0u)) & 0xffffu;
+        if (lagging) {
+            lag_seen++;
+            calm = 0;
+            if (!hi && __builtin_popcount(window) >= kLagsToRaise) {
+                hi = 1;
+                switched_on++;
+            }
+        } else if (hi && ++calm >= kCalm) {
+            hi = 0;
+            calm = 0;
+            window = 0;
+        }
+    }
+};
+struct HelperPriorityScope {   // the enqueues of one analyzer call carry its priority; stage-level calls on this thread stay at 0
+    explicit HelperPriorityScope(int hi) { pc::set_helper_prio(hi); }
+    ~HelperPriorityScope() { pc::set_helper_prio(0); }
 };
 
 }  // namespace
@@ -56,6 +98,10 @@ struct pc_analyzer {
     static constexpr int kLaneEvents = 16;
     hipEvent_t lk_done[2][kLaneEvents] = {};
     bool gate_armed = false;             // a gated launch is ahead: the next one waits for its "all dispatched" signal
+    HelperPriorityControl prio;
+    int32_t put_newest = 0, put_previous = 0;   // frame ids of the two most recent put_frame calls
+    int puts = 0;
+    bool host_records = true;            // download every job's records to pinned host memory
     uint8_t* d_log = nullptr;            // optional device-resident record log
     size_t log_cap = 0, log_used = 0;
     std::vector<PinBuf<long long>> log_hdr;  // one pinned header per job slot
@@ -125,6 +171,7 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
     a->gopt = *gftt;
     a->fopt = *flow;
     a->grid = grid0;
+    a->prio.init();
     // spare slots: a frame can be overwritten (prep stream) while the LK launches that read its predecessors in the
     // ring are still running, without the streams waiting on each other, and the drivers make frame1 + 9 resident
     // one step before the first launch that reads it (PC_ANALYZER_LOOKAHEAD) so that its pyramid never sits on
@@ -223,6 +270,10 @@ static int analyzer_put(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, si
     Slot& s = a->slots[(size_t)(((frame_id % n) + n) % n)];
     PC_HIP(hipSetDevice(a->ctx->device));
     PrepScope prep(a->ctx);
+    HelperPriorityScope prio_scope(a->prio.hi);
+    a->put_previous = a->put_newest;
+    a->put_newest = frame_id;
+    a->puts++;
     // an LK launch in flight may still read the frame this slot holds
     for (hipEvent_t& e : s.last_read) {
         if (e) PC_HIP(hipStreamWaitEvent(a->ctx->prep_stream, e, 0));
@@ -274,6 +325,7 @@ int pc_analyzer_set_keypoints(pc_analyzer* a, int32_t frame_id, const float* xy,
     if (!a || n < 0 || (!xy && n > 0)) return fail(PC_E_INVALID, "bad argument");
     Slot* s = find_slot(a, frame_id);
     if (!s) return fail(PC_E_STATE, "frame %d is not resident", frame_id);
+    HelperPriorityScope prio_scope(a->prio.hi);
     int rc = ensure_kp_capacity(s->frame, n);
     if (rc != PC_OK) return rc;
     if (n > 0) {
@@ -302,6 +354,7 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     if (a->job_count == a->jobs.size()) return fail(PC_E_STATE, "%zu jobs already in flight: call pc_analyzer_collect", a->job_count);
     pc_context* ctx = a->ctx;
     PC_HIP(hipSetDevice(ctx->device));
+    HelperPriorityScope prio_scope(a->prio.hi);
     Slot* s1 = find_slot(a, frame1);
     if (!s1) return fail(PC_E_STATE, "frame1 %d is not resident", frame1);
     const pc_frame* tg[PC_MAX_TARGETS];
@@ -340,6 +393,10 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     j.o_xy = up16(j.o_idx + rows * 4);
     j.o_err = up16(j.o_xy + rows * 8);
     j.pack_bytes = up16(j.o_err + rows * 4);
+    // a record that does not fit the device log is refused before anything of the job is enqueued (the caller may
+    // redirect the log and submit again)
+    if (a->d_log && a->log_used + 128 + j.pack_bytes > a->log_cap)
+        return fail(PC_E_CAPACITY, "device log full (%zu of %zu bytes)", a->log_used + 128 + j.pack_bytes, a->log_cap);
     {
         SlowSection ss("submit/ensure pack");
         PC_HIP(j.h_pack.ensure(j.pack_bytes));
@@ -384,11 +441,11 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     long long* const p_ro = reinterpret_cast<long long*>(pack);
     PC_HIP(hipMemsetAsync(pack, 0, 128, ls));
     if (n_targets > 0) {
-        const int nblocks = pc::compact_num_blocks(n);
-        PC_HIP(ctx->lk_block_counts[lane].ensure((size_t)nblocks * n_targets + 1));
+        const size_t scratch_cap_before = ctx->lk_block_counts[lane].cap;   // a reallocation changes the capacity (the address may repeat)
+        PC_HIP(ctx->lk_block_counts[lane].ensure(pc::compact_scratch_words(n, n_targets)));
         ScopedTimer t(ctx, PC_K_COMPACT, ls);
-        pc::launch_compact(ctx->lk_rec[lane].p, ctx->lk_slot_of[lane], n, n_targets,
-                           ctx->lk_block_counts[lane].p, p_ro, reinterpret_cast<uint32_t*>(pack + j.o_idx),
+        pc::launch_compact(ctx->lk_rec[lane].p, ctx->lk_slot_of[lane], n, n_targets, ctx->lk_block_counts[lane].p,
+                           ctx->lk_block_counts[lane].cap != scratch_cap_before, p_ro, reinterpret_cast<uint32_t*>(pack + j.o_idx),
                            reinterpret_cast<float2*>(pack + j.o_xy), reinterpret_cast<float*>(pack + j.o_err), ls);
     }
     pc::launch_copy_keypoints(s1->frame->d_kps, reinterpret_cast<float2*>(pack + j.o_kps), n, ls);
@@ -420,7 +477,9 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     a->submitted++;
     // (4) download: ONE copy with fixed endpoints (the lane's pack -> the job's pinned pack).  The runtime stalls the
     // host for 5-8 ms the first time it sees a buffer as a copy source, so per-frame buffers must not appear here.
-    PC_HIP(hipMemcpyAsync(j.h_pack.p, pack, j.pack_bytes, hipMemcpyDeviceToHost, ls));
+    if (a->host_records) PC_HIP(hipMemcpyAsync(j.h_pack.p, pack, j.pack_bytes, hipMemcpyDeviceToHost, ls));
+    else PC_HIP(hipMemcpyAsync(j.h_pack.p, pack, 128, hipMemcpyDeviceToHost, ls));   // the row offsets only
+    j.host_records = a->host_records;
     PC_HIP(hipEventRecord(j.done, ls));
     a->job_count++;
     return PC_OK;
@@ -439,6 +498,22 @@ int pc_analyzer_set_device_log(pc_analyzer* a, void* d_log, size_t capacity_byte
     return PC_OK;
 }
 
+int pc_analyzer_redirect_device_log(pc_analyzer* a, void* d_log, size_t capacity_bytes) {
+    if (!a || !d_log) return fail(PC_E_INVALID, "null argument");
+    if (reinterpret_cast<uintptr_t>(d_log) & 15) return fail(PC_E_INVALID, "device log must be 16-byte aligned");
+    // no synchronisation: the appends already enqueued keep their addresses, the next submit writes to the new buffer
+    a->d_log = static_cast<uint8_t*>(d_log);
+    a->log_cap = capacity_bytes;
+    a->log_used = 0;
+    return PC_OK;
+}
+
+int pc_analyzer_set_host_records(pc_analyzer* a, int enabled) {
+    if (!a) return fail(PC_E_INVALID, "null analyzer");
+    a->host_records = enabled != 0;
+    return PC_OK;
+}
+
 int pc_analyzer_device_log_used(const pc_analyzer* a, size_t* bytes) {
     if (!a || !bytes) return fail(PC_E_INVALID, "null argument");
     *bytes = a->log_used;
@@ -450,6 +525,11 @@ int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out) {
     if (a->job_count == 0) return fail(PC_E_STATE, "no job in flight");
     Job& j = a->jobs[a->job_head];
     PC_HIP(hipEventSynchronize(j.done));
+    // is the preparation stream keeping up?  (HelperPriorityControl)
+    if (a->puts >= 2) {
+        Slot* const sp = find_slot(a, a->put_previous);
+        a->prio.observe(sp && sp->img_ready && hipEventQuery(sp->img_ready) == hipErrorNotReady);
+    }
     // let the runtime retire the finished commands of the other streams now, a few at a time: left alone it does
     // so in one batch of several milliseconds every couple of hundred frames, inside some later launch
     (void)hipStreamQuery(a->ctx->stream);
@@ -459,14 +539,14 @@ int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out) {
     out->frame1 = j.frame1;
     out->n_keypoints = j.n_kps;
     out->keypoints_detected = j.detected ? 1 : 0;
-    out->keypoints_xy = reinterpret_cast<const float*>(j.h_pack.p + j.o_kps);
+    out->keypoints_xy = j.host_records ? reinterpret_cast<const float*>(j.h_pack.p + j.o_kps) : nullptr;
     out->n_targets = j.n_targets;
     for (int t = 0; t < PC_MAX_TARGETS; t++) out->targets[t] = t < j.n_targets ? j.targets[t] : 0;
     const long long* h_ro = reinterpret_cast<const long long*>(j.h_pack.p);
     for (int t = 0; t <= PC_MAX_TARGETS; t++) out->row_offset[t] = (int64_t)h_ro[std::min(t, j.n_targets)];
-    out->src_indices = reinterpret_cast<const uint32_t*>(j.h_pack.p + j.o_idx);
-    out->tgt_xy = reinterpret_cast<const float*>(j.h_pack.p + j.o_xy);
-    out->flow_err = reinterpret_cast<const float*>(j.h_pack.p + j.o_err);
+    out->src_indices = j.host_records ? reinterpret_cast<const uint32_t*>(j.h_pack.p + j.o_idx) : nullptr;
+    out->tgt_xy = j.host_records ? reinterpret_cast<const float*>(j.h_pack.p + j.o_xy) : nullptr;
+    out->flow_err = j.host_records ? reinterpret_cast<const float*>(j.h_pack.p + j.o_err) : nullptr;
     a->job_head = (a->job_head + 1) % a->jobs.size();
     a->job_count--;
     return PC_OK;

@@ -53,6 +53,19 @@ __host__ __device__ __forceinline__ float ordered_to_float(uint32_t k) {
 #define PC_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
 #ifdef __HIPCC__
+// Issue priority of the helper kernels (frame preparation, compaction).  Beside a running LK launch a helper wavefront
+// shares its SIMD with three LK wavefronts; at equal priority it gets a quarter of the issue slots.  When the chain of
+// helper kernels of a frame -- a dozen dependent launches on one stream -- then takes longer than an LK launch, it and not
+// LK sets the step (tools/lane_probe.py at 1080p: 0.25 ms per step with the job lanes alone, 0.35 with the detection
+// beside them although it adds only 11 % to the instructions).  s_setprio puts a wavefront in front of the SIMD's
+// arbiter: the helpers then run at the speed of a lone wavefront and LK takes every other slot (1080p: 0.31 ms).  When
+// the chain keeps up anyway (4K: LK 1.26 ms, the chain 0.6) the low priority is the better one -- the helpers fill the
+// slots LK leaves, 1.41 ms per step against 1.47 -- so the priority is a launch argument that the analyzer sets from
+// what it observes (api_analyzer.hip: HelperPriorityControl).
+__device__ __forceinline__ void helper_priority(int hi) {
+    if (hi) __builtin_amdgcn_s_setprio(3);
+}
+
 // "The last workgroup finishes the job": true in the workgroup that arrives last (of `total`) at `*ticket` (zero before
 // the launch).  Every lane of every workgroup must call it.  What it buys: a dependent single-workgroup step (a scan of
 // per-workgroup counts) runs in the tail of the kernel that produced its input instead of as a launch of its own --

@@ -6,6 +6,11 @@
 
 namespace pc {
 
+// Issue priority the helper kernels (frame preparation, compaction) are launched with from this thread: 0 or 1
+// (common.hpp: helper_priority).  Set by the analyzer around its enqueues; stage-level calls leave it at 0.
+int helper_prio_arg();
+void set_helper_prio(int hi);
+
 // ---- kernels_image.hip ----
 // K1: RGB u8 -> gray u8 written straight into the level-0 plane interior (cvtColor RGB2GRAY).
 void launch_rgb2gray(const uint8_t* rgb, size_t rgb_pitch, const Level& l0, hipStream_t s);
@@ -144,10 +149,13 @@ void launch_spatial_bins_counted(const float2* pts, int n, const uint32_t* n_dev
 
 // Ordered compaction of status==1 rows per target (opticalflow.cc:130-147).
 // rec / slot_of: the LK kernel's raw records (visiting order) and the inverse visiting order.
-// block_counts: [n_targets][nblocks] scratch, row_offset: [n_targets+1] int64 (device).
-void launch_compact(const float4* rec, const uint32_t* slot_of, int n, int n_targets,
-                    uint32_t* block_counts, long long* row_offset, uint32_t* out_idx, float2* out_xy,
-                    float* out_err, hipStream_t s);
+// scratch: compact_scratch_words(n, n_targets) words; scratch_fresh: the buffer has not been through a launch_compact
+// since it was allocated (its ticket words are then zeroed first; afterwards the launches keep them zero).
+// row_offset: [n_targets+1] int64 (device).
+constexpr int kCompactTicketWords = 1024;   // pc::last_workgroup_words(blocks) for up to 8.3 M keypoints
+size_t compact_scratch_words(int n, int n_targets);
+void launch_compact(const float4* rec, const uint32_t* slot_of, int n, int n_targets, uint32_t* scratch, bool scratch_fresh,
+                    long long* row_offset, uint32_t* out_idx, float2* out_xy, float* out_err, hipStream_t s);
 // raw records -> [target][n] arrays in keypoint order (pc_lk_track)
 void launch_unpack_records(const float4* rec, const uint32_t* slot_of, int n, int n_targets, float2* xy, uint8_t* status,
                            float* err, hipStream_t s);

@@ -37,7 +37,8 @@ constexpr int CW = TW + 2, CH = TH + 2;   // covariance tile: x0 - 1 .. x0 + 64,
 
 __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict__ img, int pitch, int w, int h,
                                                       float* __restrict__ eig, GfttGrid g,
-                                                      uint32_t* __restrict__ cell_max, float f1, float f0) {
+                                                      uint32_t* __restrict__ cell_max, float f1, float f0, int hi_prio) {
+    helper_priority(hi_prio);
     __shared__ __attribute__((aligned(16))) uint8_t s_gray[GH][G_PITCH];
     __shared__ float s_cxx[CH][CW + 1];
     __shared__ float s_cxy[CH][CW + 1];
@@ -165,7 +166,7 @@ void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* ce
     const double scale_d = 1.0 / (4.0 * 3.0 * 255.0);
     const float f1 = (float)(1.0 * scale_d), f0 = (float)(2.0 * scale_d);
     dim3 grid((l0.w + TW - 1) / TW, (l0.h + TH - 1) / TH);
-    hipLaunchKernelGGL(min_eig_kernel, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0);
+    hipLaunchKernelGGL(min_eig_kernel, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, helper_prio_arg());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ eig,
                                                   uint32_t* __restrict__ counter, uint8_t* __restrict__ cstate,
                                                   uint32_t* __restrict__ sort_params, uint32_t* __restrict__ hist,
                                                   uint32_t* __restrict__ ticket, uint32_t* __restrict__ bucket_offsets,
-                                                  uint32_t* __restrict__ bin_hist, int n_tiles) {
+                                                  uint32_t* __restrict__ bin_hist, int n_tiles, int hi_prio) {
+    helper_priority(hi_prio);
     __shared__ float s_thr[kMaxGridCells];
     __shared__ uint32_t s_hi, s_lo;
     __shared__ float s_v[CH][CW + 2];
@@ -373,7 +375,7 @@ void launch_nms(const float* eig, int w, int h, const GfttGrid& g, const uint32_
                 uint32_t* ticket, uint32_t* bucket_offsets, uint32_t* bin_hist, hipStream_t s) {
     dim3 grid((w + TW - 1) / TW, (h + NMS_SUB * TH - 1) / (NMS_SUB * TH));
     hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, s, eig, w, h, g, cell_max, quality_level, keys, cap, counter, cstate,
-                       sort_params, hist, ticket, bucket_offsets, bin_hist, bin_hist ? bin_num_tiles(w, h) : 0);
+                       sort_params, hist, ticket, bucket_offsets, bin_hist, bin_hist ? bin_num_tiles(w, h) : 0, helper_prio_arg());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -389,7 +391,8 @@ constexpr int kBucketLds = 512;    // keys a bucket may hold on the fast path (4
 __global__ __launch_bounds__(256) void bucket_scatter_kernel(const unsigned long long* __restrict__ keys, uint32_t cap,
                                                              const uint32_t* __restrict__ counter, const uint32_t* __restrict__ sort_params,
                                                              const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
-                                                             unsigned long long* __restrict__ out) {
+                                                             unsigned long long* __restrict__ out, int hi_prio) {
+    helper_priority(hi_prio);
     const uint32_t n = min(*counter, cap);
     SortRange range;
     range.hi = sort_params[0];
@@ -406,7 +409,8 @@ constexpr int kBucketsPerWave = 4;
 // one wavefront per workgroup (small workgroups with 4 KB of LDS find room beside the LK wavefronts, which hold 120 of a
 // CU's 160 KB), four consecutive buckets each, one after the other in the same LDS buffer
 __global__ __launch_bounds__(64) void bucket_sort_kernel(const unsigned long long* __restrict__ in, const uint32_t* __restrict__ offsets,
-                                                         unsigned long long* __restrict__ out, uint32_t* __restrict__ overflow) {
+                                                         unsigned long long* __restrict__ out, uint32_t* __restrict__ overflow, int hi_prio) {
+    helper_priority(hi_prio);
     __shared__ unsigned long long s_keys[kBucketLds];
     const int lane = threadIdx.x;
     const int b0 = blockIdx.x * kBucketsPerWave;
@@ -437,8 +441,8 @@ void launch_bucket_sort(const unsigned long long* keys, uint32_t cap, uint32_t n
                         const uint32_t* offsets, uint32_t* cursor, unsigned long long* scratch, unsigned long long* out,
                         uint32_t* overflow, hipStream_t s) {
     const unsigned blocks = std::max(1u, std::min<unsigned>(1024u, (n_launch + 255u) / 256u));
-    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(blocks), dim3(256), 0, s, keys, cap, counter, sort_params, offsets, cursor, scratch);
-    hipLaunchKernelGGL(bucket_sort_kernel, dim3(kSortBuckets / kBucketsPerWave), dim3(64), 0, s, scratch, offsets, out, overflow);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3(blocks), dim3(256), 0, s, keys, cap, counter, sort_params, offsets, cursor, scratch, helper_prio_arg());
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3(kSortBuckets / kBucketsPerWave), dim3(64), 0, s, scratch, offsets, out, overflow, helper_prio_arg());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -488,7 +492,8 @@ __global__ __launch_bounds__(SUP_BLOCK) void suppress_sorted_kernel(const unsign
                                                                     const int2* __restrict__ offsets, int n_offsets,
                                                                     const int* __restrict__ row_hw, int R,
                                                                     uint32_t* __restrict__ accepted_per_block,
-                                                                    uint32_t* __restrict__ stuck, AcceptedScan fin) {
+                                                                    uint32_t* __restrict__ stuck, AcceptedScan fin, int hi_prio) {
+    helper_priority(hi_prio);
     const uint32_t n = n_dev ? min(*n_dev, n_max) : n_max;   // the launch covers n_max; workgroups past the count leave at once
     const uint32_t i = blockIdx.x * SUP_BLOCK + threadIdx.x;
     const bool live = i < n;
@@ -587,7 +592,8 @@ __global__ __launch_bounds__(SUP_BLOCK) void suppress_sorted_kernel(const unsign
 // no suppression (min_distance < 1, gftt.cc:165-181): every candidate is accepted
 __global__ __launch_bounds__(SUP_BLOCK) void accept_all_kernel(const unsigned long long* __restrict__ keys, uint32_t n_max,
                                                                const uint32_t* __restrict__ n_dev, uint8_t* cstate,
-                                                               uint32_t* __restrict__ accepted_per_block, AcceptedScan fin) {
+                                                               uint32_t* __restrict__ accepted_per_block, AcceptedScan fin, int hi_prio) {
+    helper_priority(hi_prio);
     const uint32_t n = n_dev ? min(*n_dev, n_max) : n_max;
     const uint32_t i = blockIdx.x * SUP_BLOCK + threadIdx.x;
     if (i < n) cstate[(uint32_t)keys[i]] = CS_ACCEPTED;
@@ -602,7 +608,8 @@ __global__ __launch_bounds__(SUP_BLOCK) void accepted_scatter_kernel(const unsig
                                                                      const uint8_t* __restrict__ cstate,
                                                                      const uint32_t* __restrict__ block_offset, uint32_t max_corners,
                                                                      float2* __restrict__ xy, uint32_t* __restrict__ bin_hist, int tiles_x,
-                                                                     int n_tiles, uint32_t* __restrict__ ticket) {
+                                                                     int n_tiles, uint32_t* __restrict__ ticket, int hi_prio) {
+    helper_priority(hi_prio);
     __shared__ uint32_t s_wave[SUP_BLOCK / 64];
     const uint32_t n = n_dev ? min(*n_dev, n_max) : n_max;
     const uint32_t i = blockIdx.x * SUP_BLOCK + threadIdx.x;
@@ -649,12 +656,12 @@ void launch_suppress_and_compact(const unsigned long long* keys, uint32_t n_max,
     const AcceptedScan fin{tickets, n_out, overflow, max_corners};
     if (suppress)
         hipLaunchKernelGGL(suppress_sorted_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, w, h, eig, cstate, offsets,
-                           n_offsets, row_hw, R, accepted_per_block, stuck, fin);
+                           n_offsets, row_hw, R, accepted_per_block, stuck, fin, helper_prio_arg());
     else
-        hipLaunchKernelGGL(accept_all_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, cstate, accepted_per_block, fin);
+        hipLaunchKernelGGL(accept_all_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, cstate, accepted_per_block, fin, helper_prio_arg());
     const int tiles_x = (w + 63) >> 6, n_tiles = bin_hist ? bin_num_tiles(w, h) : 0;
     hipLaunchKernelGGL(accepted_scatter_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, w, cstate, per_block, max_corners, xy,
-                       bin_hist, tiles_x, n_tiles, tickets + ticket_stride);
+                       bin_hist, tiles_x, n_tiles, tickets + ticket_stride, helper_prio_arg());
 }
 
 // ------------------------------------------------------------------------------------------------

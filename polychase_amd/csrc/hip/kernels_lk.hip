@@ -335,7 +335,8 @@ bool launch_lk(const LKParams& p, int win, hipStream_t s) {
 constexpr int BIN_SHIFT = 6;
 
 __global__ __launch_bounds__(256) void bin_count_kernel(const float2* __restrict__ pts, int n_max, const uint32_t* __restrict__ n_dev, int tiles_x, int n_tiles,
-                                                        uint32_t* __restrict__ hist) {
+                                                        uint32_t* __restrict__ hist, int hi_prio) {
+    helper_priority(hi_prio);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = n_dev ? min((int)*n_dev, n_max) : n_max;
     if (i >= n) return;
@@ -347,7 +348,8 @@ __global__ __launch_bounds__(256) void bin_count_kernel(const float2* __restrict
 // (256 lanes: beside a running LK launch a workgroup needs its wavefronts resident together, and 1024-lane
 // workgroups -- 4 wavefronts per SIMD -- do not fit the registers three LK wavefronts per SIMD leave over; they
 // waited for the whole LK launch to drain, measured 2 ms for a 50-us kernel)
-__global__ __launch_bounds__(256) void bin_scan_kernel(uint32_t* __restrict__ hist, int n_tiles) {
+__global__ __launch_bounds__(256) void bin_scan_kernel(uint32_t* __restrict__ hist, int n_tiles, int hi_prio) {
+    helper_priority(hi_prio);
     __shared__ uint32_t s_sum[256];
     const int per = (n_tiles + 255) / 256;
     const int b = threadIdx.x * per, e = min(b + per, n_tiles);
@@ -372,7 +374,8 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(uint32_t* __restrict__ hi
 __global__ __launch_bounds__(256) void bin_scatter_kernel(const float2* __restrict__ pts, int n_max, const uint32_t* __restrict__ n_dev, int tiles_x, int n_tiles,
                                                           uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm,
                                                           uint32_t* __restrict__ slot_of, const uint32_t* __restrict__ copy_src,
-                                                          uint32_t* __restrict__ copy_dst, int copy_words) {
+                                                          uint32_t* __restrict__ copy_dst, int copy_words, int hi_prio) {
+    helper_priority(hi_prio);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0 && (int)threadIdx.x < copy_words) copy_dst[threadIdx.x] = copy_src[threadIdx.x];
     const int n = n_dev ? min((int)*n_dev, n_max) : n_max;
@@ -408,53 +411,43 @@ void launch_spatial_bins(const float2* pts, int n, const uint32_t* n_dev, int w,
     if (n <= 0) return;
     const int tiles_x = (w + 63) >> BIN_SHIFT, n_tiles = bin_num_tiles(w, h);
     (void)hipMemsetAsync(hist, 0, (size_t)n_tiles * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(bin_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist);
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, hist, n_tiles);
+    hipLaunchKernelGGL(bin_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist, helper_prio_arg());
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(256), 0, s, hist, n_tiles, helper_prio_arg());
     hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist, perm, slot_of,
-                       (const uint32_t*)nullptr, (uint32_t*)nullptr, 0);
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, helper_prio_arg());
 }
 
 void launch_spatial_bins_counted(const float2* pts, int n, const uint32_t* n_dev, int w, int h, uint32_t* hist, uint32_t* perm,
                                  uint32_t* slot_of, const uint32_t* copy_src, uint32_t* copy_dst, int copy_words, hipStream_t s) {
     const int tiles_x = (w + 63) >> BIN_SHIFT, n_tiles = bin_num_tiles(w, h);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3((std::max(n, 1) + 255) / 256), dim3(256), 0, s, pts, n, n_dev, tiles_x, n_tiles, hist, perm,
-                       slot_of, copy_src, copy_dst, copy_words);
+                       slot_of, copy_src, copy_dst, copy_words, helper_prio_arg());
 }
 
 // ------------------------------------------------------------------------------------------------
-// Ordered compaction of status == 1 rows (opticalflow.cc:130-147): count per block of 128 keypoints,
-// exclusive scan of the block counts (one small workgroup), scatter.  The LK kernel leaves its records
-// in visiting order (8 per slot, 128 contiguous bytes); here lane = (keypoint i, target t) with t the
-// fast index, so the 8 lanes of a keypoint read exactly that line through the inverse permutation
-// and write one run per target in ascending keypoint order.
+// Ordered compaction of status == 1 rows (opticalflow.cc:130-147) in TWO launches: count per block of 256 keypoints --
+// whose last workgroup turns the counts into offsets (pc::last_workgroup: the scan is the tail of the kernel that
+// produces its input, not a launch of its own) -- and scatter.  The LK kernel leaves its records in visiting order
+// (8 per slot, 128 contiguous bytes); here lane = (keypoint i, target t) with t the fast index, so the 8 lanes of a
+// keypoint read exactly that line through the inverse permutation and write one run per target in ascending keypoint
+// order.  A 256-lane workgroup walks its 256 keypoints in 8 passes of 32.
+// (Round 2: 32 keypoints per workgroup and a scan kernel of ONE workgroup that walked nblocks x 8 counters in two serial
+// passes -- 10 k counters at 1080p, 40 k at 4K: 58 / 294 us on the job lane between the LK launch and the download.)
+// scratch: [kCompactTicketWords tickets, zero before the launch and zeroed again by the scatter][n_targets x nblocks counts]
 // ------------------------------------------------------------------------------------------------
-constexpr int CF = 32;    // keypoints per 256-lane workgroup (small workgroups: see bin_scan_kernel)
-constexpr int CT = CF * kRecStride;
+constexpr int CF = 256;                  // keypoints per workgroup
+constexpr int CT = 256;                  // lanes (small workgroups: see bin_scan_kernel)
+constexpr int CPASS = CF * kRecStride / CT;   // passes of CT / kRecStride = 32 keypoints
 int compact_num_blocks(int n) { return (n + CF - 1) / CF; }
+size_t compact_scratch_words(int n, int n_targets) {
+    return (size_t)kCompactTicketWords + (size_t)compact_num_blocks(n) * (size_t)std::max(n_targets, 1) + 1;
+}
 
 __device__ __forceinline__ unsigned long long target_lanes(int t) { return 0x0101010101010101ull << t; }
 
-__global__ __launch_bounds__(CT) void compact_count_kernel(const float4* __restrict__ rec, const uint32_t* __restrict__ slot_of,
-                                                             int n, int n_targets, int nblocks,
-                                                             uint32_t* __restrict__ block_counts) {
-    __shared__ uint32_t s_cnt[kRecStride];
-    const int t = threadIdx.x & 7, i = blockIdx.x * CF + (int)(threadIdx.x >> 3), lane = threadIdx.x & 63;
-    if (threadIdx.x < kRecStride) s_cnt[threadIdx.x] = 0u;
-    __syncthreads();
-    bool keep = false;
-    if (i < n && t < n_targets) keep = __float_as_uint(rec[(size_t)slot_of[i] * kRecStride + t].w) == 1u;
-    const unsigned long long b = __ballot(keep);
-    if (lane < kRecStride) {
-        const uint32_t c = (uint32_t)__popcll(b & target_lanes(lane));
-        if (c) atomicAdd(&s_cnt[lane], c);
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < n_targets) block_counts[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_cnt[threadIdx.x];
-}
-
-// one workgroup: turns block_counts into exclusive offsets (global, target-major) + row_offset[]
-__global__ __launch_bounds__(256) void compact_scan_kernel(uint32_t* __restrict__ block_counts, int nblocks,
-                                                           int n_targets, long long* __restrict__ row_offset) {
+// block_counts[t][b] -> exclusive offsets (global, target-major) + row_offset[]; all 256 lanes of one workgroup
+__device__ __forceinline__ void compact_scan_body(uint32_t* __restrict__ block_counts, int nblocks, int n_targets,
+                                                  long long* __restrict__ row_offset) {
     __shared__ long long s_part[256];
     const int total = nblocks * n_targets;
     const int per = (total + 255) / 256;
@@ -469,8 +462,7 @@ __global__ __launch_bounds__(256) void compact_scan_kernel(uint32_t* __restrict_
         s_part[threadIdx.x] += v;
         __syncthreads();
     }
-    s_part[threadIdx.x] -= sum;   // exclusive (each lane touches only its own entry)
-    long long run = s_part[threadIdx.x];
+    long long run = s_part[threadIdx.x] - sum;   // exclusive
     for (int i = b; i < e; i++) {
         const uint32_t c = block_counts[i];
         if (i % nblocks == 0) row_offset[i / nblocks] = run;
@@ -478,39 +470,85 @@ __global__ __launch_bounds__(256) void compact_scan_kernel(uint32_t* __restrict_
         run += c;
     }
     if (e == total && b < e) row_offset[n_targets] = run;
-    if (total == 0 && threadIdx.x == 0)
-        for (int t = 0; t <= n_targets; t++) row_offset[t] = 0;
+}
+
+__global__ __launch_bounds__(CT) void compact_count_kernel(const float4* __restrict__ rec, const uint32_t* __restrict__ slot_of,
+                                                             int n, int n_targets, int nblocks,
+                                                             uint32_t* __restrict__ tickets, uint32_t* __restrict__ block_counts,
+                                                             long long* __restrict__ row_offset, int hi_prio) {
+    helper_priority(hi_prio);
+    __shared__ uint32_t s_cnt[kRecStride];
+    const int t = threadIdx.x & 7, lane = threadIdx.x & 63;
+    if (threadIdx.x < kRecStride) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t mine = 0;   // lanes 0-7 of a wavefront: rows of target `lane` among the wavefront's keypoints
+#pragma unroll
+    for (int k = 0; k < CPASS; k++) {
+        const int i = blockIdx.x * CF + k * (CT / kRecStride) + (int)(threadIdx.x >> 3);
+        bool keep = false;
+        if (i < n && t < n_targets) keep = __float_as_uint(rec[(size_t)slot_of[i] * kRecStride + t].w) == 1u;
+        const unsigned long long b = __ballot(keep);
+        if (lane < kRecStride) mine += (uint32_t)__popcll(b & target_lanes(lane));
+    }
+    if (lane < kRecStride && mine) atomicAdd(&s_cnt[lane], mine);
+    __syncthreads();
+    // agent-scope store: the workgroup that finishes last reads the counts of all the others (last_workgroup's contract)
+    if ((int)threadIdx.x < n_targets) publish(&block_counts[(size_t)threadIdx.x * nblocks + blockIdx.x], s_cnt[threadIdx.x]);
+    if (last_workgroup(tickets, (uint32_t)nblocks)) compact_scan_body(block_counts, nblocks, n_targets, row_offset);
 }
 
 __global__ __launch_bounds__(CT) void compact_scatter_kernel(const float4* __restrict__ rec, const uint32_t* __restrict__ slot_of,
-                                                               int n, int n_targets, int nblocks,
+                                                               int n, int n_targets, int nblocks, uint32_t* __restrict__ tickets,
                                                                const uint32_t* __restrict__ block_offsets,
                                                                uint32_t* __restrict__ out_idx,
-                                                               float2* __restrict__ out_xy, float* __restrict__ out_err) {
-    __shared__ uint32_t s_wave[CT / 64][kRecStride];
-    const int t = threadIdx.x & 7, i = blockIdx.x * CF + (int)(threadIdx.x >> 3);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool live = i < n && t < n_targets;
-    if (live) r = rec[(size_t)slot_of[i] * kRecStride + t];
-    const bool keep = live && __float_as_uint(r.w) == 1u;
-    const unsigned long long b = __ballot(keep);
-    if (lane < kRecStride) s_wave[wave][lane] = (uint32_t)__popcll(b & target_lanes(lane));
+                                                               float2* __restrict__ out_xy, float* __restrict__ out_err, int hi_prio) {
+    helper_priority(hi_prio);
+    // rows of target t in (pass k, wavefront w), then their exclusive prefix in keypoint order = (k, w) order
+    __shared__ uint32_t s_cnt[CPASS * (CT / 64)][kRecStride];
+    const int t = threadIdx.x & 7, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the tickets of the count kernel are zero again for the next launch on this lane
+    if (blockIdx.x == 0)
+        for (uint32_t k = threadIdx.x; k < last_workgroup_words((uint32_t)nblocks); k += CT) tickets[k] = 0u;
+    float4 r[CPASS];
+    unsigned long long bal[CPASS];
+#pragma unroll
+    for (int k = 0; k < CPASS; k++) {
+        const int i = blockIdx.x * CF + k * (CT / kRecStride) + (int)(threadIdx.x >> 3);
+        r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool live = i < n && t < n_targets;
+        if (live) r[k] = rec[(size_t)slot_of[i] * kRecStride + t];
+        bal[k] = __ballot(live && __float_as_uint(r[k].w) == 1u);
+        if (lane < kRecStride) s_cnt[k * (CT / 64) + wave][lane] = (uint32_t)__popcll(bal[k] & target_lanes(lane));
+    }
     __syncthreads();
-    if (keep) {
-        uint32_t pos = block_offsets[(size_t)t * nblocks + blockIdx.x];
-        for (int wv = 0; wv < wave; wv++) pos += s_wave[wv][t];
-        pos += (uint32_t)__popcll(b & target_lanes(t) & ((1ull << lane) - 1ull));
-        out_idx[pos] = (uint32_t)i;
-        out_xy[pos] = make_float2(r.x, r.y);
-        out_err[pos] = r.z;
+    {
+        // lane (q, t): exclusive prefix over q' < q of target t (32 x 8 entries, one per lane)
+        const int q = threadIdx.x >> 3;
+        uint32_t run = 0;
+        for (int qq = 0; qq < q; qq++) run += s_cnt[qq][t];
+        __syncthreads();
+        s_cnt[q][t] = run;
+        __syncthreads();
+    }
+    const uint32_t base = (t < n_targets) ? block_offsets[(size_t)t * nblocks + blockIdx.x] : 0u;
+#pragma unroll
+    for (int k = 0; k < CPASS; k++) {
+        if ((bal[k] >> lane) & 1ull) {
+            const int i = blockIdx.x * CF + k * (CT / kRecStride) + (int)(threadIdx.x >> 3);
+            const uint32_t pos = base + s_cnt[k * (CT / 64) + wave][t] +
+                                 (uint32_t)__popcll(bal[k] & target_lanes(t) & ((1ull << lane) - 1ull));
+            out_idx[pos] = (uint32_t)i;
+            out_xy[pos] = make_float2(r[k].x, r[k].y);
+            out_err[pos] = r[k].z;
+        }
     }
 }
 
 // raw records -> the [target][n] arrays of pc_lk_track, keypoint order
 __global__ __launch_bounds__(256) void unpack_records_kernel(const float4* __restrict__ rec, const uint32_t* __restrict__ slot_of,
                                                              int n, float2* __restrict__ xy, uint8_t* __restrict__ status,
-                                                             float* __restrict__ err) {
+                                                             float* __restrict__ err, int hi_prio) {
+    helper_priority(hi_prio);
     const int i = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
     if (i >= n) return;
     const float4 r = rec[(size_t)slot_of[i] * kRecStride + t];
@@ -523,11 +561,12 @@ __global__ __launch_bounds__(256) void unpack_records_kernel(const float4* __res
 void launch_unpack_records(const float4* rec, const uint32_t* slot_of, int n, int n_targets, float2* xy, uint8_t* status,
                            float* err, hipStream_t s) {
     if (n <= 0 || n_targets <= 0) return;
-    hipLaunchKernelGGL(unpack_records_kernel, dim3((n + 255) / 256, n_targets), dim3(256), 0, s, rec, slot_of, n, xy, status, err);
+    hipLaunchKernelGGL(unpack_records_kernel, dim3((n + 255) / 256, n_targets), dim3(256), 0, s, rec, slot_of, n, xy, status, err, helper_prio_arg());
 }
 
 // keypoints of frame1 -> the job's packed record buffer (device to device, 16 bytes per lane)
-__global__ __launch_bounds__(256) void copy_keypoints_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int n) {
+__global__ __launch_bounds__(256) void copy_keypoints_kernel(const float2* __restrict__ src, float2* __restrict__ dst, int n, int hi_prio) {
+    helper_priority(hi_prio);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // one pair of keypoints
     if (2 * i + 1 < n) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
     else if (2 * i < n) dst[2 * i] = src[2 * i];
@@ -535,19 +574,24 @@ __global__ __launch_bounds__(256) void copy_keypoints_kernel(const float2* __res
 void launch_copy_keypoints(const float2* src, float2* dst, int n, hipStream_t s) {
     if (n <= 0) return;
     const int pairs = (n + 1) / 2;
-    hipLaunchKernelGGL(copy_keypoints_kernel, dim3((pairs + 255) / 256), dim3(256), 0, s, src, dst, n);
+    hipLaunchKernelGGL(copy_keypoints_kernel, dim3((pairs + 255) / 256), dim3(256), 0, s, src, dst, n, helper_prio_arg());
 }
 
-void launch_compact(const float4* rec, const uint32_t* slot_of, int n, int n_targets,
-                    uint32_t* block_counts, long long* row_offset, uint32_t* out_idx, float2* out_xy,
-                    float* out_err, hipStream_t s) {
+void launch_compact(const float4* rec, const uint32_t* slot_of, int n, int n_targets, uint32_t* scratch, bool scratch_fresh,
+                    long long* row_offset, uint32_t* out_idx, float2* out_xy, float* out_err, hipStream_t s) {
     const int nblocks = compact_num_blocks(n);
-    if (nblocks > 0)
-        hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(CT), 0, s, rec, slot_of, n, n_targets, nblocks, block_counts);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(256), 0, s, block_counts, nblocks, n_targets, row_offset);
-    if (nblocks > 0)
-        hipLaunchKernelGGL(compact_scatter_kernel, dim3(nblocks), dim3(CT), 0, s, rec, slot_of, n, n_targets, nblocks,
-                           block_counts, out_idx, out_xy, out_err);
+    if (nblocks == 0 || n_targets <= 0) {
+        (void)hipMemsetAsync(row_offset, 0, (size_t)(std::max(n_targets, 0) + 1) * sizeof(long long), s);
+        return;
+    }
+    uint32_t* const tickets = scratch;
+    uint32_t* const block_counts = scratch + kCompactTicketWords;
+    // tickets: zero at the first use of a (re)allocated scratch buffer, afterwards the scatter kernel leaves them zero
+    if (scratch_fresh) (void)hipMemsetAsync(tickets, 0, (size_t)kCompactTicketWords * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(CT), 0, s, rec, slot_of, n, n_targets, nblocks, tickets, block_counts,
+                       row_offset, helper_prio_arg());
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3(nblocks), dim3(CT), 0, s, rec, slot_of, n, n_targets, nblocks, tickets,
+                       block_counts, out_idx, out_xy, out_err, helper_prio_arg());
 }
 
 }  // namespace pc

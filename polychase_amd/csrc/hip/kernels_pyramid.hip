@@ -15,6 +15,10 @@
 
 namespace pc {
 
+static thread_local int tl_helper_prio = 0;
+int helper_prio_arg() { return tl_helper_prio; }
+void set_helper_prio(int hi) { tl_helper_prio = hi ? 1 : 0; }
+
 namespace {
 
 constexpr int TW = 64, TH = 16;                   // output tile
@@ -62,7 +66,8 @@ __device__ __forceinline__ void mirrors(int v, int len, int win, int m[3]) {
 }  // namespace
 
 template <int SRC>
-__global__ __launch_bounds__(256) void level_kernel(const LevelSource in, const Level out, const int win) {
+__global__ __launch_bounds__(256) void level_kernel(const LevelSource in, const Level out, const int win, int hi_prio) {
+    helper_priority(hi_prio);
     __shared__ __attribute__((aligned(16))) uint8_t s_c[CH][C_PITCH];           // the level's tile + halo
     __shared__ __attribute__((aligned(16))) uint8_t s_p[SRC == SRC_PYR ? P_H : 1][P_PITCH];
     __shared__ __attribute__((aligned(16))) uint16_t s_h[SRC == SRC_PYR ? P_H : 1][H_PITCH];
@@ -248,10 +253,10 @@ __global__ __launch_bounds__(256) void level_kernel(const LevelSource in, const 
 void launch_level(const LevelSource& in, const Level& out, int win, hipStream_t s) {
     dim3 grid((out.w + TW - 1) / TW, (out.h + TH - 1) / TH);
     switch (in.kind) {
-        case SRC_PYR: hipLaunchKernelGGL(level_kernel<SRC_PYR>, grid, dim3(256), 0, s, in, out, win); break;
-        case SRC_RGB8: hipLaunchKernelGGL(level_kernel<SRC_RGB8>, grid, dim3(256), 0, s, in, out, win); break;
-        case SRC_GRAY8: hipLaunchKernelGGL(level_kernel<SRC_GRAY8>, grid, dim3(256), 0, s, in, out, win); break;
-        default: hipLaunchKernelGGL(level_kernel<SRC_RGBF32>, grid, dim3(256), 0, s, in, out, win); break;
+        case SRC_PYR: hipLaunchKernelGGL(level_kernel<SRC_PYR>, grid, dim3(256), 0, s, in, out, win, helper_prio_arg()); break;
+        case SRC_RGB8: hipLaunchKernelGGL(level_kernel<SRC_RGB8>, grid, dim3(256), 0, s, in, out, win, helper_prio_arg()); break;
+        case SRC_GRAY8: hipLaunchKernelGGL(level_kernel<SRC_GRAY8>, grid, dim3(256), 0, s, in, out, win, helper_prio_arg()); break;
+        default: hipLaunchKernelGGL(level_kernel<SRC_RGBF32>, grid, dim3(256), 0, s, in, out, win, helper_prio_arg()); break;
     }
 }
 

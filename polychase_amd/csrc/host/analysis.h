@@ -91,12 +91,37 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
 // ---- multi-GPU analysis (one process per GPU, frame1 ranges sharded, RCCL only for the stitch) ----------
 
 // One shard of the clip: the frame1 loop of GenerateOpticalFlowDatabase (cpp/opticalflow.cc:237-316) for
-// frame1 in [shard_begin, shard_end) only.  Frames up to 8 outside the shard are requested from the accessor as
-// tracking targets (gray + pyramid, no detection); pairs are clipped to the clip of `video_info`, so the records do not
-// depend on how the clip is cut.  Nothing is stored: every frame1's record (keypoints + the status == 1 rows of its
-// pairs) is appended on the GPU to `device_log` (HIP device memory of the GPU in use, 16-byte aligned, capacity_bytes
-// long) in the analyzer's log format (include/polychase_hip.h, pc_analyzer_set_device_log) -- the bytes the ranks
-// exchange with one all-gather.  Returns the bytes used; throws when the log is too small.
+// frame1 in [begin, end) only.  Frames up to 8 outside the shard are requested from the accessor as tracking targets
+// (gray + pyramid, no detection); pairs are clipped to the clip of `video_info`, so the records do not depend on how
+// the clip is cut.  Where the records go:
+//   * database_path non-empty: into the SQLite file, exactly like GenerateOpticalFlowDatabase (the rank that owns the
+//     file runs its own shard this way: the inserts overlap the analysis);
+//   * device_log non-null: every frame1's record (keypoints + the status == 1 rows of its pairs) is appended on the
+//     GPU to `device_log` (HIP device memory of the GPU in use, 16-byte aligned) in the analyzer's log format
+//     (include/polychase_hip.h, pc_analyzer_set_device_log) -- the bytes the ranks exchange over RCCL.
+// The log buffer is used as `log_buffers` equal parts that are filled in turn, one PIECE each: a piece ends after
+// `piece_frames` frame1s (0: never) or when the next record does not fit the part.  on_piece is called on the
+// driver's thread when all records of a piece are complete in device memory; the part may be overwritten as soon as
+// the call returns (with two parts the analysis of the next piece runs meanwhile).  Memory is therefore bounded by the
+// buffer, whatever the length of the clip.
+struct OpticalFlowShard {
+    int32_t begin = 0, end = 0;
+    void* device_log = nullptr;
+    size_t capacity_bytes = 0;
+    int log_buffers = 1;
+    int piece_frames = 0;
+    std::function<void(int piece, size_t offset_bytes, size_t bytes, int32_t first_frame1, int n_frames)> on_piece;
+    bool host_records = true;   // false (and no database): the records are not downloaded to host memory as well
+    // results
+    size_t used_bytes = 0;      // bytes of the last piece (a run with one piece: of the run)
+    int pieces = 0;
+    bool cancelled = false;     // the progress callback returned false: the records end early
+};
+void GenerateOpticalFlowShard(const VideoInfo& video_info, FrameAccessorFunction frame_accessor, OpticalFlowProgressCallback callback,
+                              const std::string& database_path, OpticalFlowShard& shard, const GFTTOptions& detector_options = {},
+                              const OpticalFlowOptions& flow_options = {}, OpticalFlowRunStats* stats = nullptr);
+// The same with ONE piece in a buffer of capacity_bytes and nothing stored.  Returns the bytes used; throws
+// ("device log full") when the log is too small.
 size_t GenerateOpticalFlowRecords(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
                                   OpticalFlowProgressCallback callback, int32_t shard_begin, int32_t shard_end,
                                   void* device_log, size_t capacity_bytes, const GFTTOptions& detector_options = {},
@@ -105,5 +130,19 @@ size_t GenerateOpticalFlowRecords(const VideoInfo& video_info, FrameAccessorFunc
 // Stores a record log (host copy, e.g. one rank's part of the all-gather) in the database: per record one transaction
 // with the `keypoints` row and its `optical_flow` rows, rows that exist are kept (opticalflow.cc:168-178, :286) --
 // the statements of the single-process run in the same order, so logs written in frame order give the same file.
+// A `keypoints` row that exists must hold the record's keypoints (else: std::runtime_error, nothing of the record stored).
 void WriteOpticalFlowRecords(const std::string& database_path, const uint8_t* log, size_t bytes,
                              OpticalFlowRunStats* stats = nullptr);
+// The same for a sequence of logs (the pieces rank 0 receives): one connection, rows loaded under a rollback journal
+// like GenerateOpticalFlowDatabase's own inserts, the file back in WAL mode when the writer is closed or destroyed.
+class OpticalFlowRecordWriter {
+   public:
+    explicit OpticalFlowRecordWriter(const std::string& database_path);
+    ~OpticalFlowRecordWriter();
+    void Write(const uint8_t* log, size_t bytes, OpticalFlowRunStats* stats = nullptr);
+    void Close();
+
+   private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+};

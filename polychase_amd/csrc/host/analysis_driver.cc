@@ -12,6 +12,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <exception>
 #include <mutex>
@@ -151,18 +152,19 @@ class RecordWriter {
 
 }  // namespace
 
-// A shard of the frame1 loop; the whole clip when shard == nullptr
-struct Shard {
-    int32_t begin, end;       // frame1 ids [begin, end)
-    void* device_log;         // records go here instead of a database
-    size_t capacity_bytes;
-    size_t used_bytes = 0;
+// One piece of a shard's device log: the frame1 jobs submitted into one part of the log buffer
+struct LogPiece {
+    int index = 0;
+    size_t offset = 0, bytes = 0;
+    int32_t first_frame1 = 0;
+    int submitted = 0, collected = 0;
+    bool closed = false;
 };
 
 static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
                         OpticalFlowProgressCallback callback, const std::string& database_path,
                         const GFTTOptions& detector_options, const OpticalFlowOptions& flow_options,
-                        OpticalFlowRunStats* stats, Shard* shard) {
+                        OpticalFlowRunStats* stats, OpticalFlowShard* shard) {
     CHECK(frame_accessor);
     const double t_begin = Now();
     std::unique_ptr<Database> db;
@@ -222,8 +224,19 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
     if (pc_analyzer_create(eng.ctx, static_cast<int>(video_info.width), static_cast<int>(video_info.height), &gopt,
                            &fopt, kRing, kMaxJobs, &eng.an) != PC_OK)
         ThrowHip("pc_analyzer_create");
-    if (shard && pc_analyzer_set_device_log(eng.an, shard->device_log, shard->capacity_bytes) != PC_OK)
-        ThrowHip("pc_analyzer_set_device_log");
+    // The shard's device log: `log_buffers` equal parts of the caller's buffer, filled in turn; a part is handed to
+    // on_piece when every job submitted into it has been collected, and reused `log_buffers` pieces later.
+    const bool with_log = shard && shard->device_log != nullptr;
+    const int n_parts = with_log ? std::max(1, shard->log_buffers) : 1;
+    const size_t part_bytes = with_log ? (shard->capacity_bytes / static_cast<size_t>(n_parts)) & ~static_cast<size_t>(15) : 0;
+    std::deque<LogPiece> pieces;   // oldest first; the back one is open (jobs are still being submitted into it)
+    int next_piece = 0;
+    auto log_part = [&](int piece) { return static_cast<uint8_t*>(shard->device_log) + static_cast<size_t>(piece % n_parts) * part_bytes; };
+    if (with_log) {
+        CHECK(part_bytes >= 512);
+        if (pc_analyzer_set_device_log(eng.an, log_part(0), part_bytes) != PC_OK) ThrowHip("pc_analyzer_set_device_log");
+        if (!db && !shard->host_records && pc_analyzer_set_host_records(eng.an, 0) != PC_OK) ThrowHip("pc_analyzer_set_host_records");
+    }
 
     OpticalFlowRunStats local_stats;
     std::mutex db_mtx;
@@ -242,14 +255,53 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
         return f;
     };
 
+    auto hand_off_complete_pieces = [&]() {
+        while (!pieces.empty() && pieces.front().closed && pieces.front().collected == pieces.front().submitted) {
+            const LogPiece pc = pieces.front();
+            pieces.pop_front();
+            shard->used_bytes = pc.bytes;
+            shard->pieces++;
+            if (shard->on_piece) shard->on_piece(pc.index, pc.offset, pc.bytes, pc.first_frame1, pc.submitted);
+        }
+    };
     auto collect_one = [&]() {
         pc_frame_result r;
         if (pc_analyzer_collect(eng.an, &r) != PC_OK) ThrowHip("pc_analyzer_collect");
         local_stats.frames_processed++;
         if (writer) writer->Enqueue(r);
+        if (with_log) {
+            // jobs come back in submission order: this one belongs to the oldest piece that still misses one
+            for (LogPiece& pc : pieces)
+                if (pc.collected < pc.submitted) {
+                    pc.collected++;
+                    break;
+                }
+            hand_off_complete_pieces();
+        }
+    };
+    // the open piece takes no more jobs: its bytes are final; the next job goes to the next part of the buffer -- once
+    // the piece that used that part has been handed off
+    auto close_piece = [&]() {
+        if (pieces.empty() || pieces.back().closed) return;
+        LogPiece& pc = pieces.back();
+        if (pc_analyzer_device_log_used(eng.an, &pc.bytes) != PC_OK) ThrowHip("pc_analyzer_device_log_used");
+        pc.closed = true;
+        hand_off_complete_pieces();
+    };
+    auto open_piece = [&](int32_t first_frame1) {
+        const int index = next_piece++;
+        while (!pieces.empty() && pieces.front().index <= index - n_parts) collect_one();   // that part of the buffer is still in use
+        LogPiece pc;
+        pc.index = index;
+        pc.offset = static_cast<size_t>(index % n_parts) * part_bytes;
+        pc.first_frame1 = first_frame1;
+        pieces.push_back(pc);
+        if (index > 0 && pc_analyzer_redirect_device_log(eng.an, log_part(index), part_bytes) != PC_OK)
+            ThrowHip("pc_analyzer_redirect_device_log");
     };
     auto drain = [&]() {
         while (pc_analyzer_pending(eng.an) > 0) collect_one();
+        if (with_log) close_piece();
         if (writer) writer->Flush();
     };
     auto finish_stats = [&]() {
@@ -279,7 +331,8 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
                                          : static_cast<float>(frame_id1 - from) / static_cast<float>(video_info.num_frames);
             const bool ok = callback(progress, "Processing frame " + std::to_string(frame_id1));
             if (!ok) {
-                drain();  // jobs already on the GPU are complete work: keep them
+                drain();  // jobs already on the GPU are complete work: keep them (a shard: their pieces have been handed off)
+                if (shard) shard->cancelled = true;
                 finish_stats();
                 callback(1.0f, "Cancelled");
                 return;
@@ -298,7 +351,7 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
                     "Exiting optical flow generation prematurely because some frames were not provided");
             }
             bool will_detect = fid >= f1_begin && fid < f1_end;   // the halo of a shard is tracked into, never from
-            if (db) {
+            if (db && will_detect) {
                 std::lock_guard<std::mutex> lk(db_mtx);
                 will_detect = !db->KeypointsExist(fid);
             }
@@ -309,8 +362,10 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
                     ? pc_analyzer_put_frame_f32(eng.an, fid, reinterpret_cast<const float*>(f->data), f->row_pitch, f->channels,
                                                 where, will_detect ? 1 : 0)
                     : pc_analyzer_put_frame(eng.an, fid, f->data, f->row_pitch, where, will_detect ? 1 : 0);
-            if (put_rc != PC_OK) ThrowHip("pc_analyzer_put_frame");
+            // the owner first: put_frame may have enqueued a copy out of the buffer before it failed, and
+            // frames_in_flight outlives the engine (whose destructor synchronises) while `f` does not
             if (f->on_device && f->owner) frames_in_flight.emplace_back(fid, std::move(f->owner));
+            if (put_rc != PC_OK) ThrowHip("pc_analyzer_put_frame");
             release_ingested(frames_in_flight.size() > 24);   // bounded: the pool behind the owners is finite
             highest_put = fid;
         }
@@ -337,10 +392,22 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
             targets[n_targets++] = frame_id2;
         }
         while (pc_analyzer_pending(eng.an) >= kGpuDepth) collect_one();
-        if (pc_analyzer_submit(eng.an, frame_id1, targets, n_targets) != PC_OK) ThrowHip("pc_analyzer_submit");
+        if (with_log) {
+            if (!pieces.empty() && !pieces.back().closed && shard->piece_frames > 0 && pieces.back().submitted >= shard->piece_frames)
+                close_piece();
+            if (pieces.empty() || pieces.back().closed) open_piece(frame_id1);
+        }
+        int rc = pc_analyzer_submit(eng.an, frame_id1, targets, n_targets);
+        if (rc == PC_E_CAPACITY && with_log && pieces.back().submitted > 0 && (shard->piece_frames > 0 || n_parts > 1)) {
+            // the record does not fit what is left of this part of the log: the piece ends here
+            close_piece();
+            open_piece(frame_id1);
+            rc = pc_analyzer_submit(eng.an, frame_id1, targets, n_targets);
+        }
+        if (rc != PC_OK) ThrowHip("pc_analyzer_submit");
+        if (with_log) pieces.back().submitted++;
     }
     drain();
-    if (shard && pc_analyzer_device_log_used(eng.an, &shard->used_bytes) != PC_OK) ThrowHip("pc_analyzer_device_log_used");
     finish_stats();
     if (callback) callback(1.0f, "Done");
 }
@@ -354,21 +421,59 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
                 nullptr);
 }
 
+void GenerateOpticalFlowShard(const VideoInfo& video_info, FrameAccessorFunction frame_accessor, OpticalFlowProgressCallback callback,
+                              const std::string& database_path, OpticalFlowShard& shard, const GFTTOptions& detector_options,
+                              const OpticalFlowOptions& flow_options, OpticalFlowRunStats* stats) {
+    CHECK(shard.begin <= shard.end);
+    CHECK(shard.device_log != nullptr || !database_path.empty());
+    shard.used_bytes = 0;
+    shard.pieces = 0;
+    shard.cancelled = false;
+    RunAnalysis(video_info, std::move(frame_accessor), std::move(callback), database_path, detector_options, flow_options, stats, &shard);
+}
+
 size_t GenerateOpticalFlowRecords(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
                                   OpticalFlowProgressCallback callback, int32_t shard_begin, int32_t shard_end,
                                   void* device_log, size_t capacity_bytes, const GFTTOptions& detector_options,
                                   const OpticalFlowOptions& flow_options, OpticalFlowRunStats* stats) {
     CHECK(device_log != nullptr);
-    CHECK(shard_begin <= shard_end);
-    Shard shard{shard_begin, shard_end, device_log, capacity_bytes};
-    RunAnalysis(video_info, std::move(frame_accessor), std::move(callback), "", detector_options, flow_options, stats, &shard);
+    OpticalFlowShard shard;
+    shard.begin = shard_begin;
+    shard.end = shard_end;
+    shard.device_log = device_log;
+    shard.capacity_bytes = capacity_bytes;
+    GenerateOpticalFlowShard(video_info, std::move(frame_accessor), std::move(callback), "", shard, detector_options, flow_options, stats);
     return shard.used_bytes;
 }
 
-void WriteOpticalFlowRecords(const std::string& database_path, const uint8_t* log, size_t bytes, OpticalFlowRunStats* stats) {
+// ---- OpticalFlowRecordWriter: record logs -> database, one connection (bulk-load journal) for many logs --------------
+struct OpticalFlowRecordWriter::Impl {
+    Database db;
+    bool bulk = false;
+    explicit Impl(const std::string& path) : db(path) {
+        const char* env = std::getenv("POLYCHASE_DB_BULK_LOAD");
+        bulk = !(env && env[0] == '0') && db.SetJournalMode("TRUNCATE") == "truncate";   // see RunAnalysis
+    }
+    ~Impl() {
+        if (!bulk) return;
+        try {
+            db.SetJournalMode("WAL");
+        } catch (...) {
+        }
+    }
+};
+OpticalFlowRecordWriter::OpticalFlowRecordWriter(const std::string& database_path) {
     CHECK(!database_path.empty());
-    Database db(database_path);
+    impl_ = std::make_unique<Impl>(database_path);
+}
+OpticalFlowRecordWriter::~OpticalFlowRecordWriter() = default;
+void OpticalFlowRecordWriter::Close() { impl_.reset(); }
+
+void OpticalFlowRecordWriter::Write(const uint8_t* log, size_t bytes, OpticalFlowRunStats* stats) {
+    if (!impl_) throw std::runtime_error("OpticalFlowRecordWriter is closed");
+    Database& db = impl_->db;
     OpticalFlowRunStats local;
+    Keypoints known;
     const double t0 = Now();
     auto up16 = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
     size_t o = 0;
@@ -390,6 +495,17 @@ void WriteOpticalFlowRecords(const std::string& database_path, const uint8_t* lo
         if (!db.KeypointsExist(frame1)) {
             db.WriteKeypoints(frame1, reinterpret_cast<const float*>(log + o_kps), n);
             local.keypoint_rows_written++;
+        } else {
+            // the flows of this record index the record's keypoints: a stored row must be the same list (a database of
+            // another run -- other detector options, the reference's detector -- would end up with flows that point
+            // at the wrong corners; the single-process path tracks FROM the stored keypoints instead, :168-178)
+            known.clear();
+            db.ReadKeypoints(frame1, known);
+            if (known.size() != n || (n > 0 && std::memcmp(known[0].data(), log + o_kps, n * 8) != 0)) {
+                db.Rollback();
+                throw std::runtime_error("keypoints of frame " + std::to_string(frame1) +
+                                         " stored in the database differ from the record's: refusing to mix two analyses");
+            }
         }
         for (int t = 0; t < nt; t++) {
             const int32_t frame2 = static_cast<int32_t>(hdr[4 + t]);
@@ -406,4 +522,9 @@ void WriteOpticalFlowRecords(const std::string& database_path, const uint8_t* lo
     }
     local.seconds_db = local.seconds_total = Now() - t0;
     if (stats) *stats = local;
+}
+
+void WriteOpticalFlowRecords(const std::string& database_path, const uint8_t* log, size_t bytes, OpticalFlowRunStats* stats) {
+    OpticalFlowRecordWriter w(database_path);
+    w.Write(log, bytes, stats);
 }

@@ -142,6 +142,53 @@ py::tuple GenerateOpticalFlowRecordsPy(const VideoInfo& video_info, py::object f
     return py::make_tuple(used, stats);
 }
 
+// one shard with everything the multi-rank driver needs: records into the database (the rank that owns the file) and / or
+// into a device log that is handed over piece by piece (on_piece(piece, offset_bytes, bytes, first_frame1, n_frames),
+// called with the GIL on the driver's thread; the part of the log may be reused when it returns)
+py::dict GenerateOpticalFlowShardPy(const VideoInfo& video_info, py::object frame_accessor, py::object callback,
+                                    const std::string& database_path, int32_t shard_begin, int32_t shard_end, uintptr_t device_log,
+                                    size_t capacity_bytes, int log_buffers, int piece_frames, py::object on_piece, bool host_records,
+                                    const GFTTOptions& detector_options, const OpticalFlowOptions& flow_options) {
+    std::deque<py::object> keep_alive;
+    FrameAccessorFunction accessor;
+    if (!frame_accessor.is_none())
+        accessor = [&](int32_t frame_id) -> std::optional<FrameView> {
+            py::gil_scoped_acquire gil;
+            return FrameFromPython(frame_accessor(frame_id), keep_alive);
+        };
+    OpticalFlowProgressCallback cb;
+    if (!callback.is_none())
+        cb = [&](float progress, const std::string& msg) -> bool {
+            py::gil_scoped_acquire gil;
+            return callback(progress, msg).cast<bool>();
+        };
+    OpticalFlowShard shard;
+    shard.begin = shard_begin;
+    shard.end = shard_end;
+    shard.device_log = reinterpret_cast<void*>(device_log);
+    shard.capacity_bytes = capacity_bytes;
+    shard.log_buffers = log_buffers;
+    shard.piece_frames = piece_frames;
+    shard.host_records = host_records;
+    if (!on_piece.is_none())
+        shard.on_piece = [&](int piece, size_t offset, size_t bytes, int32_t first_frame1, int n_frames) {
+            py::gil_scoped_acquire gil;
+            on_piece(piece, offset, bytes, first_frame1, n_frames);
+        };
+    OpticalFlowRunStats stats;
+    {
+        py::gil_scoped_release release;
+        GenerateOpticalFlowShard(video_info, accessor, cb, database_path, shard, detector_options, flow_options, &stats);
+    }
+    keep_alive.clear();
+    py::dict out;
+    out["used_bytes"] = shard.used_bytes;
+    out["pieces"] = shard.pieces;
+    out["cancelled"] = shard.cancelled;
+    out["stats"] = stats;
+    return out;
+}
+
 OpticalFlowRunStats WriteOpticalFlowRecordsPy(const std::string& database_path, const U8Array& log, size_t bytes) {
     if (bytes > static_cast<size_t>(log.size())) throw py::value_error("bytes exceeds the buffer");
     OpticalFlowRunStats stats;
@@ -275,6 +322,24 @@ PYBIND11_MODULE(polychase_core, m) {
     m.def("generate_optical_flow_records", &GenerateOpticalFlowRecordsPy, py::arg("video_info"), py::arg("frame_accessor_function"),
           py::arg("callback"), py::arg("shard_begin"), py::arg("shard_end"), py::arg("device_log"), py::arg("capacity_bytes"),
           py::arg("detector_options") = GFTTOptions{}, py::arg("flow_options") = OpticalFlowOptions{});
+    m.def("generate_optical_flow_shard", &GenerateOpticalFlowShardPy, py::arg("video_info"), py::arg("frame_accessor_function"),
+          py::arg("callback"), py::arg("database_path"), py::arg("shard_begin"), py::arg("shard_end"), py::arg("device_log") = 0,
+          py::arg("capacity_bytes") = 0, py::arg("log_buffers") = 1, py::arg("piece_frames") = 0, py::arg("on_piece") = py::none(),
+          py::arg("host_records") = true, py::arg("detector_options") = GFTTOptions{}, py::arg("flow_options") = OpticalFlowOptions{});
+    py::class_<OpticalFlowRecordWriter>(m, "OpticalFlowRecordWriter")
+        .def(py::init<const std::string&>(), py::arg("database_path"))
+        .def("write",
+             [](OpticalFlowRecordWriter& w, const U8Array& log, size_t bytes) {
+                 if (bytes > static_cast<size_t>(log.size())) throw py::value_error("bytes exceeds the buffer");
+                 OpticalFlowRunStats stats;
+                 {
+                     py::gil_scoped_release release;
+                     w.Write(log.data(), bytes, &stats);
+                 }
+                 return stats;
+             },
+             py::arg("log"), py::arg("bytes"))
+        .def("close", &OpticalFlowRecordWriter::Close);
     m.def("write_optical_flow_records", &WriteOpticalFlowRecordsPy, py::arg("database_path"), py::arg("log"), py::arg("bytes"));
     m.def("generate_optical_flow_database", &GenerateOpticalFlowDatabasePy, py::arg("video_info"),
           py::arg("frame_accessor_function"), py::arg("callback"), py::arg("database_path"),

@@ -31,7 +31,8 @@ SYMBOLS = [
     "pc_analyzer_create", "pc_analyzer_destroy", "pc_analyzer_put_frame", "pc_analyzer_put_frame_f32",
     "pc_analyzer_has_frame", "pc_analyzer_frame_ingested",
     "pc_analyzer_set_keypoints", "pc_analyzer_submit", "pc_analyzer_pending", "pc_analyzer_collect",
-    "pc_analyzer_set_device_log", "pc_analyzer_device_log_used",
+    "pc_analyzer_set_device_log", "pc_analyzer_device_log_used", "pc_analyzer_redirect_device_log",
+    "pc_analyzer_set_host_records",
     "pc_mesh_create", "pc_mesh_set_mask", "pc_mesh_destroy", "pc_raycast_pixels", "pc_raycast_pixels_sweep",
     "pc_corr_set_create", "pc_corr_set_destroy", "pc_corr_set_clear", "pc_corr_set_append", "pc_corr_set_size",
     "pc_corr_set_download", "pc_pnp_problem_from_set",
@@ -138,6 +139,8 @@ def load():
     L.pc_analyzer_collect.argtypes = [vp, C.POINTER(FrameResult)]
     L.pc_analyzer_set_device_log.argtypes = [vp, vp, C.c_size_t]
     L.pc_analyzer_device_log_used.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.pc_analyzer_redirect_device_log.argtypes = [vp, vp, C.c_size_t]
+    L.pc_analyzer_set_host_records.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -435,6 +438,15 @@ class Analyzer:
         assert tensor.is_cuda and tensor.is_contiguous() and tensor.element_size() == 1
         _check(load().pc_analyzer_set_device_log(self._h, tensor.data_ptr(), tensor.numel()))
         self._log = tensor
+
+    def redirect_device_log(self, tensor):
+        """The following jobs append to `tensor` from offset 0; nothing is waited for (pc_analyzer_redirect_device_log)."""
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.element_size() == 1
+        _check(load().pc_analyzer_redirect_device_log(self._h, tensor.data_ptr(), tensor.numel()))
+        self._log = tensor
+
+    def set_host_records(self, enabled: bool):
+        _check(load().pc_analyzer_set_host_records(self._h, 1 if enabled else 0))
 
     @property
     def device_log_used(self) -> int:

@@ -242,3 +242,78 @@ def test_record_log_roundtrip_and_corruption():
             core.write_optical_flow_records(os.path.join(td, "x.db"), bad, len(bad))
         with pytest.raises(RuntimeError):
             core.write_optical_flow_records(os.path.join(td, "y.db"), log, len(log) - 40)
+
+
+# ----------------------------------------------------------------------------------------------
+# The streamed stitch of the product (polychase_amd/analyze.py): pieces of the ranks' logs travel to rank 0 in frame
+# order under credit flow control (distributed.OrderedPieceGather) and are stored as they arrive.
+# ----------------------------------------------------------------------------------------------
+def _gather_worker(rank, world, port, first, n, out_dir, per, delay_start):
+    import time
+
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b, e = D.shard_range(first, n, world, rank)
+    g = D.OrderedPieceGather(depth=2)
+    core = _core()
+    if rank == 0:
+        if delay_start:
+            time.sleep(delay_start)            # the senders fill their queues and block meanwhile
+        g.start()
+        own = D.pack_device_log([fake_record(f, first, n) for f in range(b, e)])
+        w = core.OpticalFlowRecordWriter(os.path.join(out_dir, "streamed.db"))
+        w.write(own, len(own))
+        order = []
+        for r, piece_first, frames, host in g.pieces():
+            order.append((r, piece_first, frames))
+            w.write(host, len(host))
+        w.close()
+        # frame order: ranks ascending, within a rank the pieces ascending and contiguous
+        expect = []
+        for r in range(1, world):
+            rb, re_ = D.shard_range(first, n, world, r)
+            expect += [(r, f, min(per, re_ - f)) for f in range(rb, re_, per)]
+        assert order == expect, (order, expect)
+    else:
+        log_np, bounds = _fake_log(range(b, e), first, n)
+        log = torch.from_numpy(log_np) if len(log_np) else torch.zeros(0, dtype=torch.uint8)
+        for lo in range(0, e - b, per):
+            hi = min(lo + per, e - b)
+            g.put(log[bounds[lo]:bounds[hi]], b + lo, hi - lo)
+        g.finish()
+        if delay_start and (e - b + per - 1) // per > 3:
+            assert g.seconds_blocked > 0.2, "more pieces than the queue holds must have waited for rank 0"
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,per,delay", [(2, 21, 3, 0.0), (3, 31, 2, 1.0), (3, 2, 4, 0.0)])
+def test_ordered_piece_gather_streams_the_single_rank_database(tmp_path, world, n, per, delay):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    first = 3
+    mp.spawn(_gather_worker, args=(world, port, first, n, str(tmp_path), per, delay), nprocs=world, join=True)
+    core = _core()
+    one = D.pack_device_log([fake_record(f, first, n) for f in range(first, first + n)])
+    core.write_optical_flow_records(str(tmp_path / "single.db"), one, len(one))
+    assert _db_dump(str(tmp_path / "streamed.db")) == _db_dump(str(tmp_path / "single.db"))
+
+
+def test_record_writer_refuses_other_keypoints(tmp_path):
+    """A database that already holds ANOTHER analysis of a frame (other keypoints) must not receive this one's flows."""
+    core = _core()
+    a = D.pack_device_log([fake_record(5, 1, 12)])
+    f, kps, flows = fake_record(5, 1, 12)
+    b = D.pack_device_log([(f, kps[::-1].copy(), flows)])
+    path = str(tmp_path / "x.db")
+    core.write_optical_flow_records(path, a, len(a))
+    before = _db_dump(path)
+    with pytest.raises(RuntimeError, match="differ from the record's"):
+        core.write_optical_flow_records(path, b, len(b))
+    assert _db_dump(path) == before
+    core.write_optical_flow_records(path, a, len(a))     # the same analysis again is fine (rows kept)
+    assert _db_dump(path) == before
