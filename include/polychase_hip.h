@@ -72,6 +72,24 @@ const char* pc_version(void);
 int pc_context_create(int device_index, pc_context** out);
 void pc_context_destroy(pc_context* ctx);
 int pc_context_synchronize(pc_context* ctx);
+/* Arithmetic mode: where OpenCV's result depends on how the host executes it, which execution the GPU reproduces.
+ *   PC_ARITH_CANONICAL      no FMA anywhere; the LK sums (structure tensor, mismatch vector) exact in integers, rounded once
+ *   PC_ARITH_LK_X86_ORDER   the LK sums in fp32 in the order of LKTrackerInvoker's CV_SIMD128 path on x86 (four vector lanes
+ *                           over the first (win / 8) * 8 columns, a scalar accumulator over the rest; calcOpticalFlowPyrLK,
+ *                           cpp/opticalflow.cc:119-125): differs from the canonical order only where a window's partial
+ *                           sums exceed 2^24 (step edges), by <= ~2e-3 px; runs on the generic LK kernel (several times slower)
+ *   PC_ARITH_SOBEL_FMA      the fused multiply-add of the AVX2-dispatched symmetric column filter of Sobel inside
+ *                           cornerMinEigenVal (cpp/feature_detection/gftt.cc:35): same corners, the (value, address)
+ *                           order of near-ties -- i.e. keypoint indices -- as a stock x86 build produces them
+ *   PC_ARITH_OPENCV_X86     both
+ * Bit for bit what oracle/pc_oracle.c computes under pco_set_opencv_emulation(flags).  Default: PC_ARITH_CANONICAL, or the
+ * environment variable POLYCHASE_ARITH = canonical | opencv_x86 | lk_x86 | sobel_fma at context creation. */
+#define PC_ARITH_CANONICAL 0
+#define PC_ARITH_LK_X86_ORDER 1
+#define PC_ARITH_SOBEL_FMA 2
+#define PC_ARITH_OPENCV_X86 3
+int pc_context_set_arithmetic(pc_context* ctx, int flags);
+int pc_context_get_arithmetic(const pc_context* ctx);
 /* hipStream_t the context enqueues on (for callers that time with HIP events / torch streams). */
 void* pc_context_stream(pc_context* ctx);
 /* Timing of the context's kernels with HIP events on the stream each launch is enqueued on.  `class_mask` bit k

@@ -222,7 +222,7 @@ int detect_enqueue(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const
     d.cleared = false;
     {
         ScopedTimer t(ctx, PC_K_MINEIG);
-        pc::launch_min_eig(f->levels[0], d.eig.p, grid, cnt + kCellMaxAt, ctx->work);
+        pc::launch_min_eig(f->levels[0], d.eig.p, grid, cnt + kCellMaxAt, (ctx->arith & PC_ARITH_SOBEL_FMA) != 0, ctx->work);
     }
     {
         ScopedTimer t(ctx, PC_K_NMS);
@@ -272,7 +272,7 @@ static int detect_slow_path(pc_context* ctx, pc_frame* f, const pc::GfttGrid& gr
     d.cleared = false;
     PC_HIP(hipMemsetAsync(cnt, 0, (size_t)d.counter_words * sizeof(uint32_t), ctx->work));
     uint32_t* const tickets = cnt + kTicketsAt;
-    pc::launch_min_eig(f->levels[0], d.eig.p, grid, cnt + kCellMaxAt, ctx->work);
+    pc::launch_min_eig(f->levels[0], d.eig.p, grid, cnt + kCellMaxAt, (ctx->arith & PC_ARITH_SOBEL_FMA) != 0, ctx->work);
     pc::launch_nms(d.eig.p, w, h, grid, cnt + kCellMaxAt, opt.quality_level, d.keys.p, npx, cnt + kCntCand, d.cstate.p,
                    cnt + kCntSortParams, cnt + kHistAt, tickets, d.bucket_offsets.p, hist.p, ctx->work);
     PC_HIP(hipMemcpyAsync(d.h_counters.p, cnt, kHostCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));
@@ -416,6 +416,7 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
     p.min_eig_thr = (float)opt->min_eigen_threshold;
     p.out_rec = ctx->lk_rec[set].p;
     p.prof = nullptr;
+    p.x86_order = (ctx->arith & PC_ARITH_LK_X86_ORDER) ? 1 : 0;
     p.gate = ctx->lk_gate_next ? ctx->lk_gate.p : nullptr;
     p.gate_value = ctx->lk_gate_next;
     ctx->lk_gate_next = 0;
@@ -495,6 +496,16 @@ int pc_context_create(int device_index, pc_context** out) {
         }
     }
     c->work = c->stream;
+    if (const char* m = getenv("POLYCHASE_ARITH")) {
+        const std::string mode(m);
+        if (mode == "opencv_x86") c->arith = PC_ARITH_OPENCV_X86;
+        else if (mode == "lk_x86") c->arith = PC_ARITH_LK_X86_ORDER;
+        else if (mode == "sobel_fma") c->arith = PC_ARITH_SOBEL_FMA;
+        else if (mode != "canonical" && !mode.empty()) {
+            delete c;
+            return fail(PC_E_INVALID, "POLYCHASE_ARITH=%s: expected canonical, opencv_x86, lk_x86 or sobel_fma", m);
+        }
+    }
     if (e != hipSuccess) {
         delete c;
         return fail(PC_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -502,6 +513,15 @@ int pc_context_create(int device_index, pc_context** out) {
     *out = c;
     return PC_OK;
 }
+
+int pc_context_set_arithmetic(pc_context* c, int flags) {
+    if (!c) return fail(PC_E_INVALID, "null context");
+    if (flags & ~PC_ARITH_OPENCV_X86) return fail(PC_E_INVALID, "unknown arithmetic flags %d", flags);
+    c->arith = flags;
+    c->eig_owner = nullptr;   // a min-eig map computed under the other mode is not this mode's
+    return PC_OK;
+}
+int pc_context_get_arithmetic(const pc_context* c) { return c ? c->arith : -1; }
 
 void pc_context_destroy(pc_context* c) {
     if (!c) return;

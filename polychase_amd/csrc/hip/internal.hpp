@@ -140,6 +140,7 @@ struct DetectScratch {
 
 struct pc_context {
     int device = 0;
+    int arith = PC_ARITH_CANONICAL;      // pc_context_set_arithmetic
     // Stage-level calls run on `stream`.  pc_analyzer alternates its jobs (LK launch + compaction + device-log append +
     // record download of one frame1) over two job lanes, `stream` and `stream_b`: the launches of consecutive frames
     // overlap, so the tail of one launch and the gap before the next are filled by the other lane's wavefronts.

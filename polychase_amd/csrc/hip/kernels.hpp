@@ -52,7 +52,8 @@ struct GfttGrid {
 constexpr int kMaxGridCells = 256;
 // K2: cornerMinEigenVal (block 3, Sobel 3) of the level-0 interior + per-cell max (ordered keys,
 // cell_max must be zeroed first).
-void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, hipStream_t s);
+// sobel_fma: the column pass of Dx as ONE fused multiply-add (PC_ARITH_SOBEL_FMA: the AVX2 dispatch of OpenCV's filter)
+void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, bool sobel_fma, hipStream_t s);
 // K3: per-cell THRESH_TOZERO + 3x3 dilate + strict-interior local maxima -> 64-bit keys
 // (ordered(value) << 32 | y*w+x) appended to `keys` (capacity `cap`), count in *counter; cstate (w*h bytes): 1 at
 // candidates, 0 elsewhere, every pixel written; sort_params[2] / hist[kSortBuckets]: value range and per-bucket counts
@@ -118,6 +119,7 @@ struct LKParams {
     // the next launch fills the tail of this one -- and no more than the tail.  May be null.
     uint32_t* gate;
     uint32_t gate_value;
+    int x86_order;            // PC_ARITH_LK_X86_ORDER: fp32 lane sums in the order of OpenCV's SSE path (kernels_lk.hip, X86 = true)
 };
 // the stream waits (one idle wavefront) until *gate has reached `value` (wrap-around compare); gives up after ~50 ms
 // and stores 1 to *timed_out (device-visible host memory, may be null)

@@ -37,7 +37,7 @@ constexpr int CW = TW + 2, CH = TH + 2;   // covariance tile: x0 - 1 .. x0 + 64,
 
 __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict__ img, int pitch, int w, int h,
                                                       float* __restrict__ eig, GfttGrid g,
-                                                      uint32_t* __restrict__ cell_max, float f1, float f0, int hi_prio) {
+                                                      uint32_t* __restrict__ cell_max, float f1, float f0, int sobel_fma, int hi_prio) {
     helper_priority(hi_prio);
     __shared__ __attribute__((aligned(16))) uint8_t s_gray[GH][G_PITCH];
     __shared__ float s_cxx[CH][CW + 1];
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict_
             t += f1 * c;
             ry[2] = t;
             // Dx: row [-1,0,1] then column (S0 + S2)*f1 + S1*f0;  Dy: row [1,2,1]*scale then column S2 - S0
-            const float dx = (rx[0] + rx[2]) * f1 + rx[1] * f0;
+            // PC_ARITH_SOBEL_FMA: v_muladd(S0 + S2, k1, S1 * k0) fused, as the AVX2 build of the filter executes it
+            const float dx = sobel_fma ? __fmaf_rn(rx[0] + rx[2], f1, rx[1] * f0) : (rx[0] + rx[2]) * f1 + rx[1] * f0;
             const float dy = ry[2] - ry[0];
             const int ay = y0 - 1 + cy;
             const bool in = ax >= 0 && ax < w && ay >= 0 && ay < h;
@@ -161,12 +162,12 @@ __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict_
     }
 }
 
-void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, hipStream_t s) {
+void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, bool sobel_fma, hipStream_t s) {
     // scale = 1 / (2^(ksize-1) * block_size * 255), folded into the smoothing taps (see oracle)
     const double scale_d = 1.0 / (4.0 * 3.0 * 255.0);
     const float f1 = (float)(1.0 * scale_d), f0 = (float)(2.0 * scale_d);
     dim3 grid((l0.w + TW - 1) / TW, (l0.h + TH - 1) / TH);
-    hipLaunchKernelGGL(min_eig_kernel, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, helper_prio_arg());
+    hipLaunchKernelGGL(min_eig_kernel, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, sobel_fma ? 1 : 0, helper_prio_arg());
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -28,14 +28,23 @@
 namespace pc {
 
 // One wavefront per keypoint; group g = lane / 8 tracks it into target g (v3).
-template <int WIN>
+//
+// X86 = true: the sums of the structure tensor and of the mismatch vector in the ORDER an x86 OpenCV build executes them
+// (LKTrackerInvoker's CV_SIMD128 path: four fp32 lane accumulators over the first (WIN / 8) * 8 columns, a scalar fp32
+// accumulator over the rest, combined at the end) instead of exactly in integers -- PC_ARITH_LK_X86_ORDER, bit for bit
+// oracle/pc_oracle.c under PCO_EMU_LK_SIMD.  Where every partial sum stays below 2^24 the two orders agree; on step
+// edges they differ by up to ~2e-3 px.  The fp32 accumulations are sequential by definition,
+// so this mode runs on the generic kernel only and costs about 3x its iteration.
+template <int WIN, bool X86>
 __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
     using G = LKGeo<WIN>;
     constexpr int GL = 8;
     constexpr int NPX = WIN * WIN;
     constexpr int K = (NPX + GL - 1) / GL;
     constexpr int KW = (NPX + 63) / 64;  // pixels per lane in the cooperative (wave-wide) I-side pass
-    __shared__ __attribute__((aligned(16))) uint32_t s_buf[4][G::WAVE_DW];
+    constexpr int SIMD_W = (WIN / 8) * 8;                      // columns the x86 path handles with vector lanes
+    constexpr int DIF_DW = X86 ? 8 * NPX : 0;                  // X86: every group's per-pixel differences of one iteration
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[4][G::WAVE_DW + DIF_DW];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = lane >> 3, lg = lane & 7;
@@ -55,6 +64,7 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
     uint8_t* const dbuf = reinterpret_cast<uint8_t*>(wbase + G::I_DW);             // raw Scharr window
     uint32_t* const xbuf = wbase + G::I_DW + G::D_DW;                              // (Ival, Dxy) exchange
     uint8_t* const jbuf = reinterpret_cast<uint8_t*>(wbase + G::I_DW + G::D_DW + G::X_DW + grp * G::J_DW);
+    int32_t* const dif = reinterpret_cast<int32_t*>(wbase + G::WAVE_DW) + grp * NPX;   // X86 only
 
     // Window pixels owned by this lane.  Main part: lane lg < WIN owns COLUMN lg (rows 0..WIN-1), so
     // the bottom taps of row y are the top taps of row y+1 and one LDS read per pixel suffices.
@@ -148,10 +158,44 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
                 }
             }
         }
-        // |ix|,|iy| <= 4080: per-lane partials fit int32; totals reduced as exact (hi, lo) halves
-        const float A11 = wave_exact_sum(sA11) * FLT_SCALE;
-        const float A12 = wave_exact_sum(sA12) * FLT_SCALE;
-        const float A22 = wave_exact_sum(sA22) * FLT_SCALE;
+        float A11, A12, A22;
+        if constexpr (X86) {
+            // lane j < 4: the vector lane that takes columns j, j + 4, ... < SIMD_W of every row, in row order;
+            // lane 4: the scalar accumulator over the remaining columns; then fA += q0 + q1 + q2 + q3
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            float q11 = 0.f, q12 = 0.f, q22 = 0.f;
+            for (int y = 0; y < WIN; y++) {
+                if (lane < 4) {
+                    for (int x = lane; x < SIMD_W; x += 4) {
+                        const uint32_t d = xbuf[2 * (y * WIN + x) + 1];
+                        const float fx = (float)(int)(int16_t)(d & 0xffffu), fy = (float)((int)d >> 16);
+                        q22 = fy * fy + q22;
+                        q12 = fx * fy + q12;
+                        q11 = fx * fx + q11;
+                    }
+                } else if (lane == 4) {
+                    for (int x = SIMD_W; x < WIN; x++) {
+                        const uint32_t d = xbuf[2 * (y * WIN + x) + 1];
+                        const int ix = (int)(int16_t)(d & 0xffffu), iy = (int)d >> 16;
+                        q11 += (float)(ix * ix);
+                        q12 += (float)(ix * iy);
+                        q22 += (float)(iy * iy);
+                    }
+                }
+            }
+            auto combine = [](float q) {
+                const float s = ((__shfl(q, 0) + __shfl(q, 1)) + __shfl(q, 2)) + __shfl(q, 3);
+                return __shfl(q, 4) + s;
+            };
+            A11 = combine(q11) * FLT_SCALE;
+            A12 = combine(q12) * FLT_SCALE;
+            A22 = combine(q22) * FLT_SCALE;
+        } else {
+            // |ix|,|iy| <= 4080: per-lane partials fit int32; totals reduced as exact (hi, lo) halves
+            A11 = wave_exact_sum(sA11) * FLT_SCALE;
+            A12 = wave_exact_sum(sA12) * FLT_SCALE;
+            A22 = wave_exact_sum(sA22) * FLT_SCALE;
+        }
         float D = A11 * A22 - A12 * A12;
         const float tdiff = A11 - A22;
         const float min_eig = (A22 + A11 - sqrtf(tdiff * tdiff + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
@@ -212,19 +256,61 @@ __global__ __launch_bounds__(256) void lk_kernel(const LKParams p) {
                     const uint32_t bot = widen_pair(*reinterpret_cast<const uint16_t*>(cb + (k + 1) * G::PAIR_PITCH));
                     const int diff = interp_diff(top, bot, wJ, Ival[k]);
                     top = bot;
-                    sb1 = mad16_lo(diff, (uint32_t)Dxy[k], sb1);
-                    sb2 = mad16_hi(diff, (uint32_t)Dxy[k], sb2);
+                    if constexpr (X86) {
+                        if (main_valid) dif[k * WIN + lg] = diff;
+                    } else {
+                        sb1 = mad16_lo(diff, (uint32_t)Dxy[k], sb1);
+                        sb2 = mad16_hi(diff, (uint32_t)Dxy[k], sb2);
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < KE; e++) {
                     const uint16_t* q = reinterpret_cast<const uint16_t*>(jb + offE[e]);
                     const int diff = interp_diff(widen_pair(q[0]), widen_pair(q[G::RWB]), wJ, Ival[KM + e]);
-                    sb1 = mad16_lo(diff, (uint32_t)Dxy[KM + e], sb1);
-                    sb2 = mad16_hi(diff, (uint32_t)Dxy[KM + e], sb2);
+                    if constexpr (X86) {
+                        if (qE[e] >= 0) dif[qE[e]] = diff;
+                    } else {
+                        sb1 = mad16_lo(diff, (uint32_t)Dxy[KM + e], sb1);
+                        sb2 = mad16_hi(diff, (uint32_t)Dxy[KM + e], sb2);
+                    }
                 }
             }
             float b1, b2;
-            if constexpr ((long long)K * 8160 * 4080 < (1ll << 29)) {
+            if constexpr (X86) {
+                // per 8 columns the products of columns (c, c + 4) are added as int32 pairs (v_dotprod), converted to
+                // fp32 and accumulated row by row in vector lane c (lanes 0-3 of the group); the scalar accumulator
+                // (lane 4) takes the remaining columns; b = scalar + ((q[c=0] + q[c=2]) + (q[c=1] + q[c=3]))
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                float q1 = 0.f, q2 = 0.f;
+                for (int y = 0; y < WIN; y++) {
+                    if (lg < 4) {
+                        for (int x0 = 0; x0 < SIMD_W; x0 += 8) {
+                            const int qa = y * WIN + x0 + lg, qb = qa + 4;
+                            const int da = dif[qa], db = dif[qb];
+                            const uint32_t ea = xbuf[2 * qa + 1], eb = xbuf[2 * qb + 1];
+                            const int p1 = da * (int)(int16_t)(ea & 0xffffu) + db * (int)(int16_t)(eb & 0xffffu);
+                            const int p2 = da * ((int)ea >> 16) + db * ((int)eb >> 16);
+                            q1 += (float)p1;
+                            q2 += (float)p2;
+                        }
+                    } else if (lg == 4) {
+                        for (int x = SIMD_W; x < WIN; x++) {
+                            const int qq = y * WIN + x;
+                            const int d = dif[qq];
+                            const uint32_t e2 = xbuf[2 * qq + 1];
+                            q1 += (float)(d * (int)(int16_t)(e2 & 0xffffu));
+                            q2 += (float)(d * ((int)e2 >> 16));
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the differences are consumed: the next iteration may overwrite them
+                auto combine = [](float q) {
+                    const float v = (__shfl(q, 0, 8) + __shfl(q, 2, 8)) + (__shfl(q, 1, 8) + __shfl(q, 3, 8));
+                    return __shfl(q, 4, 8) + v;
+                };
+                b1 = combine(q1) * FLT_SCALE;
+                b2 = combine(q2) * FLT_SCALE;
+            } else if constexpr ((long long)K * 8160 * 4080 < (1ll << 29)) {
                 b1 = group8_exact_sum_small(sb1) * FLT_SCALE;
                 b2 = group8_exact_sum_small(sb2) * FLT_SCALE;
             } else {
@@ -299,7 +385,8 @@ static void launch_lk_t(const LKParams& p0, hipStream_t s) {
     const int blocks = (p.n + 3) / 4;   // one wavefront per keypoint, 4 per workgroup
     if (blocks == 0) return;
     p.blocks_per_xcd = (blocks + 7) / 8;
-    hipLaunchKernelGGL((lk_kernel<WIN>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(256), 0, s, p);
+    if (p.x86_order) hipLaunchKernelGGL((lk_kernel<WIN, true>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((lk_kernel<WIN, false>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(256), 0, s, p);
 }
 
 // POLYCHASE_LK_VARIANT=1 forces the one-keypoint-per-wavefront kernel, =2 the two-keypoint kernel on the u8 planes;
@@ -313,7 +400,7 @@ static int lk_variant() {
 }
 
 bool launch_lk(const LKParams& p, int win, hipStream_t s) {
-    const int v = lk_variant();
+    const int v = p.x86_order ? 1 : lk_variant();   // the x86 summation order exists on the generic kernel only
     if ((v == 0 || v == 3) && launch_lk3(p, win, s)) return true;
     if (v != 1 && win >= 4 && win <= 11 && launch_lk2(p, win, s)) return true;
     switch (win) {
@@ -580,14 +667,15 @@ void launch_copy_keypoints(const float2* src, float2* dst, int n, hipStream_t s)
 void launch_compact(const float4* rec, const uint32_t* slot_of, int n, int n_targets, uint32_t* scratch, bool scratch_fresh,
                     long long* row_offset, uint32_t* out_idx, float2* out_xy, float* out_err, hipStream_t s) {
     const int nblocks = compact_num_blocks(n);
+    uint32_t* const tickets = scratch;
+    uint32_t* const block_counts = scratch + kCompactTicketWords;
+    // tickets: zero at the first use of a (re)allocated scratch buffer -- also when this call has nothing to compact:
+    // the next one no longer knows that the buffer is new --, afterwards the scatter kernel leaves them zero
+    if (scratch_fresh) (void)hipMemsetAsync(tickets, 0, (size_t)kCompactTicketWords * sizeof(uint32_t), s);
     if (nblocks == 0 || n_targets <= 0) {
         (void)hipMemsetAsync(row_offset, 0, (size_t)(std::max(n_targets, 0) + 1) * sizeof(long long), s);
         return;
     }
-    uint32_t* const tickets = scratch;
-    uint32_t* const block_counts = scratch + kCompactTicketWords;
-    // tickets: zero at the first use of a (re)allocated scratch buffer, afterwards the scatter kernel leaves them zero
-    if (scratch_fresh) (void)hipMemsetAsync(tickets, 0, (size_t)kCompactTicketWords * sizeof(uint32_t), s);
     hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(CT), 0, s, rec, slot_of, n, n_targets, nblocks, tickets, block_counts,
                        row_offset, helper_prio_arg());
     hipLaunchKernelGGL(compact_scatter_kernel, dim3(nblocks), dim3(CT), 0, s, rec, slot_of, n, n_targets, nblocks, tickets,

@@ -74,6 +74,14 @@ struct OpticalFlowRunStats {
     int flow_rows_written = 0;
     double seconds_total = 0;
     double seconds_db = 0;
+    // where the driver's thread spent the call (the stage clock of tools/e2e_bench.py)
+    double seconds_setup = 0;        // database open, context + analyzer creation (before the first frame is asked for)
+    double seconds_accessor = 0;     // inside frame_accessor (Python: the GIL, the copy into a pinned buffer)
+    double seconds_put = 0;          // pc_analyzer_put_frame* (enqueue of the frame's preparation)
+    double seconds_submit = 0;       // pc_analyzer_submit (keypoint count of frame1 + enqueue of its job)
+    double seconds_collect = 0;      // pc_analyzer_collect (waiting for the GPU)
+    double seconds_writer_wait = 0;  // RecordWriter::Enqueue / Flush (waiting for SQLite)
+    double seconds_callback = 0;     // progress callback + database look-ups of the loop
 };
 
 // ---- entry point -------------------------------------------------------------------------------

@@ -239,13 +239,24 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
     }
 
     OpticalFlowRunStats local_stats;
+    local_stats.seconds_setup = Now() - t_begin;
+    struct StageClock {   // adds the time of a scope to one of the stage counters
+        double* acc;
+        double t0;
+        explicit StageClock(double* a) : acc(a), t0(Now()) {}
+        ~StageClock() { *acc += Now() - t0; }
+    };
     std::mutex db_mtx;
     std::unique_ptr<RecordWriter> writer;
     if (db) writer = std::make_unique<RecordWriter>(db.get(), &db_mtx, &local_stats);
 
     // RequestFrame + shape checks (cpp/opticalflow.cc:189-202)
     auto fetch = [&](int32_t frame_id) -> std::optional<FrameView> {
-        std::optional<FrameView> f = frame_accessor(frame_id);
+        std::optional<FrameView> f;
+        {
+            StageClock clk(&local_stats.seconds_accessor);
+            f = frame_accessor(frame_id);
+        }
         if (f) {
             CHECK_EQ(static_cast<uint32_t>(f->rows), video_info.height);
             CHECK_EQ(static_cast<uint32_t>(f->cols), video_info.width);
@@ -266,9 +277,15 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
     };
     auto collect_one = [&]() {
         pc_frame_result r;
-        if (pc_analyzer_collect(eng.an, &r) != PC_OK) ThrowHip("pc_analyzer_collect");
+        {
+            StageClock clk(&local_stats.seconds_collect);
+            if (pc_analyzer_collect(eng.an, &r) != PC_OK) ThrowHip("pc_analyzer_collect");
+        }
         local_stats.frames_processed++;
-        if (writer) writer->Enqueue(r);
+        if (writer) {
+            StageClock clk(&local_stats.seconds_writer_wait);
+            writer->Enqueue(r);
+        }
         if (with_log) {
             // jobs come back in submission order: this one belongs to the oldest piece that still misses one
             for (LogPiece& pc : pieces)
@@ -302,7 +319,10 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
     auto drain = [&]() {
         while (pc_analyzer_pending(eng.an) > 0) collect_one();
         if (with_log) close_piece();
-        if (writer) writer->Flush();
+        if (writer) {
+            StageClock clk(&local_stats.seconds_writer_wait);
+            writer->Flush();
+        }
     };
     auto finish_stats = [&]() {
         local_stats.seconds_total = Now() - t_begin;
@@ -357,6 +377,7 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
             }
             static const bool ingest_dma = !(std::getenv("POLYCHASE_INGEST_DMA") && std::atoi(std::getenv("POLYCHASE_INGEST_DMA")) == 0);
             const int where = !f->on_device ? 0 : (f->pinned_host && f->owner && ingest_dma ? PC_FRAME_PINNED_HOST : 1);
+            StageClock put_clk(&local_stats.seconds_put);
             const int put_rc =
                 f->elem_size == 4
                     ? pc_analyzer_put_frame_f32(eng.an, fid, reinterpret_cast<const float*>(f->data), f->row_pitch, f->channels,
@@ -397,6 +418,7 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
                 close_piece();
             if (pieces.empty() || pieces.back().closed) open_piece(frame_id1);
         }
+        StageClock submit_clk(&local_stats.seconds_submit);
         int rc = pc_analyzer_submit(eng.an, frame_id1, targets, n_targets);
         if (rc == PC_E_CAPACITY && with_log && pieces.back().submitted > 0 && (shard->piece_frames > 0 || n_parts > 1)) {
             // the record does not fit what is left of this part of the log: the piece ends here

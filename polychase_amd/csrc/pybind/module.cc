@@ -291,7 +291,13 @@ PYBIND11_MODULE(polychase_core, m) {
         .def_readonly("keypoint_rows_written", &OpticalFlowRunStats::keypoint_rows_written)
         .def_readonly("flow_rows_written", &OpticalFlowRunStats::flow_rows_written)
         .def_readonly("seconds_total", &OpticalFlowRunStats::seconds_total)
-        .def_readonly("seconds_db", &OpticalFlowRunStats::seconds_db);
+        .def_readonly("seconds_db", &OpticalFlowRunStats::seconds_db)
+        .def_readonly("seconds_setup", &OpticalFlowRunStats::seconds_setup)
+        .def_readonly("seconds_accessor", &OpticalFlowRunStats::seconds_accessor)
+        .def_readonly("seconds_put", &OpticalFlowRunStats::seconds_put)
+        .def_readonly("seconds_submit", &OpticalFlowRunStats::seconds_submit)
+        .def_readonly("seconds_collect", &OpticalFlowRunStats::seconds_collect)
+        .def_readonly("seconds_writer_wait", &OpticalFlowRunStats::seconds_writer_wait);
 
     py::class_<OpticalFlowThread>(m, "OpticalFlowThread")
         .def(py::init<VideoInfo, std::string, GFTTOptions, OpticalFlowOptions, bool>(), py::arg("video_info"),

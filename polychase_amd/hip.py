@@ -20,6 +20,7 @@ KERNEL_CLASSES = ["gray", "pyramid", "min_eig", "nms", "sort", "suppress", "lk",
 SYMBOLS = [
     "pc_gftt_default_options", "pc_flow_default_options", "pc_last_error", "pc_version",
     "pc_context_create", "pc_context_destroy", "pc_context_synchronize", "pc_context_stream",
+    "pc_context_set_arithmetic", "pc_context_get_arithmetic",
     "pc_context_enable_timing", "pc_context_get_timing", "pc_context_get_busy_time", "pc_context_reset_timing",
     "pc_debug_lk_profile", "pc_debug_llt9",
     "pc_frame_create", "pc_frame_destroy", "pc_frame_set_rgb", "pc_frame_set_rgb_f32", "pc_frame_set_gray",
@@ -40,6 +41,9 @@ SYMBOLS = [
     "pc_pnp_solve", "pc_pnp_total_cost",
     "pc_refine_problem_create", "pc_refine_problem_destroy", "pc_refine_total_cost", "pc_refine_normal_equations",
 ]
+
+
+ARITH_CANONICAL, ARITH_LK_X86_ORDER, ARITH_SOBEL_FMA, ARITH_OPENCV_X86 = 0, 1, 2, 3
 
 
 class GfttOptions(C.Structure):
@@ -99,6 +103,8 @@ def load():
     L.pc_context_destroy.restype = None
     L.pc_context_synchronize.argtypes = [vp]
     L.pc_context_stream.argtypes = [vp]
+    L.pc_context_set_arithmetic.argtypes = [vp, C.c_int]
+    L.pc_context_get_arithmetic.argtypes = [vp]
     L.pc_context_stream.restype = vp
     L.pc_context_enable_timing.argtypes = [vp, C.c_int]
     L.pc_context_get_timing.argtypes = [vp, C.c_int, ip, C.POINTER(C.c_double)]
@@ -181,6 +187,14 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_arithmetic(self, flags: int):
+        """ARITH_CANONICAL | ARITH_LK_X86_ORDER | ARITH_SOBEL_FMA (include/polychase_hip.h: pc_context_set_arithmetic)."""
+        _check(load().pc_context_set_arithmetic(self._h, int(flags)))
+
+    @property
+    def arithmetic(self) -> int:
+        return load().pc_context_get_arithmetic(self._h)
 
     def synchronize(self):
         _check(load().pc_context_synchronize(self._h))

@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c2")
-    ap.add_argument("--frames", type=int, default=60)
+    ap.add_argument("--frames", type=int, default=300)
     a = ap.parse_args()
     import torch
     from polychase_amd import synth
@@ -44,8 +44,12 @@ def main():
             t0 = time.perf_counter()
             st = core.generate_optical_flow_database(vi, lambda f: frames[f - 1], None, db, core.GFTTOptions(), fo)
             dt = time.perf_counter() - t0
-            out[name] = {"fps": a.frames / dt, "seconds_db": st.seconds_db,
-                         "db_bytes": os.path.getsize(db) if db else 0}
+            out[name] = {"fps": a.frames / dt, "fps_without_setup": a.frames / (dt - st.seconds_setup), "seconds_db": st.seconds_db,
+                         "db_bytes": os.path.getsize(db) if db else 0,
+                         # the driver thread's stage clock, ms per frame
+                         "driver_ms_per_frame": {k: round(1e3 * getattr(st, "seconds_" + k) / a.frames, 4)
+                                                 for k in ("accessor", "put", "submit", "collect", "writer_wait")},
+                         "setup_ms": round(1e3 * st.seconds_setup, 1)}
     print(json.dumps({"config": a.config, "frames": a.frames, **out}))
 
 
