@@ -221,6 +221,11 @@ typedef struct pc_frame_result {
 int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_options* gftt,
                        const pc_flow_options* flow, int ring_frames, int max_jobs, pc_analyzer** out);
 void pc_analyzer_destroy(pc_analyzer* a);
+/* Back to the state after pc_analyzer_create -- no resident frame, no job, no device log -- keeping every allocation
+ * (frame slabs, detection scratch, pinned result buffers, streams and events): the next clip of the same geometry and
+ * options starts without the tens of milliseconds of creation and destruction (analysis_driver.cc keeps one idle engine
+ * per process).  Fails with PC_E_STATE while jobs are in flight.  Synchronises the analyzer's streams. */
+int pc_analyzer_reset(pc_analyzer* a);
 /* Make `frame_id` resident (evicting the frame ring_frames + PC_ANALYZER_SPARE_SLOTS ids back: the ring holds three
  * slots more than asked for, so that a put never waits for LK launches that still read older frames and the caller
  * can run PC_ANALYZER_LOOKAHEAD = 1 frame ahead of the window frame1 - 8 .. frame1 + 8 of the current submit):

@@ -263,6 +263,31 @@ void pc_analyzer_destroy(pc_analyzer* a) {
     delete a;
 }
 
+int pc_analyzer_reset(pc_analyzer* a) {
+    if (!a) return fail(PC_E_INVALID, "null analyzer");
+    if (a->job_count != 0) return fail(PC_E_STATE, "%zu jobs in flight: collect them first", a->job_count);
+    PC_HIP(hipSetDevice(a->ctx->device));
+    PC_HIP(a->ctx->sync_side_streams());
+    PC_HIP(hipStreamSynchronize(a->ctx->stream));
+    for (auto& s : a->slots) {
+        s.valid = false;
+        s.det = DET_NONE;
+        s.supplied = false;
+        s.frame_id = 0;
+        s.last_read[0] = s.last_read[1] = nullptr;
+        s.scratch.cleared = false;
+    }
+    a->job_head = 0;
+    a->d_log = nullptr;
+    a->log_cap = a->log_used = 0;
+    a->host_records = true;
+    a->put_newest = a->put_previous = 0;
+    a->puts = 0;
+    a->prio = HelperPriorityControl();
+    a->prio.init();
+    return PC_OK;
+}
+
 static int analyzer_put(pc_analyzer* a, int32_t frame_id, const uint8_t* rgb, size_t row_pitch, int on_device,
                         int will_detect, int channels, int elem_size) {
     if (!a || !rgb) return fail(PC_E_INVALID, "null argument");

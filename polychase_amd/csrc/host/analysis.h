@@ -96,6 +96,10 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
                                  const GFTTOptions& detector_options = {}, const OpticalFlowOptions& flow_options = {},
                                  bool write_images = false, OpticalFlowRunStats* stats = nullptr);
 
+// Frees the idle engine a finished run has parked for the next one (GPU memory of ~20 resident frames; analysis_driver.cc:
+// EngineCache).  POLYCHASE_ENGINE_CACHE=0 disables the parking altogether.
+void ReleaseCachedEngine();
+
 // ---- multi-GPU analysis (one process per GPU, frame1 ranges sharded, RCCL only for the stitch) ----------
 
 // One shard of the clip: the frame1 loop of GenerateOpticalFlowDatabase (cpp/opticalflow.cc:237-316) for

@@ -38,9 +38,64 @@ constexpr int kMaxJobs = kGpuDepth + kWriteBacklog + 1;  // pinned result slots:
 struct Engine {
     pc_context* ctx = nullptr;
     pc_analyzer* an = nullptr;
+    // what the engine was created for: an idle engine is reused by a run with the same key
+    int device = -1;
+    uint32_t width = 0, height = 0;
+    pc_gftt_options gopt{};
+    pc_flow_options fopt{};
+    Engine() = default;
+    Engine(const Engine&) = delete;
+    Engine& operator=(const Engine&) = delete;
     ~Engine() {
         if (an) pc_analyzer_destroy(an);
         if (ctx) pc_context_destroy(ctx);
+    }
+    bool Matches(int dev, uint32_t w, uint32_t h, const pc_gftt_options& g, const pc_flow_options& f) const {
+        return dev == device && w == width && h == height && std::memcmp(&g, &gopt, sizeof g) == 0 && std::memcmp(&f, &fopt, sizeof f) == 0;
+    }
+};
+
+// ONE idle engine per process.  Creating a context + analyzer (streams, 20 frame slabs, detection scratch, pinned
+// result buffers, the copy engines' warm-up) takes 10-20 ms and destroying them 50-80 ms (every hipFree synchronises):
+// 0.25 ms per frame of a 300-frame clip at 1080p, more than the analysis of a frame takes.  A run that ends normally
+// parks its engine here (pc_analyzer_reset: allocations kept, no state); the next run with the same device, geometry and
+// options takes it, any other run replaces it.  release_cached_engine() / POLYCHASE_ENGINE_CACHE=0 give the memory back.
+class EngineCache {
+   public:
+    static std::unique_ptr<Engine> Take(int dev, uint32_t w, uint32_t h, const pc_gftt_options& g, const pc_flow_options& f) {
+        std::unique_ptr<Engine> e;
+        {
+            std::lock_guard<std::mutex> lk(Mutex());
+            e = std::move(Slot());
+        }
+        if (e && !e->Matches(dev, w, h, g, f)) e.reset();   // destroyed here, outside the lock
+        return e;
+    }
+    static void Park(std::unique_ptr<Engine> e) {
+        static const bool enabled = !(std::getenv("POLYCHASE_ENGINE_CACHE") && std::atoi(std::getenv("POLYCHASE_ENGINE_CACHE")) == 0);
+        if (!enabled || !e || pc_analyzer_reset(e->an) != PC_OK) return;   // e is destroyed
+        std::unique_ptr<Engine> old;
+        {
+            std::lock_guard<std::mutex> lk(Mutex());
+            old = std::move(Slot());
+            Slot() = std::move(e);
+        }
+    }
+    static void Clear() {
+        std::unique_ptr<Engine> old;
+        std::lock_guard<std::mutex> lk(Mutex());
+        old = std::move(Slot());
+    }
+
+   private:
+    static std::mutex& Mutex() {
+        static std::mutex m;
+        return m;
+    }
+    static std::unique_ptr<Engine>& Slot() {
+        // leaked on purpose: at process exit the HIP runtime may be gone before a static destructor would run
+        static std::unique_ptr<Engine>* slot = new std::unique_ptr<Engine>();
+        return *slot;
     }
 };
 
@@ -197,7 +252,7 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
     const int32_t res_begin = shard ? std::max(from, f1_begin - 8) : from;
     const int32_t res_end = shard ? std::min(to, f1_end + 8) : to;
 
-    pc_gftt_options gopt;
+    pc_gftt_options gopt{};
     gopt.quality_level = detector_options.quality_level;
     gopt.min_distance = detector_options.min_distance;
     gopt.block_size = detector_options.block_size;
@@ -207,7 +262,7 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
     gopt.harris_k = detector_options.harris_k;
     gopt.grid_rows = detector_options.grid_rows;
     gopt.grid_cols = detector_options.grid_cols;
-    pc_flow_options fopt;
+    pc_flow_options fopt{};
     fopt.window_size = flow_options.window_size;
     fopt.max_level = flow_options.max_level;
     fopt.term_max_iters = flow_options.term_max_iters;
@@ -217,13 +272,22 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
     // owners of frames the GPU may still be reading; declared BEFORE the engine, i.e. destroyed AFTER it: on every way
     // out (exceptions included) the analyzer has synchronised its streams before a buffer goes back to the pool
     std::deque<std::pair<int32_t, std::shared_ptr<void>>> frames_in_flight;
-    Engine eng;
     int device = 0;
     if (const char* env = std::getenv("POLYCHASE_DEVICE")) device = std::atoi(env);
-    if (pc_context_create(device, &eng.ctx) != PC_OK) ThrowHip("pc_context_create");
-    if (pc_analyzer_create(eng.ctx, static_cast<int>(video_info.width), static_cast<int>(video_info.height), &gopt,
-                           &fopt, kRing, kMaxJobs, &eng.an) != PC_OK)
-        ThrowHip("pc_analyzer_create");
+    std::unique_ptr<Engine> engine = EngineCache::Take(device, video_info.width, video_info.height, gopt, fopt);
+    if (!engine) {
+        engine = std::make_unique<Engine>();
+        engine->device = device;
+        engine->width = video_info.width;
+        engine->height = video_info.height;
+        engine->gopt = gopt;
+        engine->fopt = fopt;
+        if (pc_context_create(device, &engine->ctx) != PC_OK) ThrowHip("pc_context_create");
+        if (pc_analyzer_create(engine->ctx, static_cast<int>(video_info.width), static_cast<int>(video_info.height), &gopt,
+                               &fopt, kRing, kMaxJobs, &engine->an) != PC_OK)
+            ThrowHip("pc_analyzer_create");
+    }
+    Engine& eng = *engine;
     // The shard's device log: `log_buffers` equal parts of the caller's buffer, filled in turn; a part is handed to
     // on_piece when every job submitted into it has been collected, and reused `log_buffers` pieces later.
     const bool with_log = shard && shard->device_log != nullptr;
@@ -354,6 +418,8 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
                 drain();  // jobs already on the GPU are complete work: keep them (a shard: their pieces have been handed off)
                 if (shard) shard->cancelled = true;
                 finish_stats();
+                release_ingested(true);
+                EngineCache::Park(std::move(engine));
                 callback(1.0f, "Cancelled");
                 return;
             }
@@ -431,8 +497,12 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
     }
     drain();
     finish_stats();
+    release_ingested(true);               // no pinned frame buffer is still being read
+    EngineCache::Park(std::move(engine));   // (an exception on the way leaves `engine` to its destructor instead)
     if (callback) callback(1.0f, "Done");
 }
+
+void ReleaseCachedEngine() { EngineCache::Clear(); }
 
 void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
                                  OpticalFlowProgressCallback callback, const std::string& database_path,

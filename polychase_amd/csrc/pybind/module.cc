@@ -328,6 +328,7 @@ PYBIND11_MODULE(polychase_core, m) {
     m.def("generate_optical_flow_records", &GenerateOpticalFlowRecordsPy, py::arg("video_info"), py::arg("frame_accessor_function"),
           py::arg("callback"), py::arg("shard_begin"), py::arg("shard_end"), py::arg("device_log"), py::arg("capacity_bytes"),
           py::arg("detector_options") = GFTTOptions{}, py::arg("flow_options") = OpticalFlowOptions{});
+    m.def("release_cached_engine", &ReleaseCachedEngine);   // not in the reference: gives the parked GPU engine's memory back
     m.def("generate_optical_flow_shard", &GenerateOpticalFlowShardPy, py::arg("video_info"), py::arg("frame_accessor_function"),
           py::arg("callback"), py::arg("database_path"), py::arg("shard_begin"), py::arg("shard_end"), py::arg("device_log") = 0,
           py::arg("capacity_bytes") = 0, py::arg("log_buffers") = 1, py::arg("piece_frames") = 0, py::arg("on_piece") = py::none(),

@@ -29,7 +29,7 @@ SYMBOLS = [
     "pc_frame_download_deriv", "pc_frame_detect", "pc_frame_download_min_eig", "pc_frame_num_candidates",
     "pc_frame_num_keypoints", "pc_frame_download_keypoints", "pc_frame_set_keypoints",
     "pc_lk_track", "pc_lk_track_filtered",
-    "pc_analyzer_create", "pc_analyzer_destroy", "pc_analyzer_put_frame", "pc_analyzer_put_frame_f32",
+    "pc_analyzer_create", "pc_analyzer_destroy", "pc_analyzer_reset", "pc_analyzer_put_frame", "pc_analyzer_put_frame_f32",
     "pc_analyzer_has_frame", "pc_analyzer_frame_ingested",
     "pc_analyzer_set_keypoints", "pc_analyzer_submit", "pc_analyzer_pending", "pc_analyzer_collect",
     "pc_analyzer_set_device_log", "pc_analyzer_device_log_used", "pc_analyzer_redirect_device_log",
@@ -145,6 +145,7 @@ def load():
     L.pc_analyzer_collect.argtypes = [vp, C.POINTER(FrameResult)]
     L.pc_analyzer_set_device_log.argtypes = [vp, vp, C.c_size_t]
     L.pc_analyzer_device_log_used.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.pc_analyzer_reset.argtypes = [vp]
     L.pc_analyzer_redirect_device_log.argtypes = [vp, vp, C.c_size_t]
     L.pc_analyzer_set_host_records.argtypes = [vp, C.c_int]
     _lib = L
@@ -414,6 +415,11 @@ class Analyzer:
             self.close()
         except Exception:
             pass
+
+    def reset(self):
+        """No resident frame, no job, no log; allocations kept (pc_analyzer_reset)."""
+        _check(load().pc_analyzer_reset(self._h))
+        self._keep = {}
 
     def put_frame(self, frame_id: int, rgb, will_detect: bool = True):
         p, dev, pitch = _ptr(rgb)
