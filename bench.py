@@ -45,8 +45,14 @@ CONFIGS = {
     "c3": (3840, 2160, 4, "C3 3840x2160 300-frame clip, 4-level LK (max_level=4) + feature detect"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-# one wave64 VALU instruction occupies a SIMD for 4 cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 4
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
+# VALU issue ceiling of the LK kernel's instruction mix, MEASURED (tools/valu_issue.hip, profiles/r03_valu_issue.json):
+# v_dot2_i32_i16, v_mad_i32_i16, v_perm_b32 (and every other integer / packed / fp64 / conversion instruction tried) issue
+# at 4.2 cycles per wave64 instruction and SIMD with 8 wavefronts per SIMD (4.5 with the kernel's 3), i.e. the 16 lanes per
+# clock of the classic CDNA SIMD; only v_fma/mul/add_f32, v_add_u32, v_and_b32, v_ashrrev, v_mov reach the 2.3 cycles
+# of the guide's "v_fma_f32 2 cyc (SIMD-32)" row (MI355X_MICROARCH.md, per-instruction constants) -- and only back to
+# back with each other: alternating with a dot2 they take a full slot too.
+VALU_CYCLES_PER_INST = 4.2
+VALU_PEAK_GINST = 256 * 4 * 2.4 / VALU_CYCLES_PER_INST
 CLIP_FRAMES = 300
 MIN_PREWARM = 24
 MIN_REGION_S = 0.5
@@ -104,9 +110,11 @@ def cpu_baseline(fetch_host, f1_candidates, gopt_kw, fopt_kw, target_seconds=12.
     return out
 
 
-def end_to_end(cfg, frames_dev, n_frames=60):
-    """GenerateOpticalFlowDatabase through the polychase_core module (what the Blender addon calls): frames as host
-    numpy arrays (PCIe upload inside the call), with and without the SQLite insert.  Not part of `value`."""
+def end_to_end(cfg, frames_dev, n_frames):
+    """GenerateOpticalFlowDatabase through the polychase_core module (what the Blender addon calls) on n_frames frames of
+    the clip: frames already on the GPU / as host numpy arrays (PCIe upload inside the call), without and with the SQLite
+    insert.  Not part of `value`.  The engine (context + analyzer: 20 resident frame slots) is created by the first call
+    of the process and parked for the next one (analysis_driver.cc: EngineCache): its creation is reported separately."""
     sys.path.insert(0, os.path.join(ROOT, "polychase_amd", "core"))
     import polychase_core as core
 
@@ -116,16 +124,25 @@ def end_to_end(cfg, frames_dev, n_frames=60):
     fo = core.OpticalFlowOptions()
     fo.max_level = ml
     vi = core.VideoInfo(w, h, 1, n_frames)
-    out = {"frames": n_frames, "note": "whole call incl. engine creation, clip edges and first-use allocations"}
+    core.release_cached_engine()
+    t0 = time.perf_counter()
+    st = core.generate_optical_flow_database(core.VideoInfo(w, h, 1, 12), lambda f: dev[f - 1], None, "", core.GFTTOptions(), fo)
+    out = {"frames": n_frames, "engine_creation_ms": 1e3 * st.seconds_setup, "first_call_12_frames_ms": 1e3 * (time.perf_counter() - t0),
+           "note": "whole calls (clip edges, first-use allocations of the call included) with the process's engine already created; "
+                   "engine creation + the cold 12-frame call are the two numbers above"}
     with tempfile.TemporaryDirectory() as td:
         for name, frames, db in [("device_frames_no_db_fps", dev, ""), ("host_frames_over_pcie_no_db_fps", host, ""),
                                  ("host_frames_over_pcie_sqlite_fps", host, os.path.join(td, "a.db"))]:
-            core.generate_optical_flow_database(core.VideoInfo(w, h, 1, 12), lambda f: frames[f - 1], None, "", core.GFTTOptions(), fo)
             t0 = time.perf_counter()
-            core.generate_optical_flow_database(vi, lambda f: frames[f - 1], None, db, core.GFTTOptions(), fo)
+            st = core.generate_optical_flow_database(vi, lambda f: frames[f - 1], None, db, core.GFTTOptions(), fo)
             out[name] = n_frames / (time.perf_counter() - t0)
             if db:
                 out["sqlite_bytes_per_frame"] = os.path.getsize(db) / n_frames
+                out["sqlite_insert_ms_per_frame"] = 1e3 * st.seconds_db / n_frames
+            out[name.replace("_fps", "_driver_ms_per_frame")] = {
+                k: round(1e3 * getattr(st, "seconds_" + k) / n_frames, 4) for k in ("accessor", "put", "submit", "collect", "writer_wait")}
+    core.release_cached_engine()
+    del host
     return out
 
 
@@ -300,14 +317,45 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
         frame_bytes = 14 * P + (12 + 8) * S
         achieved = lk_bytes / (lk_avg_ms * 1e-3) / 1e9 if lk_avg_ms > 0 else 0.0
         fps = world * K / dt
-        # counters of the LK launch from separate rocprofv3 --pmc passes (they cannot be collected in-process)
-        traffic = valu = None
+        # counters of the LK launch: they cannot be collected in-process, so they come from the committed rocprofv3 --pmc
+        # passes of the same command (profiles/lk_hbm_traffic.json names the run); labelled as such below
+        traffic = valu = src = calib = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "lk_hbm_traffic.json")))
             traffic = tj[cfg]["traffic_bytes"]
             valu = tj[cfg].get("valu_insts")
+            src = tj.get("source")
+            calib = tj.get("fetch_size_calibration")
         except Exception:
             pass
+        hbm = {"bound": "hbm", "kernel": LK_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+               "traffic_source": src or "profiles/lk_hbm_traffic.json (builder-run rocprofv3 --pmc passes, not this run)",
+               "traffic_calibration": calib,
+               "algorithmic_bytes_per_launch": lk_bytes, "avg_launch_ms": lk_avg_ms, "launches": lk_launches,
+               # two launches are in flight at a time (job lanes): each one's start-to-end time exceeds the GPU time it
+               # costs.  `achieved` uses the start-to-end time (comparable with rocprofv3's per-dispatch durations); the
+               # per-launch share of the GPU is given beside it.
+               "launch_overlap": lk_avg_ms / lk_busy_ms if lk_busy_ms > 0 else None,
+               "busy_ms_per_launch": lk_busy_ms,
+               "achieved_per_busy_time": lk_bytes / (lk_busy_ms * 1e-3) / 1e9 if lk_busy_ms > 0 else None}
+        # What bounds the dominant kernel is VALU issue (a gather: its HBM traffic is about its algorithmic bytes and 1-2 %
+        # of the HBM peak by construction).  `roofline` therefore states the limiter -- wave-instructions per second against
+        # the measured issue ceiling of the kernel's instruction mix -- and carries the HBM block the contract asks for
+        # beside it (`hbm`; also at the top level as `hbm_roofline`).
+        if valu and lk_busy_ms > 0:
+            v_ach = valu / (lk_busy_ms * 1e-3) / 1e9
+            roofline = {"bound": "valu", "kernel": LK_KERNEL, "achieved": v_ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                        "frac": v_ach / VALU_PEAK_GINST, "traffic": traffic,
+                        "valu_wave_instructions_per_launch": valu,
+                        "valu_source": src or "profiles/lk_hbm_traffic.json (SQ_INSTS_VALU of a builder-run rocprofv3 --pmc pass, not this run)",
+                        "peak_source": f"tools/valu_issue.hip, profiles/r03_valu_issue.json: {VALU_CYCLES_PER_INST} cycles per wave64 "
+                                       "v_dot2_i32_i16 / v_mad_i32_i16 / v_perm_b32 and SIMD at 8 wavefronts per SIMD (4.5 at the kernel's 3); "
+                                       "1024 SIMDs x 2.4 GHz",
+                        "time_base": "GPU-busy time of the launches (busy_ms_per_launch), measured in this run with HIP events on the lanes' streams",
+                        "hbm": hbm}
+        else:
+            roofline = dict(hbm, note="no VALU counter file: the HBM block only")
         out = {
             "metric": "optical-flow frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
@@ -319,24 +367,8 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
                        "parallelism": f"frame-shard x{world}" if world > 1 else "single GPU",
                        "untimed_prewarm_steps": prewarm + 8, "timed_regions": len(region_s),
                        "region_ms_min_median_max": [min(region_s) * 1e3, dt * 1e3, max(region_s) * 1e3]},
-            "roofline": {"bound": "hbm", "kernel": LK_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": lk_bytes, "avg_launch_ms": lk_avg_ms,
-                         "launches": lk_launches,
-                         # the contract's two bounds are "hbm" and "mfma"; what the counters say limits this gather
-                         # kernel is neither (see valu_roofline and DESIGN.md section 4)
-                         "observed_limiter": "VALU issue + dependent latency at 3 wavefronts/SIMD; HBM traffic is at the algorithmic bytes",
-                         # two launches are in flight at a time (job lanes): each one's start-to-end time exceeds
-                         # the GPU time it costs.  `achieved` uses the start-to-end time (comparable with
-                         # rocprofv3's per-dispatch durations); the per-launch share of the GPU is given beside it.
-                         "launch_overlap": lk_avg_ms / lk_busy_ms if lk_busy_ms > 0 else None,
-                         "busy_ms_per_launch": lk_busy_ms,
-                         "achieved_per_busy_time": lk_bytes / (lk_busy_ms * 1e-3) / 1e9 if lk_busy_ms > 0 else None},
-            "valu_roofline": None if not valu else {
-                "kernel": LK_KERNEL, "valu_wave_instructions_per_launch": valu,
-                "achieved": valu / (lk_busy_ms * 1e-3) / 1e9, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-                "frac": valu / (lk_busy_ms * 1e-3) / 1e9 / VALU_PEAK_GINST,
-                "note": "SQ_INSTS_VALU of a separate rocprofv3 --pmc pass (profiles/) over the launch's GPU-busy time; peak = 1024 SIMDs x 2.4 GHz / 4 cycles"},
+            "roofline": roofline,
+            "hbm_roofline": hbm,
             "path_roofline": {"algorithmic_bytes_per_frame": frame_bytes,
                               "achieved_GBs": frame_bytes * (K / dt) / 1e9,
                               "frac": frame_bytes * (K / dt) / 1e9 / HBM_PEAK_GBS},
@@ -349,7 +381,7 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
             out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]
         if with_e2e:
             try:
-                out["end_to_end"] = end_to_end(cfg, clip_frames)
+                out["end_to_end"] = end_to_end(cfg, clip_frames, 300 if cfg != "c3" else 100)
             except Exception as e:   # the module is optional for the kernel benchmark
                 out["end_to_end"] = {"error": str(e)}
     ctx.close()
@@ -427,11 +459,12 @@ def main():
     K, W = args.steps, args.warmup
     single = world == 1 and not args.force_dist_path
     out = run_config(args.config, K, W, args, rank, world, dev, with_cpu=single and not args.no_cpu_baseline,
-                     with_e2e=single and not args.no_end_to_end and args.config == "c2")
+                     with_e2e=single and not args.no_end_to_end)
     if args.config == "c2" and not args.no_c3:
         # the 4K configuration rides along (fewer steps: a step is 4.5x longer); its CPU sample is shorter
         args.cpu_seconds = min(args.cpu_seconds, 8.0)
-        c3 = run_config("c3", max(10, K // 2), W, args, rank, world, dev, with_cpu=single and not args.no_cpu_baseline, with_e2e=False)
+        c3 = run_config("c3", max(10, K // 2), W, args, rank, world, dev, with_cpu=single and not args.no_cpu_baseline,
+                        with_e2e=single and not args.no_end_to_end)
         if rank == 0:
             out["c3"] = c3
     if rank == 0:
