@@ -163,7 +163,8 @@ struct pc_context {
         return n_detect > 0 ? detect_stream[(unsigned)frame_id % (unsigned)n_detect] : prep_stream;
     }
     hipError_t sync_side_streams() const {
-        hipError_t e = hipStreamSynchronize(prep_stream);
+        hipError_t e = copy_stream ? hipStreamSynchronize(copy_stream) : hipSuccess;
+        if (e == hipSuccess) e = hipStreamSynchronize(prep_stream);
         if (stream_b && e == hipSuccess) e = hipStreamSynchronize(stream_b);
         for (int k = 0; k < n_detect && e == hipSuccess; k++) e = hipStreamSynchronize(detect_stream[k]);
         return e;
@@ -173,6 +174,12 @@ struct pc_context {
     bool prep_dirty = false;
     // staging of host-provided frames
     DevBuf<uint8_t> staging;
+    // the analyzer's host frames (PC_FRAME_PINNED_HOST): transfers on a stream of their own, two buffers in turn;
+    // staging_ev[b] = {copy into b complete (copy stream), the kernel that reads b has run (preparation stream)}
+    hipStream_t copy_stream = nullptr;   // POLYCHASE_COPY_STREAM=0: none (the transfer is enqueued in front of the frame's kernels)
+    DevBuf<uint8_t> staging2[2];
+    hipEvent_t staging_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    int staging_turn = 0;
     // GFTT scratch
     DevBuf<int2> sup_offsets;              // suppression neighbourhood for sup_min_distance
     DevBuf<int> sup_rows;                  // the same as half-widths per row, [2 * sup_R + 1]

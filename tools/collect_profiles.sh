@@ -11,9 +11,14 @@ cd /tmp
 for c in c2 c3; do
   python "$ROOT/bench.py" --no-c3 --config $c 2>/dev/null | tail -1 > "$OUT/${TAG}_${c}_bench.json"
 done
-# per-kernel durations (rocprofv3 --kernel-trace --stats) of the default bench command, and of the 4K configuration
+# the driver's own command line
+python "$ROOT/bench.py" --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_driver_style.json"
+# per-kernel durations (rocprofv3 --kernel-trace --stats) of the default bench command, and of the 4K configuration.
+# POLYCHASE_LK_GATE=0: under the profiler a dispatch is not handed to the GPU before the previous one of ANY stream has
+# been timestamped, so the gate kernel (which waits for a launch of the other lane) only adds its polling to the trace --
+# without the gate the per-dispatch durations are the kernels' own (the bench line beside the CSV is the profiled run's).
 for c in c2 c3; do
-  rm -rf /tmp/kstats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats -- python "$ROOT/bench.py" --no-cpu-baseline --no-c3 --no-end-to-end --no-breakdown --config $c > /tmp/kstats.log 2>&1
+  rm -rf /tmp/kstats && POLYCHASE_LK_GATE=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats -- python "$ROOT/bench.py" --no-cpu-baseline --no-c3 --no-end-to-end --no-breakdown --config $c > /tmp/kstats.log 2>&1
   grep "^{" /tmp/kstats.log | tail -1 > "$OUT/${TAG}_${c}_bench_under_rocprofv3.json"
   f=$(find /tmp/kstats -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${TAG}_${c}_rocprofv3_kernel_stats.csv"
@@ -22,7 +27,21 @@ done
 for c in c2 c3; do
   python "$ROOT/tools/pmc_collect.py" --kernel lk3_kernel --config $c --steps 10 --out "$OUT/${TAG}_${c}_lk_hbm_pmc.json" FETCH_SIZE WRITE_SIZE > /dev/null 2>&1
 done
-python "$ROOT/tools/pmc_collect.py" --kernel lk3_kernel --config c2 --steps 10 --out "$OUT/${TAG}_c2_lk_sq_pmc.json" \
+for c in c2 c3; do
+python "$ROOT/tools/pmc_collect.py" --kernel lk3_kernel --config $c --steps 10 --out "$OUT/${TAG}_${c}_lk_sq_pmc.json" \
   SQ_WAVES,SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS,SQ_INSTS_VMEM_RD,SQ_WAVE_CYCLES,SQ_BUSY_CYCLES \
   SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_LDS,SQ_ACTIVE_INST_ANY,SQ_WAIT_INST_ANY,SQ_WAIT_INST_LDS,SQ_WAIT_ANY > /dev/null 2>&1
+done
+python "$ROOT/tools/pmc_collect.py" --by-kernel --config c2 --steps 10 --out "$OUT/${TAG}_c2_pipeline_by_kernel_pmc.json" SQ_WAVES,SQ_INSTS_VALU,SQ_WAVE_CYCLES,SQ_BUSY_CYCLES > /dev/null 2>&1
+# where a step goes: job lanes alone / + pyramid / + detection, helper priority pinned and automatic
+for c in c2 c3; do
+  for m in auto 0 1; do POLYCHASE_HELPER_PRIO=$m python "$ROOT/tools/lane_probe.py" --config $c --steps 200 2>/dev/null | grep "^{" | sed "s/^{/{\"helper_prio\": \"$m\", /"; done > "$OUT/${TAG}_${c}_lane_probe.jsonl"
+  python "$ROOT/tools/lk_bench.py" --config $c 2>/dev/null | grep "^{" > "$OUT/${TAG}_${c}_lk_isolated.json"
+  python "$ROOT/tools/prep_bench.py" --config $c 2>/dev/null | grep "^{" > "$OUT/${TAG}_${c}_prep.json"
+done
+python "$ROOT/tools/e2e_bench.py" --config c2 --frames 300 2>/dev/null | grep "^{" > "$OUT/${TAG}_e2e_c2.json"
+python "$ROOT/tools/e2e_bench.py" --config c3 --frames 100 2>/dev/null | grep "^{" > "$OUT/${TAG}_e2e_c3.json"
+python "$ROOT/tools/ingest_bench.py" --config c2 --frames 300 2>/dev/null | grep "^{" > "$OUT/${TAG}_ingest.json"
+"$ROOT/tools/bin/valu_issue" > "$OUT/${TAG}_valu_issue.json" 2>/dev/null
+python "$ROOT/tools/fetch_calib.py" run > "$OUT/${TAG}_fetch_calibration.json" 2>/dev/null
 ls -la "$OUT" | grep "$TAG"
