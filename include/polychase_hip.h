@@ -88,6 +88,9 @@ int pc_context_synchronize(pc_context* ctx);
 #define PC_ARITH_LK_X86_ORDER 1
 #define PC_ARITH_SOBEL_FMA 2
 #define PC_ARITH_OPENCV_X86 3
+/* Synchronous copy of `bytes` bytes of this context's device memory to host memory (debug dump of frames that were handed
+ * over as device memory, cpp/opticalflow.cc:80-96). */
+int pc_context_download(pc_context* ctx, void* dst_host, const void* src_device, size_t bytes);
 int pc_context_set_arithmetic(pc_context* ctx, int flags);
 int pc_context_get_arithmetic(const pc_context* ctx);
 /* hipStream_t the context enqueues on (for callers that time with HIP events / torch streams). */

@@ -122,7 +122,7 @@ def build_core(force: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(compile_one, zip(srcs, objs)))
     # $ORIGIN/../lib: libpolychase_hip.so travels in-tree; libsqlite3.so.0 is the system one
-    _run(["g++", "-shared", "-o", out, *objs, "-L" + LIB_DIR, "-lpolychase_hip", "-l:libsqlite3.so.0",
+    _run(["g++", "-shared", "-o", out, *objs, "-L" + LIB_DIR, "-lpolychase_hip", "-l:libsqlite3.so.0", "-l:libz.so.1",
           "-L/usr/lib/x86_64-linux-gnu", "-Wl,-rpath,$ORIGIN/../lib", "-pthread"])
     return out
 

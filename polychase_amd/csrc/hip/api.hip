@@ -518,6 +518,13 @@ int pc_context_create(int device_index, pc_context** out) {
     return PC_OK;
 }
 
+int pc_context_download(pc_context* c, void* dst_host, const void* src_device, size_t bytes) {
+    if (!c || (bytes && (!dst_host || !src_device))) return fail(PC_E_INVALID, "null argument");
+    PC_HIP(hipSetDevice(c->device));
+    if (bytes) PC_HIP(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
+    return PC_OK;
+}
+
 int pc_context_set_arithmetic(pc_context* c, int flags) {
     if (!c) return fail(PC_E_INVALID, "null context");
     if (flags & ~PC_ARITH_OPENCV_X86) return fail(PC_E_INVALID, "unknown arithmetic flags %d", flags);

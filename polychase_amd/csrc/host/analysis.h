@@ -89,8 +89,8 @@ struct OpticalFlowRunStats {
 // Detects keypoints in every frame and tracks them into the frames at distance 1, 2, 4 and 8 on
 // both sides, storing `keypoints` and `optical_flow` rows in the SQLite file at database_path
 // (created if missing; existing rows are kept and not recomputed, so an interrupted run resumes).
-// An empty database_path produces the records without storing them.  write_images is accepted for
-// signature compatibility; the reference's debug PNG dump is not produced.
+// An empty database_path produces the records without storing them.  write_images: the reference's debug dump
+// (opticalflow.cc:80-96): <directory of the database>/frames/%06d.png and keypoints_%06d.png of every frame1.
 void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
                                  OpticalFlowProgressCallback callback, const std::string& database_path,
                                  const GFTTOptions& detector_options = {}, const OpticalFlowOptions& flow_options = {},

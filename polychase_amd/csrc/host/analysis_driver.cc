@@ -15,11 +15,14 @@
 #include <cstring>
 #include <deque>
 #include <exception>
+#include <filesystem>
+#include <map>
 #include <mutex>
 #include <stdexcept>
 #include <thread>
 
 #include "../../../include/polychase_hip.h"
+#include "debug_images.h"
 #include "flow_database.h"
 #include "utils.h"
 
@@ -219,7 +222,7 @@ struct LogPiece {
 static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
                         OpticalFlowProgressCallback callback, const std::string& database_path,
                         const GFTTOptions& detector_options, const OpticalFlowOptions& flow_options,
-                        OpticalFlowRunStats* stats, OpticalFlowShard* shard) {
+                        OpticalFlowRunStats* stats, OpticalFlowShard* shard, bool write_images) {
     CHECK(frame_accessor);
     const double t_begin = Now();
     std::unique_ptr<Database> db;
@@ -302,6 +305,15 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
         if (!db && !shard->host_records && pc_analyzer_set_host_records(eng.an, 0) != PC_OK) ThrowHip("pc_analyzer_set_host_records");
     }
 
+    // write_images (opticalflow.cc:228-232, :265-267): <database dir>/frames/%06d.png and keypoints_%06d.png of every
+    // frame1.  The keypoints are known when the job is collected: host copies of the frames wait for that here.
+    std::string frames_dir;
+    std::map<int32_t, std::vector<uint8_t>> debug_frames;
+    if (write_images) {
+        const std::filesystem::path dir = std::filesystem::path(database_path).parent_path() / "frames";
+        std::filesystem::create_directory(dir);
+        frames_dir = dir.string();
+    }
     OpticalFlowRunStats local_stats;
     local_stats.seconds_setup = Now() - t_begin;
     struct StageClock {   // adds the time of a scope to one of the stage counters
@@ -346,6 +358,14 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
             if (pc_analyzer_collect(eng.an, &r) != PC_OK) ThrowHip("pc_analyzer_collect");
         }
         local_stats.frames_processed++;
+        if (write_images) {
+            auto it = debug_frames.find(r.frame1);
+            if (it != debug_frames.end()) {
+                SaveImageForDebugging(it->second.data(), static_cast<int>(video_info.width), static_cast<int>(video_info.height), r.frame1,
+                                      frames_dir, r.keypoints_xy, r.n_keypoints);
+                debug_frames.erase(debug_frames.begin(), std::next(it));   // frame1 ids only grow
+            }
+        }
         if (writer) {
             StageClock clk(&local_stats.seconds_writer_wait);
             writer->Enqueue(r);
@@ -449,6 +469,29 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
                     ? pc_analyzer_put_frame_f32(eng.an, fid, reinterpret_cast<const float*>(f->data), f->row_pitch, f->channels,
                                                 where, will_detect ? 1 : 0)
                     : pc_analyzer_put_frame(eng.an, fid, f->data, f->row_pitch, where, will_detect ? 1 : 0);
+            if (write_images && fid >= f1_begin && fid < f1_end) {
+                // tightly packed 8-bit RGB on the host; float frames like the addon's `(image * 255).astype(np.uint8)`
+                const size_t w = video_info.width, h = video_info.height, row = static_cast<size_t>(f->row_pitch);
+                std::vector<uint8_t> raw(row * h);
+                if (f->on_device && !f->pinned_host) {
+                    if (pc_context_download(eng.ctx, raw.data(), f->data, row * (h - 1) + w * f->channels * f->elem_size) != PC_OK)
+                        ThrowHip("pc_context_download");
+                } else {
+                    std::memcpy(raw.data(), f->data, row * (h - 1) + w * f->channels * f->elem_size);
+                }
+                std::vector<uint8_t>& img = debug_frames[fid];
+                img.resize(w * h * 3);
+                for (size_t y = 0; y < h; y++)
+                    for (size_t x = 0; x < w; x++)
+                        for (int c = 0; c < 3; c++) {
+                            if (f->elem_size == 4) {
+                                const float val = reinterpret_cast<const float*>(raw.data() + y * row)[x * f->channels + c] * 255.f;
+                                img[(y * w + x) * 3 + c] = static_cast<uint8_t>(val < 0.f ? 0.f : (val > 255.f ? 255.f : val));
+                            } else {
+                                img[(y * w + x) * 3 + c] = raw[y * row + x * 3 + c];
+                            }
+                        }
+            }
             // the owner first: put_frame may have enqueued a copy out of the buffer before it failed, and
             // frames_in_flight outlives the engine (whose destructor synchronises) while `f` does not
             if (f->on_device && f->owner) frames_in_flight.emplace_back(fid, std::move(f->owner));
@@ -507,10 +550,9 @@ void ReleaseCachedEngine() { EngineCache::Clear(); }
 void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
                                  OpticalFlowProgressCallback callback, const std::string& database_path,
                                  const GFTTOptions& detector_options, const OpticalFlowOptions& flow_options,
-                                 bool /*write_images: debug PNG dump of the reference (:80-96) is not produced*/,
-                                 OpticalFlowRunStats* stats) {
+                                 bool write_images, OpticalFlowRunStats* stats) {
     RunAnalysis(video_info, std::move(frame_accessor), std::move(callback), database_path, detector_options, flow_options, stats,
-                nullptr);
+                nullptr, write_images);
 }
 
 void GenerateOpticalFlowShard(const VideoInfo& video_info, FrameAccessorFunction frame_accessor, OpticalFlowProgressCallback callback,
@@ -521,7 +563,7 @@ void GenerateOpticalFlowShard(const VideoInfo& video_info, FrameAccessorFunction
     shard.used_bytes = 0;
     shard.pieces = 0;
     shard.cancelled = false;
-    RunAnalysis(video_info, std::move(frame_accessor), std::move(callback), database_path, detector_options, flow_options, stats, &shard);
+    RunAnalysis(video_info, std::move(frame_accessor), std::move(callback), database_path, detector_options, flow_options, stats, &shard, false);
 }
 
 size_t GenerateOpticalFlowRecords(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,

@@ -7,6 +7,7 @@
 
 #include <deque>
 
+#include "../host/debug_images.h"
 #include "../host/flow_database.h"
 #include "../host/analysis.h"
 #include "../host/frame_pool.h"
@@ -328,6 +329,13 @@ PYBIND11_MODULE(polychase_core, m) {
     m.def("generate_optical_flow_records", &GenerateOpticalFlowRecordsPy, py::arg("video_info"), py::arg("frame_accessor_function"),
           py::arg("callback"), py::arg("shard_begin"), py::arg("shard_end"), py::arg("device_log"), py::arg("capacity_bytes"),
           py::arg("detector_options") = GFTTOptions{}, py::arg("flow_options") = OpticalFlowOptions{});
+    // not in the reference's module: its SaveImageForDebugging (cpp/opticalflow.cc:80-96) by itself, for the tests
+    m.def("_save_image_for_debugging", [](const U8Array& rgb, int32_t frame_id, const std::string& dir, const F32Array& kps) {
+        if (rgb.ndim() != 3 || rgb.shape(2) != 3) throw py::value_error("rgb must be (H, W, 3) uint8");
+        std::vector<uint8_t> img(rgb.data(), rgb.data() + rgb.size());
+        SaveImageForDebugging(img.data(), static_cast<int>(rgb.shape(1)), static_cast<int>(rgb.shape(0)), frame_id, dir, kps.data(),
+                              static_cast<int>(kps.size() / 2));
+    });
     m.def("release_cached_engine", &ReleaseCachedEngine);   // not in the reference: gives the parked GPU engine's memory back
     m.def("generate_optical_flow_shard", &GenerateOpticalFlowShardPy, py::arg("video_info"), py::arg("frame_accessor_function"),
           py::arg("callback"), py::arg("database_path"), py::arg("shard_begin"), py::arg("shard_end"), py::arg("device_log") = 0,

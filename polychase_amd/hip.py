@@ -20,7 +20,7 @@ KERNEL_CLASSES = ["gray", "pyramid", "min_eig", "nms", "sort", "suppress", "lk",
 SYMBOLS = [
     "pc_gftt_default_options", "pc_flow_default_options", "pc_last_error", "pc_version",
     "pc_context_create", "pc_context_destroy", "pc_context_synchronize", "pc_context_stream",
-    "pc_context_set_arithmetic", "pc_context_get_arithmetic",
+    "pc_context_set_arithmetic", "pc_context_get_arithmetic", "pc_context_download",
     "pc_context_enable_timing", "pc_context_get_timing", "pc_context_get_busy_time", "pc_context_reset_timing",
     "pc_debug_lk_profile", "pc_debug_llt9",
     "pc_frame_create", "pc_frame_destroy", "pc_frame_set_rgb", "pc_frame_set_rgb_f32", "pc_frame_set_gray",
@@ -103,6 +103,7 @@ def load():
     L.pc_context_destroy.restype = None
     L.pc_context_synchronize.argtypes = [vp]
     L.pc_context_stream.argtypes = [vp]
+    L.pc_context_download.argtypes = [vp, vp, vp, C.c_size_t]
     L.pc_context_set_arithmetic.argtypes = [vp, C.c_int]
     L.pc_context_get_arithmetic.argtypes = [vp]
     L.pc_context_stream.restype = vp

@@ -180,3 +180,42 @@ def test_float_frames_through_thread_and_sync_binding(core, tmp_path):
     assert not errors and requested == list(range(1, 13))
     core.generate_optical_flow_database(core.VideoInfo(256, 192, 1, 12), lambda fid: f32[fid - 1], None, c)
     assert _dump(a) == _dump(b) == _dump(c)
+
+
+def test_write_images_dumps_the_frames_and_their_keypoints(core, tmp_path):
+    """write_images=True (reference cpp/opticalflow.cc:80-96, :228-232, :265-267): <database dir>/frames/%06d.png is
+    the frame, keypoints_%06d.png differs from it exactly on the crosses of the frame's stored keypoints -- for host
+    frames, device frames and Blender's float frames."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_debug_images_cpu import read_png
+
+    w, h, n = 160, 120, 10
+    clip = synth.NoiseClip(w, h, n)
+    frames = [clip.frame(t) for t in range(n)]
+    variants = {"host": lambda fid: frames[fid - 1],
+                "device": lambda fid: torch.from_numpy(frames[fid - 1]).cuda(),
+                "float": lambda fid: np.concatenate([frames[fid - 1].astype(np.float32) / 255.0, np.ones((h, w, 1), np.float32)], axis=2)}
+    for name, acc in variants.items():
+        d = tmp_path / name
+        d.mkdir()
+        db = str(d / "clip.db")
+        core.generate_optical_flow_database(core.VideoInfo(w, h, 1, n), acc, None, db, write_images=True)
+        con = core.Database(db)
+        for fid in (1, 5, n):
+            plain = read_png(d / "frames" / f"{fid:06d}.png")
+            marked = read_png(d / "frames" / f"keypoints_{fid:06d}.png")
+            if name == "float":
+                # (x / 255 * 255).astype(uint8) truncates: within one grey level of the original
+                assert np.abs(plain.astype(int) - frames[fid - 1].astype(int)).max() <= 1
+            else:
+                assert np.array_equal(plain, frames[fid - 1])
+            kps = con.read_keypoints(fid).astype(int)
+            mask = np.zeros((h, w), bool)
+            for x, y in kps:
+                mask[y, max(0, x - 5):x + 6] = True
+                mask[max(0, y - 5):y + 6, x] = True
+            changed = (marked != plain).any(axis=2)
+            assert len(kps) > 20 and not (changed & ~mask).any() and changed.sum() > 0.5 * mask.sum()
+        con.close()
+        assert len(list((d / "frames").glob("*.png"))) == 2 * n
