@@ -401,7 +401,10 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     Job& j = a->jobs[(a->job_head + a->job_count) % a->jobs.size()];
     // (2) the job's lane; its LK launch needs this frame's keypoints and the pyramids of the frames it reads -- not the
     // detection of frames that were made resident for later
-    const int lane = (int)(a->submitted & 1);
+    // POLYCHASE_LK_LANES=1: every job on lane 0, i.e. no two LK launches in flight -- the recipe for per-dispatch durations under
+    // rocprofv3 (tools/collect_profiles.sh); the product runs two lanes
+    static const bool one_lane = getenv("POLYCHASE_LK_LANES") && atoi(getenv("POLYCHASE_LK_LANES")) == 1;
+    const int lane = one_lane ? 0 : (int)(a->submitted & 1);
     hipStream_t const ls = ctx->lane_stream(lane);
     {
         SlowSection ss("submit/waits");
@@ -476,7 +479,7 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     pc::launch_copy_keypoints(s1->frame->d_kps, reinterpret_cast<float2*>(pack + j.o_kps), n, ls);
     // Everything that reads the resident frames is enqueued: the pyramids (LK), frame1's keypoints (LK, the copy
     // above) and its inverse visiting order (compaction).  A slot may be overwritten once this event has fired.
-    hipEvent_t const lk_done = a->lk_done[lane][(a->submitted >> 1) % pc_analyzer::kLaneEvents];
+    hipEvent_t const lk_done = a->lk_done[lane][(one_lane ? a->submitted : (a->submitted >> 1)) % pc_analyzer::kLaneEvents];
     PC_HIP(hipEventRecord(lk_done, ls));
     s1->last_read[lane] = lk_done;
     for (int t = 0; t < n_targets; t++) find_slot(a, targets[t])->last_read[lane] = lk_done;

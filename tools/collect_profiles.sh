@@ -14,11 +14,13 @@ done
 # the driver's own command line
 python "$ROOT/bench.py" --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_driver_style.json"
 # per-kernel durations (rocprofv3 --kernel-trace --stats) of the default bench command, and of the 4K configuration.
-# POLYCHASE_LK_GATE=0: under the profiler a dispatch is not handed to the GPU before the previous one of ANY stream has
-# been timestamped, so the gate kernel (which waits for a launch of the other lane) only adds its polling to the trace --
-# without the gate the per-dispatch durations are the kernels' own (the bench line beside the CSV is the profiled run's).
+# POLYCHASE_LK_LANES=1: all jobs on one lane, so no two LK launches overlap and a dispatch's duration is the launch's
+# own (with two lanes the tail of a launch overlaps the next one: start-to-end times exceed the GPU time a launch
+# costs, and under the profiler -- which serialises dispatch hand-over -- the gate between the lanes only adds its
+# polling).  The bench line saved beside the CSV is the same profiled run: its roofline.hbm.avg_launch_ms is the
+# number the CSV's average must agree with.
 for c in c2 c3; do
-  rm -rf /tmp/kstats && POLYCHASE_LK_GATE=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats -- python "$ROOT/bench.py" --no-cpu-baseline --no-c3 --no-end-to-end --no-breakdown --config $c > /tmp/kstats.log 2>&1
+  rm -rf /tmp/kstats && POLYCHASE_LK_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats -- python "$ROOT/bench.py" --no-cpu-baseline --no-c3 --no-end-to-end --no-breakdown --config $c > /tmp/kstats.log 2>&1
   grep "^{" /tmp/kstats.log | tail -1 > "$OUT/${TAG}_${c}_bench_under_rocprofv3.json"
   f=$(find /tmp/kstats -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${TAG}_${c}_rocprofv3_kernel_stats.csv"
