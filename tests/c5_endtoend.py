@@ -37,6 +37,9 @@ def main(argv=None) -> int:
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--oracle-frames", type=int, default=6, help="frames solved by the CPU reference as well")
+    ap.add_argument("--oracle-stride", type=int, default=0,
+                    help="> 0: every stride-th frame of the WHOLE clip is also solved by the CPU reference, from the GPU's poses of "
+                         "its source frames and the GPU's pose of the frame before it as the initial guess")
     ap.add_argument("--refine-iterations", type=int, default=30)
     ap.add_argument("--out", default=None)
     a = ap.parse_args(argv)
@@ -165,6 +168,36 @@ def main(argv=None) -> int:
         out["tracking"]["vs_cpu_reference"] = {"frames": k, "rotation_rad_max": max(ang), "translation_rel_max": max(tr),
                                                "cpu_seconds_per_frame": dt_o / k,
                                                "what": "float64 numpy restatement of tracker.cc (oracle/pnp_oracle.py)"}
+
+    # ---- the same check spread over the whole clip: every stride-th frame, each from the GPU's own source poses ----
+    if a.oracle_stride > 0:
+        t0 = time.time()
+        db = core.Database(path)
+        model = np.eye(4)
+        gpu_cam = {1: ocam(*true_pose(1))}
+        for f, (q, t, _) in got.items():
+            gpu_cam[f] = po.Camera(fx=-F, fy=-F, cx=W / 2, cy=H / 2, aspect_ratio=1.0, width=float(W), height=float(H), opencv=False,
+                                   q=np.asarray(q, float), t=np.asarray(t, float))
+        ang, tr, checked = [], [], []
+        for f in range(2 + a.oracle_stride - 1, n + 1, a.oracle_stride):
+            Xs, xs_ = [], []
+            for src in db.find_optical_flows_to_image(f):
+                if src >= f:            # forward tracking: only frames solved before f were filled (tracker.cc:43-50)
+                    continue
+                kps = db.read_keypoints(src)
+                fl = db.read_image_pair_flow(src, f)
+                origin, dirs = T.rays_object_space(gpu_cam[src], model, kps[fl.src_kps_indices])
+                hit, _, _, _, _, pos = po.raycast_closest(verts, tris, origin, dirs)
+                Xs.append(pos[hit])
+                xs_.append(fl.tgt_kps[hit])
+            cam, _ = po.solve_pnp(np.concatenate(Xs).astype(np.float32), np.concatenate(xs_).astype(np.float32), gpu_cam[f - 1],
+                                  kind="cauchy", scale=1.0)
+            ang.append(T._angle(po.quat_to_R(got[f][0]), cam.R()))
+            tr.append(float(np.linalg.norm(got[f][1] - cam.t) / np.linalg.norm(cam.t)))
+            checked.append(f)
+        db.close()
+        out["tracking"]["vs_cpu_reference_sampled"] = {"frames": checked, "rotation_rad_max": max(ang), "translation_rel_max": max(tr),
+                                                       "cpu_seconds_per_frame": (time.time() - t0) / max(1, len(checked))}
 
     # ---- refinement ----
     traj_c = core.CameraTrajectory(1, n)

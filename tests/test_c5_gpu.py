@@ -33,3 +33,24 @@ def test_c5_1080p_analysis_tracking_refinement(tmp_path):
     rf = r["refinement"]
     assert rf["cost"][1] <= rf["cost"][0]
     assert rf["vs_truth"]["rotation_rad_max"] <= 1e-3 and rf["vs_truth"]["translation_max"] <= 6e-3
+
+
+def test_c5_1080p_300_frames_poses_sampled_against_the_cpu_reference(tmp_path):
+    """BASELINE config C5 with all 300 frames: analysis, tracking and refinement of the whole clip; every 10th frame's pose
+    against the float64 CPU reference of the tracking step (cpp/tracker.cc:36-131 restated in oracle/pnp_oracle.py) solved
+    from the same database, the GPU's poses of its source frames and the same initial guess."""
+    sys.path.insert(0, HERE)
+    import c5_endtoend
+    out_path = str(tmp_path / "c5_300.json")
+    assert c5_endtoend.main(["--width", "1920", "--height", "1080", "--frames", "300", "--oracle-frames", "0", "--oracle-stride", "10",
+                             "--refine-iterations", "10", "--out", out_path]) == 0
+    r = json.load(open(out_path))
+    print(json.dumps(r, indent=1))
+    tr = r["tracking"]
+    s = tr["vs_cpu_reference_sampled"]
+    assert s["frames"] == list(range(11, 301, 10))          # 29 frames spread over the clip
+    assert s["rotation_rad_max"] <= 1e-4 and s["translation_rel_max"] <= 1e-4
+    assert tr["min_inlier_ratio"] >= 0.9
+    assert tr["vs_truth"]["rotation_rad_max"] <= 1e-3 and tr["vs_truth"]["translation_max"] <= 6e-3
+    rf = r["refinement"]
+    assert rf["cost"][1] <= rf["cost"][0]

@@ -219,3 +219,42 @@ def test_write_images_dumps_the_frames_and_their_keypoints(core, tmp_path):
             assert len(kps) > 20 and not (changed & ~mask).any() and changed.sum() > 0.5 * mask.sum()
         con.close()
         assert len(list((d / "frames").glob("*.png"))) == 2 * n
+
+
+def test_parked_engine_is_reused_and_replaced(core, tmp_path):
+    """A finished call parks its engine (pc_analyzer_reset) for the next one: same geometry -> reused, other geometry or
+    options -> replaced; the databases equal those of a process that never parks (tests/test_env_variants_gpu.py covers
+    POLYCHASE_ENGINE_CACHE=0 across processes) and of the oracle."""
+    clip_a = synth.NoiseClip(320, 240, 20)
+    clip_b = synth.NoiseClip(256, 192, 14)
+    fa = [clip_a.frame(t) for t in range(20)]
+    fb = [clip_b.frame(t) for t in range(14)]
+
+    def run(frames, name, first=1, **opt):
+        h, w, _ = frames[0].shape
+        fo = core.OpticalFlowOptions()
+        for k, val in opt.items():
+            setattr(fo, k, val)
+        p = str(tmp_path / name)
+        st = core.generate_optical_flow_database(core.VideoInfo(w, h, first, len(frames)), lambda fid: frames[fid - first], None, p,
+                                                 core.GFTTOptions(), fo)
+        return p, st
+
+    core.release_cached_engine()
+    p1, s1 = run(fa, "a1.db")
+    p2, s2 = run(fa, "a2.db", first=7)        # same geometry, other frame ids: a stale resident frame must not be found
+    assert s1.seconds_setup > 5 * s2.seconds_setup, (s1.seconds_setup, s2.seconds_setup)   # the second call found the engine
+    p3, _ = run(fb, "b.db")                   # other geometry: the parked engine is replaced
+    p4, _ = run(fa, "a4.db", max_level=2)     # other options
+    p5, _ = run(fa, "a5.db")
+    core.release_cached_engine()
+    p6, s6 = run(fa, "a6.db")
+    assert s6.seconds_setup > 5 * s2.seconds_setup
+    assert _dump(p1) == _dump(p5) == _dump(p6)
+    k1, k2 = _dump(p1)[0], _dump(p2)[0]
+    assert {f + 6: kv for f, kv in k1.items()} == k2                          # the same keypoints under shifted ids
+    assert _dump(p1) == _expect(fa, 1)                                        # ... and the oracle's database
+    grays = [oracle.rgb2gray(f) for f in fb]
+    got = core.Database(p3).read_keypoints(5)
+    assert np.array_equal(got, oracle.gftt(grays[4]))
+    assert _dump(p4)[1] != _dump(p1)[1]

@@ -2,7 +2,7 @@
 
 The knobs select kernels (LK variants 1/2/3, fused / unfused pyramid), the detection path (device-count bucket sort / the
 synchronous slow path with the rocPRIM sort) and the stream layout of the analyzer (gate between the job lanes, detection
-on its own stream(s)).  They are read when the library or a context is created, so each variant runs in its own process
+on its own stream(s), the helper kernels' issue priority, the copy stream of host frames, one job lane, the parked engine).  They are read when the library or a context is created, so each variant runs in its own process
 (tests/_analyze_hash.py: polychase_core.generate_optical_flow_database on a 26-frame clip -> sha256 of all rows)."""
 import os
 import subprocess
@@ -21,13 +21,19 @@ VARIANTS = [
     {"POLYCHASE_LK_VARIANT": "2"},
     {"POLYCHASE_LK_VARIANT": "1"},
     {"POLYCHASE_PYRAMID_VARIANT": "1"},
+    {"POLYCHASE_HELPER_PRIO": "0"},
+    {"POLYCHASE_HELPER_PRIO": "1"},
+    {"POLYCHASE_COPY_STREAM": "0"},
+    {"POLYCHASE_LK_LANES": "1"},
+    {"POLYCHASE_ENGINE_CACHE": "0"},
 ]
 
 
 def _hash(extra_env, size=(416, 304, 26)):
     env = dict(os.environ)
     for k in ("POLYCHASE_LK_GATE", "POLYCHASE_DETECT_STREAMS", "POLYCHASE_GFTT_SLOW_PATH", "POLYCHASE_LK_VARIANT",
-              "POLYCHASE_PYRAMID_VARIANT", "GPU_MAX_HW_QUEUES"):
+              "POLYCHASE_PYRAMID_VARIANT", "GPU_MAX_HW_QUEUES", "POLYCHASE_HELPER_PRIO", "POLYCHASE_COPY_STREAM", "POLYCHASE_LK_LANES",
+              "POLYCHASE_ENGINE_CACHE", "POLYCHASE_ARITH"):
         env.pop(k, None)
     env.update(extra_env)
     r = subprocess.run([sys.executable, os.path.join(HERE, "_analyze_hash.py"), *map(str, size)], env=env, text=True,
