@@ -63,7 +63,20 @@ int pco_get_opencv_emulation(void) { return g_emulation; }
  *   (exact for 8-bit inputs: every product is a multiple of 2^-47 and |sum| < 2^6), rounded to
  *   fp32; eig = (a + c) - sqrtf((a - c)*(a - c) + b*b), a = cxx*0.5f, b = cxy, c = cyy*0.5f.
  * Canonical choice: no FMA contraction (OpenCV's AVX2 dispatch may fuse v_muladd). */
+static int corner_response(const uint8_t* gray, int w, int h, int block_size, int ksize, int harris, double harris_k, float* eig);
 int pco_min_eigen_val(const uint8_t* gray, int w, int h, int block_size, int ksize, float* eig) {
+    return corner_response(gray, w, h, block_size, ksize, 0, 0.0, eig);
+}
+/* cv::cornerHarris(gray, dst, block_size, ksize, k)  (cpp/feature_detection/gftt.cc:31-33): the same covariance sums
+ * (cornerEigenValsVecs, same scale), then calcHarris' scalar expression
+ *     dst = (float)(a * c - b * b - k * (a + c) * (a + c)),   a = cxx, b = cxy, c = cyy (float), k double
+ * evaluated as C does: a*c, b*b and their difference in float; k * (a + c) * (a + c) in double.  (OpenCV's SIMD branch
+ * of calcHarris computes the same in float with (float)k for the first width / 4 * 4 columns of a row -- an execution
+ * order of its own, not emulated here: Harris is the reference's unused branch.)  [recalled] */
+int pco_corner_harris(const uint8_t* gray, int w, int h, int block_size, int ksize, double k, float* dst) {
+    return corner_response(gray, w, h, block_size, ksize, 1, k, dst);
+}
+static int corner_response(const uint8_t* gray, int w, int h, int block_size, int ksize, int harris, double harris_k, float* eig) {
     if (ksize != 3 || block_size < 1 || w < 1 || h < 1) return -1;
     const double scale_d = 1.0 / ((double)(1 << (ksize - 1)) * block_size * 255.0);
     const float f1 = (float)(1.0 * scale_d);
@@ -122,6 +135,14 @@ int pco_min_eigen_val(const uint8_t* gray, int w, int h, int block_size, int ksi
                     syy += (double)c[2];
                 }
             }
+            if (harris) {
+                const float a = (float)sxx, b = (float)sxy, c = (float)syy;
+                const float ac = a * c, bb = b * b;
+                const float det = ac - bb;
+                const float tr = a + c;
+                eig[(size_t)y * w + x] = (float)((double)det - harris_k * (double)tr * (double)tr);
+                continue;
+            }
             const float a = (float)sxx * 0.5f;
             const float b = (float)sxy;
             const float c = (float)syy * 0.5f;
@@ -166,12 +187,11 @@ int pco_gftt(const uint8_t* gray, int w, int h, const pco_gftt_options* opt, flo
              int capacity, float* eig_thresholded, int* n_candidates) {
     /* gftt.cc:18-19 */
     if (!(opt->quality_level > 0 && opt->min_distance >= 0 && opt->max_corners >= 0)) return -1;
-    if (opt->use_harris) return -1; /* harris branch (gftt.cc:31-33) not restated */
     if (w <= 0 || h <= 0) return 0; /* gftt.cc:23-27 */
     const size_t n = (size_t)w * (size_t)h;
     float* eig = (float*)malloc(n * sizeof(float));
     if (!eig) return -1;
-    if (pco_min_eigen_val(gray, w, h, opt->block_size, opt->gradient_size, eig) != 0) {
+    if (corner_response(gray, w, h, opt->block_size, opt->gradient_size, opt->use_harris, opt->harris_k, eig) != 0) {   /* gftt.cc:31-36 */
         free(eig);
         return -1;
     }

@@ -36,6 +36,8 @@ void pco_rgb2gray(const uint8_t* rgb, int w, int h, uint8_t* gray);
 /* ---- cv::cornerMinEigenVal(gray, eig, block_size=3, ksize=3)  (cpp/feature_detection/gftt.cc:35) ----
  * Only block_size >= 1 (anchor at centre) and ksize == 3 are restated. Returns 0 on success. */
 int pco_min_eigen_val(const uint8_t* gray, int w, int h, int block_size, int ksize, float* eig);
+/* cv::cornerHarris(gray, dst, block_size, ksize, k)  (gftt.cc:31-33), scalar expression of calcHarris. */
+int pco_corner_harris(const uint8_t* gray, int w, int h, int block_size, int ksize, double k, float* dst);
 
 /* GFTTOptions (cpp/feature_detection/gftt.h:5-21) */
 typedef struct {
@@ -44,7 +46,7 @@ typedef struct {
     int block_size;       /* 3 */
     int gradient_size;    /* 3 */
     int max_corners;      /* 0 = unlimited */
-    int use_harris;       /* 0 (harris branch not restated) */
+    int use_harris;       /* 0 */
     double harris_k;      /* 0.04 */
     int grid_rows;        /* 4 */
     int grid_cols;        /* 4 */

@@ -131,15 +131,28 @@ int validate_gftt(const pc_gftt_options* opt, int w, int h, pc::GfttGrid* g) {
     // CHECKs of gftt.cc:18-19
     if (!(opt->quality_level > 0 && opt->min_distance >= 0 && opt->max_corners >= 0))
         return fail(PC_E_INVALID, "GFTT options violate quality_level > 0 && min_distance >= 0 && max_corners >= 0");
-    if (opt->use_harris) return fail(PC_E_INVALID, "use_harris is not implemented on the HIP path");
-    if (opt->block_size != 3 || opt->gradient_size != 3)
-        return fail(PC_E_INVALID, "only block_size == 3 and gradient_size == 3 are implemented on the HIP path");
+    if (opt->gradient_size != 3) return fail(PC_E_INVALID, "only gradient_size == 3 (the 3x3 Sobel) is implemented on the HIP path");
+    if (opt->block_size < 1 || opt->block_size > 31) return fail(PC_E_INVALID, "block_size must be in [1,31] on the HIP path");
     if (opt->min_distance > 64.0) return fail(PC_E_INVALID, "min_distance > 64 is not supported on the HIP path");
     g->rows = std::max(1, opt->grid_rows);
     g->cols = std::max(1, opt->grid_cols);
     if (g->rows * g->cols > pc::kMaxGridCells) return fail(PC_E_INVALID, "grid_rows*grid_cols must be <= %d", pc::kMaxGridCells);
     g->cell_h = (h + g->rows - 1) / g->rows;
     g->cell_w = (w + g->cols - 1) / g->cols;
+    return PC_OK;
+}
+
+// cornerMinEigenVal / cornerHarris of the frame (gftt.cc:31-36) + per-cell maxima: the tiled kernel for the detector's
+// default, the general pair of kernels otherwise (their covariance scratch is allocated on first use: not the addon's path)
+static int corner_response(pc_context* ctx, const pc_frame* f, DetectScratch& d, const pc::GfttGrid& grid, const pc_gftt_options& opt,
+                           uint32_t* cell_max) {
+    const bool fma = (ctx->arith & PC_ARITH_SOBEL_FMA) != 0;
+    if (opt.block_size == 3 && !opt.use_harris) {
+        pc::launch_min_eig(f->levels[0], d.eig.p, grid, cell_max, fma, ctx->work);
+        return PC_OK;
+    }
+    PC_HIP(d.cov.ensure((size_t)3 * f->w * f->h));
+    pc::launch_corner_response(f->levels[0], d.eig.p, d.cov.p, grid, cell_max, opt.block_size, opt.use_harris != 0, opt.harris_k, fma, ctx->work);
     return PC_OK;
 }
 
@@ -222,7 +235,7 @@ int detect_enqueue(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const
     d.cleared = false;
     {
         ScopedTimer t(ctx, PC_K_MINEIG);
-        pc::launch_min_eig(f->levels[0], d.eig.p, grid, cnt + kCellMaxAt, (ctx->arith & PC_ARITH_SOBEL_FMA) != 0, ctx->work);
+        if ((rc = corner_response(ctx, f, d, grid, opt, cnt + kCellMaxAt)) != PC_OK) return rc;
     }
     {
         ScopedTimer t(ctx, PC_K_NMS);
@@ -272,7 +285,7 @@ static int detect_slow_path(pc_context* ctx, pc_frame* f, const pc::GfttGrid& gr
     d.cleared = false;
     PC_HIP(hipMemsetAsync(cnt, 0, (size_t)d.counter_words * sizeof(uint32_t), ctx->work));
     uint32_t* const tickets = cnt + kTicketsAt;
-    pc::launch_min_eig(f->levels[0], d.eig.p, grid, cnt + kCellMaxAt, (ctx->arith & PC_ARITH_SOBEL_FMA) != 0, ctx->work);
+    if (int crc = corner_response(ctx, f, d, grid, opt, cnt + kCellMaxAt)) return crc;
     pc::launch_nms(d.eig.p, w, h, grid, cnt + kCellMaxAt, opt.quality_level, d.keys.p, npx, cnt + kCntCand, d.cstate.p,
                    cnt + kCntSortParams, cnt + kHistAt, tickets, d.bucket_offsets.p, hist.p, ctx->work);
     PC_HIP(hipMemcpyAsync(d.h_counters.p, cnt, kHostCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));

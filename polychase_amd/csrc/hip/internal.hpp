@@ -109,6 +109,7 @@ using pc::fail;
 struct DetectScratch {
     DevBuf<unsigned long long> keys, keys_bucketed, keys_sorted;
     DevBuf<float> eig;                     // min-eig map (K2 -> K3, K5)
+    DevBuf<float> cov;                     // covariance planes of the general corner response (block_size != 3 / Harris), on demand
     DevBuf<uint8_t> cstate;                // 0 no candidate / 1 candidate / 2 accepted / 3 rejected
     // [0] candidates, [1] keypoints, [2] stuck lanes, [3] fast-path overflow bits, [4] sort range hi, [5] sort shift, [6..7] pad,
     // [8 ..] cell max [kMaxGridCells], bucket counts [kSortBuckets], bucket cursors [kSortBuckets]
@@ -127,6 +128,7 @@ struct DetectScratch {
         keys_bucketed.release();
         keys_sorted.release();
         eig.release();
+        cov.release();
         cstate.release();
         counters.release();
         bucket_offsets.release();

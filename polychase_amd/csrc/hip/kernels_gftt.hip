@@ -171,6 +171,91 @@ void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* ce
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2, general form: any block_size, cornerMinEigenVal or cornerHarris (gftt.cc:31-36).  The detector's default
+// (block 3, min-eig) has the LDS-tiled kernel above; everything else -- never used by the addon -- takes two plain
+// kernels with the same arithmetic as oracle/pc_oracle.c: the covariance products of every pixel into three float planes,
+// then block x block box sums of those planes in fp64 (BORDER_REFLECT_101 applies to the covariance image, anchor
+// block / 2) and the response.  Scale 1 / (2^(ksize-1) * block * 255) folded into the smoothing taps.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cov_kernel(const uint8_t* __restrict__ img, int pitch, int w, int h, float* __restrict__ cov,
+                                                  float f1, float f0, int sobel_fma, int hi_prio) {
+    helper_priority(hi_prio);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    // the level-0 plane carries REFLECT_101 padding: rows y - 1 .. y + 1, columns x - 1 .. x + 1 are addressable
+    float rdx[3], rdy[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint8_t* row = img + (ptrdiff_t)(y - 1 + k) * pitch + x;
+        const float sm = row[-1], sc = row[0], sp = row[1];
+        rdx[k] = (0.0f - sm) + sp;
+        float t = f1 * sm;
+        t += f0 * sc;
+        t += f1 * sp;
+        rdy[k] = t;
+    }
+    const float dx = sobel_fma ? __fmaf_rn(rdx[0] + rdx[2], f1, rdx[1] * f0) : (rdx[0] + rdx[2]) * f1 + rdx[1] * f0;
+    const float dy = rdy[2] - rdy[0];
+    const size_t n = (size_t)w * h, i = (size_t)y * w + x;
+    cov[i] = dx * dx;
+    cov[n + i] = dx * dy;
+    cov[2 * n + i] = dy * dy;
+}
+
+__global__ __launch_bounds__(256) void box_response_kernel(const float* __restrict__ cov, int w, int h, int block, int harris, double harris_k,
+                                                           float* __restrict__ eig, GfttGrid g, uint32_t* __restrict__ cell_max, int hi_prio) {
+    helper_priority(hi_prio);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const size_t n = (size_t)w * h;
+    const int a0 = block / 2;
+    double sxx = 0, sxy = 0, syy = 0;   // exact for 8-bit inputs: the order of the additions is free
+    for (int j = 0; j < block; j++) {
+        const size_t row = (size_t)reflect101(y + j - a0, h) * w;
+        for (int i = 0; i < block; i++) {
+            const size_t at = row + reflect101(x + i - a0, w);
+            sxx += (double)cov[at];
+            sxy += (double)cov[n + at];
+            syy += (double)cov[2 * n + at];
+        }
+    }
+    float e;
+    if (harris) {
+        // calcHarris' scalar expression: (float)(a * c - b * b - k * (a + c) * (a + c)), the k term in double
+        const float a = (float)sxx, b = (float)sxy, c = (float)syy;
+        const float ac = a * c, bb = b * b;
+        const float det = ac - bb, tr = a + c;
+        e = (float)((double)det - harris_k * (double)tr * (double)tr);
+    } else {
+        const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+        const float t = a - c;
+        e = (a + c) - sqrtf(t * t + b * b);
+    }
+    eig[(size_t)y * w + x] = e;
+    // per-cell maximum: one atomic per wavefront when its 64 pixels of a row lie in one cell
+    uint32_t key = float_to_ordered(e);
+    const int cell = (y / g.cell_h) * g.cols + x / g.cell_w;
+    const int cell0 = __builtin_amdgcn_readfirstlane(cell);
+    if (__all(cell == cell0)) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) key = max(key, (uint32_t)__shfl_xor((int)key, d));
+        if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicMax(&cell_max[cell0], key);
+    } else {
+        atomicMax(&cell_max[cell], key);
+    }
+}
+
+void launch_corner_response(const Level& l0, float* eig, float* cov, const GfttGrid& g, uint32_t* cell_max, int block_size, bool harris,
+                            double harris_k, bool sobel_fma, hipStream_t s) {
+    const double scale_d = 1.0 / (4.0 * (double)block_size * 255.0);
+    const float f1 = (float)(1.0 * scale_d), f0 = (float)(2.0 * scale_d);
+    dim3 grid((l0.w + 63) / 64, (l0.h + 3) / 4);
+    hipLaunchKernelGGL(cov_kernel, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, cov, f1, f0, sobel_fma ? 1 : 0, helper_prio_arg());
+    hipLaunchKernelGGL(box_response_kernel, grid, dim3(256), 0, s, cov, l0.w, l0.h, block_size, harris ? 1 : 0, harris_k, eig, g, cell_max,
+                       helper_prio_arg());
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3  threshold (per cell of the NEIGHBOUR) + 3x3 dilate + local-max test.  A workgroup walks a 64 x 64 block as four
 // 64 x 16 tiles of the min-eig map, each staged (already thresholded) in LDS with a 1-px ring; 4 pixels per lane.
 // Writes the candidate byte of EVERY pixel (so the map needs no clearing between frames) and appends keys =

@@ -192,9 +192,19 @@ def main(argv=None) -> int:
                 xs_.append(fl.tgt_kps[hit])
             cam, _ = po.solve_pnp(np.concatenate(Xs).astype(np.float32), np.concatenate(xs_).astype(np.float32), gpu_cam[f - 1],
                                   kind="cauchy", scale=1.0)
-            ang.append(T._angle(po.quat_to_R(got[f][0]), cam.R()))
+            # rotation between the two poses from the NORMALISED quaternions: QuatStepPost (cpp/pnp/quaternion.h:11-20) never
+            # renormalises, so after hundreds of fp32 updates |q| is 1 + 1e-7, and the arccos-of-trace angle of the matrices
+            # turns that into 4e-4 "rad" (it grew linearly with the frame number) although costs and translations agree
+            qa, qb = np.asarray(got[f][0], float), np.asarray(cam.q, float)
+            qa, qb = qa / np.linalg.norm(qa), qb / np.linalg.norm(qb)
+            rel = po.quat_mul(np.array([qa[0], -qa[1], -qa[2], -qa[3]]), qb)
+            ang.append(2.0 * float(np.arctan2(np.linalg.norm(rel[1:]), abs(rel[0]))))
             tr.append(float(np.linalg.norm(got[f][1] - cam.t) / np.linalg.norm(cam.t)))
             checked.append(f)
+            if os.environ.get("C5_DEBUG"):
+                Xa, xa = np.concatenate(Xs).astype(np.float32), np.concatenate(xs_).astype(np.float32)
+                print("C5DBG", f, len(Xa), ang[-1], tr[-1], np.linalg.norm(got[f][0]) - 1.0, po.total_cost(gpu_cam[f], Xa, xa, "cauchy", 1.0), po.total_cost(cam, Xa, xa, "cauchy", 1.0),
+                      po.total_cost(gpu_cam[f - 1], Xa, xa, "cauchy", 1.0), _["iterations"], file=sys.stderr)
         db.close()
         out["tracking"]["vs_cpu_reference_sampled"] = {"frames": checked, "rotation_rad_max": max(ang), "translation_rel_max": max(tr),
                                                        "cpu_seconds_per_frame": (time.time() - t0) / max(1, len(checked))}

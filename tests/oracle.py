@@ -113,6 +113,16 @@ def rgb2gray(rgb: np.ndarray) -> np.ndarray:
     return out
 
 
+def corner_harris(gray: np.ndarray, block_size=3, ksize=3, k=0.04) -> np.ndarray:
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    out = np.empty((h, w), np.float32)
+    lib().pco_corner_harris.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    rc = lib().pco_corner_harris(gray.ctypes.data, w, h, block_size, ksize, k, out.ctypes.data)
+    assert rc == 0
+    return out
+
+
 def min_eigen_val(gray: np.ndarray, block_size=3, ksize=3) -> np.ndarray:
     gray = np.ascontiguousarray(gray, dtype=np.uint8)
     h, w = gray.shape

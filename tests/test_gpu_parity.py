@@ -119,10 +119,40 @@ def test_gftt_options(ctx):
         xy = oracle.gftt(g, oracle.gftt_options(**kw))
         assert np.array_equal(f.keypoints(), xy), kw
     with pytest.raises(hip.PolychaseHipError):
-        f.detect(hip.gftt_options(use_harris=1))
+        f.detect(hip.gftt_options(gradient_size=5))         # only the 3x3 Sobel exists here
     with pytest.raises(hip.PolychaseHipError):
         f.detect(hip.gftt_options(quality_level=0.0))
     f.close()
+
+
+@pytest.mark.parametrize("kw", [dict(use_harris=1), dict(use_harris=1, harris_k=0.15), dict(block_size=5), dict(block_size=2),
+                                dict(block_size=1), dict(block_size=7, use_harris=1), dict(block_size=4, min_distance=3.0, grid_rows=2)],
+                         ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+def test_harris_and_other_block_sizes(ctx, kw):
+    """The detector's other branches (reference cpp/feature_detection/gftt.cc:31-36: cornerHarris, any block_size), which
+    the addon never selects: response map and keypoints -- value and order -- bit-exact against the oracle, on sizes that
+    do not divide the kernels' tiles; also through the analyzer."""
+    for (w, h) in ((333, 211), (640, 360)):
+        _, (rgb,) = _noise_frames(w, h, [3])
+        g = oracle.rgb2gray(rgb)
+        f = hip.Frame(ctx, w, h)
+        f.set_rgb(rgb)
+        f.detect(hip.gftt_options(**kw))
+        bs, k = kw.get("block_size", 3), kw.get("harris_k", 0.04)
+        want = oracle.corner_harris(g, bs, 3, k) if kw.get("use_harris") else oracle.min_eigen_val(g, bs, 3)
+        assert np.array_equal(f.min_eig().view(np.uint32), want.view(np.uint32)), "response map"
+        xy = oracle.gftt(g, oracle.gftt_options(**kw))
+        assert len(xy) > 50 and np.array_equal(f.keypoints(), xy), "keypoints must match in value AND order"
+        f.close()
+    from polychase_amd.pipeline import ClipAnalyzer
+    clip = synth.NoiseClip(320, 240, 6)
+    frames = {i + 1: clip.frame(i) for i in range(6)}
+    an = ClipAnalyzer(ctx, 320, 240, 1, 6, lambda fid: frames[fid], hip.gftt_options(**kw))
+    got = {}
+    an.run(range(1, 7), lambda f1, kp, det, flows: got.__setitem__(f1, kp.copy()))
+    an.close()
+    for fid in (1, 4):
+        assert np.array_equal(got[fid], oracle.gftt(oracle.rgb2gray(frames[fid]), oracle.gftt_options(**kw)))
 
 
 def test_flat_image_has_no_keypoints(ctx):
