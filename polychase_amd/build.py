@@ -17,7 +17,7 @@ LIB_DIR = os.path.join(PKG, "lib")
 OBJ_DIR = os.path.join(PKG, "lib", "obj")
 HIP_DIR = os.path.join(PKG, "csrc", "hip")
 
-HIP_SOURCES = ["kernels_image.hip", "kernels_pyramid.hip", "kernels_gftt.hip", "kernels_lk.hip", "kernels_lk2.hip", "kernels_lk3.hip", "kernels_tracker.hip", "kernels_refiner.hip", "kernels_bvh.hip", "api.hip", "api_analyzer.hip", "api_tracker.hip"]
+HIP_SOURCES = ["kernels_image.hip", "kernels_pyramid.hip", "kernels_gftt.hip", "kernels_lk.hip", "kernels_lk3.hip", "kernels_tracker.hip", "kernels_refiner.hip", "kernels_bvh.hip", "api.hip", "api_analyzer.hip", "api_tracker.hip"]
 # -ffp-contract=off: the float stages must match the oracle bit-for-bit (no FMA fusion).
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
              "-Wno-unused-function"]

@@ -135,8 +135,6 @@ constexpr int kRecStride = 8;   // records per slot (= PC_MAX_TARGETS)
 // K8-K10: pyramidal LK, one 16-lane DPP row per (keypoint, target).  Returns false if the window
 // size is unsupported.
 bool launch_lk(const LKParams& p, int win, hipStream_t s);
-// the same with two keypoints per wavefront (kernels_lk2.hip); window sizes 4..11
-bool launch_lk2(const LKParams& p, int win, hipStream_t s);
 // two keypoints per wavefront on the uint16 planes, dword-per-position LDS regions (kernels_lk3.hip); windows 4..11
 bool launch_lk3(const LKParams& p, int win, hipStream_t s);
 bool lk_profile_enabled();   // library compiled with -DPC_LK_PROFILE: LKParams::prof takes 16 words per wavefront

@@ -1,8 +1,8 @@
 // kernels_lk3.hip -- pyramidal Lucas-Kanade (K8-K10), two keypoints per wavefront, on the uint16 planes.
 //
-// Same arithmetic and results as kernels_lk.hip / kernels_lk2.hip (bit for bit; all follow oracle/pc_oracle.c,
+// Same arithmetic and results as kernels_lk.hip (bit for bit; both follow oracle/pc_oracle.c,
 // which restates cv::calcOpticalFlowPyrLK as called at reference cpp/opticalflow.cc:119-125), same mapping as
-// lk2 -- lanes 0-31 track keypoint A, lanes 32-63 keypoint B, group g = 4 lanes tracks the keypoint into target
+// round 1's lk2 kernel -- lanes 0-31 track keypoint A, lanes 32-63 keypoint B, group g = 4 lanes tracks the keypoint into target
 // g, the I side is evaluated once per keypoint by its half-wave -- but another data path for the inner loop:
 //
 //   * The images are read from the uint16 planes (Level::img16, value = pixel << 7).  In LDS a region keeps one

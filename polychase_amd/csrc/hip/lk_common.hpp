@@ -1,5 +1,5 @@
 // lk_common.hpp -- device helpers shared by the pyramidal LK kernels (kernels_lk.hip: one keypoint per
-// wavefront, 8 lanes per target; kernels_lk2.hip: two keypoints per wavefront, 4 lanes per target):
+// wavefront, 8 lanes per target; kernels_lk3.hip: two keypoints per wavefront, 4 lanes per target):
 // fixed-point bilinear weights, interpolation on "byte pair" LDS rows, exact integer sums, staging of
 // image regions into LDS.  Arithmetic follows oracle/pc_oracle.c (OpenCV's LKTrackerInvoker).
 #pragma once

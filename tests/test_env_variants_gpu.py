@@ -18,7 +18,6 @@ VARIANTS = [
     {"POLYCHASE_DETECT_STREAMS": "1"},
     {"POLYCHASE_DETECT_STREAMS": "2", "GPU_MAX_HW_QUEUES": "8"},
     {"POLYCHASE_GFTT_SLOW_PATH": "1"},
-    {"POLYCHASE_LK_VARIANT": "2"},
     {"POLYCHASE_LK_VARIANT": "1"},
     {"POLYCHASE_PYRAMID_VARIANT": "1"},
     {"POLYCHASE_HELPER_PRIO": "0"},

@@ -17,7 +17,6 @@ run() {   # name, env assignments...
   echo "{\"variant\": \"$name\", \"isolated\": ${iso:-null}, \"pipeline\": [${lanes}]}" >> "$OUT"
 }
 run default
-run "lk2 (two keypoints per wavefront, u8 planes: round-1 kernel)" POLYCHASE_LK_VARIANT=2
 run "lk (ONE keypoint per wavefront, 8 lanes per pair: max over 8 pairs)" POLYCHASE_LK_VARIANT=1
 for v in occ4 occ2 waves2 srows2 nopf nopairs notrim; do
   lib=$ROOT/polychase_amd/lib/variants/libpolychase_hip_$v.so
