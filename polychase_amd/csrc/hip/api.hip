@@ -999,6 +999,7 @@ int pc_lk_track_filtered(pc_context* ctx, const pc_frame* frame1, const pc_frame
     PC_HIP(ctx->lk_cxy.ensure(rows + 1));
     PC_HIP(ctx->lk_cerr.ensure(rows + 1));
     PC_HIP(ctx->lk_cidx.ensure(rows + 1));
+    if (n > pc::kCompactMaxKeypoints) return fail(PC_E_CAPACITY, "%d keypoints: more than the compaction handles (%d)", n, pc::kCompactMaxKeypoints);
     const size_t scratch_cap_before = ctx->lk_block_counts[0].cap;   // a reallocation changes the capacity (the address may repeat)
     PC_HIP(ctx->lk_block_counts[0].ensure(pc::compact_scratch_words(n, n_targets)));
     PC_HIP(ctx->lk_row_offset.ensure(PC_MAX_TARGETS + 1));

@@ -469,6 +469,7 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     long long* const p_ro = reinterpret_cast<long long*>(pack);
     PC_HIP(hipMemsetAsync(pack, 0, 128, ls));
     if (n_targets > 0) {
+    if (n > pc::kCompactMaxKeypoints) return fail(PC_E_CAPACITY, "%d keypoints: more than the compaction handles (%d)", n, pc::kCompactMaxKeypoints);
         const size_t scratch_cap_before = ctx->lk_block_counts[lane].cap;   // a reallocation changes the capacity (the address may repeat)
         PC_HIP(ctx->lk_block_counts[lane].ensure(pc::compact_scratch_words(n, n_targets)));
         ScopedTimer t(ctx, PC_K_COMPACT, ls);

@@ -156,6 +156,7 @@ void launch_spatial_bins_counted(const float2* pts, int n, const uint32_t* n_dev
 // since it was allocated (its ticket words are then zeroed first; afterwards the launches keep them zero).
 // row_offset: [n_targets+1] int64 (device).
 constexpr int kCompactTicketWords = 1024;   // pc::last_workgroup_words(blocks) for up to 8.3 M keypoints
+constexpr int kCompactMaxKeypoints = 8000000;   // callers refuse more
 size_t compact_scratch_words(int n, int n_targets);
 void launch_compact(const float4* rec, const uint32_t* slot_of, int n, int n_targets, uint32_t* scratch, bool scratch_fresh,
                     long long* row_offset, uint32_t* out_idx, float2* out_xy, float* out_err, hipStream_t s);

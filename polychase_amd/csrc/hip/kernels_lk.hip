@@ -676,6 +676,7 @@ void launch_compact(const float4* rec, const uint32_t* slot_of, int n, int n_tar
         (void)hipMemsetAsync(row_offset, 0, (size_t)(std::max(n_targets, 0) + 1) * sizeof(long long), s);
         return;
     }
+    static_assert((long long)(kCompactTicketWords - 1) * kTicketGroup * CF >= kCompactMaxKeypoints, "tickets for kCompactMaxKeypoints");
     hipLaunchKernelGGL(compact_count_kernel, dim3(nblocks), dim3(CT), 0, s, rec, slot_of, n, n_targets, nblocks, tickets, block_counts,
                        row_offset, helper_prio_arg());
     hipLaunchKernelGGL(compact_scatter_kernel, dim3(nblocks), dim3(CT), 0, s, rec, slot_of, n, n_targets, nblocks, tickets,

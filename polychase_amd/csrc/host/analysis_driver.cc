@@ -391,7 +391,10 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
     };
     auto open_piece = [&](int32_t first_frame1) {
         const int index = next_piece++;
-        while (!pieces.empty() && pieces.front().index <= index - n_parts) collect_one();   // that part of the buffer is still in use
+        while (!pieces.empty() && pieces.front().index <= index - n_parts) {   // that part of the buffer is still in use
+            if (pc_analyzer_pending(eng.an) == 0) throw std::logic_error("device log piece neither collected nor handed over");
+            collect_one();
+        }
         LogPiece pc;
         pc.index = index;
         pc.offset = static_cast<size_t>(index % n_parts) * part_bytes;
