@@ -413,6 +413,8 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
         for (int t = 0; t < n_targets; t++) PC_HIP(hipStreamWaitEvent(ls, find_slot(a, targets[t])->img_ready, 0));
     }
     const int n = s1->frame->n_kps;
+    if (n > pc::kCompactMaxKeypoints)   // before anything of the job is enqueued
+        return fail(PC_E_CAPACITY, "%d keypoints: more than the compaction handles (%d)", n, pc::kCompactMaxKeypoints);
     const size_t rows = (size_t)n * (size_t)std::max(n_targets, 0);
     // packed record layout (= a device-log record without its 128-byte header)
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -469,7 +471,6 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     long long* const p_ro = reinterpret_cast<long long*>(pack);
     PC_HIP(hipMemsetAsync(pack, 0, 128, ls));
     if (n_targets > 0) {
-    if (n > pc::kCompactMaxKeypoints) return fail(PC_E_CAPACITY, "%d keypoints: more than the compaction handles (%d)", n, pc::kCompactMaxKeypoints);
         const size_t scratch_cap_before = ctx->lk_block_counts[lane].cap;   // a reallocation changes the capacity (the address may repeat)
         PC_HIP(ctx->lk_block_counts[lane].ensure(pc::compact_scratch_words(n, n_targets)));
         ScopedTimer t(ctx, PC_K_COMPACT, ls);
