@@ -484,6 +484,8 @@ class Analyzer:
         """-> (frame1, keypoints [N,2], detected, {frame2: (src_idx, tgt_xy, err)})"""
         r = self.collect_raw()
         n = r.n_keypoints
+        if n and not r.keypoints_xy:     # set_host_records(False): the records left through the device log only
+            return r.frame1, None, bool(r.keypoints_detected), {int(r.targets[t]): None for t in range(r.n_targets)}
         kps = np.ctypeslib.as_array(r.keypoints_xy, shape=(n, 2)) if n else np.zeros((0, 2), np.float32)
         flows = {}
         for t in range(r.n_targets):
