@@ -34,6 +34,8 @@ def main() -> int:
             T.test_random_configuration(ctx, seed)
             if seed % 10 == 0:   # every tenth seed also drives a whole random clip through the pipelined analyzer
                 T.test_random_clip_through_the_analyzer(ctx, seed)
+            if seed % 3 == 0:    # every third: the detector's other branches and the arithmetic modes
+                T.test_random_detector_branch_and_arithmetic_mode(ctx, seed)
         except AssertionError as e:
             failures.append({"seed": seed, "what": str(e)[:400]})
             print(f"MISMATCH seed {seed}: {str(e)[:400]}", flush=True)

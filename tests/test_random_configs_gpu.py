@@ -131,3 +131,60 @@ def test_random_clip_through_the_analyzer(ctx, seed):
     for key in flows_o:
         for a, b in zip(got_flows[key], flows_o[key]):
             assert a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"{case}: flow {key}"
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_detector_branch_and_arithmetic_mode(ctx, seed):
+    """The dimensions round 3 added: cornerHarris / any block_size (gftt.cc:31-36) and the arithmetic modes of the context
+    (pc_context_set_arithmetic: x86 LK summation order, FMA in the Sobel column filter) -- response map, keypoints in value
+    and order, LK positions / status / error against the oracle under the matching emulation, bit for bit."""
+    rng = np.random.default_rng(9000 + seed)
+    w, h = int(rng.integers(40, 300)), int(rng.integers(40, 220))
+    kind = ["noise", "blocks", "smooth"][seed % 3]
+    win, max_level = int(rng.integers(3, 17)), int(rng.integers(0, 4))
+    block = int(rng.choice([1, 2, 3, 3, 4, 5, 7]))
+    harris = bool(rng.random() < 0.35)
+    arith = int(rng.choice([hip.ARITH_CANONICAL, hip.ARITH_LK_X86_ORDER, hip.ARITH_SOBEL_FMA, hip.ARITH_OPENCV_X86]))
+    gk = dict(quality_level=float(rng.choice([0.01, 0.05, 0.3])), min_distance=float(rng.choice([0.0, 2.5, 5.0])), block_size=block,
+              use_harris=int(harris), harris_k=float(rng.choice([0.04, 0.06, 0.15])), grid_rows=int(rng.integers(1, 5)),
+              grid_cols=int(rng.integers(1, 5)))
+    fk = dict(window_size=win, max_level=max_level, term_max_iters=int(rng.choice([3, 30])))
+    n_targets = int(rng.integers(1, 5))
+    src = _image(rng, w, h, kind)
+    if seed % 4 == 0:                          # hard edges at full contrast: where the fp32 lane sums of the x86 order round
+        src = np.where(src > 127, 255, 0).astype(np.uint8)
+    tgts = [_shifted(rng, src, int(rng.integers(0, 5))) for _ in range(n_targets)]
+    case = f"seed {seed}: {w}x{h} {kind} win {win} L {max_level} gftt {gk} lk {fk} targets {n_targets} arith {arith}"
+    emu = (oracle.EMU_LK_SIMD if arith & hip.ARITH_LK_X86_ORDER else 0) | (oracle.EMU_SOBEL_FMA if arith & hip.ARITH_SOBEL_FMA else 0)
+    ctx.set_arithmetic(arith)
+    try:
+        f1 = hip.Frame(ctx, w, h, win, max_level)
+        f1.set_rgb(src)
+        g1 = oracle.rgb2gray(src)
+        f1.detect(hip.gftt_options(**gk))
+        with oracle.emulation(emu):
+            want = oracle.corner_harris(g1, block, 3, gk["harris_k"]) if harris else oracle.min_eigen_val(g1, block, 3)
+            kps_o = oracle.gftt(g1, oracle.gftt_options(**gk))
+        assert np.array_equal(f1.min_eig().view(np.uint32), want.view(np.uint32)), case
+        assert np.array_equal(f1.keypoints(), kps_o), case
+        frames = []
+        for t in tgts:
+            f = hip.Frame(ctx, w, h, win, max_level)
+            f.set_rgb(t)
+            frames.append(f)
+        if len(kps_o) == 0:
+            kps_o = np.floor(rng.uniform([0, 0], [w, h], (9, 2))).astype(np.float32)
+            f1.set_keypoints(kps_o)
+        xy, st, err = hip.lk_track(ctx, f1, frames, hip.flow_options(**fk))
+        p1 = oracle.Pyramid(g1, win, max_level)
+        with oracle.emulation(emu):
+            for k, t in enumerate(tgts):
+                oxy, ost, oerr = oracle.lk(p1, oracle.Pyramid(oracle.rgb2gray(t), win, max_level), kps_o, oracle.flow_options(**fk))
+                assert np.array_equal(st[k], ost), f"{case}: status of target {k}: {(st[k] != ost).sum()} differ"
+                m = ost == 1
+                assert np.array_equal(xy[k][m].view(np.uint32), oxy[m].view(np.uint32)), f"{case}: positions of target {k}"
+                assert np.array_equal(err[k][m].view(np.uint32), oerr[m].view(np.uint32)), f"{case}: errors of target {k}"
+        for f in [f1] + frames:
+            f.close()
+    finally:
+        ctx.set_arithmetic(hip.ARITH_CANONICAL)
