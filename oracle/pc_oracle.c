@@ -60,8 +60,9 @@ int pco_get_opencv_emulation(void) { return g_emulation; }
  *        filter as ((f1*s[-1] + f0*s[0]) + f1*s[+1]); column kernel [-1,0,1] as S2 - S0.
  *   (Sobel() folds the scale into the *smoothing* kernel.)  All BORDER_REFLECT_101.
  *   cov = (Dx*Dx, Dx*Dy, Dy*Dy) in fp32; boxFilter(block x block, normalize=false) with fp64 sums
- *   (exact for 8-bit inputs: every product is a multiple of 2^-47 and |sum| < 2^6), rounded to
- *   fp32; eig = (a + c) - sqrtf((a - c)*(a - c) + b*b), a = cxx*0.5f, b = cxy, c = cyy*0.5f.
+ *   (exact for 8-bit inputs in the canonical order: every product is a multiple of 2^-47 and |sum| < 2^6 -- NOT under
+ *   PCO_EMU_SOBEL_FMA, where a cancelling Dx leaves a ~1e-10 residual: there the row-major order below defines the result),
+ *   rounded to fp32; eig = (a + c) - sqrtf((a - c)*(a - c) + b*b), a = cxx*0.5f, b = cxy, c = cyy*0.5f.
  * Canonical choice: no FMA contraction (OpenCV's AVX2 dispatch may fuse v_muladd). */
 static int corner_response(const uint8_t* gray, int w, int h, int block_size, int ksize, int harris, double harris_k, float* eig);
 int pco_min_eigen_val(const uint8_t* gray, int w, int h, int block_size, int ksize, float* eig) {

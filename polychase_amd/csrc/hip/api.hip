@@ -147,7 +147,9 @@ int validate_gftt(const pc_gftt_options* opt, int w, int h, pc::GfttGrid* g) {
 static int corner_response(pc_context* ctx, const pc_frame* f, DetectScratch& d, const pc::GfttGrid& grid, const pc_gftt_options& opt,
                            uint32_t* cell_max) {
     const bool fma = (ctx->arith & PC_ARITH_SOBEL_FMA) != 0;
-    if (opt.block_size == 3 && !opt.use_harris) {
+    // POLYCHASE_GFTT_GENERAL=1: the general kernels for the default options too (cross-check of the tiled kernel)
+    static const bool force_general = getenv("POLYCHASE_GFTT_GENERAL") && atoi(getenv("POLYCHASE_GFTT_GENERAL")) == 1;
+    if (opt.block_size == 3 && !opt.use_harris && !force_general) {
         pc::launch_min_eig(f->levels[0], d.eig.p, grid, cell_max, fma, ctx->work);
         return PC_OK;
     }

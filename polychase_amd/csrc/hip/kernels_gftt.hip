@@ -135,14 +135,31 @@ __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict_
     for (int k = 0; k < 4; k++) {
         const int y = y0 + ty0 + k;
         if (x < w && y < h) {
-            const double sxx = (hxx[k] + hxx[k + 1]) + hxx[k + 2];
-            const double sxy = (hxy[k] + hxy[k + 1]) + hxy[k + 2];
-            const double syy = (hyy[k] + hyy[k + 1]) + hyy[k + 2];
+            double sxx = (hxx[k] + hxx[k + 1]) + hxx[k + 2];
+            double sxy = (hxy[k] + hxy[k + 1]) + hxy[k + 2];
+            double syy = (hyy[k] + hyy[k + 1]) + hyy[k + 2];
+            if (sobel_fma) {
+                // With the fused column filter a cancelling Dx leaves a residual of ~1e-10 instead of 0, its square is
+                // ~1e-19 beside sums of ~1e-3: the fp64 box sums are no longer exact and their ORDER shows in the last bit
+                // of one pixel in ~10^5.  The mode is defined by the oracle's order: row by row, left to right.
+                sxx = sxy = syy = 0.0;
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        sxx += (double)s_cxx[ty0 + k + j][tx + i];
+                        sxy += (double)s_cxy[ty0 + k + j][tx + i];
+                        syy += (double)s_cyy[ty0 + k + j][tx + i];
+                    }
+            }
             const float a = (float)sxx * 0.5f;
             const float b = (float)sxy;
             const float c = (float)syy * 0.5f;
             const float t = a - c;
-            const float e = (a + c) - sqrtf(t * t + b * b);
+            float e = (a + c) - sqrtf(t * t + b * b);
+#ifdef PC_MINEIG_DUMP   // debugging aid: the covariance tile instead of the response (column x - 1 + PC_MINEIG_DUMP, channel xy)
+            e = s_cxy[ty0 + k + 1][tx + PC_MINEIG_DUMP];
+#endif
             eig[(size_t)y * w + x] = e;
             const uint32_t key = float_to_ordered(e);
             if (small_cells) {
