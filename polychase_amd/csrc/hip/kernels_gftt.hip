@@ -35,9 +35,15 @@ constexpr int TW = 64, TH = 16;
 constexpr int GH = TH + 4, G_PITCH = 72;  // gray tile: columns x0 - 4 .. x0 + 67 (18 aligned dwords), rows y0 - 2 .. y0 + 17
 constexpr int CW = TW + 2, CH = TH + 2;   // covariance tile: x0 - 1 .. x0 + 64, y0 - 1 .. y0 + 16
 
+// SOBEL_FMA (PC_ARITH_SOBEL_FMA) is a template parameter, not a launch argument: the extra code of that mode took the
+// kernel from 64 to 106 VGPRs, and a helper wavefront with more than 104 does not fit beside three LK wavefronts per SIMD
+// (512 - 3 x 136): the detection then only ran in the gaps of the LK launches -- 4K pipeline 710 -> 537 frames/s, caught by
+// the round's last profile run.  tests/test_kernel_resources_cpu.py now holds every helper kernel to its budget.
+template <bool SOBEL_FMA>
 __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict__ img, int pitch, int w, int h,
                                                       float* __restrict__ eig, GfttGrid g,
-                                                      uint32_t* __restrict__ cell_max, float f1, float f0, int sobel_fma, int hi_prio) {
+                                                      uint32_t* __restrict__ cell_max, float f1, float f0, int hi_prio) {
+    constexpr bool sobel_fma = SOBEL_FMA;
     helper_priority(hi_prio);
     __shared__ __attribute__((aligned(16))) uint8_t s_gray[GH][G_PITCH];
     __shared__ float s_cxx[CH][CW + 1];
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict_
             double sxx = (hxx[k] + hxx[k + 1]) + hxx[k + 2];
             double sxy = (hxy[k] + hxy[k + 1]) + hxy[k + 2];
             double syy = (hyy[k] + hyy[k + 1]) + hyy[k + 2];
-            if (sobel_fma) {
+            if constexpr (SOBEL_FMA) {
                 // With the fused column filter a cancelling Dx leaves a residual of ~1e-10 instead of 0, its square is
                 // ~1e-19 beside sums of ~1e-3: the fp64 box sums are no longer exact and their ORDER shows in the last bit
                 // of one pixel in ~10^5.  The mode is defined by the oracle's order: row by row, left to right.
@@ -184,7 +190,8 @@ void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* ce
     const double scale_d = 1.0 / (4.0 * 3.0 * 255.0);
     const float f1 = (float)(1.0 * scale_d), f0 = (float)(2.0 * scale_d);
     dim3 grid((l0.w + TW - 1) / TW, (l0.h + TH - 1) / TH);
-    hipLaunchKernelGGL(min_eig_kernel, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, sobel_fma ? 1 : 0, helper_prio_arg());
+    if (sobel_fma) hipLaunchKernelGGL(min_eig_kernel<true>, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, helper_prio_arg());
+    else hipLaunchKernelGGL(min_eig_kernel<false>, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, helper_prio_arg());
 }
 
 // ------------------------------------------------------------------------------------------------
