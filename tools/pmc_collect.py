@@ -11,6 +11,7 @@ import csv
 import glob
 import json
 import os
+import signal
 import subprocess
 import sys
 import tempfile
@@ -27,14 +28,29 @@ def main():
     ap.add_argument("--by-kernel", action="store_true", help="per kernel name: counters summed over the run / frames (all kernels)")
     ap.add_argument("groups", nargs="+")
     args = ap.parse_args()
-    env = dict(os.environ, TMPDIR="/tmp")
+    # One job lane: counter collection serialises dispatches anyway, and without the second lane there is no gate
+    # kernel polling for a dispatch the profiler is holding back.
+    env = dict(os.environ, TMPDIR="/tmp", POLYCHASE_LK_LANES="1")
     result = {}
     for g in args.groups:
         d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", *g.split(","), "--output-format", "csv", "-d", d, "--",
                sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-c3", "--no-end-to-end", "--config", args.config,
                "--steps", str(args.steps), "--warmup", "4"]
-        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        r = None
+        for attempt in range(2):   # a counter pass that hangs (seen once in r03) is killed and tried once more
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                                    start_new_session=True)
+            try:
+                out, _ = proc.communicate(timeout=180)
+                r = subprocess.CompletedProcess(cmd, proc.returncode, out)
+                break
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)   # the whole session: rocprofv3 and the bench under it
+                proc.communicate()
+                print(f"[{g}] rocprofv3 pass timed out (attempt {attempt + 1})", file=sys.stderr)
+        if r is None:
+            continue
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if not files:
             print(f"[{g}] no counter file; rocprofv3 said:\n{r.stdout[-1500:]}", file=sys.stderr)
