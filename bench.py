@@ -177,7 +177,7 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
     def barrier():
         torch.cuda.synchronize()
         ctx.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
 
     n_kps, n_rows = [], []
@@ -200,7 +200,7 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
     est_step = (time.perf_counter() - t0) / 8
     nxt += 8
     regions = int(min(40, max(1, -(-MIN_REGION_S // max(K * est_step, 1e-6)))))
-    if world > 1:
+    if dist.is_initialized():
         tt = torch.tensor([regions], dtype=torch.int64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         regions = int(tt.item())
@@ -212,7 +212,7 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
         max_kp = int(1.5 * max(n_kps)) + 4096
         log = torch.empty(D.log_capacity_bytes(K + 2, max_kp), dtype=torch.uint8, device=dev)
         side = None
-        if world > 1:
+        if dist.is_initialized():
             try:
                 side = dist.new_group(backend="gloo")
             except Exception as e:   # no usable interface for gloo: the sizes go over the main group instead
@@ -264,7 +264,7 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
                 collect_one()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist.is_initialized():
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -374,6 +374,8 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
                               "frac": frame_bytes * (K / dt) / 1e9 / HBM_PEAK_GBS},
             "kernel_ms_per_frame": breakdown,
         }
+        if dist.is_initialized():
+            out["collectives_backend"] = dist.get_backend()   # "nccl" = RCCL; "gloo" only under the SHARE_GPU testing aid
         if with_cpu:
             f1s = [first_id + 8 + i for i in range(K)]
             out["cpu_baseline"] = cpu_baseline(lambda f: source(f).cpu().numpy(), f1s, gopt_kw, fopt_kw,
@@ -390,12 +392,18 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
     return out
 
 
+def free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: run N ranks of this command through torch.distributed.run (one
     process per GPU, rendezvous on 127.0.0.1) and return its exit code.  The sharded loop being launched is the
     reference's frame loop, cpp/opticalflow.cc:209-321, on N disjoint frame ranges."""
-    import socket
-
     import torch
 
     have = torch.cuda.device_count()
@@ -403,9 +411,7 @@ def self_launch(n: int) -> int:
         print(f"bench.py: --gpus {n} needs {n} GPUs, this node has {have} "
               "(POLYCHASE_BENCH_SHARE_GPU=1 puts all ranks on GPU 0 over gloo: a testing aid, not a measurement)", file=sys.stderr)
         return 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
@@ -450,11 +456,20 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # testing aid (tests/test_rccl_gpu.py): --force-dist-path with POLYCHASE_BENCH_RCCL_WORLD1=1 builds a ONE-rank RCCL
+    # communicator, and every collective of the N > 1 path (barrier, all_reduce, all_gather, all_gather_into_tensor of the
+    # log pieces) goes through RCCL on the one GPU a test box has -- the calls, dtypes and buffer shapes of --gpus N
+    rccl_world1 = world == 1 and args.force_dist_path and os.environ.get("POLYCHASE_BENCH_RCCL_WORLD1") == "1"
     if world > 1:
         if share_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    elif rccl_world1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        port = int(os.environ.get("MASTER_PORT", "0")) or free_port()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
     K, W = args.steps, args.warmup
     single = world == 1 and not args.force_dist_path
@@ -469,7 +484,7 @@ def main():
             out["c3"] = c3
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -191,7 +191,7 @@ class ChunkedLogStitch:
     gather(start, end): bytes [start, end) of the local log are complete (the job that wrote the last of them has
     been collected).  The piece sizes are agreed on through `side_group` -- a gloo group, so that the exchange does not
     queue behind the previous piece's payload on the NCCL stream -- then the payload all-gather is enqueued and the
-    call returns.  world == 1 (or no process group): the pieces are views of the local log."""
+    call returns.  Without a process group the pieces are views of the local log."""
 
     def __init__(self, log, group=None, side_group=None):
         import torch.distributed as dist
@@ -199,6 +199,9 @@ class ChunkedLogStitch:
         self.log, self.group, self.side = log, group, side_group
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.world = self.dist.get_world_size(group) if self.dist else 1
+        # no process group: the pieces are views of the local log.  A ONE-rank group still runs every collective (the
+        # RCCL calls of the N-rank job on a one-GPU test box, tests/test_rccl_gpu.py).
+        self.local_only = self.dist is None
         self.pieces = []   # (gathered [world, padded] uint8, sizes [world])
         self._pool = []    # receive buffers allocated ahead of the timed region (reserve)
 
@@ -207,7 +210,7 @@ class ChunkedLogStitch:
         allocation of half a gigabyte inside the timed region is a hipMalloc that stalls the device."""
         import torch
 
-        if self.world == 1:
+        if self.local_only:
             return
         mx = max(16, (int(max_piece_bytes) + 15) // 16 * 16)
         self._reserved = [torch.empty(self.world * mx, dtype=torch.uint8, device=self.log.device) for _ in range(n_pieces)]
@@ -224,7 +227,7 @@ class ChunkedLogStitch:
         connections (hundreds of milliseconds for RCCL)."""
         import torch
 
-        if self.world == 1:
+        if self.local_only:
             return
         dist = self.dist
         if self.side is not None:
@@ -244,7 +247,7 @@ class ChunkedLogStitch:
         import torch
 
         n = end - start
-        if self.world == 1:
+        if self.local_only:
             self.pieces.append((self.log[start:end][None], [n]))
             return
         dist = self.dist

@@ -159,6 +159,19 @@ def test_chunked_log_stitch_two_ranks(tmp_path, use_side):
         assert np.array_equal(np.load(tmp_path / f"sp{r}.npy"), p_ref)
 
 
+def test_chunked_log_stitch_one_rank_group(tmp_path):
+    """A ONE-rank process group still runs every collective of the stitch (what tests/test_rccl_gpu.py does with RCCL on
+    a one-GPU box); only the absence of a process group makes the pieces views of the local log."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    first, n = 4, 7
+    mp.spawn(_stitch_worker, args=(1, port, first, n, str(tmp_path), True), nprocs=1, join=True)
+    h_ref, p_ref = D.pack_records([fake_record(f, first, n) for f in range(first, first + n)])
+    assert np.array_equal(np.load(tmp_path / "sh0.npy"), h_ref) and np.array_equal(np.load(tmp_path / "sp0.npy"), p_ref)
+
+
 # ----------------------------------------------------------------------------------------------
 # records -> database: the product path of the multi-rank analysis (polychase_amd/analyze.py) after the GPU part.
 # Rank r holds the record log of its frame range, the logs are all-gathered (gloo here, RCCL on the GPU box), rank 0

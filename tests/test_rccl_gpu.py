@@ -29,6 +29,23 @@ def _env():
     return env
 
 
+def test_bench_collectives_over_a_one_rank_rccl_communicator():
+    """Runs on ANY GPU box: bench.py's N > 1 code path (device log, pieces all-gathered inside the timed region, region
+    agreement, max-over-ranks timing) with a ONE-rank RCCL communicator -- init_process_group("nccl", device_id=...),
+    barrier, all_reduce of int64 / float64, all_gather of the piece sizes, all_gather_into_tensor of uint8 log pieces all
+    execute in RCCL; the stitched log must parse into exactly the frames analysed (asserted inside bench.py)."""
+    env = _env()
+    env["POLYCHASE_BENCH_RCCL_WORLD1"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "4", "--config", "c1", "--no-c3",
+                        "--no-breakdown", "--force-dist-path"], text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
+                       env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-4000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert out.get("collectives_backend") == "nccl", out.get("collectives_backend")
+
+
 def test_bench_two_ranks_over_rccl():
     if _gpus() < 2:
         pytest.skip("one GPU: RCCL needs a device per rank")
