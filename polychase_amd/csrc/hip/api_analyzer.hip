@@ -558,7 +558,14 @@ int pc_analyzer_collect(pc_analyzer* a, pc_frame_result* out) {
     // is the preparation stream keeping up?  (HelperPriorityControl)
     if (a->puts >= 2) {
         Slot* const sp = find_slot(a, a->put_previous);
-        a->prio.observe(sp && sp->img_ready && hipEventQuery(sp->img_ready) == hipErrorNotReady);
+        bool lagging = sp && sp->img_ready && hipEventQuery(sp->img_ready) == hipErrorNotReady;
+        if (a->ctx->n_detect > 0 && !lagging) {
+            // detection on its own stream(s): the pyramid no longer queues behind it, so its lag shows where it is
+            // needed -- the keypoints of the frame1 after the next submit (one frame of slack) are not complete yet
+            Slot* const sd = find_slot(a, j.frame1 + (int32_t)a->job_count + 1);
+            lagging = sd && sd->det == DET_ENQUEUED && sd->kps_ready && hipEventQuery(sd->kps_ready) == hipErrorNotReady;
+        }
+        a->prio.observe(lagging);
     }
     // let the runtime retire the finished commands of the other streams now, a few at a time: left alone it does
     // so in one batch of several milliseconds every couple of hundred frames, inside some later launch
