@@ -19,8 +19,12 @@ the 4K configuration C3 under "c3" (the >= 30x target is quoted on 4K) unless --
 N > 1: `python bench.py --gpus N ...` launches N ranks by itself (it re-executes through torch.distributed.run on
 127.0.0.1 and fails if the node has fewer than N GPUs); started under torch.distributed.run / torchrun it joins that job
 instead (WORLD_SIZE must equal --gpus).  One rank per GPU; every rank analyses its own contiguous range of frame ids
-(rank r: ids from 1 + r * RANK_ID_STRIDE, no data-path collective) and the flow records are stitched over RCCL inside the
-timed region, in pieces that overlap the analysis.  scaling = "weak".
+(rank r: ids from 1 + r * RANK_ID_STRIDE, no data-path collective) and the flow records are all-gathered inside the timed
+region, in pieces that overlap the analysis: by default each rank pushes its pieces into the peers' receive buffers over xGMI
+with the copy engines (distributed.PeerLogStitch: the RCCL kernel does not fit beside the LK wavefronts and would run after
+them); POLYCHASE_BENCH_STITCH=rccl selects the RCCL all-gather, which is also the fallback when the ranks cannot map each
+other's buffers.  Control traffic (barrier, region agreement, max-over-ranks time, piece sizes) is RCCL / gloo.
+`config.stitch` names the path taken.  scaling = "weak".
 """
 from __future__ import annotations
 
@@ -217,10 +221,12 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
                 side = dist.new_group(backend="gloo")
             except Exception as e:   # no usable interface for gloo: the sizes go over the main group instead
                 print(f"[bench] gloo side group unavailable ({e}); exchanging piece sizes over RCCL", file=sys.stderr)
-        stitch = D.ChunkedLogStitch(log, side_group=side)
+        # POLYCHASE_BENCH_STITCH=rccl: the RCCL all-gather; default: peer copies over xGMI by the copy engines, falling back
+        # to the all-gather when the ranks cannot map each other's buffers (distributed.PeerLogStitch says why)
+        stitch = D.make_log_stitch(log, side_group=side, prefer=os.environ.get("POLYCHASE_BENCH_STITCH", "peer"))
         stitch.warm_up()
         piece_frames = max(1, K // 8)
-        stitch.reserve((K + piece_frames - 1) // piece_frames + 1, D.log_capacity_bytes(piece_frames + 1, max_kp))
+        stitch.reserve(K // piece_frames + piece_frames + 1, D.log_capacity_bytes(piece_frames + 1, max_kp))
 
     region_s, lk_avg, lk_busy = [], [], []
     lk_launches = 0
@@ -251,7 +257,9 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
                 r = an.an.collect(False)
                 sink(*r)
                 done = r[0] - timed.start + 1
-                if done % piece == 0 or done == K:
+                # the last frames of the region go one by one: what is still on the wire when the last job has been
+                # collected is one frame, not a piece
+                if done % piece == 0 or done > K - piece:
                     stitch.gather(piece_start, log_end[r[0]])
                     piece_start = log_end[r[0]]
 
@@ -262,6 +270,7 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
                 log_end[f] = an.an.device_log_used
             while an.an.pending:
                 collect_one()
+            stitch.finish()             # peer copies: this rank's pushes landed, sizes exchanged, the ranks have met
         barrier()
         dt = time.perf_counter() - t0
         if dist.is_initialized():
@@ -287,7 +296,10 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
                     assert [x[0] for x in recs] == list(timed)
                     assert [len(x[1]) for x in recs] == n_kps[-K:] and [sum(len(v[0]) for v in x[2].values()) for x in recs] == n_rows[-K:]
     gc.enable()
+    stitch_name = None
     if dist_path:
+        stitch_name = stitch.name
+        stitch.close()
         del stitch, log
     an.close()
     order = np.argsort(region_s)
@@ -376,6 +388,8 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
         }
         if dist.is_initialized():
             out["collectives_backend"] = dist.get_backend()   # "nccl" = RCCL; "gloo" only under the SHARE_GPU testing aid
+        if stitch_name:
+            out["config"]["stitch"] = stitch_name
         if with_cpu:
             f1s = [first_id + 8 + i for i in range(K)]
             out["cpu_baseline"] = cpu_baseline(lambda f: source(f).cpu().numpy(), f1s, gopt_kw, fopt_kw,

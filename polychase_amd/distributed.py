@@ -11,6 +11,8 @@ Record order and bytes are independent of the number of ranks.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 HALO = 8  # largest |skip| of the reference (cpp/opticalflow.cc:76-77)
@@ -193,6 +195,14 @@ class ChunkedLogStitch:
     queue behind the previous piece's payload on the NCCL stream -- then the payload all-gather is enqueued and the
     call returns.  Without a process group the pieces are views of the local log."""
 
+    name = "rccl all_gather"
+
+    def finish(self):
+        """Nothing to do here: the payload all-gathers are stream-ordered, the caller's device synchronisation ends them."""
+
+    def close(self):
+        pass
+
     def __init__(self, log, group=None, side_group=None):
         import torch.distributed as dist
 
@@ -282,6 +292,195 @@ class ChunkedLogStitch:
             buf = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
             out.append((buf, len(buf)))
         return out
+
+
+class PeerLogStitch:
+    """The same all-gather as ChunkedLogStitch -- every rank ends up with every rank's record log, piece by piece, while
+    the analysis keeps running -- moved by the COPY ENGINES instead of a collective kernel: every rank maps the receive
+    buffer of every other rank into its address space (HIP IPC, the mechanism behind torch.multiprocessing's tensor
+    sharing; dmabuf handles, HSA_ENABLE_IPC_MODE_LEGACY=0) and pushes each complete piece of its log straight into
+    slot [rank] of every peer with device-to-device copies over xGMI -- seven independent point-to-point writes, one per
+    link, no CU involved.
+
+    Why not the RCCL all-gather for this: its kernel (rcclGenericKernel, gfx950 build of this image's librccl.so)
+    allocates 261-280 registers per lane and 19.7 KB of LDS per 256-lane workgroup.  The LK launches keep three wavefronts
+    of 136 VGPRs resident on every SIMD, 104 registers per lane are free: a collective workgroup gets
+    a CU only by keeping LK off it.  Measured with a kernel of that shape beside the running pipeline
+    (tools/coresidency_probe.py): an 11 MB copy takes 0.56 ms instead of 0.03 and the step grows by 15 %; the same bytes as
+    a device-to-device copy take 0.02 ms and cost nothing.  Copy engines need no wavefront slot.
+
+    Layout: recv[r] is a copy of rank r's log (same offsets), so a piece [start, end) of the local log goes to
+    peer.recv[rank][start:end]; finish() waits for this rank's pushes, exchanges the used sizes and meets the peers, after
+    which every slot is complete.  Same interface as ChunkedLogStitch (reserve / reset / warm_up / gather / finish /
+    rank_logs)."""
+
+    name = "xgmi peer copies (copy engines, HIP IPC)"
+
+    def __init__(self, log, recv, peer, group=None, side_group=None):
+        """Built by make_log_stitch (which exchanges the IPC handles): recv [world, log bytes] on this GPU, peer[r] = rank r's
+        receive buffer mapped here."""
+        import torch
+        import torch.distributed as dist
+
+        self.log, self.group, self.side = log, group, side_group
+        self.dist = dist
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.local_only = False
+        self.recv, self.peer = recv, peer
+        # The pushes go on the NULL stream: it owns a hardware queue already and nothing else uses it while the analysis
+        # runs (the analyzer's streams are non-blocking, no implicit synchronisation with it).  A further stream would share
+        # one of the four hardware queues with a job lane and its copies would sit between that lane's launches.
+        self.stream = torch.cuda.default_stream(log.device)
+        self.used = 0
+        self.sizes = None
+        # push order: rank+1, rank+2, ... so that at any moment the ranks write to different peers / links
+        self.order = [(self.rank + k) % self.world for k in range(1, self.world)]
+
+    def reserve(self, n_pieces: int, max_piece_bytes: int):
+        pass
+
+    def reset(self):
+        self.used = 0
+        self.sizes = None
+
+    def warm_up(self):
+        pass    # make_log_stitch has probed every link already
+
+    def probe(self) -> bool:
+        """One small push to every peer, a meeting, and a look at what arrived: True when slot r of this rank's buffer
+        holds rank r's pattern for every r (the first copy to a peer also sets up the mapping).  Collective."""
+        import torch
+
+        ok = True
+        self.probe_error = None
+        try:
+            pattern = torch.full((64,), self.rank + 1, dtype=torch.uint8, device=self.log.device)
+            with torch.cuda.stream(self.stream):
+                self.recv[:, :64].zero_()
+            self.stream.synchronize()
+        except Exception as e:      # every rank still goes to both meetings
+            ok, self.probe_error = False, e
+        self._meet()
+        try:
+            with torch.cuda.stream(self.stream):
+                for r in self.order:
+                    self.peer[r][self.rank, :64].copy_(pattern, non_blocking=True)
+            self.stream.synchronize()
+        except Exception as e:
+            ok, self.probe_error = False, e
+        self._meet()
+        try:
+            got = self.recv[:, :64].cpu()
+            ok = ok and all(bool((got[r] == r + 1).all()) for r in range(self.world) if r != self.rank)
+        except Exception as e:
+            ok, self.probe_error = False, e
+        return ok
+
+    def _meet(self):
+        import torch
+
+        if self.side is not None:
+            self.dist.barrier(group=self.side)
+        else:
+            self.dist.barrier(group=self.group)
+
+    def gather(self, start: int, end: int):
+        import torch
+
+        if end <= start:
+            return
+        src = self.log[start:end]
+        with torch.cuda.stream(self.stream):
+            for r in self.order:
+                self.peer[r][self.rank, start:end].copy_(src, non_blocking=True)
+        self.used = max(self.used, end)
+
+    def finish(self):
+        """Inside the timed region, after the last gather: this rank's pushes have landed in the peers' memory.  The
+        barrier that ends the region (every rank has passed this point) then means every slot of `recv` is complete."""
+        self.stream.synchronize()
+
+    def rank_logs(self):
+        """-> per rank: (numpy uint8 log, used bytes).  Collective (the used sizes are exchanged here, outside the timed
+        region); call after finish() and a barrier."""
+        import torch
+
+        g = self.side if self.side is not None else self.group
+        on_host = self.side is not None or self.dist.get_backend(self.group) != "nccl"
+        dev = "cpu" if on_host else self.log.device
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        self.dist.all_gather(sizes, torch.tensor([self.used], dtype=torch.int64, device=dev), group=g)
+        self.sizes = [int(t.item()) for t in sizes]
+        out = []
+        for r in range(self.world):
+            src = self.log if r == self.rank else self.recv[r]
+            out.append((src[:self.sizes[r]].cpu().numpy(), self.sizes[r]))
+        return out
+
+    def close(self):
+        """Peers must drop their mappings before the owner frees the buffer: meet, drop, meet."""
+        self._meet()
+        self.peer = None
+        self._meet()
+        self.recv = None
+
+
+def make_log_stitch(log, group=None, side_group=None, prefer: str = "peer"):
+    """The stitch of the benchmark's N > 1 path: peer copies when EVERY rank can set them up, else the RCCL all-gather.
+    Every rank takes part in every exchange below whatever happened to it locally, so a failure on one rank cannot leave
+    the others waiting."""
+    import pickle
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    if prefer != "peer" or not log.is_cuda or not (dist.is_available() and dist.is_initialized()):
+        return ChunkedLogStitch(log, group=group, side_group=side_group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    g = side_group if side_group is not None else group
+    on_host = side_group is not None or dist.get_backend(group) != "nccl"
+    recv, mine, err = None, None, None
+    try:
+        from multiprocessing.reduction import ForkingPickler
+
+        import torch.multiprocessing   # registers the CUDA-tensor reductions (IPC handles) with ForkingPickler
+
+        if os.environ.get("POLYCHASE_TEST_BREAK_PEER_EXPORT") == str(rank):     # tests: one rank cannot export
+            raise RuntimeError("test: buffer export disabled on this rank")
+        recv = torch.empty((world, log.numel()), dtype=torch.uint8, device=log.device)
+        # one handle per consumer: torch counts references per exported handle
+        mine = [None if r == rank else bytes(ForkingPickler.dumps(recv)) for r in range(world)]
+    except Exception as e:
+        err = e
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine, group=g)
+    peer = None
+    if err is None and all(e is not None for e in everyone):
+        try:
+            peer = [recv if r == rank else pickle.loads(everyone[r][rank]) for r in range(world)]
+        except Exception as e:
+            err = e
+    def agreed(flag: bool) -> bool:
+        ok = torch.tensor([1 if flag else 0], dtype=torch.int64, device="cpu" if on_host else log.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=g)
+        return int(ok.item()) == 1
+
+    if agreed(err is None and peer is not None):
+        st = PeerLogStitch(log, recv, peer, group=group, side_group=side_group)
+        arrived = st.probe()
+        if agreed(arrived):
+            return st
+        err = st.probe_error or RuntimeError("a probe push did not arrive in a peer's buffer (here or on another rank)")
+        st.peer = st.recv = None
+        st = None
+    if err is not None:
+        print(f"[polychase_amd.distributed] peer copies unavailable ({type(err).__name__}: {err}); stitching with the RCCL all-gather",
+              file=sys.stderr)
+    peer = None
+    dist.barrier(group=g)      # mappings dropped everywhere before the buffers go
+    recv = None
+    return ChunkedLogStitch(log, group=group, side_group=side_group)
 
 
 class OrderedPieceGather:

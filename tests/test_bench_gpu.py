@@ -23,11 +23,18 @@ def test_forced_dist_path_runs_several_regions():
     assert out["config"]["timed_regions"] > 1, "the short C1 regions must repeat (the case that reuses the stitch)"
 
 
-def test_two_ranks_on_one_gpu_over_gloo():
+@pytest.mark.parametrize("stitch", ["peer", "rccl", "peer-broken"])
+def test_two_ranks_on_one_gpu_over_gloo(stitch):
     """bench.py exactly as the driver launches it for --gpus 2 (torch.distributed.run, two processes), except that both
     ranks sit on GPU 0 and the process group is gloo (POLYCHASE_BENCH_SHARE_GPU=1): the region count agreed by all-reduce,
-    the chunked stitch with two shards, the per-rank record checks and the max-over-ranks timing all run."""
-    env = dict(os.environ, POLYCHASE_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    the stitch with two shards, the per-rank record checks and the max-over-ranks timing all run.  "peer" (the default): each
+    rank maps the other's receive buffer through HIP IPC and pushes its pieces with device-to-device copies
+    (distributed.PeerLogStitch; here both buffers live on GPU 0); "rccl": the chunked all-gather (gloo here);
+    "peer-broken": rank 1 cannot export its buffer -- BOTH ranks must fall back to the all-gather, nobody waits."""
+    env = dict(os.environ, POLYCHASE_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", POLYCHASE_BENCH_STITCH=stitch.split("-")[0],
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if stitch == "peer-broken":
+        env["POLYCHASE_TEST_BREAK_PEER_EXPORT"] = "1"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16",
                         "--warmup", "4", "--config", "c1", "--no-c3", "--no-breakdown"],
@@ -36,6 +43,7 @@ def test_two_ranks_on_one_gpu_over_gloo():
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 16 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["stitch"].startswith("xgmi peer copies" if stitch == "peer" else "rccl all_gather"), (out["config"]["stitch"], r.stderr[-2000:])
 
 
 def test_gpus_flag_launches_the_ranks_itself():

@@ -36,6 +36,7 @@ def test_bench_collectives_over_a_one_rank_rccl_communicator():
     execute in RCCL; the stitched log must parse into exactly the frames analysed (asserted inside bench.py)."""
     env = _env()
     env["POLYCHASE_BENCH_RCCL_WORLD1"] = "1"
+    env["POLYCHASE_BENCH_STITCH"] = "rccl"      # the all-gather itself (the default stitch pushes with the copy engines)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "4", "--config", "c1", "--no-c3",
                         "--no-breakdown", "--force-dist-path"], text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
                        env=env, cwd=ROOT)
@@ -46,15 +47,19 @@ def test_bench_collectives_over_a_one_rank_rccl_communicator():
     assert out.get("collectives_backend") == "nccl", out.get("collectives_backend")
 
 
-def test_bench_two_ranks_over_rccl():
+@pytest.mark.parametrize("stitch", ["peer", "rccl"])
+def test_bench_two_ranks_over_rccl(stitch):
     if _gpus() < 2:
         pytest.skip("one GPU: RCCL needs a device per rank")
+    env = _env()
+    env["POLYCHASE_BENCH_STITCH"] = stitch
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "4", "--config", "c1",
-                        "--no-c3", "--no-breakdown"], text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200, env=_env(), cwd=ROOT)
+                        "--no-c3", "--no-breakdown"], text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200, env=env, cwd=ROOT)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-4000:])
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["parallelism"] == "frame-shard x2"
+    assert out["config"]["stitch"].startswith("xgmi peer copies" if stitch == "peer" else "rccl all_gather")
 
 
 def test_analyze_two_ranks_over_rccl(tmp_path):
