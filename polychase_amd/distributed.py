@@ -327,14 +327,24 @@ class PeerLogStitch:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.local_only = False
         self.recv, self.peer = recv, peer
-        # The pushes go on the NULL stream: it owns a hardware queue already and nothing else uses it while the analysis
-        # runs (the analyzer's streams are non-blocking, no implicit synchronisation with it).  A further stream would share
-        # one of the four hardware queues with a job lane and its copies would sit between that lane's launches.
-        self.stream = torch.cuda.default_stream(log.device)
+        # Copies on ONE stream run one after the other -- one link at a time, ~55 GB/s -- and eight ranks at 1080p need
+        # 7 x 5.5 MB per 0.31 ms = 124 GB/s out of every GPU.  Up to four ranks one stream is enough and it is the NULL
+        # stream: it owns a hardware queue already, is otherwise idle while the analysis runs (the analyzer's streams are
+        # non-blocking: no implicit synchronisation with it), and copies on it cost the pipeline nothing (measured,
+        # tools/coresidency_probe.py).  Beyond four ranks the peers are dealt round-robin onto three copy-only streams, whose
+        # transfers run side by side on different SDMA engines / links.  bench.py raises GPU_MAX_HW_QUEUES for N > 1 so that
+        # none of this shares a hardware queue with a job lane (shared, a copy on the null stream costs the step 35-60 %).
+        n_streams = 1 if self.world <= 4 else 3
+        if os.environ.get("POLYCHASE_PEER_PUSH_STREAMS"):
+            n_streams = max(1, min(8, int(os.environ["POLYCHASE_PEER_PUSH_STREAMS"])))
+        n_streams = min(n_streams, max(1, self.world - 1))
+        self.streams = [torch.cuda.default_stream(log.device)] + [torch.cuda.Stream(device=log.device) for _ in range(n_streams - 1)]
+        self.stream = self.streams[0]
         self.used = 0
         self.sizes = None
         # push order: rank+1, rank+2, ... so that at any moment the ranks write to different peers / links
         self.order = [(self.rank + k) % self.world for k in range(1, self.world)]
+        self.stream_of = {r: self.streams[i % n_streams] for i, r in enumerate(self.order)}
 
     def reserve(self, n_pieces: int, max_piece_bytes: int):
         pass
@@ -362,10 +372,11 @@ class PeerLogStitch:
             ok, self.probe_error = False, e
         self._meet()
         try:
-            with torch.cuda.stream(self.stream):
-                for r in self.order:
+            for r in self.order:
+                with torch.cuda.stream(self.stream_of[r]):
                     self.peer[r][self.rank, :64].copy_(pattern, non_blocking=True)
-            self.stream.synchronize()
+            for st in self.streams:
+                st.synchronize()
         except Exception as e:
             ok, self.probe_error = False, e
         self._meet()
@@ -390,15 +401,16 @@ class PeerLogStitch:
         if end <= start:
             return
         src = self.log[start:end]
-        with torch.cuda.stream(self.stream):
-            for r in self.order:
+        for r in self.order:
+            with torch.cuda.stream(self.stream_of[r]):
                 self.peer[r][self.rank, start:end].copy_(src, non_blocking=True)
         self.used = max(self.used, end)
 
     def finish(self):
         """Inside the timed region, after the last gather: this rank's pushes have landed in the peers' memory.  The
         barrier that ends the region (every rank has passed this point) then means every slot of `recv` is complete."""
-        self.stream.synchronize()
+        for st in self.streams:
+            st.synchronize()
 
     def rank_logs(self):
         """-> per rank: (numpy uint8 log, used bytes).  Collective (the used sizes are exchanged here, outside the timed

@@ -63,6 +63,21 @@ def test_gpus_flag_launches_the_ranks_itself():
     assert out["config"]["parallelism"] == "frame-shard x2"
 
 
+def test_four_ranks_push_on_three_streams():
+    """The stitch of more than four ranks deals the peers onto three copy streams; here four ranks on GPU 0 are told to
+    (POLYCHASE_PEER_PUSH_STREAMS=3): every rank must still end up with every rank's records (asserted inside bench.py)."""
+    env = dict(os.environ, POLYCHASE_BENCH_SHARE_GPU="1", POLYCHASE_PEER_PUSH_STREAMS="3", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "16", "--warmup", "4",
+                        "--config", "c1", "--no-c3", "--no-breakdown"],
+                       text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["config"]["stitch"].startswith("xgmi peer copies")
+
+
 def test_gpus_flag_fails_loudly_without_enough_gpus():
     """Without the testing aid a one-GPU box must refuse --gpus 2 instead of measuring one GPU and labelling it two."""
     import torch

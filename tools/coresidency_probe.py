@@ -6,6 +6,8 @@ tools/lane_probe.py's "full" mode).  Every second step a copy of --mbytes is iss
     fat    a kernel with the resource shape of rcclGenericKernel (256 lanes, 280 registers, 19.7 KB LDS), --workgroups of them
     slim   the same loop in 10 registers
     dma    hipMemcpyAsync device to device
+    d2h    hipMemcpyAsync device to pinned host in --parts parts, one after the other on the null stream
+    d2h-streams   the same parts, each on a copy-only stream of its own (concurrent SDMA transfers)
 (tools/coresidency.hip).  Reported per kind: the step time, the copy's duration alone and beside LK (event to event, i.e.
 from the moment the copy ahead of it finished), and the BACKLOG: how long the null stream still runs after the last job has
 been collected -- copies that could not run beside LK pile up there.
@@ -34,6 +36,8 @@ def main():
     ap.add_argument("--mbytes", type=float, default=11.0, help="bytes per copy (two 1080p frames of records = 11 MB)")
     ap.add_argument("--workgroups", type=int, default=16)
     ap.add_argument("--every", type=int, default=2, help="one copy every N steps")
+    ap.add_argument("--parts", type=int, default=7, help="parts of a d2h copy (the pushes to seven peers)")
+    ap.add_argument("--kinds", default="fat,slim,dma,d2h,d2h-streams")
     args = ap.parse_args()
     import torch
     from polychase_amd import hip, synth
@@ -54,15 +58,17 @@ def main():
         return mean.value, mx.value, n.value
 
     alone = {}
-    for kind, name in enumerate(("fat", "slim", "dma")):
+    KINDS = [(k, n) for k, n in [(0, "fat"), (1, "slim"), (2, "dma"), (3, "d2h"), (4, "d2h-streams")] if n in args.kinds.split(",")]
+    arg = lambda kind: args.workgroups if kind < 3 else args.parts
+    for kind, name in KINDS:
         for _ in range(4):
-            L.cr_launch(kind, args.workgroups)
+            L.cr_launch(kind, arg(kind))
         collect()
         for _ in range(20):
-            L.cr_launch(kind, args.workgroups)
+            L.cr_launch(kind, arg(kind))
         alone[name] = collect()[0]
 
-    for kind, name in [(-1, "none"), (0, "fat"), (1, "slim"), (2, "dma")]:
+    for kind, name in [(-1, "none")] + KINDS:
         an = hip.Analyzer(ctx, w, h, hip.gftt_options(), hip.flow_options(max_level=ml), 17, 3)
         for f in range(1, 18):
             an.put_frame(f, frames[f], will_detect=True)
@@ -79,7 +85,7 @@ def main():
                 an.collect_raw()
             an.submit(9, targets)
             if side and kind >= 0 and k % args.every == 0:
-                L.cr_launch(kind, args.workgroups)
+                L.cr_launch(kind, arg(kind))
 
         for _ in range(30):
             step(False)
@@ -101,7 +107,7 @@ def main():
         gc.enable()
         out = {"config": args.config, "copy": name, "steps": args.steps, "ms_per_step": (t1 - t0) / args.steps * 1e3}
         if kind >= 0:
-            out.update(copies=n, mbytes=args.mbytes, workgroups=args.workgroups if kind < 2 else None,
+            out.update(copies=n, mbytes=args.mbytes, workgroups=args.workgroups if kind < 2 else None, parts=args.parts if kind >= 3 else None,
                        copy_ms_alone=alone[name], copy_ms_beside_lk_mean=mean, copy_ms_beside_lk_max=mx,
                        copies_done_when_the_lanes_drained=idle_at_end, backlog_ms=(t2 - t1) * 1e3)
         print(json.dumps(out), flush=True)
