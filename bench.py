@@ -451,11 +451,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))     # N ranks of this very command; rank 0 of them prints the JSON line
-    if args.gpus > 1:
-        # before the process first touches HIP: the peer pushes of the stitch and RCCL's stream get hardware queues of their
-        # own instead of sharing the default four with the analyzer's job lanes (idle queues cost nothing:
-        # profiles/r03_stream_layouts.jsonl, "one preparation stream, 8 queues")
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+    # Before the process first touches HIP: every stream of the engine gets a hardware queue of its own (the runtime's default
+    # is four for the whole process; the library raises it to sixteen when it is loaded first -- here torch initialises HIP
+    # before that -- csrc/hip/api.hip: pc_runtime_defaults).  N > 1 adds the stitch's push streams and RCCL's stream.  Idle
+    # queues cost nothing (profiles/r03_stream_layouts.jsonl, "one preparation stream, 8 queues").
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import torch.distributed as dist
 

@@ -450,6 +450,14 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
 
 using namespace pc_api;
 
+// The engine keeps five streams busy (two job lanes, preparation, frame upload, and whatever the host uses); the HIP runtime
+// multiplexes streams onto GPU_MAX_HW_QUEUES = 4 hardware queues by default, and two streams on one queue wait for each
+// other's commands: with host frames the upload stream then shares a queue with a lane or the preparation stream
+// (generate_optical_flow_database on 300 host frames at 1080p: 2050 frames/s on 4 queues, 2650-2840 with a queue per stream;
+// idle queues cost nothing; sixteen cover two contexts -- analysis engine and tracker -- plus the host's own streams).  The runtime reads the variable when the process first touches HIP, so the default is raised when this library is
+// LOADED -- effective whenever that happens before the host's first HIP call; a value set by the user is left alone.
+__attribute__((constructor)) static void pc_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 extern "C" {
 
 void pc_gftt_default_options(pc_gftt_options* o) {
