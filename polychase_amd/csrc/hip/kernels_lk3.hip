@@ -46,6 +46,13 @@ namespace pc {
 #ifndef PC_LK3_PREFETCH
 #define PC_LK3_PREFETCH 1   // LDS reads of the pixel loop one step ahead of the arithmetic
 #endif
+// PC_LK3_PRIO (experiment, tools/lk_ab.sh): 1 = a wavefront raises its issue priority (s_setprio 2) while it loads and evaluates
+// the I side and stages its J regions -- the latency-bound phases -- and drops it for the iterations; 2 = the other way round.
+#ifndef PC_LK3_PRIO
+#define PC_LK3_PRIO 0
+#endif
+#define PC_LK3_SETPRIO_STAGING() do { if (PC_LK3_PRIO == 1) __builtin_amdgcn_s_setprio(2); else if (PC_LK3_PRIO == 2) __builtin_amdgcn_s_setprio(0); } while (0)
+#define PC_LK3_SETPRIO_ITER() do { if (PC_LK3_PRIO == 1) __builtin_amdgcn_s_setprio(0); else if (PC_LK3_PRIO == 2) __builtin_amdgcn_s_setprio(2); } while (0)
 #ifndef PC_LK3_WAVES
 #define PC_LK3_WAVES 1   // wavefronts per workgroup
 #endif
@@ -313,6 +320,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         ny = qy;
 
         // ---- I side: identical for all targets of a keypoint -> computed once by its half-wave ----
+        PC_LK3_SETPRIO_STAGING();
         px -= half_win;
         py -= half_win;
         const int ipx = (int)floorf(px), ipy = (int)floorf(py);
@@ -502,9 +510,11 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 ox = G::MX;
                 oy = G::MY;
                 PC_PROF(4);
+                PC_LK3_SETPRIO_STAGING();
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 stage_region<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                PC_LK3_SETPRIO_ITER();
                 staged = true;
                 PC_PROF_COUNT(9);
                 PC_PROF(3);

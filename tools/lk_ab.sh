@@ -18,7 +18,7 @@ run() {   # name, env assignments...
 }
 run default
 run "lk (ONE keypoint per wavefront, 8 lanes per pair: max over 8 pairs)" POLYCHASE_LK_VARIANT=1
-for v in occ4 occ2 waves2 srows2 nopf nopairs notrim; do
+for v in occ4 occ2 waves2 srows2 nopf nopairs notrim prio1 prio2; do
   lib=$ROOT/polychase_amd/lib/variants/libpolychase_hip_$v.so
   [ -f "$lib" ] && run "$v" POLYCHASE_HIP_LIB=$lib
 done
