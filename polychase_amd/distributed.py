@@ -327,14 +327,15 @@ class PeerLogStitch:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.local_only = False
         self.recv, self.peer = recv, peer
-        # Copies on ONE stream run one after the other -- one link at a time, ~55 GB/s -- and eight ranks at 1080p need
-        # 7 x 5.5 MB per 0.31 ms = 124 GB/s out of every GPU.  Up to four ranks one stream is enough and it is the NULL
-        # stream: it owns a hardware queue already, is otherwise idle while the analysis runs (the analyzer's streams are
-        # non-blocking: no implicit synchronisation with it), and copies on it cost the pipeline nothing (measured,
-        # tools/coresidency_probe.py).  Beyond four ranks the peers are dealt round-robin onto three copy-only streams, whose
-        # transfers run side by side on different SDMA engines / links.  bench.py raises GPU_MAX_HW_QUEUES for N > 1 so that
-        # none of this shares a hardware queue with a job lane (shared, a copy on the null stream costs the step 35-60 %).
-        n_streams = 1 if self.world <= 4 else 3
+        # Copies on ONE stream run one after the other -- one link at a time, 40-60 GB/s -- and eight ranks at 1080p need
+        # 7 x 5.5 MB per 0.31 ms = 124 GB/s out of every GPU (four ranks: 53 GB/s).  So the peers are dealt round-robin onto
+        # one stream for two ranks, two up to four ranks, four beyond; their transfers run side by side on different SDMA
+        # engines / links.  The first is the NULL stream: it owns a hardware queue already, is otherwise idle while the
+        # analysis runs (the analyzer's streams are non-blocking: no implicit synchronisation with it), and copies on it cost
+        # the pipeline nothing (measured, tools/coresidency_probe.py; further copy-only streams cost up to 10 % there with
+        # device-to-host copies -- an upper bound, section 6 of DESIGN.md).  bench.py raises GPU_MAX_HW_QUEUES so that none of
+        # this shares a hardware queue with a job lane (shared, a copy on the null stream costs the step 35-60 %).
+        n_streams = 1 if self.world <= 2 else (2 if self.world <= 4 else 4)
         if os.environ.get("POLYCHASE_PEER_PUSH_STREAMS"):
             n_streams = max(1, min(8, int(os.environ["POLYCHASE_PEER_PUSH_STREAMS"])))
         n_streams = min(n_streams, max(1, self.world - 1))
