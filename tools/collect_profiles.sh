@@ -64,5 +64,7 @@ fi
 if want micro; then
 $T "$ROOT/tools/bin/valu_issue" > "$OUT/${TAG}_valu_issue.json" 2>/dev/null
 $T python "$ROOT/tools/fetch_calib.py" run > "$OUT/${TAG}_fetch_calibration.json" 2>/dev/null
+# what runs beside the LK launches: a kernel of RCCL's resource shape, a slim one, copies (tools/coresidency.hip)
+[ -f "$ROOT/tools/bin/libcoresidency.so" ] && $T python "$ROOT/tools/coresidency_probe.py" --config c2 2>/dev/null | grep "^{" > "$OUT/${TAG}_coresidency_c2.jsonl"
 fi
 ls -la "$OUT" | grep "$TAG"
