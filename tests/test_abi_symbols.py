@@ -44,3 +44,32 @@ def test_default_options_match_reference():
             g.harris_k, g.grid_rows, g.grid_cols) == (0.01, 5.0, 3, 3, 0, 0, 0.04, 4, 4)
     f = hip.flow_options()
     assert (f.window_size, f.max_level, f.term_max_iters, f.term_epsilon, f.min_eigen_threshold) == (10, 3, 30, 0.01, 1e-4)
+
+
+@pytest.mark.parametrize("preset", [None, "5"])
+def test_loading_the_library_raises_the_hardware_queue_default(preset):
+    """csrc/hip/api.hip: pc_runtime_defaults -- loading the library sets GPU_MAX_HW_QUEUES=16 in the process environment
+    (the HIP runtime reads it at its first call: a stream per hardware queue) and leaves a user's
+    value alone.  Checked through libc's getenv in a fresh process (os.environ is a snapshot taken at interpreter start)."""
+    import subprocess
+    import sys
+
+    path = build.hip_library_path()
+    if not os.path.exists(path):
+        build.build_hip()
+    code = ("import ctypes, sys\n"
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+            "before = libc.getenv(b'GPU_MAX_HW_QUEUES')\n"
+            f"ctypes.CDLL({path!r})\n"
+            "after = libc.getenv(b'GPU_MAX_HW_QUEUES')\n"
+            "print(before, after)\n")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    if preset is not None:
+        env["GPU_MAX_HW_QUEUES"] = preset
+    r = subprocess.run([sys.executable, "-c", code], env=env, text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    before, after = r.stdout.split()
+    if preset is None:
+        assert before == "None" and after == "b'16'", r.stdout
+    else:
+        assert before == after == f"b'{preset}'", r.stdout
