@@ -146,8 +146,8 @@ struct pc_context {
     // Stage-level calls run on `stream`.  pc_analyzer alternates its jobs (LK launch + compaction + device-log append +
     // record download of one frame1) over two job lanes, `stream` and `stream_b`: the launches of consecutive frames
     // overlap, so the tail of one launch and the gap before the next are filled by the other lane's wavefronts.
-    // (No further stream: HIP multiplexes streams onto 4 hardware queues -- the null stream, the two lanes and the
-    // prep stream -- and a stream that shares a queue waits behind the other's kernels.)
+    // (HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, 4 unless raised, and a stream that shares a queue
+    // waits behind the other's commands: api.hip raises the default when the library is loaded -- pc_runtime_defaults.)
     hipStream_t stream = nullptr;
     hipStream_t stream_b = nullptr;
     hipStream_t lane_stream(int lane) const { return lane ? stream_b : stream; }
