@@ -455,7 +455,9 @@ def main():
     # is four for the whole process; the library raises it to sixteen when it is loaded first -- here torch initialises HIP
     # before that -- csrc/hip/api.hip: pc_runtime_defaults).  N > 1 adds the stitch's push streams and RCCL's stream.  Idle
     # queues cost nothing (profiles/r03_stream_layouts.jsonl, "one preparation stream, 8 queues").
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # Several processes on ONE GPU (the SHARE_GPU testing aid) keep the runtime's four: a GPU whose hardware queue slots are
+    # oversubscribed by several processes time-slices them (two ranks with 16 queues each on one GPU: 10 x slower).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4" if os.environ.get("POLYCHASE_BENCH_SHARE_GPU") == "1" else ("8" if args.gpus > 1 else "16"))
     import torch
     import torch.distributed as dist
 

@@ -439,6 +439,23 @@ int pc_refine_total_cost(pc_context* ctx, pc_refine_problem* prob, const pc_refi
 int pc_refine_normal_equations(pc_context* ctx, pc_refine_problem* prob, const pc_refine_camera* cameras,
                                int loss_type, float loss_scale, double* edge_blocks, int* edge_valid);
 
+/* ---- record exchange between the ranks of a multi-GPU analysis (one process per GPU) --------------------------------
+ * The stitch of the flow database (the reference's store, cpp/opticalflow.cc:149-151, sharded): a rank exports a
+ * device buffer, its peers map it INTO THEIR OWN device's address space (HIP IPC) and write their record pieces into it with
+ * device-to-device copies on a stream of their own device -- xGMI is point to point, the copy engines move the bytes, no
+ * kernel and no queue on the peer's GPU is involved.  polychase_amd/distributed.py: PeerLogStitch. */
+#define PC_PEER_HANDLE_BYTES 64
+int pc_peer_buffer_alloc(int device_index, size_t bytes, void** device_ptr);           /* hipMalloc on that device */
+int pc_peer_buffer_free(int device_index, void* device_ptr);
+int pc_peer_buffer_export(int device_index, void* device_ptr, unsigned char handle[PC_PEER_HANDLE_BYTES]);
+/* maps a peer's exported buffer for `device_index` (this process's GPU); *device_ptr is valid for copies issued here */
+int pc_peer_buffer_open(int device_index, const unsigned char handle[PC_PEER_HANDLE_BYTES], void** device_ptr);
+int pc_peer_buffer_close(int device_index, void* device_ptr);
+/* hipMemcpyAsync(dst, src, bytes, device-to-device) on `stream` (a hipStream_t of device_index; NULL = the null stream) */
+int pc_peer_copy_async(int device_index, void* dst, const void* src, size_t bytes, void* stream);
+/* blocking device-to-host copy (verification of what the peers wrote) */
+int pc_peer_buffer_download(int device_index, void* dst_host, const void* src_device, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

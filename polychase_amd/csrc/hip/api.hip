@@ -548,6 +548,58 @@ int pc_context_download(pc_context* c, void* dst_host, const void* src_device, s
     return PC_OK;
 }
 
+// ---- peer buffers (include/polychase_hip.h: record exchange between ranks) ----
+int pc_peer_buffer_alloc(int device_index, size_t bytes, void** device_ptr) {
+    if (!device_ptr || bytes == 0) return fail(PC_E_INVALID, "bad argument");
+    *device_ptr = nullptr;
+    PC_HIP(hipSetDevice(device_index));
+    PC_HIP(hipMalloc(device_ptr, bytes));
+    return PC_OK;
+}
+int pc_peer_buffer_free(int device_index, void* device_ptr) {
+    if (!device_ptr) return PC_OK;
+    PC_HIP(hipSetDevice(device_index));
+    PC_HIP(hipFree(device_ptr));
+    return PC_OK;
+}
+int pc_peer_buffer_export(int device_index, void* device_ptr, unsigned char handle[PC_PEER_HANDLE_BYTES]) {
+    static_assert(sizeof(hipIpcMemHandle_t) <= PC_PEER_HANDLE_BYTES, "IPC handle larger than PC_PEER_HANDLE_BYTES");
+    if (!device_ptr || !handle) return fail(PC_E_INVALID, "null argument");
+    PC_HIP(hipSetDevice(device_index));
+    hipIpcMemHandle_t h;
+    PC_HIP(hipIpcGetMemHandle(&h, device_ptr));
+    memset(handle, 0, PC_PEER_HANDLE_BYTES);
+    memcpy(handle, &h, sizeof(h));
+    return PC_OK;
+}
+int pc_peer_buffer_open(int device_index, const unsigned char handle[PC_PEER_HANDLE_BYTES], void** device_ptr) {
+    if (!device_ptr || !handle) return fail(PC_E_INVALID, "null argument");
+    *device_ptr = nullptr;
+    PC_HIP(hipSetDevice(device_index));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    PC_HIP(hipIpcOpenMemHandle(device_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return PC_OK;
+}
+int pc_peer_buffer_close(int device_index, void* device_ptr) {
+    if (!device_ptr) return PC_OK;
+    PC_HIP(hipSetDevice(device_index));
+    PC_HIP(hipIpcCloseMemHandle(device_ptr));
+    return PC_OK;
+}
+int pc_peer_copy_async(int device_index, void* dst, const void* src, size_t bytes, void* stream) {
+    if (bytes && (!dst || !src)) return fail(PC_E_INVALID, "null argument");
+    PC_HIP(hipSetDevice(device_index));
+    if (bytes) PC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return PC_OK;
+}
+int pc_peer_buffer_download(int device_index, void* dst_host, const void* src_device, size_t bytes) {
+    if (bytes && (!dst_host || !src_device)) return fail(PC_E_INVALID, "null argument");
+    PC_HIP(hipSetDevice(device_index));
+    if (bytes) PC_HIP(hipMemcpy(dst_host, src_device, bytes, hipMemcpyDeviceToHost));
+    return PC_OK;
+}
+
 int pc_context_set_arithmetic(pc_context* c, int flags) {
     if (!c) return fail(PC_E_INVALID, "null context");
     if (flags & ~PC_ARITH_OPENCV_X86) return fail(PC_E_INVALID, "unknown arithmetic flags %d", flags);

@@ -296,37 +296,45 @@ class ChunkedLogStitch:
 
 class PeerLogStitch:
     """The same all-gather as ChunkedLogStitch -- every rank ends up with every rank's record log, piece by piece, while
-    the analysis keeps running -- moved by the COPY ENGINES instead of a collective kernel: every rank maps the receive
-    buffer of every other rank into its address space (HIP IPC, the mechanism behind torch.multiprocessing's tensor
-    sharing; dmabuf handles, HSA_ENABLE_IPC_MODE_LEGACY=0) and pushes each complete piece of its log straight into
-    slot [rank] of every peer with device-to-device copies over xGMI -- seven independent point-to-point writes, one per
-    link, no CU involved.
+    the analysis keeps running -- moved by the COPY ENGINES instead of a collective kernel: every rank allocates a receive
+    buffer and exports it (HIP IPC: include/polychase_hip.h, pc_peer_buffer_*), maps the buffers of all other ranks into
+    ITS OWN device's address space, and pushes each complete piece of its log straight into slot [rank] of every peer with
+    device-to-device copies issued on streams of its own device -- seven independent point-to-point writes over xGMI, no
+    CU involved, and nothing of this process ever runs on a peer's GPU (no context, no queue there: with torch's
+    cross-device tensors every process would hold queues on all eight GPUs, and a GPU whose hardware queue slots are
+    oversubscribed by several processes time-slices them -- two ranks sharing one GPU with 16 queues each: 10 x slower).
 
     Why not the RCCL all-gather for this: its kernel (rcclGenericKernel, gfx950 build of this image's librccl.so)
     allocates 261-280 registers per lane and 19.7 KB of LDS per 256-lane workgroup.  The LK launches keep three wavefronts
     of 136 VGPRs resident on every SIMD, 104 registers per lane are free: a collective workgroup gets
     a CU only by keeping LK off it.  Measured with a kernel of that shape beside the running pipeline
-    (tools/coresidency_probe.py): an 11 MB copy takes 0.56 ms instead of 0.03 and the step grows by 15 %; the same bytes as
+    (tools/coresidency_probe.py): an 11 MB copy takes 0.54 ms instead of 0.03 and the step grows by 12 %; the same bytes as
     a device-to-device copy take 0.02 ms and cost nothing.  Copy engines need no wavefront slot.
 
     Layout: recv[r] is a copy of rank r's log (same offsets), so a piece [start, end) of the local log goes to
-    peer.recv[rank][start:end]; finish() waits for this rank's pushes, exchanges the used sizes and meets the peers, after
-    which every slot is complete.  Same interface as ChunkedLogStitch (reserve / reset / warm_up / gather / finish /
-    rank_logs)."""
+    peer.recv[rank][start:end]; finish() waits for this rank's pushes; the barrier that ends the caller's timed region
+    then means every slot is complete; rank_logs() exchanges the used sizes (outside the timed region).  Same interface as
+    ChunkedLogStitch (reserve / reset / warm_up / gather / finish / rank_logs / close)."""
 
     name = "xgmi peer copies (copy engines, HIP IPC)"
 
-    def __init__(self, log, recv, peer, group=None, side_group=None):
-        """Built by make_log_stitch (which exchanges the IPC handles): recv [world, log bytes] on this GPU, peer[r] = rank r's
-        receive buffer mapped here."""
+    def __init__(self, log, recv_ptr: int, peer_ptrs, slot_bytes: int, group=None, side_group=None):
+        """Built by make_log_stitch (which exchanges the IPC handles): recv_ptr = this rank's receive buffer
+        [world x slot_bytes] (slot_bytes >= every rank's log), peer_ptrs[r] = rank r's receive buffer mapped for this device
+        (None for r == rank)."""
         import torch
         import torch.distributed as dist
 
+        from . import hip
+
+        self.L = hip.load()
         self.log, self.group, self.side = log, group, side_group
         self.dist = dist
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.local_only = False
-        self.recv, self.peer = recv, peer
+        self.dev = log.device.index or 0
+        self.slot = int(slot_bytes)
+        self.recv_ptr, self.peer_ptrs = recv_ptr, peer_ptrs
         # Copies on ONE stream run one after the other -- one link at a time, 40-60 GB/s -- and eight ranks at 1080p need
         # 7 x 5.5 MB per 0.31 ms = 124 GB/s out of every GPU (four ranks: 53 GB/s).  So the peers are dealt round-robin onto
         # one stream for two ranks, two up to four ranks, four beyond; their transfers run side by side on different SDMA
@@ -340,12 +348,32 @@ class PeerLogStitch:
             n_streams = max(1, min(8, int(os.environ["POLYCHASE_PEER_PUSH_STREAMS"])))
         n_streams = min(n_streams, max(1, self.world - 1))
         self.streams = [torch.cuda.default_stream(log.device)] + [torch.cuda.Stream(device=log.device) for _ in range(n_streams - 1)]
-        self.stream = self.streams[0]
         self.used = 0
         self.sizes = None
         # push order: rank+1, rank+2, ... so that at any moment the ranks write to different peers / links
         self.order = [(self.rank + k) % self.world for k in range(1, self.world)]
         self.stream_of = {r: self.streams[i % n_streams] for i, r in enumerate(self.order)}
+        # (The pushes are issued by the thread that drives the analyzer.  A pusher thread was tried: every hand-over of the
+        # interpreter lock between the two threads costs up to Python's 5 ms switch interval.)
+
+    def _push(self, r: int, dst_off: int, src_ptr: int, nbytes: int):
+        from . import hip
+
+        hip._check(self.L.pc_peer_copy_async(self.dev, self.peer_ptrs[r] + self.rank * self.slot + dst_off, src_ptr, nbytes,
+                                            self.stream_of[r].cuda_stream or None))
+
+    def _sync(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def _download(self, r: int, nbytes: int) -> np.ndarray:
+        """slot r of this rank's receive buffer"""
+        from . import hip
+
+        out = np.empty(nbytes, np.uint8)
+        if nbytes:
+            hip._check(self.L.pc_peer_buffer_download(self.dev, out.ctypes.data, self.recv_ptr + r * self.slot, nbytes))
+        return out
 
     def reserve(self, n_pieces: int, max_piece_bytes: int):
         pass
@@ -359,59 +387,57 @@ class PeerLogStitch:
 
     def probe(self) -> bool:
         """One small push to every peer, a meeting, and a look at what arrived: True when slot r of this rank's buffer
-        holds rank r's pattern for every r (the first copy to a peer also sets up the mapping).  Collective."""
+        holds rank r's pattern for every r (the first copy to a peer also sets up the mapping).  Collective; every rank
+        goes to both meetings whatever happens to it."""
         import torch
 
         ok = True
         self.probe_error = None
+        pattern = None
         try:
             pattern = torch.full((64,), self.rank + 1, dtype=torch.uint8, device=self.log.device)
-            with torch.cuda.stream(self.stream):
-                self.recv[:, :64].zero_()
-            self.stream.synchronize()
-        except Exception as e:      # every rank still goes to both meetings
-            ok, self.probe_error = False, e
-        self._meet()
-        try:
-            for r in self.order:
-                with torch.cuda.stream(self.stream_of[r]):
-                    self.peer[r][self.rank, :64].copy_(pattern, non_blocking=True)
-            for st in self.streams:
-                st.synchronize()
+            zeros = torch.zeros(64, dtype=torch.uint8, device=self.log.device)
+            torch.cuda.synchronize(self.log.device)
+            for r in range(self.world):      # clear the first bytes of every slot of the own buffer
+                from . import hip
+                hip._check(self.L.pc_peer_copy_async(self.dev, self.recv_ptr + r * self.slot, zeros.data_ptr(), 64, None))
+            self._sync()
         except Exception as e:
             ok, self.probe_error = False, e
         self._meet()
         try:
-            got = self.recv[:, :64].cpu()
-            ok = ok and all(bool((got[r] == r + 1).all()) for r in range(self.world) if r != self.rank)
+            for r in self.order:
+                self._push(r, 0, pattern.data_ptr(), 64)
+            self._sync()
+        except Exception as e:
+            ok, self.probe_error = False, e
+        self._meet()
+        try:
+            for r in range(self.world):
+                if r != self.rank:
+                    got = self._download(r, 64)
+                    if not bool((got == r + 1).all()):
+                        ok = False
+                        self.probe_error = RuntimeError(f"rank {self.rank}: slot {r} holds {got[:4].tolist()} instead of {r + 1}")
         except Exception as e:
             ok, self.probe_error = False, e
         return ok
 
     def _meet(self):
-        import torch
-
-        if self.side is not None:
-            self.dist.barrier(group=self.side)
-        else:
-            self.dist.barrier(group=self.group)
+        self.dist.barrier(group=self.side if self.side is not None else self.group)
 
     def gather(self, start: int, end: int):
-        import torch
-
         if end <= start:
             return
-        src = self.log[start:end]
+        src = self.log.data_ptr() + start
         for r in self.order:
-            with torch.cuda.stream(self.stream_of[r]):
-                self.peer[r][self.rank, start:end].copy_(src, non_blocking=True)
+            self._push(r, start, src, end - start)
         self.used = max(self.used, end)
 
     def finish(self):
         """Inside the timed region, after the last gather: this rank's pushes have landed in the peers' memory.  The
-        barrier that ends the region (every rank has passed this point) then means every slot of `recv` is complete."""
-        for st in self.streams:
-            st.synchronize()
+        barrier that ends the region (every rank has passed this point) then means every slot is complete."""
+        self._sync()
 
     def rank_logs(self):
         """-> per rank: (numpy uint8 log, used bytes).  Collective (the used sizes are exchanged here, outside the timed
@@ -426,23 +452,29 @@ class PeerLogStitch:
         self.sizes = [int(t.item()) for t in sizes]
         out = []
         for r in range(self.world):
-            src = self.log if r == self.rank else self.recv[r]
-            out.append((src[:self.sizes[r]].cpu().numpy(), self.sizes[r]))
+            buf = self.log[:self.sizes[r]].cpu().numpy() if r == self.rank else self._download(r, self.sizes[r])
+            out.append((buf, self.sizes[r]))
         return out
 
     def close(self):
-        """Peers must drop their mappings before the owner frees the buffer: meet, drop, meet."""
+        """Peers drop their mappings before the owner frees the buffer: meet, unmap, meet, free."""
+        self._sync()
         self._meet()
-        self.peer = None
+        for r, ptr in enumerate(self.peer_ptrs or []):
+            if ptr:
+                self.L.pc_peer_buffer_close(self.dev, ptr)
+        self.peer_ptrs = None
         self._meet()
-        self.recv = None
+        if self.recv_ptr:
+            self.L.pc_peer_buffer_free(self.dev, self.recv_ptr)
+        self.recv_ptr = 0
 
 
-def make_log_stitch(log, group=None, side_group=None, prefer: str = "peer"):
-    """The stitch of the benchmark's N > 1 path: peer copies when EVERY rank can set them up, else the RCCL all-gather.
-    Every rank takes part in every exchange below whatever happened to it locally, so a failure on one rank cannot leave
-    the others waiting."""
-    import pickle
+def make_log_stitch(log, group=None, side_group=None, prefer: str = "rccl"):
+    """The stitch of the benchmark's N > 1 path: `prefer` = "rccl" (ChunkedLogStitch) or "peer" (PeerLogStitch when EVERY
+    rank can set it up, else the all-gather).  Every rank takes part in every exchange below whatever happened to it
+    locally, so a failure on one rank cannot leave the others waiting."""
+    import ctypes as C
     import sys
 
     import torch
@@ -450,49 +482,66 @@ def make_log_stitch(log, group=None, side_group=None, prefer: str = "peer"):
 
     if prefer != "peer" or not log.is_cuda or not (dist.is_available() and dist.is_initialized()):
         return ChunkedLogStitch(log, group=group, side_group=side_group)
+    from . import hip
+
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     g = side_group if side_group is not None else group
     on_host = side_group is not None or dist.get_backend(group) != "nccl"
-    recv, mine, err = None, None, None
+    dev = log.device.index or 0
+    L = None
+    recv, handle, err = C.c_void_p(), None, None
+    # one slot size for everybody: the ranks size their logs from their own frames' keypoint counts
+    slot = torch.tensor([int(log.numel())], dtype=torch.int64, device="cpu" if on_host else log.device)
+    dist.all_reduce(slot, op=dist.ReduceOp.MAX, group=g)
+    slot = (int(slot.item()) + 255) // 256 * 256
     try:
-        from multiprocessing.reduction import ForkingPickler
-
-        import torch.multiprocessing   # registers the CUDA-tensor reductions (IPC handles) with ForkingPickler
-
+        L = hip.load()
         if os.environ.get("POLYCHASE_TEST_BREAK_PEER_EXPORT") == str(rank):     # tests: one rank cannot export
             raise RuntimeError("test: buffer export disabled on this rank")
-        recv = torch.empty((world, log.numel()), dtype=torch.uint8, device=log.device)
-        # one handle per consumer: torch counts references per exported handle
-        mine = [None if r == rank else bytes(ForkingPickler.dumps(recv)) for r in range(world)]
+        hip._check(L.pc_peer_buffer_alloc(dev, world * slot, C.byref(recv)))
+        hb = C.create_string_buffer(64)
+        hip._check(L.pc_peer_buffer_export(dev, recv, hb))
+        handle = hb.raw
     except Exception as e:
         err = e
     everyone = [None] * world
-    dist.all_gather_object(everyone, mine, group=g)
-    peer = None
-    if err is None and all(e is not None for e in everyone):
+    dist.all_gather_object(everyone, handle, group=g)
+    peers = [None] * world
+    if err is None and all(h is not None for h in everyone):
         try:
-            peer = [recv if r == rank else pickle.loads(everyone[r][rank]) for r in range(world)]
+            for r in range(world):
+                if r != rank:
+                    ptr = C.c_void_p()
+                    hip._check(L.pc_peer_buffer_open(dev, everyone[r], C.byref(ptr)))
+                    peers[r] = ptr.value
         except Exception as e:
             err = e
+
     def agreed(flag: bool) -> bool:
         ok = torch.tensor([1 if flag else 0], dtype=torch.int64, device="cpu" if on_host else log.device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=g)
         return int(ok.item()) == 1
 
-    if agreed(err is None and peer is not None):
-        st = PeerLogStitch(log, recv, peer, group=group, side_group=side_group)
-        arrived = st.probe()
-        if agreed(arrived):
+    def release():
+        for ptr in peers:
+            if ptr:
+                L.pc_peer_buffer_close(dev, ptr)
+        dist.barrier(group=g)      # mappings dropped everywhere before the buffers go
+        if recv.value:
+            L.pc_peer_buffer_free(dev, recv)
+
+    if agreed(err is None and all(peers[r] for r in range(world) if r != rank)):
+        st = PeerLogStitch(log, recv.value, peers, slot, group=group, side_group=side_group)
+        if agreed(st.probe()):
             return st
         err = st.probe_error or RuntimeError("a probe push did not arrive in a peer's buffer (here or on another rank)")
-        st.peer = st.recv = None
-        st = None
     if err is not None:
         print(f"[polychase_amd.distributed] peer copies unavailable ({type(err).__name__}: {err}); stitching with the RCCL all-gather",
               file=sys.stderr)
-    peer = None
-    dist.barrier(group=g)      # mappings dropped everywhere before the buffers go
-    recv = None
+    if L is not None:
+        release()
+    else:
+        dist.barrier(group=g)
     return ChunkedLogStitch(log, group=group, side_group=side_group)
 
 

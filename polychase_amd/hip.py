@@ -34,6 +34,8 @@ SYMBOLS = [
     "pc_analyzer_set_keypoints", "pc_analyzer_submit", "pc_analyzer_pending", "pc_analyzer_collect",
     "pc_analyzer_set_device_log", "pc_analyzer_device_log_used", "pc_analyzer_redirect_device_log",
     "pc_analyzer_set_host_records",
+    "pc_peer_buffer_alloc", "pc_peer_buffer_free", "pc_peer_buffer_export", "pc_peer_buffer_open", "pc_peer_buffer_close",
+    "pc_peer_copy_async", "pc_peer_buffer_download",
     "pc_mesh_create", "pc_mesh_set_mask", "pc_mesh_destroy", "pc_raycast_pixels", "pc_raycast_pixels_sweep",
     "pc_corr_set_create", "pc_corr_set_destroy", "pc_corr_set_clear", "pc_corr_set_append", "pc_corr_set_size",
     "pc_corr_set_download", "pc_pnp_problem_from_set",
@@ -149,6 +151,13 @@ def load():
     L.pc_analyzer_reset.argtypes = [vp]
     L.pc_analyzer_redirect_device_log.argtypes = [vp, vp, C.c_size_t]
     L.pc_analyzer_set_host_records.argtypes = [vp, C.c_int]
+    L.pc_peer_buffer_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(vp)]
+    L.pc_peer_buffer_free.argtypes = [C.c_int, vp]
+    L.pc_peer_buffer_export.argtypes = [C.c_int, vp, C.c_char_p]
+    L.pc_peer_buffer_open.argtypes = [C.c_int, C.c_char_p, C.POINTER(vp)]
+    L.pc_peer_buffer_close.argtypes = [C.c_int, vp]
+    L.pc_peer_copy_async.argtypes = [C.c_int, vp, vp, C.c_size_t, vp]
+    L.pc_peer_buffer_download.argtypes = [C.c_int, vp, vp, C.c_size_t]
     _lib = L
     return L
 
