@@ -21,8 +21,8 @@ N > 1: `python bench.py --gpus N ...` launches N ranks by itself (it re-executes
 instead (WORLD_SIZE must equal --gpus).  One rank per GPU; every rank analyses its own contiguous range of frame ids
 (rank r: ids from 1 + r * RANK_ID_STRIDE, no data-path collective) and the flow records are all-gathered inside the timed
 region, in pieces that overlap the analysis: by default each rank pushes its pieces into the peers' receive buffers over xGMI
-with the copy engines (distributed.PeerLogStitch: the RCCL kernel does not fit beside the LK wavefronts and would run after
-them); POLYCHASE_BENCH_STITCH=rccl selects the RCCL all-gather, which is also the fallback when the ranks cannot map each
+with the copy engines (distributed.PeerLogStitch: RCCL's kernel allocates 280 registers per lane and gets a CU only by keeping
+LK off it -- measured: +12 % on the step); POLYCHASE_BENCH_STITCH=rccl selects the RCCL all-gather, which is also the fallback when the ranks cannot map each
 other's buffers.  Control traffic (barrier, region agreement, max-over-ranks time, piece sizes) is RCCL / gloo.
 `config.stitch` names the path taken.  scaling = "weak".
 """
