@@ -460,7 +460,7 @@ class PeerLogStitch:
         """Peers drop their mappings before the owner frees the buffer: meet, unmap, meet, free."""
         self._sync()
         self._meet()
-        for r, ptr in enumerate(self.peer_ptrs or []):
+        for ptr in self.peer_ptrs or []:
             if ptr:
                 self.L.pc_peer_buffer_close(self.dev, ptr)
         self.peer_ptrs = None
