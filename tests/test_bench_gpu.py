@@ -63,6 +63,18 @@ def test_gpus_flag_launches_the_ranks_itself():
     assert out["config"]["parallelism"] == "frame-shard x2"
 
 
+def test_peer_stitch_selftest_three_ranks_with_logs_of_different_sizes():
+    """distributed.PeerLogStitch alone, three processes on GPU 0: every rank reads back every rank's bytes, twice (the slot
+    size must be agreed: each rank's log has its own length -- the first version used the local length and wrote to the
+    wrong offsets of the peers' buffers)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(ROOT, "tools", "peer_stitch_selftest.py")],
+                       text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_four_ranks_push_on_three_streams():
     """The stitch of more than four ranks deals the peers onto three copy streams; here four ranks on GPU 0 are told to
     (POLYCHASE_PEER_PUSH_STREAMS=3): every rank must still end up with every rank's records (asserted inside bench.py)."""
