@@ -119,7 +119,8 @@ def _stitch_worker(rank, world, port, first, n, out_dir, use_side):
     log_np, bounds = _fake_log(range(b, e), first, n)
     log = torch.zeros(len(log_np) + 4096, dtype=torch.uint8)     # slack for the padded pieces
     log[:len(log_np)] = torch.from_numpy(log_np)
-    st = D.ChunkedLogStitch(log, side_group=side)
+    st = D.make_log_stitch(log, side_group=side, prefer="peer")     # host tensors: the factory must hand out the all-gather stitch
+    assert isinstance(st, D.ChunkedLogStitch)
     st.warm_up()
     st.reserve(2, 1 << 15)                                         # two pooled receive buffers, the rest allocated on demand
     per = 3                                                        # frames per piece (the last piece is ragged)
