@@ -111,6 +111,13 @@ int pc_context_reset_timing(pc_context* ctx);
  * [5] error pass, [6] wavefront life time, [7] wavefronts, [8] wavefront-iterations, [9] region stagings. */
 #define PC_LK_PROFILE_SLOTS 16
 int pc_debug_lk_profile(pc_context* ctx, unsigned long long* out /* [PC_LK_PROFILE_SLOTS] */);
+/* Diagnostics of PC_ARITH_LK_X86_ORDER on the two-keypoint LK kernel (windows 4-11).  That kernel runs the canonical
+ * integer data path and proves, per level and per iteration, that the fp32 sums of the x86 order would be exact (then
+ * they equal the canonical values); only where the proof fails it evaluates the sums in the x86 order.  out (may be
+ * null) receives the counters accumulated since counting was enabled: [0] (pair, iteration)s decided by the proof,
+ * [1] evaluated in the x86 order, [2] (keypoint, level)s, [3] of those with the structure tensor in the x86 order.
+ * enable != 0 (re)starts counting from zero, 0 stops it.  Counting costs a few atomics per wavefront. */
+int pc_debug_lk_x86_stats(pc_context* ctx, int enable, unsigned long long* out /* [4] */);
 /* Diagnostics of the device-resident PnP solver: ONE damped 9x9 system through the in-kernel float32 Cholesky
  * factorisation and solve that pc_pnp_solve uses (row-major a81, only the lower triangle is read; l81 receives the
  * factor, x9 the solution of L L^T x = b; *positive_definite = 0 and x9 = 0 when the factorisation fails).  Exists so

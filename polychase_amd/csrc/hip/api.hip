@@ -432,6 +432,7 @@ int run_lk(pc_context* ctx, const pc_frame* frame1, const pc_frame* const* targe
     p.out_rec = ctx->lk_rec[set].p;
     p.prof = nullptr;
     p.x86_order = (ctx->arith & PC_ARITH_LK_X86_ORDER) ? 1 : 0;
+    p.x86_stats = ctx->lk_x86_stats.p;
     p.gate = ctx->lk_gate_next ? ctx->lk_gate.p : nullptr;
     p.gate_value = ctx->lk_gate_next;
     ctx->lk_gate_next = 0;
@@ -642,6 +643,7 @@ void pc_context_destroy(pc_context* c) {
     for (auto& b : c->lk_block_counts) b.release();
     c->lk_perm.release();
     c->lk_prof.release();
+    c->lk_x86_stats.release();
     c->lk_gate.release();
     c->lk_gate_timed_out.release();
     c->lk_hist.release();
@@ -703,6 +705,22 @@ int pc_debug_lk_profile(pc_context* c, unsigned long long* out) {
     PC_HIP(hipMemcpy(h.data(), c->lk_prof.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (size_t r = 0; r < c->lk_prof_rows; r++)
         for (int k = 0; k < PC_LK_PROFILE_SLOTS; k++) out[k] += h[r * PC_LK_PROFILE_SLOTS + k];
+    return PC_OK;
+}
+
+int pc_debug_lk_x86_stats(pc_context* c, int enable, unsigned long long* out) {
+    if (!c) return fail(PC_E_INVALID, "null context");
+    PC_HIP(hipDeviceSynchronize());
+    if (out) {
+        for (int k = 0; k < 4; k++) out[k] = 0;
+        if (c->lk_x86_stats.p) PC_HIP(hipMemcpy(out, c->lk_x86_stats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    if (enable) {
+        PC_HIP(c->lk_x86_stats.ensure(4));
+        PC_HIP(hipMemset(c->lk_x86_stats.p, 0, 4 * sizeof(unsigned long long)));
+    } else {
+        c->lk_x86_stats.release();
+    }
     return PC_OK;
 }
 

@@ -209,6 +209,7 @@ struct pc_context {
     bool lk_gate_on = true;                // POLYCHASE_LK_GATE=0 switches the gate off
     DevBuf<unsigned long long> lk_prof;    // pc_debug_lk_profile: 16 words per wavefront of the latest launch
     size_t lk_prof_rows = 0;
+    DevBuf<unsigned long long> lk_x86_stats;   // pc_debug_lk_x86_stats: four counters, or unallocated (not counting)
     DevBuf<long long> lk_row_offset;
     // the analyzer's compacted records of one job, packed like a device-log record without its header:
     // row offsets (128 B) | keypoints | src indices | tgt xy | errors, every part 16-byte aligned

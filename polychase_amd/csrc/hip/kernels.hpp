@@ -122,7 +122,10 @@ struct LKParams {
     // the next launch fills the tail of this one -- and no more than the tail.  May be null.
     uint32_t* gate;
     uint32_t gate_value;
-    int x86_order;            // PC_ARITH_LK_X86_ORDER: fp32 lane sums in the order of OpenCV's SSE path (kernels_lk.hip, X86 = true)
+    int x86_order;            // PC_ARITH_LK_X86_ORDER: fp32 lane sums in the order of OpenCV's SSE path (X86 = true in both kernels)
+    // lk3, x86_order, diagnostics (or null): [0] iterations decided by the exactness proof, [1] iterations evaluated in the
+    // x86 order, [2] (keypoint, level) pairs, [3] of those with the structure tensor evaluated in the x86 order
+    unsigned long long* x86_stats;
 };
 // the stream waits (one idle wavefront) until *gate has reached `value` (wrap-around compare); gives up after ~50 ms
 // and stores 1 to *timed_out (device-visible host memory, may be null)

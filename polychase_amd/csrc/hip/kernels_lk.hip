@@ -401,7 +401,7 @@ static int lk_variant() {
 }
 
 bool launch_lk(const LKParams& p, int win, hipStream_t s) {
-    const int v = p.x86_order ? 1 : lk_variant();   // the x86 summation order exists on the generic kernel only
+    const int v = lk_variant();
     if ((v == 0 || v == 3) && launch_lk3(p, win, s)) return true;
     switch (win) {
 #define PC_LK_CASE(W) case W: launch_lk_t<W>(p, s); return true;

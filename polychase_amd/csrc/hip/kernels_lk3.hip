@@ -236,9 +236,220 @@ __device__ __forceinline__ void stage_region(const uint16_t* __restrict__ J16, i
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// X86 = true (PC_ARITH_LK_X86_ORDER): the sums of the structure tensor and of the mismatch vector as an x86 OpenCV build
+// forms them -- LKTrackerInvoker's CV_SIMD128 path: over the first SIMD_W = (WIN / 8) * 8 columns vector lane j = x & 3
+// accumulates in fp32, row by row (the mismatch vector: the int32 pair sum of columns (c, c + 4), converted, one term per
+// row), a scalar fp32 accumulator takes the remaining columns in row-major order, combined at the end -- bit for bit
+// oracle/pc_oracle.c under PCO_EMU_LK_SIMD.
+//
+// Every term of those sums is an integer.  While the sum of the MAGNITUDES of a sum's terms stays <= 2^24, every partial
+// sum in ANY order is an integer <= 2^24 in magnitude, i.e. exact in fp32: the x86 order then gives the float of the
+// exact integer total -- the canonical value.  So the kernel runs the canonical integer data path and PROVES, per level
+// for the structure tensor (S11, S22 < 2^24; |ix iy| <= (ix^2 + iy^2) / 2) and per iteration for the mismatch vector
+// (Cauchy-Schwarz: sum |d ix| <= sqrt(sum d^2 * S11); sum d^2 costs one v_dot2 per pixel pair), that the bound holds; only
+// where the proof fails does it evaluate the sums in the x86 order (x86_structure_tensor / x86_mismatch_ordered below).
+// The lane mapping is already the right one for that: lane lg of a group owns columns lg and lg + 4 = vector lane x & 3,
+// and the int32 pair sum of columns (c, c + 4) is one v_dot2_i32_i16.
 template <int WIN>
+struct X86Geo {
+    using G = LK3Geo<WIN>;
+    static constexpr int SIMD_W = (WIN / 8) * 8, NXS = WIN - SIMD_W, NS = NXS * WIN;   // vector columns, scalar columns, scalar steps
+    static constexpr int CL = WIN * (SIMD_W / 4);                                       // terms of a vector lane's chain (structure tensor)
+    static constexpr int KSC0 = SIMD_W == 0 ? G::KM : 0;   // WIN < 8: the canonical column chain belongs to the scalar chain
+    static constexpr int NSL = KSC0 + G::KE;               // scalar-chain slots of a lane
+    static constexpr int PA_DW = 3 * G::NPX + 16;          // LDS of the ordered structure tensor, per half
+    static_assert(2 * G::HALF_I_DW + 2 * PA_DW <= G::WAVE_DW, "the ordered structure tensor's products fit behind the I-side buffers");
+    static_assert(SIMD_W == 0 || (SIMD_W == 8 && G::WM == 8 && G::NCH == 2), "vector lanes = the two column chains");
+    // scalar step s (row-major over the scalar columns) -> the lane that owns the pixel and its index among that lane's slots
+    static constexpr int sx(int s) { return SIMD_W + s % (NXS > 0 ? NXS : 1); }
+    static constexpr int sy(int s) { return s / (NXS > 0 ? NXS : 1); }
+    static constexpr bool in_chain0(int s) { return SIMD_W == 0 && sx(s) < G::WM; }
+    static constexpr int se(int s) { return (sx(s) - G::WM) * WIN + sy(s); }            // column-major index among the extra pixels
+    static constexpr int lane_of(int s) { return in_chain0(s) ? sx(s) : se(s) / (G::KE > 0 ? G::KE : 1); }
+    static constexpr int slot_of(int s) { return in_chain0(s) ? sy(s) : KSC0 + se(s) % (G::KE > 0 ? G::KE : 1); }
+};
+
+__device__ __forceinline__ float dpp_bcast4(float v, int src_lane) {   // the value of lane `src_lane` of the 4-lane group
+    const int i = __float_as_int(v);
+    switch (src_lane) {
+        case 0: return __int_as_float(dpp_i32<0x00>(i));
+        case 1: return __int_as_float(dpp_i32<0x55>(i));
+        case 2: return __int_as_float(dpp_i32<0xAA>(i));
+        default: return __int_as_float(dpp_i32<0xFF>(i));
+    }
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) { return __int_as_float(dpp_i32<CTRL>(__float_as_int(v))); }
+
+// (ix, iy) of the pixel in slot k as one dword, out of the paired register layout of the iteration loop (PC_LK3_PAIRS)
+// (sel_lo / sel_hi: the v_perm selectors 0x05040100 / 0x07060302 as OPAQUE values of the calling iteration -- with literal
+// selectors these permutations are invariants of the iteration loop, and hoisted out of it they occupy a register each)
+template <int WIN, int K>
+__device__ __forceinline__ uint32_t x86_unpacked_dxy(const int (&Dxy)[K], int k, uint32_t sel_lo, uint32_t sel_hi) {
+    using G = LK3Geo<WIN>;
+    constexpr int H1 = (WIN + 1) / 2, H2 = WIN - H1;
+    if (k < G::KM) {
+        const int c = k / WIN, r = k - c * WIN;
+        if (r < H2) return __builtin_amdgcn_perm((uint32_t)Dxy[c * WIN + H1 + r], (uint32_t)Dxy[c * WIN + r], sel_lo);
+        if (r >= H1) return __builtin_amdgcn_perm((uint32_t)Dxy[c * WIN + r], (uint32_t)Dxy[c * WIN + r - H1], sel_hi);
+        return (uint32_t)Dxy[k];   // an odd window's middle row
+    }
+    const int e = k - G::KM;
+    if (G::KE > 1 && G::RUNS) {
+        if ((e & 1) == 0 && e + 1 < G::KE) return __builtin_amdgcn_perm((uint32_t)Dxy[k + 1], (uint32_t)Dxy[k], sel_lo);
+        if (e & 1) return __builtin_amdgcn_perm((uint32_t)Dxy[k], (uint32_t)Dxy[k - 1], sel_hi);
+    }
+    return (uint32_t)Dxy[k];
+}
+
+// The mismatch vector of one iteration in the x86 order (see above).  Returns the raw sums (b * 2^20) in all lanes of the group.
+template <int WIN, int K, int KEA>
+__device__ __forceinline__ void x86_mismatch_ordered(const uint32_t* jq, int lg, const Weights& wJ, const int (&Bias)[K], const int (&Dxy)[K],
+                                                     int e_off, const int (&offE)[KEA], float& b1, float& b2) {
+    using G = LK3Geo<WIN>;
+    using X = X86Geo<WIN>;
+    constexpr int H1 = (WIN + 1) / 2, H2 = WIN - H1;
+    uint32_t sel_lo = 0x05040100u, sel_hi = 0x07060302u;
+    asm volatile("" : "+v"(sel_lo), "+v"(sel_hi));   // see x86_unpacked_dxy
+    float q1 = 0.f, q2 = 0.f;   // this vector lane's accumulators
+    if constexpr (X::SIMD_W == 8) {
+        const uint32_t* cb0 = jq + lg;
+        const uint32_t* cb1 = jq + lg + G::GL;
+        uint32_t top0 = cb0[0], top1 = cb1[0];
+#pragma unroll
+        for (int r = 0; r < WIN; r++) {
+            const uint32_t bot0 = cb0[(r + 1) * G::PITCH], bot1 = cb1[(r + 1) * G::PITCH];
+            const int R0 = interp_r(top0, bot0, wJ, Bias[r]), R1 = interp_r(top1, bot1, wJ, Bias[WIN + r]);
+            top0 = bot0;
+            top1 = bot1;
+            const uint32_t Rp = __builtin_amdgcn_perm((uint32_t)R1, (uint32_t)R0, 0x07060302u);   // (diff of column c, diff of column c + 4)
+            uint32_t IX, IY;
+            if (r < H2) {
+                IX = __builtin_amdgcn_perm((uint32_t)Dxy[WIN + r], (uint32_t)Dxy[r], sel_lo);
+                IY = __builtin_amdgcn_perm((uint32_t)Dxy[WIN + H1 + r], (uint32_t)Dxy[H1 + r], sel_lo);
+            } else if (r >= H1) {
+                IX = __builtin_amdgcn_perm((uint32_t)Dxy[WIN + r - H1], (uint32_t)Dxy[r - H1], sel_hi);
+                IY = __builtin_amdgcn_perm((uint32_t)Dxy[WIN + r], (uint32_t)Dxy[r], sel_hi);
+            } else {
+                IX = __builtin_amdgcn_perm((uint32_t)Dxy[WIN + r], (uint32_t)Dxy[r], sel_lo);
+                IY = __builtin_amdgcn_perm((uint32_t)Dxy[WIN + r], (uint32_t)Dxy[r], sel_hi);
+            }
+            q1 = q1 + (float)sdot2_zero(Rp, IX);   // the int32 pair sum, converted, one term per row
+            q2 = q2 + (float)sdot2_zero(Rp, IY);
+        }
+    }
+    // the scalar chain: every lane converts the products of the pixels it owns, then the terms are added in row-major
+    // order -- in all four lanes alike, each term broadcast from its owner (v_add_f32 with a DPP operand)
+    float f1[X::NSL > 0 ? X::NSL : 1], f2[X::NSL > 0 ? X::NSL : 1];
+    if constexpr (X::KSC0 > 0) {
+        const uint32_t* cb = jq + lg;
+        uint32_t top = cb[0];
+#pragma unroll
+        for (int r = 0; r < WIN; r++) {
+            const uint32_t bot = cb[(r + 1) * G::PITCH];
+            const int R = interp_r(top, bot, wJ, Bias[r]);
+            top = bot;
+            const uint32_t u = x86_unpacked_dxy<WIN, K>(Dxy, r, sel_lo, sel_hi);
+            f1[r] = (float)mad16_hl(R, u, 0);
+            f2[r] = (float)mad16_hh(R, u, 0);
+        }
+    }
+    if constexpr (G::KE > 0) {
+        if constexpr (G::RUNS) {
+            const uint32_t* cb = jq + e_off;
+            uint32_t top = cb[0];
+#pragma unroll
+            for (int e = 0; e < G::KE; e++) {
+                const uint32_t bot = cb[(e + 1) * G::PITCH];
+                const int R = interp_r(top, bot, wJ, Bias[G::KM + e]);
+                top = bot;
+                const uint32_t u = x86_unpacked_dxy<WIN, K>(Dxy, G::KM + e, sel_lo, sel_hi);
+                f1[X::KSC0 + e] = (float)mad16_hl(R, u, 0);
+                f2[X::KSC0 + e] = (float)mad16_hh(R, u, 0);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < G::KE; e++) {
+                const uint32_t* q = jq + offE[e];
+                const int R = interp_r(q[0], q[G::PITCH], wJ, Bias[G::KM + e]);
+                const uint32_t u = (uint32_t)Dxy[G::KM + e];
+                f1[X::KSC0 + e] = (float)mad16_hl(R, u, 0);
+                f2[X::KSC0 + e] = (float)mad16_hh(R, u, 0);
+            }
+        }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < X::NS; s++) {
+        s1 = s1 + dpp_bcast4(f1[X::slot_of(s)], X::lane_of(s));
+        s2 = s2 + dpp_bcast4(f2[X::slot_of(s)], X::lane_of(s));
+    }
+    if constexpr (X::SIMD_W == 8) {
+        // bbuf[k] = qb0[k] + qb1[k]: lanes (0, 2) and (1, 3); fb += bbuf[0] + bbuf[2]
+        const float t1 = q1 + dpp_f32<0x4E>(q1), t2 = q2 + dpp_f32<0x4E>(q2);
+        const float u1 = t1 + dpp_f32<0xB1>(t1), u2 = t2 + dpp_f32<0xB1>(t2);
+        // lanes 1 and 3 hold (q1 + q3) + (q0 + q2): the same bits (one commutative addition of the same two values)
+        b1 = s1 + u1;
+        b2 = s2 + u2;
+    } else {
+        b1 = s1;
+        b2 = s2;
+    }
+}
+
+// The structure tensor of both keypoints of the wavefront in the x86 order: each lane writes the three products of the
+// pixels it evaluated into LDS at their position in their chain; lane 5 k + c of a half adds chain c (0-3: vector lanes, 4: the
+// scalar accumulator) of quantity k sequentially; A = scalar + (((q0 + q1) + q2) + q3).  Called by the whole wavefront.
+template <int WIN>
+__device__ __forceinline__ void x86_structure_tensor(uint32_t* wbase, const uint32_t* xbuf_o, int lane_o, bool i_in, float& S11, float& S12, float& S22) {
+    using G = LK3Geo<WIN>;
+    using X = X86Geo<WIN>;
+    constexpr int NPX = G::NPX, KW = (NPX + 31) / 32;
+    constexpr int MAXL = X::CL > X::NS ? X::CL : X::NS;
+    const int l32 = lane_o & 31;
+    float* const pa = reinterpret_cast<float*>(wbase + 2 * G::HALF_I_DW) + (lane_o >> 5) * X::PA_DW;
+    if (i_in) {
+#pragma unroll
+        for (int m = 0; m < KW; m++) {
+            const int q = l32 + 32 * m;
+            if (q < NPX) {
+                const int y = q / WIN, x = q - y * WIN;
+                const uint32_t d = xbuf_o[2 * q + 1];   // written by this lane
+                const int ix = (int)(int16_t)(d & 0xffffu), iy = (int)d >> 16;
+                const int off = x < X::SIMD_W ? (x & 3) * X::CL + y * (X::SIMD_W / 4) + (x >> 2) : 4 * X::CL + y * X::NXS + (x - X::SIMD_W);
+                pa[off] = (float)__mul24(ix, ix);              // |products| <= 4080^2 < 2^24: exact
+                pa[NPX + off] = (float)__mul24(ix, iy);
+                pa[2 * NPX + off] = (float)__mul24(iy, iy);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (i_in && l32 < 15) {
+        const int k = l32 / 5, c = l32 - 5 * k;
+        const int len = c < 4 ? X::CL : X::NS;
+        const float* src = pa + k * NPX + c * X::CL;
+        float acc = 0.f;
+#pragma unroll 4
+        for (int i = 0; i < MAXL; i++) {
+            const float v = src[i < len ? i : 0];
+            acc = i < len ? v + acc : acc;
+        }
+        pa[3 * NPX + l32] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (i_in) {
+        const float* r = pa + 3 * NPX;
+        S11 = r[4] + (((r[0] + r[1]) + r[2]) + r[3]);
+        S12 = r[9] + (((r[5] + r[6]) + r[7]) + r[8]);
+        S22 = r[14] + (((r[10] + r[11]) + r[12]) + r[13]);
+    }
+}
+
+template <int WIN, bool X86>
 __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(const LKParams p) {
     using G = LK3Geo<WIN>;
+    static_assert(!X86 || (PC_LK3_PAIRS * PC_LK3_TRIM) != 0, "the x86 summation order is written on the paired, trimmed data path");
     constexpr int GL = G::GL, NPX = G::NPX, NCH = G::NCH, KM = G::KM, KE = G::KE, K = G::K;
     constexpr int KW = (NPX + 31) / 32;   // pixels per lane in the half-wave I-side pass
     // + slack: slots past a lane's run of extra pixels read up to KE rows below the last region (and contribute 0)
@@ -297,6 +508,11 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
     bool status = true;
     float err = 0.f;
     PC_PROF_DECL
+    // X86 diagnostics (LKParams::x86_stats): levels (low half) / levels with the ordered structure tensor (high half);
+    // iterations decided by the exactness proof / evaluated in the x86 order
+    int x86_levels = 0, x86_iters = 0;
+    (void)x86_levels;
+    (void)x86_iters;
 
     for (int level = p.max_level; level >= 0; --level) {
         const Level L = p.src[level];
@@ -395,9 +611,27 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
 #if PC_LK3_TRIM
         static_assert((long long)NPX * 4080 * 4080 < (1ll << 31), "structure tensor sums fit int32");
         const int S11 = half_sum3_i32(sA11), S22 = half_sum3_i32(sA22);
-        const float A11 = (float)S11 * FLT_SCALE;
-        const float A12 = half_exact_sum3_small(sA12) * FLT_SCALE;
-        const float A22 = (float)S22 * FLT_SCALE;
+        float A11 = (float)S11 * FLT_SCALE;
+        float A12 = half_exact_sum3_small(sA12) * FLT_SCALE;
+        float A22 = (float)S22 * FLT_SCALE;
+        float cert_s = 0.f;   // X86: max(S11, S22), the structure-tensor factor of the mismatch vector's exactness bound
+        if constexpr (X86) {
+            // S11, S22 < 2^24: every partial sum of ix^2, iy^2 and ix iy in any order is exact -- the x86 order gives the
+            // canonical values above.  Otherwise (wavefront-uniform branch) both keypoints take the ordered evaluation,
+            // which gives the same bits for a keypoint that did not need it.
+            cert_s = (float)max(S11, S22);
+            if (__any(i_in && (S11 >= (1 << 24) || S22 >= (1 << 24)))) {
+                float f11 = 0.f, f12 = 0.f, f22 = 0.f;
+                x86_structure_tensor<WIN>(wbase, xbuf_o, lane_o, i_in, f11, f12, f22);
+                if (i_in) {
+                    A11 = f11 * FLT_SCALE;
+                    A12 = f12 * FLT_SCALE;
+                    A22 = f22 * FLT_SCALE;
+                }
+                x86_levels += 1 << 16;
+            }
+            x86_levels += 1;
+        }
         // |sum over any subset of the window of diff * ix| <= sqrt(NPX) * 8160 * sqrt(S11) (Cauchy-Schwarz, |diff| <= 8160):
         // below 2^31 the b-vector's sums over the four lanes of a group can be formed in int32 (then ONE conversion, the
         // same single rounding as the fp64 route).  True for every keypoint of the benchmark clips; a window full of
@@ -494,6 +728,11 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         float pdx = 0.f, pdy = 0.f;
         int rx0 = 0, ry0 = 0;
         bool staged = false;
+        // X86: once the exactness proof of an iteration fails for any pair of the wavefront, the rest of the level runs in
+        // the x86 order for all of them (always correct; the proof only saves work) -- wavefront-uniform, so that a
+        // wavefront never executes both paths iteration after iteration
+        bool x86_ordered = false;
+        (void)x86_ordered;
         for (int j = 0; j < p.max_iters; j++) {
             PC_PROF_COUNT(8);
 #if PC_LK3_TRIM
@@ -542,6 +781,12 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
             const uint32_t* jq = jbuf + (iqy - ry0) * G::PITCH + (iqx - rx0);
 #endif
             int sb1 = 0, sb2 = 0;  // per-lane partials: <= K * 8160 * 4080
+            int dd0 = 0, dd1 = 0;  // X86: the lane's sum of squared differences (<= K * 8160^2 < 2^31), for the exactness proof
+            (void)dd0;
+            (void)dd1;
+            constexpr bool kExtrasFull = G::NEXTRA == GL * KE;   // every lane's run of extra pixels is complete
+            (void)kExtrasFull;
+            if (!X86 || !x86_ordered) {
             // A pixel is a dependent chain dot2 -> dot2 -> mad with wait states after each dot product; walked one
             // pixel after the other that chain, not instruction issue, sets the pace (lk2 and a first version of this
             // loop: 2 x s_nop 2 per pixel).  So the lane's pixels are cut into NR independent vertical runs -- every
@@ -618,12 +863,20 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                                 sb2 = sdot2(Rp[c], (uint32_t)Dxy[c * WIN + H1 + st], sb2);
                             }
                         }
+                        if constexpr (X86) {
+#pragma unroll
+                            for (int c = 0; c < NCH; c++) {
+                                if (c & 1) dd1 = sdot2(Rp[c], Rp[c], dd1);
+                                else dd0 = sdot2(Rp[c], Rp[c], dd0);
+                            }
+                        }
                     } else {   // an odd window's middle row: the upper runs only
 #pragma unroll
                         for (int c = 0; c < NCH; c++) {
                             if (st < H1) {
                                 sb1 = mad16_hl(R[2 * c], (uint32_t)Dxy[c * WIN + st], sb1);
                                 sb2 = mad16_hh(R[2 * c], (uint32_t)Dxy[c * WIN + st], sb2);
+                                if constexpr (X86) dd0 = mad16_hh(R[2 * c], (uint32_t)R[2 * c], dd0);
                             }
                         }
                     }
@@ -636,9 +889,15 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                                 const uint32_t rp = __builtin_amdgcn_perm((uint32_t)R[NRC], (uint32_t)r_even, 0x07060302u);
                                 tb1 = sdot2(rp, (uint32_t)Dxy[KM + st - 1], tb1);
                                 tb2 = sdot2(rp, (uint32_t)Dxy[KM + st], tb2);
+                                if constexpr (X86 && kExtrasFull) dd1 = sdot2(rp, rp, dd1);
                             } else {
                                 tb1 = mad16_hl(R[NRC], (uint32_t)Dxy[KM + st], tb1);
                                 tb2 = mad16_hh(R[NRC], (uint32_t)Dxy[KM + st], tb2);
+                                if constexpr (X86 && kExtrasFull) dd1 = mad16_hh(R[NRC], (uint32_t)R[NRC], dd1);
+                            }
+                            if constexpr (X86 && !kExtrasFull) {   // slots past a short run hold arbitrary differences: keep them out
+                                const int d2 = mad16_hh(R[NRC], (uint32_t)R[NRC], 0);
+                                dd1 += st < e_len ? d2 : 0;
                             }
                         }
                     }
@@ -679,19 +938,48 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 for (int e = 0; e < KE; e++) {
                     sb1 = mad16_hl(R[e], (uint32_t)Dxy[KM + e], sb1);
                     sb2 = mad16_hh(R[e], (uint32_t)Dxy[KM + e], sb2);
+                    if constexpr (X86) {
+                        const int d2 = mad16_hh(R[e], (uint32_t)R[e], 0);
+                        dd0 += (kExtrasFull || qE[e] >= 0) ? d2 : 0;
+                    }
                 }
             }
+            }   // !x86_ordered
 #if PC_LK3_TRIM
-            float b1, b2;
-            if (int_sums) {
-                int t1 = sb1 + dpp_i32<0xB1>(sb1), t2 = sb2 + dpp_i32<0xB1>(sb2);
-                t1 += dpp_i32<0x4E>(t1);
-                t2 += dpp_i32<0x4E>(t2);
-                b1 = (float)t1;
-                b2 = (float)t2;
-            } else {
-                b1 = group4_exact_sum3<K>(sb1);
-                b2 = group4_exact_sum3<K>(sb2);
+            float b1 = 0.f, b2 = 0.f;
+            bool run_ordered = X86 && x86_ordered;
+            if (!run_ordered) {
+                if (int_sums) {
+                    int t1 = sb1 + dpp_i32<0xB1>(sb1), t2 = sb2 + dpp_i32<0xB1>(sb2);
+                    t1 += dpp_i32<0x4E>(t1);
+                    t2 += dpp_i32<0x4E>(t2);
+                    b1 = (float)t1;
+                    b2 = (float)t2;
+                } else {
+                    b1 = group4_exact_sum3<K>(sb1);
+                    b2 = group4_exact_sum3<K>(sb2);
+                }
+                if constexpr (X86) {
+                    // sum over the window of |d ix| <= sqrt(sum d^2 * S11) <= 2^24 (and the same for iy): every partial sum of
+                    // the x86 order is exact and its result is the float of the integer total, b1 / b2 above.  The margin
+                    // (2^-10) covers the roundings of this test itself (five fp32 operations, < 2^-21 relative).
+                    float ddf = (float)(dd0 + dd1);
+                    ddf += dpp_f32<0xB1>(ddf);
+                    ddf += dpp_f32<0x4E>(ddf);
+                    const bool proven = ddf * cert_s <= 281474976710656.f * (1.f - 1.f / 1024.f);
+                    if (__any(!proven)) {
+                        x86_ordered = true;
+                        run_ordered = true;
+                    }
+                }
+            }
+            if constexpr (X86) {
+                if (run_ordered) {
+                    x86_mismatch_ordered<WIN, K, (KE > 0 ? KE : 1)>(jq, lg, wJ, Bias, Dxy, e_off, offE, b1, b2);
+                    x86_iters += 1 << 16;
+                } else {
+                    x86_iters += 1;
+                }
             }
 #else
             const float b1 = group4_exact_sum3<K>(sb1) * FLT_SCALE;
@@ -791,6 +1079,18 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
     // one 16-byte record per (slot, target): the wavefront's results are contiguous
     if (lg == 0 && tgt_active)
         p.out_rec[(size_t)slot * kRecStride + tgt] = make_float4(nx, ny, status ? err : 0.f, __uint_as_float(status ? 1u : 0u));
+    if constexpr (X86) {
+        if (p.x86_stats) {   // diagnostics only (pc_debug_lk_x86_stats)
+            if (lg == 0 && tgt_active) {
+                atomicAdd(&p.x86_stats[0], (unsigned long long)(x86_iters & 0xffff));
+                atomicAdd(&p.x86_stats[1], (unsigned long long)(x86_iters >> 16));
+            }
+            if (l32 == 0 && kp_valid) {
+                atomicAdd(&p.x86_stats[2], (unsigned long long)(x86_levels & 0xffff));
+                atomicAdd(&p.x86_stats[3], (unsigned long long)(x86_levels >> 16));
+            }
+        }
+    }
 }
 
 // smallest float x with fl(x / c) >= thr (c > 0, thr finite and positive); NaN if the search does not settle
@@ -817,7 +1117,8 @@ static void launch_lk3_t(const LKParams& p0, hipStream_t s) {
     const int blocks = (p.n + per_block - 1) / per_block;
     if (blocks == 0) return;
     p.blocks_per_xcd = (blocks + 7) / 8;
-    hipLaunchKernelGGL((lk3_kernel<WIN>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(64 * PC_LK3_WAVES), 0, s, p);
+    if (p.x86_order) hipLaunchKernelGGL((lk3_kernel<WIN, true>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(64 * PC_LK3_WAVES), 0, s, p);
+    else hipLaunchKernelGGL((lk3_kernel<WIN, false>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(64 * PC_LK3_WAVES), 0, s, p);
 }
 
 bool lk_profile_enabled() {

@@ -22,7 +22,7 @@ SYMBOLS = [
     "pc_context_create", "pc_context_destroy", "pc_context_synchronize", "pc_context_stream",
     "pc_context_set_arithmetic", "pc_context_get_arithmetic", "pc_context_download",
     "pc_context_enable_timing", "pc_context_get_timing", "pc_context_get_busy_time", "pc_context_reset_timing",
-    "pc_debug_lk_profile", "pc_debug_llt9",
+    "pc_debug_lk_profile", "pc_debug_lk_x86_stats", "pc_debug_llt9",
     "pc_frame_create", "pc_frame_destroy", "pc_frame_set_rgb", "pc_frame_set_rgb_f32", "pc_frame_set_gray",
     "pc_host_buffer_alloc", "pc_host_buffer_free",
     "pc_frame_num_levels", "pc_frame_level_size", "pc_frame_download_gray", "pc_frame_download_level",
@@ -114,6 +114,7 @@ def load():
     L.pc_context_get_busy_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.pc_context_reset_timing.argtypes = [vp]
     L.pc_debug_lk_profile.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    L.pc_debug_lk_x86_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_ulonglong)]
     L.pc_debug_llt9.argtypes = [vp, vp, vp, vp, vp, ip]
     L.pc_frame_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.pc_frame_destroy.argtypes = [vp]
@@ -240,6 +241,14 @@ class Context:
         out = (C.c_ulonglong * 16)()
         _check(load().pc_debug_lk_profile(self._h, out))
         return list(out)
+
+    def lk_x86_stats(self, enable: bool = True) -> dict:
+        """counters of the x86 summation order on the two-keypoint LK kernel since counting was enabled
+        (include/polychase_hip.h: pc_debug_lk_x86_stats); enable=True restarts counting, False stops it"""
+        out = (C.c_ulonglong * 4)()
+        _check(load().pc_debug_lk_x86_stats(self._h, 1 if enable else 0, out))
+        return {"iterations_proven_exact": out[0], "iterations_x86_order": out[1], "keypoint_levels": out[2],
+                "keypoint_levels_x86_order": out[3]}
 
     def llt9(self, a: np.ndarray, b: np.ndarray):
         """the device solver's 9x9 float32 Cholesky + solve -> (L, x, positive_definite)"""

@@ -72,9 +72,11 @@ def test_x86_lk_order_is_bit_exact_on_step_edges_and_differs_from_canonical(ctx)
     assert d.max() < 5e-3          # the two executions of OpenCV stay within 2e-3 px of each other here
 
 
-@pytest.mark.parametrize("win,max_level,n_targets", [(10, 3, 8), (7, 2, 2), (13, 3, 3), (16, 1, 1), (4, 2, 2), (8, 3, 5)])
+@pytest.mark.parametrize("win,max_level,n_targets", [(10, 3, 8), (7, 2, 2), (13, 3, 3), (16, 1, 1), (4, 2, 2), (8, 3, 5), (5, 2, 3), (6, 3, 8),
+                                                      (9, 2, 4), (11, 3, 7), (3, 1, 2), (12, 2, 1)])
 def test_x86_lk_order_every_window_geometry(ctx, win, max_level, n_targets):
-    """(win / 8) * 8 vector columns + scalar rest: 0 + 4, 0 + 7, 8 + 0, 8 + 2, 8 + 5, 16 + 0 columns"""
+    """(win / 8) * 8 vector columns + scalar rest: 0 + 3 ... 0 + 7, 8 + 0 ... 8 + 5, 16 + 0 columns; windows 4-11 run on the
+    two-keypoint kernel (kernels_lk3.hip, X86 = true), the others on the generic one"""
     frames = synth.checkerboard_clip(16, w=320, h=240)
     _lk_both(ctx, [frames[6]] + [frames[6 + k + 1] for k in range(n_targets)], hip.ARITH_LK_X86_ORDER, oracle.EMU_LK_SIMD, win, max_level)
     clip = synth.NoiseClip(320, 240, 12)
@@ -125,3 +127,92 @@ def test_opencv_x86_mode_through_the_analyzer(ctx):
                 oxy, ost, oerr = oracle.lk(p0, oracle.Pyramid(grays[f2 - 1]), okps)
                 keep = np.nonzero(ost == 1)[0].astype(np.uint32)
                 assert np.array_equal(idx, keep) and np.array_equal(xy, oxy[keep]) and np.array_equal(err, oerr[keep])
+
+
+def _hard(rng, w, h, kind):
+    """content for the x86 order: white noise (huge window sums), binary blocks (step edges at full contrast), smooth"""
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if kind == "binary":
+        cell = int(rng.integers(3, 12))
+        small = rng.integers(0, 2, (h // cell + 2, w // cell + 2, 1), dtype=np.uint8) * 255
+        return np.ascontiguousarray(np.repeat(np.kron(small, np.ones((cell, cell, 1), np.uint8))[:h, :w], 3, axis=2))
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = 128 + 50 * np.sin(x / rng.uniform(4, 20)) * np.cos(y / rng.uniform(4, 20)) + rng.uniform(-4, 4, (h, w))
+    return np.repeat(np.clip(img, 0, 255).astype(np.uint8)[:, :, None], 3, axis=2)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_x86_order_on_the_two_keypoint_kernel_random(ctx, seed):
+    """Windows 4-11 in PC_ARITH_LK_X86_ORDER run the two-keypoint kernel: the canonical integer data path plus a proof that
+    the fp32 sums of the x86 order are exact, and the x86 order itself where the proof fails.  Random content of three
+    kinds (proof always fails / fails at edges / always holds), every window, 1-8 targets, odd keypoint counts -- bit for
+    bit against the oracle's emulation, and the diagnostics counters must add up."""
+    rng = np.random.default_rng(77000 + seed)
+    win = 4 + seed % 8
+    kind = ["noise", "binary", "smooth"][(seed // 8) % 3]
+    w, h = int(rng.integers(60, 260)), int(rng.integers(60, 200))
+    max_level = int(rng.integers(0, 4))
+    n_targets = int(rng.integers(1, 9))
+    src = _hard(rng, w, h, kind)
+    tgts = []
+    for _ in range(n_targets):
+        dx, dy = rng.integers(-4, 5, 2)
+        t = np.roll(src, (int(dy), int(dx)), axis=(0, 1)).astype(np.int16) + rng.integers(-5, 6, src.shape, dtype=np.int16)
+        tgts.append(np.clip(t, 0, 255).astype(np.uint8))
+    fk = dict(window_size=win, max_level=max_level, term_max_iters=int(rng.choice([3, 30])))
+    case = f"seed {seed}: {w}x{h} {kind} win {win} L {max_level} targets {n_targets} {fk}"
+    ctx.set_arithmetic(hip.ARITH_LK_X86_ORDER)
+    try:
+        f1 = hip.Frame(ctx, w, h, win, max_level)
+        f1.set_rgb(src)
+        g1 = oracle.rgb2gray(src)
+        f1.detect(hip.gftt_options(min_distance=float(rng.choice([2.0, 5.0]))))
+        kps = f1.keypoints()
+        if len(kps) == 0:
+            kps = np.floor(rng.uniform([0, 0], [w, h], (9, 2))).astype(np.float32)
+            f1.set_keypoints(kps)
+        frames = []
+        for t in tgts:
+            f = hip.Frame(ctx, w, h, win, max_level)
+            f.set_rgb(t)
+            frames.append(f)
+        ctx.lk_x86_stats(True)
+        xy, st, err = hip.lk_track(ctx, f1, frames, hip.flow_options(**fk))
+        stats = ctx.lk_x86_stats(False)
+        p1 = oracle.Pyramid(g1, win, max_level)
+        with oracle.emulation(oracle.EMU_LK_SIMD):
+            for k, t in enumerate(tgts):
+                oxy, ost, oerr = oracle.lk(p1, oracle.Pyramid(oracle.rgb2gray(t), win, max_level), kps, oracle.flow_options(**fk))
+                assert np.array_equal(st[k], ost), f"{case}: status of target {k}: {(st[k] != ost).sum()} differ"
+                m = ost == 1
+                assert np.array_equal(xy[k][m].view(np.uint32), oxy[m].view(np.uint32)), f"{case}: positions of target {k} {stats}"
+                assert np.array_equal(err[k][m].view(np.uint32), oerr[m].view(np.uint32)), f"{case}: errors of target {k}"
+        assert stats["keypoint_levels"] == len(kps) * (min(max_level, f1.num_levels - 1) + 1), (case, stats)
+        if kind == "noise" and win >= 6:
+            assert stats["iterations_x86_order"] > 0 and stats["keypoint_levels_x86_order"] > 0, (case, stats)
+        for f in [f1] + frames:
+            f.close()
+    finally:
+        ctx.set_arithmetic(hip.ARITH_CANONICAL)
+
+
+def test_x86_order_is_decided_by_the_proof_on_benchmark_content(ctx):
+    """On the benchmark's band-limited texture the exactness proof holds nearly everywhere: the x86 mode runs at the
+    canonical kernel's speed plus the proof.  (C1's step edges: the other extreme, see the counters there.)"""
+    clip = synth.NoiseClip(960, 540, 12)
+    rgbs = [clip.frame(4)] + [clip.frame(t) for t in (3, 5, 6, 8)]
+    ctx.set_arithmetic(hip.ARITH_LK_X86_ORDER)
+    try:
+        fr = _frames(ctx, rgbs)
+        fr[0].detect()
+        ctx.lk_x86_stats(True)
+        hip.lk_track(ctx, fr[0], fr[1:], hip.flow_options())
+        stats = ctx.lk_x86_stats(False)
+        for f in fr:
+            f.close()
+    finally:
+        ctx.set_arithmetic(hip.ARITH_CANONICAL)
+    total = stats["iterations_proven_exact"] + stats["iterations_x86_order"]
+    print("x86 stats on C2 content:", stats)
+    assert total > 0 and stats["iterations_x86_order"] <= 0.2 * total, stats

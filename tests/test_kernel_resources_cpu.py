@@ -84,9 +84,11 @@ def test_helper_kernels_fit_beside_three_lk_wavefronts(kernels):
 
 
 def test_lk_kernel_allocation_is_what_the_budget_assumes(kernels):
-    lk = [k for n, k in kernels.items() if "lk3_kernelILi10" in n]
-    assert len(lk) == 1
-    k = lk[0]
-    assert 129 <= k[".vgpr_count"] <= 136, k[".vgpr_count"]          # three wavefronts per SIMD, not two, not four
-    assert k.get(".agpr_count", 0) == 0 and k.get(".private_segment_fixed_size", 0) == 0
-    assert k[".group_segment_fixed_size"] <= 10 * 1024 + 512           # 12 wavefronts per CU hold <= 126 KB of the 160 KB
+    # ELb0: the canonical arithmetic; ELb1: the x86 summation order (PC_ARITH_LK_X86_ORDER) -- the same budget for both
+    for variant in ("lk3_kernelILi10ELb0", "lk3_kernelILi10ELb1"):
+        lk = [k for n, k in kernels.items() if variant in n]
+        assert len(lk) == 1, variant
+        k = lk[0]
+        assert 129 <= k[".vgpr_count"] <= 136, (variant, k[".vgpr_count"])   # three wavefronts per SIMD, not two, not four
+        assert k.get(".agpr_count", 0) == 0 and k.get(".private_segment_fixed_size", 0) == 0, variant
+        assert k[".group_segment_fixed_size"] <= 10 * 1024 + 512, variant       # 12 wavefronts per CU hold <= 126 KB of the 160 KB

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--frame", type=int, default=100)
     ap.add_argument("--window", type=int, default=10)
+    ap.add_argument("--arith", default="canonical", choices=["canonical", "lk_x86", "sobel_fma", "opencv_x86"])
     args = ap.parse_args()
 
     import torch
@@ -43,6 +44,8 @@ def main():
     dev = torch.device("cuda", 0)
     clip = synth.NoiseClip(w, h, 300, device=str(dev))
     ctx = hip.Context(0)
+    ctx.set_arithmetic({"canonical": hip.ARITH_CANONICAL, "lk_x86": hip.ARITH_LK_X86_ORDER, "sobel_fma": hip.ARITH_SOBEL_FMA,
+                        "opencv_x86": hip.ARITH_OPENCV_X86}[args.arith])
     fopt = hip.flow_options(max_level=max_level, window_size=args.window)
     frames = {}
     for s in (0,) + SKIPS:
@@ -76,9 +79,16 @@ def main():
     for t, (idx, fxy, ferr) in enumerate(filt):
         keep = np.nonzero(st[t] == 1)[0]
         assert np.array_equal(idx, keep.astype(np.uint32)) and np.array_equal(fxy, xy[t][keep]) and np.array_equal(ferr, err[t][keep])
-    out = {"config": args.config, "window": args.window, "keypoints": n, "launches": launches,
+    x86_stats = None
+    if ctx.arithmetic & hip.ARITH_LK_X86_ORDER:   # one more launch with the diagnostics counters on
+        ctx.lk_x86_stats(True)
+        hip.lk_track(ctx, f1, targets, fopt)
+        x86_stats = ctx.lk_x86_stats(False)
+    out = {"config": args.config, "window": args.window, "arith": args.arith, "keypoints": n, "launches": launches,
            "lk_ms_per_launch": ms / max(1, launches), "tracked_rows": int((st == 1).sum()),
            "sha256": hsh.hexdigest()[:16], "lib": os.environ.get("POLYCHASE_HIP_LIB", "default")}
+    if x86_stats is not None:
+        out["x86_stats_one_launch"] = x86_stats
     prof = ctx.lk_profile()
     if any(prof):
         names = ["i_stage", "i_eval", "pickup", "j_stage", "iterate", "err", "life", "waves", "wave_iters", "stagings"]
