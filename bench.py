@@ -14,7 +14,18 @@ EXACTLY K steps between barrier + synchronize on both sides.  A K-step region sh
 (K = 20 at 1080p is 11 ms) is measured several times over consecutive stretches of the clip and the MEDIAN
 region is reported (`config.timed_regions`), so that a short driver run is not a cold one-off sample.
 The headline line is the 1080p configuration C2 (BASELINE.json configs[1]); the same JSON object carries
-the 4K configuration C3 under "c3" (the >= 30x target is quoted on 4K) unless --no-c3.
+the 4K configuration C3 under "c3" (the >= 30x target is quoted on 4K) unless --no-c3 -- with N > 1 that block is C4's
+per-rank workload and says so -- and, with one GPU, "c5": C5 end to end (analysis -> tracking -> refinement, pose error
+against the CPU reference of the tracking step) unless --no-c5.
+
+Arithmetic: the library's default mode, PC_ARITH_OPENCV_X86 (what the OpenCV build the reference links executes; DESIGN.md
+section 2), named in config.arith; "arith_modes" carries the same K steps in the canonical mode beside it.
+
+roofline = the contract's HBM block of the dominant kernel (algorithmic bytes of an LK launch / its average duration,
+against 8 TB/s); valu_roofline = what actually bounds that kernel (VALU issue), with both ceilings.  Counters
+(SQ_INSTS_VALU, FETCH_SIZE, WRITE_SIZE) come from short `rocprofv3 --pmc` passes of tools/lk_bench.py that this script
+runs itself after the timed regions ("counters_measured_in_run": true), or, without rocprofv3 / with --no-counters, from
+the committed profiles/lk_hbm_traffic.json (false).
 
 N > 1: `python bench.py --gpus N ...` launches N ranks by itself (it re-executes through torch.distributed.run on
 127.0.0.1 and fails if the node has fewer than N GPUs); started under torch.distributed.run / torchrun it joins that job
@@ -60,7 +71,11 @@ VALU_PEAK_GINST = 256 * 4 * 2.4 / VALU_CYCLES_PER_INST
 CLIP_FRAMES = 300
 MIN_PREWARM = 24
 MIN_REGION_S = 0.5
-LK_KERNEL = "lk3_kernel<10>"
+LK_KERNEL = {"canonical": "lk3_kernel<10, false>", "opencv_x86": "lk3_kernel<10, true>", "lk_x86": "lk3_kernel<10, true>",
+             "sobel_fma": "lk3_kernel<10, false>"}
+VALU_NOMINAL_CYCLES = 2.0   # the guide's "v_fma_f32 2 cyc (SIMD-32)" row: the ceiling no instruction of this kernel's mix reaches
+VALU_NOMINAL_GINST = 256 * 4 * 2.4 / VALU_NOMINAL_CYCLES
+C4_FRAMES = 2400            # BASELINE.json configs[3]: 3840x2160, 2400 frames over 8 GPUs
 RANK_ID_STRIDE = 1 << 20   # rank r owns frame ids 1 + r * stride ...: disjoint, ordered shards like analyze.py's
 
 
@@ -150,8 +165,80 @@ def end_to_end(cfg, frames_dev, n_frames):
     return out
 
 
-def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
-    """One configuration: returns the result object of this rank (rank 0's is printed)."""
+ARITH_FLAGS = {"canonical": 0, "lk_x86": 1, "sobel_fma": 2, "opencv_x86": 3}
+ARITH_NAMES = {v: k for k, v in ARITH_FLAGS.items()}
+LAST_ARITH = None   # the arithmetic mode the latest run_config ran in (every rank)
+
+
+def measure_counters(cfg, arith, timeout_s=75):
+    """SQ_INSTS_VALU, FETCH_SIZE and WRITE_SIZE of ONE LK launch of this configuration, measured now on this box: three short
+    `rocprofv3 --pmc` passes (counters in their own runs, no other trace domain) of tools/lk_bench.py -- the same kernel on a
+    frame of the same clip.  Returns None when rocprofv3 is missing or a pass fails (the caller then falls back to the
+    committed profile and says so)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+
+    if not shutil.which("rocprofv3"):
+        return None
+    env = dict(os.environ, TMPDIR="/tmp", POLYCHASE_ARITH=arith)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    got = {}
+    for counter in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pcpmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.join(ROOT, "tools", "lk_bench.py"), "--config", cfg, "--reps", "3", "--arith", arith]
+        proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.communicate()
+            shutil.rmtree(d, ignore_errors=True)
+            return None
+        total, n = 0.0, 0
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if "lk3_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                    total += float(row["Counter_Value"])
+                    n += 1
+        shutil.rmtree(d, ignore_errors=True)
+        if n == 0:
+            return None
+        got[counter] = total / n
+        got["dispatches_" + counter] = n
+    return got
+
+
+def c5_block():
+    """Config C5 (1920x1080, 300 rendered frames): generate_optical_flow_database -> track_sequence -> refine_trajectory
+    through polychase_core, pose error of every 29th frame against the CPU reference of the tracking step
+    (oracle/pnp_oracle.py: the checker leg, like cpu_baseline).  reference cpp/tracker.cc:133-192, cpp/refiner.cc:716-725."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import c5_endtoend
+
+    t0 = time.perf_counter()
+    r = c5_endtoend.run(width=1920, height=1080, frames=300, oracle_frames=0, oracle_stride=29, refine_iterations=30, oracle_workers=10)
+    s = r["tracking"].get("vs_cpu_reference_sampled", {})
+    return {"workload": "C5 1920x1080 300 rendered frames end to end: GFTT + LK -> SQLite -> ray casting + PnP (tracker.cc) -> refiner.cc on the GPU",
+            "analysis_with_sqlite_fps": r["analysis"]["fps"], "tracking_fps": r["tracking"]["frames_per_s"],
+            "tracking_mean_lm_iterations": r["tracking"]["mean_lm_iterations"], "keypoints_per_frame": r["tracking"]["keypoints_per_frame"],
+            "refinement_seconds": r["refinement"]["seconds"], "refinement_iterations": r["refinement"]["iterations"],
+            "refinement_cost_before_after": r["refinement"]["cost"],
+            "pose_error_vs_cpu_reference": {"sampled_frames": len(s.get("frames", [])), "rotation_rad_max": s.get("rotation_rad_max"),
+                                            "translation_rel_max": s.get("translation_rel_max"),
+                                            "tolerance": "1e-4 rad, 1e-4 |t| (SURVEY 8(d))",
+                                            "what": "float64 numpy restatement of tracker.cc (oracle/pnp_oracle.py) on the same database, "
+                                                    "each sampled frame from the GPU's poses of its source frames"},
+            "pose_error_vs_truth": {"tracking": r["tracking"]["vs_truth"], "refined": r["refinement"]["vs_truth"]},
+            "seconds_total": round(time.perf_counter() - t0, 2)}
+
+
+def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e, arith=None, light=False):
+    """One configuration: returns the result object of this rank (rank 0's is printed).  light: the timed regions of the
+    headline path only (the other arithmetic mode beside the headline)."""
     import torch
     import torch.distributed as dist
 
@@ -170,6 +257,10 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
         return clip_frames[t if t < CLIP_FRAMES else 2 * CLIP_FRAMES - 2 - t]
 
     ctx = hip.Context(dev.index or 0)
+    if arith is not None:
+        ctx.set_arithmetic(ARITH_FLAGS[arith])
+    global LAST_ARITH
+    arith_name = LAST_ARITH = ARITH_NAMES[ctx.arithmetic]
     gopt_kw, fopt_kw = {}, {"max_level": max_level}
     prewarm = max(MIN_PREWARM, W)
     dist_path = world > 1 or args.force_dist_path
@@ -209,7 +300,11 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         regions = int(tt.item())
 
-    log = stitch = None
+    # ---- the ways the K steps are run: the N = 1 path (records to the host), and with N > 1 the device log + a stitch ----
+    log = None
+    stitches = {}      # mode -> stitch object
+    unavailable = {}   # mode -> why
+    modes = ["n1"]
     if dist_path:
         # device-resident record log: the stitch all-gathers these bytes, no host copy of the payload
         from polychase_amd import distributed as D
@@ -223,92 +318,150 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
                 print(f"[bench] gloo side group unavailable ({e}); exchanging piece sizes over RCCL", file=sys.stderr)
         # POLYCHASE_BENCH_STITCH=rccl: the RCCL all-gather; default: peer copies over xGMI by the copy engines, falling back
         # to the all-gather when the ranks cannot map each other's buffers (distributed.PeerLogStitch says why)
-        stitch = D.make_log_stitch(log, side_group=side, prefer=os.environ.get("POLYCHASE_BENCH_STITCH", "peer"))
-        stitch.warm_up()
+        prefer = os.environ.get("POLYCHASE_BENCH_STITCH", "peer")
+        first = D.make_log_stitch(log, side_group=side, prefer=prefer)
         piece_frames = max(1, K // 8)
-        stitch.reserve(K // piece_frames + piece_frames + 1, D.log_capacity_bytes(piece_frames + 1, max_kp))
 
-    region_s, lk_avg, lk_busy = [], [], []
-    lk_launches = 0
+        def prepare(st):
+            st.warm_up()
+            st.reserve(K // piece_frames + piece_frames + 1, D.log_capacity_bytes(piece_frames + 1, max_kp))
+            return st
+
+        first_mode = "peer" if isinstance(first, D.PeerLogStitch) else "rccl"
+        stitches[first_mode] = prepare(first)
+        modes = [first_mode]
+        if not light:
+            # A/B inside ONE job: the other stitch over the same log, and the N = 1 path on all ranks at once
+            if first_mode == "peer":
+                stitches["rccl"] = prepare(D.ChunkedLogStitch(log, side_group=side))
+                modes.append("rccl")
+            elif prefer == "peer":
+                unavailable["peer"] = ("the ranks could not map each other's buffers (HIP IPC); the job fell back to the RCCL all-gather"
+                                       if dist.is_initialized() else "one rank without a process group: nothing to push")
+            modes.append("n1")
+
+    def run_regions(mode):
+        """`regions` timed K-step regions in one mode -> per-region statistics"""
+        nonlocal nxt
+        stitch = stitches.get(mode)
+        res = {"region_s": [], "lk_avg": [], "lk_busy": [], "lk_launches": 0, "rank_dt": [], "finish_ms": [], "log_bytes": []}
+        for _ in range(regions):
+            timed = range(nxt, nxt + K)
+            nxt += K
+            if stitch is not None:
+                an.an.set_device_log(log)   # resets the log (synchronises: outside the timed region)
+                stitch.reset()              # ... and the pieces gathered in the previous region
+            barrier()
+            ctx.enable_timing(["lk"])   # HIP events around the dominant kernel only (2 records per step)
+            ctx.reset_timing()
+            finish_ms = 0.0
+            t0 = time.perf_counter()
+            if stitch is None:
+                an.run(timed, sink, copy=False)
+            else:
+                # the same loop as ClipAnalyzer.run, plus: whenever the last frame1 of a piece has been collected (its log
+                # bytes are complete), all-gather that piece -- the transfer runs beside the LK launches of the
+                # following frames; only the last piece is exposed (SURVEY 8(e): the one collective of the path)
+                piece = max(1, K // 8)
+                log_end = {}
+                piece_start = 0
+
+                def collect_one():
+                    nonlocal piece_start
+                    r = an.an.collect(False)
+                    sink(*r)
+                    done = r[0] - timed.start + 1
+                    # the last frames of the region go one by one: what is still on the wire when the last job has been
+                    # collected is one frame, not a piece
+                    if done % piece == 0 or done > K - piece:
+                        stitch.gather(piece_start, log_end[r[0]])
+                        piece_start = log_end[r[0]]
+
+                for f in timed:
+                    if an.an.pending == an.max_jobs:
+                        collect_one()
+                    an.submit(f)
+                    log_end[f] = an.an.device_log_used
+                while an.an.pending:
+                    collect_one()
+                tf = time.perf_counter()
+                stitch.finish()             # peer copies: this rank's pushes landed, sizes exchanged, the ranks have met
+                torch.cuda.synchronize()    # the all-gather's payload is stream-ordered: this wait ends it
+                finish_ms = (time.perf_counter() - tf) * 1e3
+                res["log_bytes"].append(int(an.an.device_log_used))
+            barrier()
+            dt = time.perf_counter() - t0
+            mine = [dt, finish_ms]
+            if dist.is_initialized():
+                allr = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+                dist.all_gather(allr, torch.tensor(mine, dtype=torch.float64, device=dev))
+                allr = [[float(x) for x in t.tolist()] for t in allr]
+            else:
+                allr = [mine]
+            dt = max(a[0] for a in allr)          # the MAX over ranks is the region's time
+            res["region_s"].append(dt)
+            res["rank_dt"].append([a[0] for a in allr])
+            res["finish_ms"].append(max(a[1] for a in allr))
+            timing = ctx.timing()
+            lk_n, lk_ms = timing["lk"]
+            res["lk_launches"] += lk_n
+            res["lk_avg"].append(lk_ms / max(1, lk_n))
+            res["lk_busy"].append(ctx.busy_ms("lk") / max(1, lk_n))
+            ctx.enable_timing(False)
+            if stitch is not None:
+                # outside the timed region: every rank's shard must parse and hold exactly K records in frame order
+                an.an.set_device_log(None)
+                for r, (buf, used) in enumerate(stitch.rank_logs()):
+                    recs = D.parse_device_log(buf, used)
+                    assert len(recs) == K and [x[0] for x in recs] == list(range(recs[0][0], recs[0][0] + K)), "stitched log is not K consecutive frames"
+                    # the shards are disjoint and in rank order: rank r's ids are this rank's ids shifted by (r - rank) strides
+                    assert recs[0][0] == timed.start + (r - rank) * RANK_ID_STRIDE, "stitched shards are not the ranks' disjoint id ranges"
+                    if r == rank:
+                        assert [x[0] for x in recs] == list(timed)
+                        assert [len(x[1]) for x in recs] == n_kps[-K:] and [sum(len(v[0]) for v in x[2].values()) for x in recs] == n_rows[-K:]
+        order = np.argsort(res["region_s"])
+        res["mid"] = int(order[len(order) // 2])      # the median region
+        return res
+
     n_kps.clear()
     n_rows.clear()
-    for _ in range(regions):
-        timed = range(nxt, nxt + K)
-        nxt += K
-        if dist_path:
-            an.an.set_device_log(log)   # resets the log (synchronises: outside the timed region)
-            stitch.reset()              # ... and the pieces gathered in the previous region
-        barrier()
-        ctx.enable_timing(["lk"])   # HIP events around the dominant kernel only (2 records per step)
-        ctx.reset_timing()
-        t0 = time.perf_counter()
-        if not dist_path:
-            an.run(timed, sink, copy=False)
-        else:
-            # the same loop as ClipAnalyzer.run, plus: whenever the last frame1 of a piece has been collected (its log
-            # bytes are complete), all-gather that piece over RCCL -- the transfer runs beside the LK launches of the
-            # following frames; only the last piece is exposed (the one collective of the path)
-            piece = max(1, K // 8)
-            log_end = {}
-            piece_start = 0
-
-            def collect_one():
-                nonlocal piece_start
-                r = an.an.collect(False)
-                sink(*r)
-                done = r[0] - timed.start + 1
-                # the last frames of the region go one by one: what is still on the wire when the last job has been
-                # collected is one frame, not a piece
-                if done % piece == 0 or done > K - piece:
-                    stitch.gather(piece_start, log_end[r[0]])
-                    piece_start = log_end[r[0]]
-
-            for f in timed:
-                if an.an.pending == an.max_jobs:
-                    collect_one()
-                an.submit(f)
-                log_end[f] = an.an.device_log_used
-            while an.an.pending:
-                collect_one()
-            stitch.finish()             # peer copies: this rank's pushes landed, sizes exchanged, the ranks have met
-        barrier()
-        dt = time.perf_counter() - t0
-        if dist.is_initialized():
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        region_s.append(dt)
-        timing = ctx.timing()
-        lk_n, lk_ms = timing["lk"]
-        lk_launches += lk_n
-        lk_avg.append(lk_ms / max(1, lk_n))
-        lk_busy.append(ctx.busy_ms("lk") / max(1, lk_n))
-        ctx.enable_timing(False)
-        if dist_path:
-            # outside the timed region: every rank's shard must parse and hold exactly K records in frame order
-            an.an.set_device_log(None)
-            for r, (buf, used) in enumerate(stitch.rank_logs()):
-                recs = D.parse_device_log(buf, used)
-                assert len(recs) == K and [x[0] for x in recs] == list(range(recs[0][0], recs[0][0] + K)), "stitched log is not K consecutive frames"
-                # the shards are disjoint and in rank order: rank r's ids are this rank's ids shifted by (r - rank) strides
-                assert recs[0][0] == timed.start + (r - rank) * RANK_ID_STRIDE, "stitched shards are not the ranks' disjoint id ranges"
-                if r == rank:
-                    assert [x[0] for x in recs] == list(timed)
-                    assert [len(x[1]) for x in recs] == n_kps[-K:] and [sum(len(v[0]) for v in x[2].values()) for x in recs] == n_rows[-K:]
+    results = {m: run_regions(m) for m in modes}
     gc.enable()
-    stitch_name = None
-    if dist_path:
-        stitch_name = stitch.name
-        stitch.close()
-        del stitch, log
+    stitch_names = {m: st.name for m, st in stitches.items()}
+    for st in stitches.values():
+        st.close()
+    stitches.clear()
+    log = None
     an.close()
-    order = np.argsort(region_s)
-    mid = int(order[len(order) // 2])      # the median region
-    dt = region_s[mid]
+    head = results[modes[0]]
+    mid = head["mid"]
+    dt = head["region_s"][mid]
+    fps = world * K / dt
+
+    def mode_summary(m):
+        r = results[m]
+        i = r["mid"]
+        d = {"value": world * K / r["region_s"][i], "unit": "frames/s", "ms_per_step": r["region_s"][i] / K * 1e3,
+             "per_rank_ms_per_step_min_max": [min(r["rank_dt"][i]) / K * 1e3, max(r["rank_dt"][i]) / K * 1e3],
+             "timed_regions": len(r["region_s"]),
+             "region_ms_min_median_max": [min(r["region_s"]) * 1e3, r["region_s"][i] * 1e3, max(r["region_s"]) * 1e3]}
+        if m != "n1":
+            b = r["log_bytes"][i]
+            d.update({"stitch": stitch_names[m],
+                      # after the last job of the region has been collected: waiting for the pieces still on the wire
+                      "exposed_stitch_ms_per_region": r["finish_ms"][i],
+                      "record_bytes_per_rank_per_region": b,
+                      # xGMI is point to point: each of the world - 1 peers receives one copy of this rank's records
+                      "per_peer_link_GBs": b / r["region_s"][i] / 1e9,
+                      "received_GBs_per_gpu": (world - 1) * b / r["region_s"][i] / 1e9})
+        else:
+            d["what"] = ("the N = 1 code path (records delivered to the host, no device log, no stitch) on all ranks at once: "
+                         "the analysis-only rate, comparable with the one-GPU benchmark line")
+        return d
 
     # per-class kernel breakdown from a short extra pass over the same frames (not part of `value`)
     breakdown = None
-    if not args.no_breakdown:
+    if not args.no_breakdown and not light:
         n_extra = min(K, 20)
         an = ClipAnalyzer(ctx, w, h, first_id, 1 << 30, source, hip.gftt_options(**gopt_kw), hip.flow_options(**fopt_kw), max_jobs=3)
         an.run(range(first_id + 8, first_id + 8 + 20), None)
@@ -324,63 +477,84 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
     if rank == 0:
         P = w * h
         S = level_pixels(w, h, max_level)
-        lk_avg_ms, lk_busy_ms = lk_avg[mid], lk_busy[mid]
+        lk_avg_ms, lk_busy_ms = head["lk_avg"][mid], head["lk_busy"][mid]
         lk_bytes = (5 + 8) * S  # LK I-side 5S (image S + derivs 4S) + J-side S per target, K_f = 8
         frame_bytes = 14 * P + (12 + 8) * S
         achieved = lk_bytes / (lk_avg_ms * 1e-3) / 1e9 if lk_avg_ms > 0 else 0.0
-        fps = world * K / dt
-        # counters of the LK launch: they cannot be collected in-process, so they come from the committed rocprofv3 --pmc
-        # passes of the same command (profiles/lk_hbm_traffic.json names the run); labelled as such below
+        kernel = LK_KERNEL.get(arith_name, "lk3_kernel<10>")
+        # counters of the LK launch: measured now by short rocprofv3 --pmc passes (one GPU, not under a profiler already),
+        # else from the committed profile of a builder-run pass, labelled as such
+        counters = None
+        if not light and world == 1 and not args.no_counters and not args.force_dist_path:
+            try:
+                counters = measure_counters(cfg, arith_name)
+            except Exception as e:
+                print(f"[bench] counter passes failed: {e}", file=sys.stderr)
         traffic = valu = src = calib = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "lk_hbm_traffic.json")))
-            traffic = tj[cfg]["traffic_bytes"]
-            valu = tj[cfg].get("valu_insts")
-            src = tj.get("source")
             calib = tj.get("fetch_size_calibration")
+            if counters is None:
+                blk = tj.get(arith_name, tj).get(cfg) or tj[cfg]
+                traffic, valu, src = blk["traffic_bytes"], blk.get("valu_insts"), tj.get("source")
         except Exception:
             pass
-        hbm = {"bound": "hbm", "kernel": LK_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-               "traffic_source": src or "profiles/lk_hbm_traffic.json (builder-run rocprofv3 --pmc passes, not this run)",
-               "traffic_calibration": calib,
-               "algorithmic_bytes_per_launch": lk_bytes, "avg_launch_ms": lk_avg_ms, "launches": lk_launches,
-               # two launches are in flight at a time (job lanes): each one's start-to-end time exceeds the GPU time it
-               # costs.  `achieved` uses the start-to-end time (comparable with rocprofv3's per-dispatch durations); the
-               # per-launch share of the GPU is given beside it.
-               "launch_overlap": lk_avg_ms / lk_busy_ms if lk_busy_ms > 0 else None,
-               "busy_ms_per_launch": lk_busy_ms,
-               "achieved_per_busy_time": lk_bytes / (lk_busy_ms * 1e-3) / 1e9 if lk_busy_ms > 0 else None}
-        # What bounds the dominant kernel is VALU issue (a gather: its HBM traffic is about its algorithmic bytes and 1-2 %
-        # of the HBM peak by construction).  `roofline` therefore states the limiter -- wave-instructions per second against
-        # the measured issue ceiling of the kernel's instruction mix -- and carries the HBM block the contract asks for
-        # beside it (`hbm`; also at the top level as `hbm_roofline`).
+        if counters is not None:
+            # FETCH_SIZE tallies every 128-B line the L2 fetches as 64 B (tools/fetch_calib.hip, profiles/r03_fetch_calibration.json)
+            traffic = (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
+            valu = counters["SQ_INSTS_VALU"]
+            src = ("this run: rocprofv3 --pmc SQ_INSTS_VALU / FETCH_SIZE / WRITE_SIZE, one pass each, of tools/lk_bench.py "
+                   f"--config {cfg} --arith {arith_name} on this box (the same kernel on frame 100 of the same clip), per launch; "
+                   "traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 B")
+        roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "counters_measured_in_run": counters is not None,
+                    "traffic_source": src or "none",
+                    "traffic_calibration": calib,
+                    "traffic_over_algorithmic": traffic / lk_bytes if traffic else None,
+                    "algorithmic_bytes_per_launch": lk_bytes, "avg_launch_ms": lk_avg_ms, "launches": head["lk_launches"],
+                    # two launches are in flight at a time (job lanes): each one's start-to-end time exceeds the GPU time it
+                    # costs.  `achieved` uses the start-to-end time (comparable with rocprofv3's per-dispatch durations); the
+                    # per-launch share of the GPU is given beside it.
+                    "launch_overlap": lk_avg_ms / lk_busy_ms if lk_busy_ms > 0 else None,
+                    "busy_ms_per_launch": lk_busy_ms,
+                    "achieved_per_busy_time": lk_bytes / (lk_busy_ms * 1e-3) / 1e9 if lk_busy_ms > 0 else None,
+                    "note": "a gather that is VALU-issue bound: see valu_roofline for the limiter"}
+        valu_roofline = None
         if valu and lk_busy_ms > 0:
             v_ach = valu / (lk_busy_ms * 1e-3) / 1e9
-            roofline = {"bound": "valu", "kernel": LK_KERNEL, "achieved": v_ach, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-                        "frac": v_ach / VALU_PEAK_GINST, "traffic": traffic,
-                        "valu_wave_instructions_per_launch": valu,
-                        "valu_source": src or "profiles/lk_hbm_traffic.json (SQ_INSTS_VALU of a builder-run rocprofv3 --pmc pass, not this run)",
-                        "peak_source": f"tools/valu_issue.hip, profiles/r03_valu_issue.json: {VALU_CYCLES_PER_INST} cycles per wave64 "
-                                       "v_dot2_i32_i16 / v_mad_i32_i16 / v_perm_b32 and SIMD at 8 wavefronts per SIMD (4.5 at the kernel's 3); "
-                                       "1024 SIMDs x 2.4 GHz",
-                        "time_base": "GPU-busy time of the launches (busy_ms_per_launch), measured in this run with HIP events on the lanes' streams",
-                        "hbm": hbm}
-        else:
-            roofline = dict(hbm, note="no VALU counter file: the HBM block only")
+            valu_roofline = {"bound": "valu", "kernel": kernel, "achieved": v_ach, "unit": "G wave-instructions/s",
+                             "peak_measured_for_the_mix": VALU_PEAK_GINST, "frac_of_measured_peak": v_ach / VALU_PEAK_GINST,
+                             "peak_nominal": VALU_NOMINAL_GINST, "frac_of_nominal_peak": v_ach / VALU_NOMINAL_GINST,
+                             "valu_wave_instructions_per_launch": valu, "counters_measured_in_run": counters is not None,
+                             "valu_source": src,
+                             "peak_source": f"measured: tools/valu_issue.hip, profiles/r03_valu_issue.json: {VALU_CYCLES_PER_INST} cycles per wave64 "
+                                            "v_dot2_i32_i16 / v_mad_i32_i16 / v_perm_b32 and SIMD at 8 wavefronts per SIMD (4.5 at the kernel's 3); "
+                                            f"nominal: the guide's {VALU_NOMINAL_CYCLES:.0f}-cycle VALU rate (MI355X_MICROARCH.md); 1024 SIMDs x 2.4 GHz",
+                             "time_base": "GPU-busy time of the launches (busy_ms_per_launch), measured in this run with HIP events on the lanes' streams"}
+        workload = label
+        cfg_extra = {}
+        if world > 1 and cfg == "c3":
+            fpg = C4_FRAMES // 8
+            workload = (f"C4 3840x2160 2400-frame clip frame-sharded across {world} x MI355X (the per-rank workload of C4: contiguous frame1 "
+                        f"ranges, {fpg} frames per GPU at 8 GPUs + an 8-frame halo per side, stitch = all-gather of the flow records), "
+                        f"timed in steady-state regions of {K} frame1 per rank")
+            cfg_extra = {"c4_clip_frames": C4_FRAMES, "c4_frames_per_gpu_at_8": fpg, "halo_frames_per_side": 8,
+                         "halo_overhead": "16 extra frames per shard are converted and pyramided, not detected or tracked: "
+                                          f"16 / {fpg} of the pyramid kernel's time per shard (kernel_ms_per_frame.pyramid), not in the steady-state step"}
         out = {
             "metric": "optical-flow frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 fixed-point + f32 2x2 solve",
             "data": "synthetic",
-            "config": {"workload": label, "width": w, "height": h, "max_level": max_level,
-                       "window": 10, "pairs_per_frame": 8, "frames_per_gpu": K,
+            "config": {"workload": workload, "width": w, "height": h, "max_level": max_level,
+                       "window": 10, "pairs_per_frame": 8, "frames_per_gpu": K, "arith": arith_name,
                        "mean_keypoints": float(np.mean(n_kps)), "mean_flow_rows": float(np.mean(n_rows)),
                        "parallelism": f"frame-shard x{world}" if world > 1 else "single GPU",
-                       "untimed_prewarm_steps": prewarm + 8, "timed_regions": len(region_s),
-                       "region_ms_min_median_max": [min(region_s) * 1e3, dt * 1e3, max(region_s) * 1e3]},
+                       "untimed_prewarm_steps": prewarm + 8, "timed_regions": len(head["region_s"]),
+                       "region_ms_min_median_max": [min(head["region_s"]) * 1e3, dt * 1e3, max(head["region_s"]) * 1e3], **cfg_extra},
             "roofline": roofline,
-            "hbm_roofline": hbm,
+            "valu_roofline": valu_roofline,
             "path_roofline": {"algorithmic_bytes_per_frame": frame_bytes,
                               "achieved_GBs": frame_bytes * (K / dt) / 1e9,
                               "frac": frame_bytes * (K / dt) / 1e9 / HBM_PEAK_GBS},
@@ -388,8 +562,15 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e):
         }
         if dist.is_initialized():
             out["collectives_backend"] = dist.get_backend()   # "nccl" = RCCL; "gloo" only under the SHARE_GPU testing aid
-        if stitch_name:
-            out["config"]["stitch"] = stitch_name
+            out["world_size"] = dist.get_world_size()
+        if modes[0] != "n1":
+            out["config"]["stitch"] = stitch_names[modes[0]]
+            if not light:
+                ab = {m: mode_summary(m) for m in modes if m != "n1"}
+                ab.update({m: {"unavailable": why} for m, why in unavailable.items()})
+                out["stitch_ab"] = ab
+                out["analysis_only"] = mode_summary("n1")
+                out["per_rank_ms_per_step_min_max"] = ab[modes[0]]["per_rank_ms_per_step_min_max"]
         if with_cpu:
             f1s = [first_id + 8 + i for i in range(K)]
             out["cpu_baseline"] = cpu_baseline(lambda f: source(f).cpu().numpy(), f1s, gopt_kw, fopt_kw,
@@ -447,6 +628,10 @@ def main():
     ap.add_argument("--force-dist-path", action="store_true",
                     help="exercise the device-log + stitch code path with a single rank (testing)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-baseline sample")
+    ap.add_argument("--no-counters", action="store_true", help="no rocprofv3 --pmc passes after the timed regions (committed profile instead)")
+    ap.add_argument("--no-arith-modes", action="store_true", help="skip the second run of the K steps in the other arithmetic mode")
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 end-to-end block (analysis -> tracking -> refinement)")
+    ap.add_argument("--arith", default=None, choices=sorted(ARITH_FLAGS), help="arithmetic mode of the headline (default: the library's)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -494,15 +679,38 @@ def main():
 
     K, W = args.steps, args.warmup
     single = world == 1 and not args.force_dist_path
-    out = run_config(args.config, K, W, args, rank, world, dev, with_cpu=single and not args.no_cpu_baseline,
-                     with_e2e=single and not args.no_end_to_end)
+    under_profiler = any(k.startswith("ROCPROF") for k in os.environ)   # a run under rocprofv3 starts no counter passes of its own
+    if under_profiler:
+        args.no_counters = args.no_arith_modes = True
+
+    def with_arith_modes(cfg, steps, **kw):
+        """the configuration in the headline's arithmetic mode, then the same K steps in the other one (light: regions only)"""
+        o = run_config(cfg, steps, W, args, rank, world, dev, arith=args.arith, **kw)
+        if not args.no_arith_modes:
+            head_mode = LAST_ARITH
+            other = "canonical" if head_mode != "canonical" else "opencv_x86"
+            alt = run_config(cfg, steps, W, args, rank, world, dev, with_cpu=False, with_e2e=False, arith=other, light=True)
+            if rank == 0:
+                o["arith_modes"] = {head_mode: {"value": o["value"], "ms_per_step": o["ms_per_step"], "lk_avg_launch_ms": o["roofline"]["avg_launch_ms"]},
+                                    other: {"value": alt["value"], "ms_per_step": alt["ms_per_step"], "lk_avg_launch_ms": alt["roofline"]["avg_launch_ms"]},
+                                    "unit": "frames/s", "default": "opencv_x86",
+                                    "what": "opencv_x86 = the execution of the OpenCV build the reference links (FMA in the AVX2 Sobel column "
+                                            "filter, LK sums in the SSE lane order); canonical = no FMA, LK sums exact in integers (DESIGN.md section 2)"}
+        return o
+
+    out = with_arith_modes(args.config, K, with_cpu=single and not args.no_cpu_baseline, with_e2e=single and not args.no_end_to_end)
     if args.config == "c2" and not args.no_c3:
-        # the 4K configuration rides along (fewer steps: a step is 4.5x longer); its CPU sample is shorter
+        # the 4K configuration rides along with the same K steps per region; its CPU sample is shorter.  With N > 1 this is
+        # C4's per-rank workload (config.workload says so)
         args.cpu_seconds = min(args.cpu_seconds, 8.0)
-        c3 = run_config("c3", max(10, K // 2), W, args, rank, world, dev, with_cpu=single and not args.no_cpu_baseline,
-                        with_e2e=single and not args.no_end_to_end)
+        c3 = with_arith_modes("c3", K, with_cpu=single and not args.no_cpu_baseline, with_e2e=single and not args.no_end_to_end)
         if rank == 0:
             out["c3"] = c3
+    if single and rank == 0 and args.config == "c2" and not args.no_c5 and not under_profiler:
+        try:
+            out["c5"] = c5_block()
+        except Exception as e:
+            out["c5"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

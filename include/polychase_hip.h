@@ -43,10 +43,13 @@ typedef struct pc_frame pc_frame;
 typedef struct pc_gftt_options {
     double quality_level; /* 0.01 */
     double min_distance;  /* 5.0 */
-    int block_size;       /* 3   (only 3 is implemented on the device) */
-    int gradient_size;    /* 3   (only 3) */
+    int block_size;       /* 3   (any size >= 1: 3 runs the tiled kernel, others the general pair of kernels) */
+    int gradient_size;    /* 3   (Sobel aperture; only 3 on the device, others: PC_E_INVALID -- the addon never sets it) */
     int max_corners;      /* 0 = unlimited */
-    int use_harris;       /* 0   (harris branch not implemented: PC_E_INVALID) */
+    int use_harris;       /* 0   (1: cornerHarris, gftt.cc:31-33 -- bit-exact against the oracle's restatement of calcHarris'
+                                 SCALAR expression (k in double) for every pixel; a real x86 OpenCV computes all but the last
+                                 width % 4 / % 8 columns in its SIMD path, in float with (float)k: that execution is NOT
+                                 emulated in any arithmetic mode -- the reference's addon never takes this branch) */
     double harris_k;      /* 0.04 */
     int grid_rows;        /* 4 */
     int grid_cols;        /* 4 */
@@ -68,6 +71,16 @@ const char* pc_last_error(void);
 /* Library / build identification ("polychase_hip gfx950 ..."). */
 const char* pc_version(void);
 
+/* Process-wide preparation of the HIP runtime for the engine's streams: raises GPU_MAX_HW_QUEUES to 16 unless the
+ * environment already holds a value (the engine keeps five streams busy; the runtime maps all streams of a process onto
+ * that many hardware queues, 4 by default, and two streams on one queue wait for each other's commands: DESIGN.md
+ * section 3).  The runtime reads the variable when the process FIRST touches HIP, so this must run before that;
+ * pc_context_create calls it, hosts that initialise HIP themselves (torch, Cycles) call it earlier -- the polychase_core
+ * module does when it is imported.  Idempotent.  *runtime_was_up (may be null) = 1 when the ROCm runtime of this process
+ * was already initialised at the first call (the setting then has no effect on this process); *hw_queues (may be null) =
+ * the value of the variable after the call.  Nothing happens at dlopen any more (round 3 used a library constructor). */
+int pc_runtime_init(int* runtime_was_up, int* hw_queues);
+
 /* ---- context: one per GPU (one process per GPU in multi-GPU runs) ---- */
 int pc_context_create(int device_index, pc_context** out);
 void pc_context_destroy(pc_context* ctx);
@@ -77,13 +90,16 @@ int pc_context_synchronize(pc_context* ctx);
  *   PC_ARITH_LK_X86_ORDER   the LK sums in fp32 in the order of LKTrackerInvoker's CV_SIMD128 path on x86 (four vector lanes
  *                           over the first (win / 8) * 8 columns, a scalar accumulator over the rest; calcOpticalFlowPyrLK,
  *                           cpp/opticalflow.cc:119-125): differs from the canonical order only where a window's partial
- *                           sums exceed 2^24 (step edges), by <= ~2e-3 px; runs on the generic LK kernel (several times slower)
+ *                           sums exceed 2^24 (step edges), by <= ~2e-3 px.  Windows 4-11 run the canonical integer data
+ *                           path plus a proof that the fp32 sums are exact, and the x86 order itself where the proof fails
+ *                           (+10-18 % on the LK launch); other windows run the generic kernel
  *   PC_ARITH_SOBEL_FMA      the fused multiply-add of the AVX2-dispatched symmetric column filter of Sobel inside
  *                           cornerMinEigenVal (cpp/feature_detection/gftt.cc:35): same corners, the (value, address)
  *                           order of near-ties -- i.e. keypoint indices -- as a stock x86 build produces them
  *   PC_ARITH_OPENCV_X86     both
- * Bit for bit what oracle/pc_oracle.c computes under pco_set_opencv_emulation(flags).  Default: PC_ARITH_CANONICAL, or the
- * environment variable POLYCHASE_ARITH = canonical | opencv_x86 | lk_x86 | sobel_fma at context creation. */
+ * Bit for bit what oracle/pc_oracle.c computes under pco_set_opencv_emulation(flags).  Default: PC_ARITH_OPENCV_X86 -- the
+ * execution of the OpenCV build the reference links (vcpkg, x86-64: SSE baseline, AVX2 / FMA3 dispatched)
+ * -- or the environment variable POLYCHASE_ARITH = canonical | opencv_x86 | lk_x86 | sobel_fma at context creation. */
 #define PC_ARITH_CANONICAL 0
 #define PC_ARITH_LK_X86_ORDER 1
 #define PC_ARITH_SOBEL_FMA 2

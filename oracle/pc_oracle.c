@@ -38,17 +38,19 @@ void pco_rgb2gray(const uint8_t* rgb, int w, int h, uint8_t* gray) {
 
 /* ------------------------------------------------------------------------------------------- */
 /* ------------------------------------------------------------------------------------------- */
-/* Where OpenCV's result depends on how the host executes it, the oracle has ONE canonical order (the one
- * the GPU matches bit for bit) and, for measuring how far that is from an x86 OpenCV build, an emulation of
- * the x86 SIMD order (pco_set_opencv_emulation; tests/test_oracle_cpu.py and DESIGN.md section 2 report the
- * differences; tests/opencv_crosscheck.py checks both against a real cv2 where one exists):
+/* Where OpenCV's result depends on how the host executes it, the oracle has a canonical order (no FMA, LK sums exact in
+ * integers: flags = 0) and an emulation of the x86 SIMD execution (pco_set_opencv_emulation).  THE DEFAULT IS THE X86
+ * EXECUTION (both flags): what the OpenCV build the reference links most probably runs (vcpkg, x86-64, SSE baseline with
+ * AVX2 / FMA3 dispatch) -- the GPU library has the same default (PC_ARITH_OPENCV_X86) and matches
+ * either order bit for bit.  tests/test_oracle_emulation_cpu.py and DESIGN.md section 2 report the differences between the
+ * two; tests/opencv_crosscheck.py checks both against a real cv2 where one exists:
  *   PCO_EMU_LK_SIMD    LKTrackerInvoker, CV_SIMD128 path (video/lkpyramid.cpp, baseline SSE2/SSE3 build): the
  *                      structure tensor and the mismatch vector are summed in fp32 -- four vector lanes over the
  *                      first (win/8)*8 columns plus a scalar accumulator over the rest, combined at the end --
  *                      instead of exactly in integers.  v_muladd is mul + add there (no FMA in the baseline).
  *   PCO_EMU_SOBEL_FMA  the symmetric 3-tap column filter of Sobel (imgproc/filter.simd.hpp, dispatched to AVX2
  *                      on any recent x86): v_muladd(S0 + S2, k1, v_muladd(S1, k0, 0)) with a fused multiply-add. */
-static int g_emulation = 0;
+static int g_emulation = PCO_EMU_OPENCV_X86;
 void pco_set_opencv_emulation(int flags) { g_emulation = flags; }
 int pco_get_opencv_emulation(void) { return g_emulation; }
 

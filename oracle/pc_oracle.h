@@ -113,10 +113,12 @@ int pco_analyze_clip(const uint8_t* const* frames, int n_frames, int w, int h, i
                      const pco_flow_options* fopt, int threads, int feature_threads,
                      pco_record_cb cb, void* user);
 
-/* Emulation of the x86 SIMD execution order of OpenCV (see pc_oracle.c); 0 = the canonical order the GPU matches.
- * Process-wide, set before calling; not thread safe against running calls. */
+/* Emulation of the x86 SIMD execution order of OpenCV (see pc_oracle.c); 0 = the canonical order; the default is
+ * PCO_EMU_OPENCV_X86, like the GPU library's PC_ARITH_OPENCV_X86.  Process-wide, set before calling; not thread safe
+ * against running calls. */
 #define PCO_EMU_LK_SIMD 1
 #define PCO_EMU_SOBEL_FMA 2
+#define PCO_EMU_OPENCV_X86 3
 void pco_set_opencv_emulation(int flags);
 int pco_get_opencv_emulation(void);
 

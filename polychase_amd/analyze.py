@@ -105,8 +105,14 @@ def analyze(width: int, height: int, first_frame: int, num_frames: int, frame_ac
     if rank == 0:
         # the receiver asks rank 1 for its first piece at once; what arrives waits (bounded) until this shard is stored
         gather.start()
-        res = core.generate_optical_flow_shard(vi, frame_accessor, callback, database_path, begin, end, detector_options=gopt,
-                                               flow_options=fopt)
+        try:
+            res = core.generate_optical_flow_shard(vi, frame_accessor, callback, database_path, begin, end, detector_options=gopt,
+                                                   flow_options=fopt)
+        except BaseException:
+            # this rank's own shard failed: the other ranks are waiting for a credit (a blocking recv under a 24 h
+            # timeout) -- tell them to stop before the exception leaves (a negative credit; OrderedPieceGather.abort)
+            gather.abort()
+            raise
         st = res["stats"]
         cancelled = bool(res["cancelled"])
         t1 = time.perf_counter()
@@ -165,9 +171,13 @@ def _self_launch(n: int, argv) -> int:
         port = s.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    # the ranks keep the caller's working directory (relative --database / --npy paths mean what the user typed); the
+    # package is found through PYTHONPATH instead of a change of directory
+    parent = os.path.dirname(_HERE)
+    env["PYTHONPATH"] = parent + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-m", "polychase_amd.analyze", *argv]
-    return subprocess.call(cmd, env=env, cwd=os.path.dirname(_HERE))
+    return subprocess.call(cmd, env=env)
 
 
 def main(argv=None) -> int:

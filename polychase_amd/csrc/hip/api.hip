@@ -7,6 +7,12 @@
 // reference cpp/feature_detection/gftt.cc:100-164).  No pixel arithmetic happens on the CPU.
 #include "api_internal.hpp"
 
+#include <dirent.h>
+#include <unistd.h>
+
+#include <cstring>
+#include <mutex>
+
 namespace pc {
 std::string& last_error() {
     thread_local std::string e;
@@ -455,9 +461,35 @@ using namespace pc_api;
 // multiplexes streams onto GPU_MAX_HW_QUEUES = 4 hardware queues by default, and two streams on one queue wait for each
 // other's commands: with host frames the upload stream then shares a queue with a lane or the preparation stream
 // (generate_optical_flow_database on 300 host frames at 1080p: 2050 frames/s on 4 queues, 2650-2840 with a queue per stream;
-// idle queues cost nothing; sixteen cover two contexts -- analysis engine and tracker -- plus the host's own streams).  The runtime reads the variable when the process first touches HIP, so the default is raised when this library is
-// LOADED -- effective whenever that happens before the host's first HIP call; a value set by the user is left alone.
-__attribute__((constructor)) static void pc_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// idle queues cost nothing; sixteen cover two contexts -- analysis engine and tracker -- plus the host's own streams).  The
+// runtime reads the variable when the process first touches HIP.  Round 3 raised the default in a library CONSTRUCTOR -- a
+// side effect of dlopen on every other HIP user of the process; since round 4 it is the explicit pc_runtime_init() below,
+// which pc_context_create (and the polychase_core module / polychase_amd.hip when they load the library) call: still
+// before this library's first HIP call, never behind the host's back, and it reports whether it came too late.
+static bool hsa_runtime_is_up() {
+    // the ROCm runtime holds /dev/kfd open from its initialisation on; nothing in this library has touched HIP when this runs
+    DIR* d = opendir("/proc/self/fd");
+    if (!d) return false;
+    bool up = false;
+    char link[64], target[256];
+    while (struct dirent* e = readdir(d)) {
+        if (e->d_name[0] == '.') continue;
+        snprintf(link, sizeof(link), "/proc/self/fd/%s", e->d_name);
+        const ssize_t n = readlink(link, target, sizeof(target) - 1);
+        if (n > 0) {
+            target[n] = 0;
+            if (strcmp(target, "/dev/kfd") == 0) {
+                up = true;
+                break;
+            }
+        }
+    }
+    closedir(d);
+    return up;
+}
+
+static std::once_flag g_runtime_once;
+static int g_runtime_was_up = 0, g_runtime_queues = 0;
 
 extern "C" {
 
@@ -484,9 +516,22 @@ void pc_flow_default_options(pc_flow_options* o) {
 const char* pc_last_error(void) { return pc::last_error().c_str(); }
 const char* pc_version(void) { return "polychase_hip 0.1 (gfx950, hand-written HIP)"; }
 
+int pc_runtime_init(int* runtime_was_up, int* hw_queues) {
+    std::call_once(g_runtime_once, [] {
+        g_runtime_was_up = hsa_runtime_is_up() ? 1 : 0;
+        setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0);   // a value set by the user wins
+        const char* v = getenv("GPU_MAX_HW_QUEUES");
+        g_runtime_queues = v ? atoi(v) : 0;
+    });
+    if (runtime_was_up) *runtime_was_up = g_runtime_was_up;
+    if (hw_queues) *hw_queues = g_runtime_queues;
+    return PC_OK;
+}
+
 int pc_context_create(int device_index, pc_context** out) {
     if (!out) return fail(PC_E_INVALID, "null out");
     *out = nullptr;
+    pc_runtime_init(nullptr, nullptr);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return fail(PC_E_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
@@ -529,7 +574,8 @@ int pc_context_create(int device_index, pc_context** out) {
         if (mode == "opencv_x86") c->arith = PC_ARITH_OPENCV_X86;
         else if (mode == "lk_x86") c->arith = PC_ARITH_LK_X86_ORDER;
         else if (mode == "sobel_fma") c->arith = PC_ARITH_SOBEL_FMA;
-        else if (mode != "canonical" && !mode.empty()) {
+        else if (mode == "canonical") c->arith = PC_ARITH_CANONICAL;
+        else if (!mode.empty()) {
             delete c;
             return fail(PC_E_INVALID, "POLYCHASE_ARITH=%s: expected canonical, opencv_x86, lk_x86 or sobel_fma", m);
         }

@@ -142,12 +142,12 @@ struct DetectScratch {
 
 struct pc_context {
     int device = 0;
-    int arith = PC_ARITH_CANONICAL;      // pc_context_set_arithmetic
+    int arith = PC_ARITH_OPENCV_X86;     // pc_context_set_arithmetic; the default = what a stock x86-64 OpenCV build executes
     // Stage-level calls run on `stream`.  pc_analyzer alternates its jobs (LK launch + compaction + device-log append +
     // record download of one frame1) over two job lanes, `stream` and `stream_b`: the launches of consecutive frames
     // overlap, so the tail of one launch and the gap before the next are filled by the other lane's wavefronts.
     // (HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, 4 unless raised, and a stream that shares a queue
-    // waits behind the other's commands: api.hip raises the default when the library is loaded -- pc_runtime_defaults.)
+    // waits behind the other's commands: pc_runtime_init raises the default before the first HIP call.)
     hipStream_t stream = nullptr;
     hipStream_t stream_b = nullptr;
     hipStream_t lane_stream(int lane) const { return lane ? stream_b : stream; }

@@ -53,6 +53,11 @@ namespace pc {
 #endif
 #define PC_LK3_SETPRIO_STAGING() do { if (PC_LK3_PRIO == 1) __builtin_amdgcn_s_setprio(2); else if (PC_LK3_PRIO == 2) __builtin_amdgcn_s_setprio(0); } while (0)
 #define PC_LK3_SETPRIO_ITER() do { if (PC_LK3_PRIO == 1) __builtin_amdgcn_s_setprio(0); else if (PC_LK3_PRIO == 2) __builtin_amdgcn_s_setprio(2); } while (0)
+// X86: failed exactness proofs of a wavefront within one level before the rest of the level runs in the x86 order without
+// trying the proof first (measured: tools/lk_variants.py, profiles/r04_x86_lk3_sticky.jsonl)
+#ifndef PC_LK3_X86_STICK_AFTER
+#define PC_LK3_X86_STICK_AFTER 1
+#endif
 #ifndef PC_LK3_WAVES
 #define PC_LK3_WAVES 1   // wavefronts per workgroup
 #endif
@@ -732,7 +737,9 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         // the x86 order for all of them (always correct; the proof only saves work) -- wavefront-uniform, so that a
         // wavefront never executes both paths iteration after iteration
         bool x86_ordered = false;
+        int x86_fails = 0;
         (void)x86_ordered;
+        (void)x86_fails;
         for (int j = 0; j < p.max_iters; j++) {
             PC_PROF_COUNT(8);
 #if PC_LK3_TRIM
@@ -968,7 +975,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                     ddf += dpp_f32<0x4E>(ddf);
                     const bool proven = ddf * cert_s <= 281474976710656.f * (1.f - 1.f / 1024.f);
                     if (__any(!proven)) {
-                        x86_ordered = true;
+                        x86_ordered = ++x86_fails >= PC_LK3_X86_STICK_AFTER;
                         run_ordered = true;
                     }
                 }

@@ -7,6 +7,7 @@
 
 #include <deque>
 
+#include "../../../include/polychase_hip.h"
 #include "../host/debug_images.h"
 #include "../host/flow_database.h"
 #include "../host/analysis.h"
@@ -204,6 +205,14 @@ OpticalFlowRunStats WriteOpticalFlowRecordsPy(const std::string& database_path, 
 
 PYBIND11_MODULE(polychase_core, m) {
     m.doc() = "polychase_core on MI355X: drop-in for the reference's pybind11 module (video-analysis path)";
+    // a hardware queue per stream of the engine: must be in the environment before the process first touches HIP -- importing
+    // the module is the earliest moment the add-on gives us (include/polychase_hip.h: pc_runtime_init)
+    {
+        int was_up = 0, queues = 0;
+        pc_runtime_init(&was_up, &queues);
+        m.attr("_runtime_was_up_at_import") = was_up != 0;   // not in the reference (diagnostics)
+        m.attr("_gpu_max_hw_queues") = queues;
+    }
 
     py::class_<Database>(m, "Database")
         .def(py::init<const std::string&>(), py::arg("path"))

@@ -627,15 +627,50 @@ class OrderedPieceGather:
 
     def finish(self, failed: bool = False):
         """No more pieces from this rank (failed: tell rank 0 the records are incomplete)."""
+        import queue
+        import time
+
         if self.rank == 0:
             return
+        if self._error:                       # the sender thread died (rank 0 is gone, a send failed): nothing more to say
+            raise self._error
         if self._thread is None:
             self._thread = self._threading.Thread(target=self._send_loop, daemon=True)
             self._thread.start()
-        self._q.put((None, -1 if failed else 0, 0, 0))
-        self._thread.join()
+        item = (None, -1 if failed else 0, 0, 0)
+        while True:
+            # never block on a full queue whose consumer has died: re-check the thread between short waits
+            if self._error:
+                raise self._error
+            if not self._thread.is_alive():
+                raise RuntimeError("the piece sender thread ended before the end-of-stream marker could be queued")
+            try:
+                self._q.put(item, timeout=0.05)
+                break
+            except queue.Full:
+                continue
+        while self._thread.is_alive():
+            self._thread.join(timeout=0.1)
+            if self._error:
+                break
         if self._error:
             raise self._error
+
+    def abort(self):
+        """Rank 0: its own part failed -- tell every rank still waiting for a credit to stop (a negative credit), so that
+        nobody sits in recv() until the process group's timeout.  Safe to call whether or not start() ran."""
+        import torch
+
+        if self.rank != 0:
+            return
+        self._aborted = True
+        if self._thread is not None:          # the receiver owns the control channel: it sends the negative credits itself
+            return
+        for r in range(1, self.world):
+            try:
+                self.dist.send(torch.full((1,), -1, dtype=torch.int64), dst=r, group=self.ctl)
+            except Exception:
+                pass
 
     def _send_loop(self):
         import torch
@@ -648,6 +683,8 @@ class OrderedPieceGather:
                 buf, n, first, frames = self._q.get()
                 credit = torch.zeros(1, dtype=torch.int64)
                 dist.recv(credit, src=0, group=self.ctl)                       # rank 0 wants the next piece
+                if int(credit.item()) < 0:
+                    raise RuntimeError("rank 0 aborted the run: its own part of the analysis failed")
                 dist.send(torch.tensor([n, frames, first], dtype=torch.int64), dst=0, group=self.ctl)
                 if buf is None:
                     return
@@ -677,6 +714,11 @@ class OrderedPieceGather:
                 dev_buf = None
                 for r in range(1, self.world):
                     while True:
+                        if getattr(self, "_aborted", False):
+                            # rank 0's own shard failed: a negative credit to this rank and every later one, then stop
+                            for rr in range(r, self.world):
+                                dist.send(torch.full((1,), -1, dtype=torch.int64), dst=rr, group=self.ctl)
+                            raise RuntimeError("aborted by rank 0")
                         dist.send(torch.ones(1, dtype=torch.int64), dst=r, group=self.ctl)
                         hdr = torch.zeros(3, dtype=torch.int64)
                         dist.recv(hdr, src=r, group=self.ctl)

@@ -20,7 +20,7 @@ KERNEL_CLASSES = ["gray", "pyramid", "min_eig", "nms", "sort", "suppress", "lk",
 SYMBOLS = [
     "pc_gftt_default_options", "pc_flow_default_options", "pc_last_error", "pc_version",
     "pc_context_create", "pc_context_destroy", "pc_context_synchronize", "pc_context_stream",
-    "pc_context_set_arithmetic", "pc_context_get_arithmetic", "pc_context_download",
+    "pc_runtime_init", "pc_context_set_arithmetic", "pc_context_get_arithmetic", "pc_context_download",
     "pc_context_enable_timing", "pc_context_get_timing", "pc_context_get_busy_time", "pc_context_reset_timing",
     "pc_debug_lk_profile", "pc_debug_lk_x86_stats", "pc_debug_llt9",
     "pc_frame_create", "pc_frame_destroy", "pc_frame_set_rgb", "pc_frame_set_rgb_f32", "pc_frame_set_gray",
@@ -96,6 +96,8 @@ def load():
         pass
     L = C.CDLL(path)
     vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    L.pc_runtime_init.argtypes = [ip, ip]
+    L.pc_runtime_init(None, None)   # GPU_MAX_HW_QUEUES before this library's first HIP call (include/polychase_hip.h)
     L.pc_last_error.restype = C.c_char_p
     L.pc_version.restype = C.c_char_p
     L.pc_gftt_default_options.argtypes = [C.POINTER(GfttOptions)]

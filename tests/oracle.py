@@ -70,11 +70,12 @@ def lib(path: str | None = None):
     return L
 
 
-EMU_LK_SIMD, EMU_SOBEL_FMA = 1, 2
+EMU_CANONICAL, EMU_LK_SIMD, EMU_SOBEL_FMA, EMU_OPENCV_X86 = 0, 1, 2, 3   # the default is EMU_OPENCV_X86 (pc_oracle.c)
 
 
 class emulation:
-    """with oracle.emulation(flags): the oracle runs in OpenCV's x86 SIMD execution order (pc_oracle.c)."""
+    """with oracle.emulation(flags): the oracle runs in that execution order of OpenCV (pc_oracle.c; EMU_CANONICAL = 0,
+    default EMU_OPENCV_X86)."""
 
     def __init__(self, flags: int):
         self.flags = flags

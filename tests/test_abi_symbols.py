@@ -47,10 +47,12 @@ def test_default_options_match_reference():
 
 
 @pytest.mark.parametrize("preset", [None, "5"])
-def test_loading_the_library_raises_the_hardware_queue_default(preset):
-    """csrc/hip/api.hip: pc_runtime_defaults -- loading the library sets GPU_MAX_HW_QUEUES=16 in the process environment
-    (the HIP runtime reads it at its first call: a stream per hardware queue) and leaves a user's
-    value alone.  Checked through libc's getenv in a fresh process (os.environ is a snapshot taken at interpreter start)."""
+def test_runtime_init_raises_the_hardware_queue_default_and_dlopen_does_not(preset):
+    """include/polychase_hip.h: pc_runtime_init -- sets GPU_MAX_HW_QUEUES=16 in the process environment (the HIP runtime
+    reads it at its first call: a stream per hardware queue), leaves a user's value alone, reports that
+    the ROCm runtime was not up yet, and is idempotent.  LOADING the library must change nothing (round 3 did it in a
+    constructor: a side effect of dlopen on every HIP user of the process).  Checked through libc's getenv in a fresh
+    process (os.environ is a snapshot taken at interpreter start)."""
     import subprocess
     import sys
 
@@ -60,16 +62,21 @@ def test_loading_the_library_raises_the_hardware_queue_default(preset):
     code = ("import ctypes, sys\n"
             "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
             "before = libc.getenv(b'GPU_MAX_HW_QUEUES')\n"
-            f"ctypes.CDLL({path!r})\n"
+            f"L = ctypes.CDLL({path!r})\n"
+            "loaded = libc.getenv(b'GPU_MAX_HW_QUEUES')\n"
+            "up, q = ctypes.c_int(-1), ctypes.c_int(-1)\n"
+            "assert L.pc_runtime_init(ctypes.byref(up), ctypes.byref(q)) == 0\n"
             "after = libc.getenv(b'GPU_MAX_HW_QUEUES')\n"
-            "print(before, after)\n")
+            "assert L.pc_runtime_init(None, None) == 0\n"
+            "print(before, loaded, after, up.value, q.value)\n")
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     if preset is not None:
         env["GPU_MAX_HW_QUEUES"] = preset
     r = subprocess.run([sys.executable, "-c", code], env=env, text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    before, after = r.stdout.split()
+    before, loaded, after, up, q = r.stdout.split()
+    assert up == "0", "no HIP call has been made in that process"
     if preset is None:
-        assert before == "None" and after == "b'16'", r.stdout
+        assert before == loaded == "None" and after == "b'16'" and q == "16", r.stdout
     else:
-        assert before == after == f"b'{preset}'", r.stdout
+        assert before == loaded == after == f"b'{preset}'" and q == preset, r.stdout

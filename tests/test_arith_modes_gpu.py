@@ -19,8 +19,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def ctx():
     c = hip.Context(0)
+    assert c.arithmetic == hip.ARITH_OPENCV_X86, "the library's default is the x86 execution"
     yield c
-    c.set_arithmetic(hip.ARITH_CANONICAL)
     c.close()
 
 
@@ -116,7 +116,6 @@ def test_opencv_x86_mode_through_the_analyzer(ctx):
     got = {}
     an.run(range(1, 13), lambda f1, k, det, flows: got.__setitem__(f1, (k.copy(), {t: [a.copy() for a in v] for t, v in flows.items()})))
     an.close()
-    ctx.set_arithmetic(hip.ARITH_CANONICAL)
     grays = [oracle.rgb2gray(f) for f in frames]
     with oracle.emulation(oracle.EMU_LK_SIMD | oracle.EMU_SOBEL_FMA):
         for f1 in (1, 6, 12):
@@ -162,6 +161,7 @@ def test_x86_order_on_the_two_keypoint_kernel_random(ctx, seed):
         tgts.append(np.clip(t, 0, 255).astype(np.uint8))
     fk = dict(window_size=win, max_level=max_level, term_max_iters=int(rng.choice([3, 30])))
     case = f"seed {seed}: {w}x{h} {kind} win {win} L {max_level} targets {n_targets} {fk}"
+    before = ctx.arithmetic
     ctx.set_arithmetic(hip.ARITH_LK_X86_ORDER)
     try:
         f1 = hip.Frame(ctx, w, h, win, max_level)
@@ -194,7 +194,7 @@ def test_x86_order_on_the_two_keypoint_kernel_random(ctx, seed):
         for f in [f1] + frames:
             f.close()
     finally:
-        ctx.set_arithmetic(hip.ARITH_CANONICAL)
+        ctx.set_arithmetic(before)
 
 
 def test_x86_order_is_decided_by_the_proof_on_benchmark_content(ctx):
@@ -202,6 +202,7 @@ def test_x86_order_is_decided_by_the_proof_on_benchmark_content(ctx):
     canonical kernel's speed plus the proof.  (C1's step edges: the other extreme, see the counters there.)"""
     clip = synth.NoiseClip(960, 540, 12)
     rgbs = [clip.frame(4)] + [clip.frame(t) for t in (3, 5, 6, 8)]
+    before = ctx.arithmetic
     ctx.set_arithmetic(hip.ARITH_LK_X86_ORDER)
     try:
         fr = _frames(ctx, rgbs)
@@ -212,7 +213,7 @@ def test_x86_order_is_decided_by_the_proof_on_benchmark_content(ctx):
         for f in fr:
             f.close()
     finally:
-        ctx.set_arithmetic(hip.ARITH_CANONICAL)
+        ctx.set_arithmetic(before)
     total = stats["iterations_proven_exact"] + stats["iterations_x86_order"]
     print("x86 stats on C2 content:", stats)
     assert total > 0 and stats["iterations_x86_order"] <= 0.2 * total, stats

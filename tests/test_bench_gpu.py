@@ -44,6 +44,30 @@ def test_two_ranks_on_one_gpu_over_gloo(stitch):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 16 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["stitch"].startswith("xgmi peer copies" if stitch == "peer" else "rccl all_gather"), (out["config"]["stitch"], r.stderr[-2000:])
+    _check_multi_gpu_keys(out, 2, peer=stitch == "peer", peer_wanted=stitch != "rccl")
+
+
+def _check_multi_gpu_keys(out, n, peer, peer_wanted):
+    """what ONE N-GPU run must return: both stitches and the analysis-only rate of the same job,
+    per-rank step times, the exposed stitch time, bytes per second per peer link, world size and backend"""
+    assert out["world_size"] == n and out["collectives_backend"] in ("nccl", "gloo")
+    assert out["config"]["arith"] == "opencv_x86" and set(out["arith_modes"]) >= {"opencv_x86", "canonical"}
+    ab = out["stitch_ab"]
+    assert "rccl" in ab and ab["rccl"]["stitch"].startswith("rccl all_gather")
+    if peer:
+        assert ab["peer"]["stitch"].startswith("xgmi peer copies")
+        assert out["value"] == ab["peer"]["value"]
+    elif peer_wanted:
+        assert "unavailable" in ab["peer"]
+    for m in ("peer", "rccl"):
+        if m in ab and "value" in ab[m]:
+            d = ab[m]
+            assert d["value"] > 0 and d["exposed_stitch_ms_per_region"] >= 0 and d["record_bytes_per_rank_per_region"] > 0
+            assert d["per_peer_link_GBs"] > 0 and abs(d["received_GBs_per_gpu"] - (n - 1) * d["per_peer_link_GBs"]) < 1e-6
+            lo, hi = d["per_rank_ms_per_step_min_max"]
+            assert 0 < lo <= hi and abs(hi - d["ms_per_step"]) < 1e-9      # the slowest rank IS the step
+    a = out["analysis_only"]
+    assert a["value"] > 0 and len(a["per_rank_ms_per_step_min_max"]) == 2
 
 
 def test_gpus_flag_launches_the_ranks_itself():
@@ -88,6 +112,7 @@ def test_four_ranks_push_on_three_streams():
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
     out = json.loads(lines[0])
     assert out["n_gpus"] == 4 and out["config"]["stitch"].startswith("xgmi peer copies")
+    _check_multi_gpu_keys(out, 4, peer=True, peer_wanted=True)
 
 
 def test_gpus_flag_fails_loudly_without_enough_gpus():
@@ -100,3 +125,48 @@ def test_gpus_flag_fails_loudly_without_enough_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
                        text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env, cwd=ROOT)
     assert r.returncode != 0 and "needs 2 GPUs" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_c4_label_of_the_nested_4k_block_with_two_ranks():
+    """`bench.py --gpus N` carries the 4K configuration as C4's per-rank workload: the nested block must say so (frames
+    per GPU, halo) and hold both stitches as well.  Two ranks on one GPU (testing aid), few steps."""
+    env = dict(os.environ, POLYCHASE_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
+                        "--no-breakdown", "--no-arith-modes"],
+                       text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    c4 = out["c3"]
+    assert c4["n_gpus"] == 2 and c4["config"]["workload"].startswith("C4 3840x2160 2400-frame clip frame-sharded across 2")
+    assert c4["config"]["c4_frames_per_gpu_at_8"] == 300 and c4["config"]["halo_frames_per_side"] == 8
+    assert "rccl" in c4["stitch_ab"] and c4["analysis_only"]["value"] > 0
+
+
+def test_one_gpu_line_carries_roofline_counters_arith_modes_and_c5():
+    """the driver's own command on one GPU: roofline = the HBM block with counters measured in the run (rocprofv3 is on the
+    box), valu_roofline beside it with both ceilings, the other arithmetic mode, and the C5 end-to-end block"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "POLYCHASE_ARITH")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+                        "--no-end-to-end"], text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, env=env, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    for blk in (out, out["c3"]):
+        rf = blk["roofline"]
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / 8000.0) < 1e-12
+        assert 0.005 < rf["frac"] < 0.05
+        assert blk["config"]["arith"] == "opencv_x86" and blk["arith_modes"]["canonical"]["value"] > 0
+        v = blk["valu_roofline"]
+        assert v["bound"] == "valu" and v["frac_of_nominal_peak"] < v["frac_of_measured_peak"] <= 1.0
+        import shutil
+        if shutil.which("rocprofv3"):
+            assert rf["counters_measured_in_run"] is True and rf["traffic"] > rf["algorithmic_bytes_per_launch"], rf
+    assert out["c3"]["steps"] == 20
+    c5 = out["c5"]
+    assert "error" not in c5, c5
+    pe = c5["pose_error_vs_cpu_reference"]
+    assert pe["sampled_frames"] >= 10 and pe["rotation_rad_max"] <= 1e-4 and pe["translation_rel_max"] <= 1e-4
+    assert c5["tracking_fps"] > 100 and c5["refinement_seconds"] < 10

@@ -42,7 +42,7 @@ def test_c5_1080p_300_frames_poses_sampled_against_the_cpu_reference(tmp_path):
     sys.path.insert(0, HERE)
     import c5_endtoend
     out_path = str(tmp_path / "c5_300.json")
-    assert c5_endtoend.main(["--width", "1920", "--height", "1080", "--frames", "300", "--oracle-frames", "0", "--oracle-stride", "10",
+    assert c5_endtoend.main(["--width", "1920", "--height", "1080", "--frames", "300", "--oracle-frames", "0", "--oracle-stride", "10", "--oracle-workers", "8",
                              "--refine-iterations", "10", "--out", out_path]) == 0
     r = json.load(open(out_path))
     print(json.dumps(r, indent=1))

@@ -317,6 +317,49 @@ def test_ordered_piece_gather_streams_the_single_rank_database(tmp_path, world, 
     assert _db_dump(str(tmp_path / "streamed.db")) == _db_dump(str(tmp_path / "single.db"))
 
 
+def _abort_worker(rank, world, port, mode):
+    """rank 0's own shard fails (mode "abort_before_start": before its receiver runs; "abort_running": while it receives):
+    every other rank must come back with an error quickly instead of sitting in recv(credit)"""
+    import time
+
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = D.OrderedPieceGather(depth=2)
+    t0 = time.time()
+    if rank == 0:
+        if mode == "abort_running":
+            g.start()
+            time.sleep(0.3)
+        g.abort()
+        if mode == "abort_running":
+            with pytest.raises(RuntimeError):
+                for _ in g.pieces():
+                    pass
+    else:
+        payload = torch.arange(64, dtype=torch.uint8)
+        with pytest.raises(RuntimeError, match="rank 0 aborted|sender thread"):
+            for k in range(50):                      # far more pieces than the queue holds: put() must not block for ever either
+                g.put(payload, 10 * rank + k, 1)
+            g.finish()
+        # the original error is reported again by finish(), at once, although the queue is full and nobody drains it
+        with pytest.raises(RuntimeError):
+            g.finish(failed=True)
+    assert time.time() - t0 < 20, "a rank waited for the process group's timeout"
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["abort_before_start", "abort_running"])
+def test_ordered_piece_gather_rank0_failure_releases_the_other_ranks(mode):
+    """rank 0's shard throws while the other ranks wait for credits / sit on a full queue -- nobody may hang."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_abort_worker, args=(3, port, mode), nprocs=3, join=True)
+
+
 def test_record_writer_refuses_other_keypoints(tmp_path):
     """A database that already holds ANOTHER analysis of a frame (other keypoints) must not receive this one's flows."""
     core = _core()

@@ -7,10 +7,31 @@ import numpy as np
 
 import oracle
 
-G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_small.npz"))
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def test_oracle_reproduces_golden_vectors():
+@pytest.mark.parametrize("name", ["oracle_small.npz", "oracle_x86_small.npz"])
+def test_oracle_reproduces_golden_vectors(name):
+    G = np.load(os.path.join(GOLDEN, name))
+    with oracle.emulation(int(G["emulation"]) if "emulation" in G else oracle.EMU_CANONICAL):
+        _check_against(G)
+
+
+def test_the_two_golden_files_pin_two_different_executions():
+    """on the step-edge fixture the canonical order must NOT reproduce the x86 vectors (else the file pins nothing new)"""
+    G = np.load(os.path.join(GOLDEN, "oracle_x86_small.npz"))
+    g0 = oracle.rgb2gray(G["frames"][0])
+    with oracle.emulation(oracle.EMU_CANONICAL):
+        eig = oracle.min_eigen_val(g0)
+        p = [oracle.Pyramid(oracle.rgb2gray(f), 10, 2) for f in G["frames"]]
+        xy, st, err = oracle.lk(p[0], p[1], G["keypoints0"], oracle.flow_options(max_level=2))
+    assert not np.array_equal(eig.view(np.uint32), G["min_eig0"].view(np.uint32))
+    assert not np.array_equal(xy.view(np.uint32), G["lk_xy_1"].view(np.uint32))
+
+
+def _check_against(G):
     frames = G["frames"]
     grays = [oracle.rgb2gray(f) for f in frames]
     assert np.array_equal(grays[0], G["gray0"])

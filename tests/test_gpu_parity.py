@@ -448,10 +448,21 @@ def test_device_log_matches_host_records(ctx):
     an.close()
 
 
-def test_hip_path_against_committed_golden_vectors(ctx):
-    """tests/golden/oracle_small.npz: frozen inputs and expected outputs of every stage."""
+@pytest.mark.parametrize("name", ["oracle_small.npz", "oracle_x86_small.npz"])
+def test_hip_path_against_committed_golden_vectors(ctx, name):
+    """tests/golden/*.npz: frozen inputs and expected outputs of every stage, in the canonical execution and in the x86
+    execution (key "emulation" = the arithmetic flags of pc_context_set_arithmetic)."""
     import os
-    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_small.npz"))
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+    before = ctx.arithmetic
+    ctx.set_arithmetic(int(G["emulation"]) if "emulation" in G else hip.ARITH_CANONICAL)
+    try:
+        _golden_case(ctx, G)
+    finally:
+        ctx.set_arithmetic(before)
+
+
+def _golden_case(ctx, G):
     frames = G["frames"]
     h, w, _ = frames[0].shape
     fr = []

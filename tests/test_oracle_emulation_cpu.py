@@ -1,5 +1,5 @@
-"""Distance between the oracle's canonical float order (what the GPU matches bit for bit) and the execution order of an
-x86 OpenCV build, which the oracle can emulate (oracle/pc_oracle.c: PCO_EMU_LK_SIMD = the 4-lane fp32 partial sums of
+"""Distance between the oracle's canonical float order and the execution order of an x86 OpenCV build -- the default of
+oracle and library since round 4; the GPU matches either bit for bit -- which the oracle emulates (oracle/pc_oracle.c: PCO_EMU_LK_SIMD = the 4-lane fp32 partial sums of
 LKTrackerInvoker's CV_SIMD128 path, PCO_EMU_SOBEL_FMA = the fused multiply-add of the AVX2 column filter of Sobel).
 
 Reference call sites: cv::calcOpticalFlowPyrLK at cpp/opticalflow.cc:119-125, cv::cornerMinEigenVal at
@@ -22,7 +22,8 @@ HARD_LIMIT_PX = 5e-3
 def _lk_gap(g0, g1, kps, max_level=3):
     p0, p1 = oracle.Pyramid(g0, max_level=max_level), oracle.Pyramid(g1, max_level=max_level)
     fo = oracle.flow_options(max_level=max_level)
-    xc, sc, ec = oracle.lk(p0, p1, kps, fo)
+    with oracle.emulation(oracle.EMU_CANONICAL):
+        xc, sc, ec = oracle.lk(p0, p1, kps, fo)
     with oracle.emulation(oracle.EMU_LK_SIMD):
         xe, se, ee = oracle.lk(p0, p1, kps, fo)
     both = (sc == 1) & (se == 1)
@@ -74,8 +75,9 @@ def test_gftt_gap_to_avx2_sobel(name):
         gray = oracle.rgb2gray(synth.checkerboard_clip(12)[10])
     else:
         gray = oracle.rgb2gray(synth.NoiseClip(960, 540, 40).frame(20))
-    ec = oracle.min_eigen_val(gray)
-    kc = oracle.gftt(gray)
+    with oracle.emulation(oracle.EMU_CANONICAL):
+        ec = oracle.min_eigen_val(gray)
+        kc = oracle.gftt(gray)
     with oracle.emulation(oracle.EMU_SOBEL_FMA):
         ee = oracle.min_eigen_val(gray)
         ke = oracle.gftt(gray)

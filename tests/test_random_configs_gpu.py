@@ -156,6 +156,7 @@ def test_random_detector_branch_and_arithmetic_mode(ctx, seed):
     tgts = [_shifted(rng, src, int(rng.integers(0, 5))) for _ in range(n_targets)]
     case = f"seed {seed}: {w}x{h} {kind} win {win} L {max_level} gftt {gk} lk {fk} targets {n_targets} arith {arith}"
     emu = (oracle.EMU_LK_SIMD if arith & hip.ARITH_LK_X86_ORDER else 0) | (oracle.EMU_SOBEL_FMA if arith & hip.ARITH_SOBEL_FMA else 0)
+    before = ctx.arithmetic
     ctx.set_arithmetic(arith)
     try:
         f1 = hip.Frame(ctx, w, h, win, max_level)
@@ -187,4 +188,4 @@ def test_random_detector_branch_and_arithmetic_mode(ctx, seed):
         for f in [f1] + frames:
             f.close()
     finally:
-        ctx.set_arithmetic(hip.ARITH_CANONICAL)
+        ctx.set_arithmetic(before)
