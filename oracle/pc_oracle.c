@@ -63,7 +63,8 @@ int pco_get_opencv_emulation(void) { return g_emulation; }
  *   (Sobel() folds the scale into the *smoothing* kernel.)  All BORDER_REFLECT_101.
  *   cov = (Dx*Dx, Dx*Dy, Dy*Dy) in fp32; boxFilter(block x block, normalize=false) with fp64 sums
  *   (exact for 8-bit inputs in the canonical order: every product is a multiple of 2^-47 and |sum| < 2^6 -- NOT under
- *   PCO_EMU_SOBEL_FMA, where a cancelling Dx leaves a ~1e-10 residual: there the row-major order below defines the result),
+ *   PCO_EMU_SOBEL_FMA, where a cancelling Dx leaves a ~1e-10 residual: there the order below -- the window's rows summed
+ *   left to right, the row sums added top to bottom, the structure of OpenCV's RowSum + ColumnSum -- defines the result),
  *   rounded to fp32; eig = (a + c) - sqrtf((a - c)*(a - c) + b*b), a = cxx*0.5f, b = cxy, c = cyy*0.5f.
  * Canonical choice: no FMA contraction (OpenCV's AVX2 dispatch may fuse v_muladd). */
 static int corner_response(const uint8_t* gray, int w, int h, int block_size, int ksize, int harris, double harris_k, float* eig);
@@ -127,16 +128,25 @@ static int corner_response(const uint8_t* gray, int w, int h, int block_size, in
     const int a0 = block_size / 2;
     for (int y = 0; y < h; y++) {
         for (int x = 0; x < w; x++) {
+            /* boxFilter = RowSum (each window row summed left to right) followed by ColumnSum (the row sums added top to
+             * bottom), both in fp64 (imgproc/box_filter.simd.hpp: RowSum<float, double>, ColumnSum<double, float>): that
+             * order.  OpenCV's RUNNING updates of both sums (s += new - old along a row / down a column) are not restated:
+             * they give the same bits wherever the sums are exact -- everywhere in the canonical execution, and all but
+             * about one pixel in 10^5 under PCO_EMU_SOBEL_FMA (see the header comment). */
             double sxx = 0, sxy = 0, syy = 0;
             for (int j = 0; j < block_size; j++) {
                 const int yy = reflect101(y + j - a0, h);
+                double rxx = 0, rxy = 0, ryy = 0;
                 for (int i = 0; i < block_size; i++) {
                     const int xx = reflect101(x + i - a0, w);
                     const float* c = cov + ((size_t)yy * w + xx) * 3;
-                    sxx += (double)c[0];
-                    sxy += (double)c[1];
-                    syy += (double)c[2];
+                    rxx += (double)c[0];
+                    rxy += (double)c[1];
+                    ryy += (double)c[2];
                 }
+                sxx += rxx;
+                sxy += rxy;
+                syy += ryy;
             }
             if (harris) {
                 const float a = (float)sxx, b = (float)sxy, c = (float)syy;

@@ -144,20 +144,10 @@ __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict_
             double sxx = (hxx[k] + hxx[k + 1]) + hxx[k + 2];
             double sxy = (hxy[k] + hxy[k + 1]) + hxy[k + 2];
             double syy = (hyy[k] + hyy[k + 1]) + hyy[k + 2];
-            if constexpr (SOBEL_FMA) {
-                // With the fused column filter a cancelling Dx leaves a residual of ~1e-10 instead of 0, its square is
-                // ~1e-19 beside sums of ~1e-3: the fp64 box sums are no longer exact and their ORDER shows in the last bit
-                // of one pixel in ~10^5.  The mode is defined by the oracle's order: row by row, left to right.
-                sxx = sxy = syy = 0.0;
-#pragma unroll
-                for (int j = 0; j < 3; j++)
-#pragma unroll
-                    for (int i = 0; i < 3; i++) {
-                        sxx += (double)s_cxx[ty0 + k + j][tx + i];
-                        sxy += (double)s_cxy[ty0 + k + j][tx + i];
-                        syy += (double)s_cyy[ty0 + k + j][tx + i];
-                    }
-            }
+            // (With the fused column filter a cancelling Dx leaves a residual of ~1e-10 instead of 0, its square is ~1e-19
+            // beside sums of ~1e-3: the fp64 box sums are no longer exact and their ORDER shows in the last bit of one pixel
+            // in ~10^5.  The oracle's order is this one: rows left to right, then the row sums top to bottom -- 0.0 + h[k] is
+            // exact, so (h[k] + h[k + 1]) + h[k + 2] is that order.)
             const float a = (float)sxx * 0.5f;
             const float b = (float)sxy;
             const float c = (float)syy * 0.5f;
@@ -185,10 +175,224 @@ __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K2, round 4: the same map without LDS.  A lane owns 2 output columns x ME_R output rows and walks down its band once,
+// everything in registers:
+//   per gray row (2 aligned dword loads = columns x - 2 .. x + 3): the Sobel row filters of the 4 covariance columns
+//       x - 1 .. x + 2 -- the products f1 * g and f0 * g of a pixel are formed once and shared by the three columns that use it;
+//   per covariance row (the gray rows above / at / below it are the last three walked): Dx, Dy, their three products for the
+//       4 columns, the window rows' sums ((c[j-1] + c[j]) + c[j+1] in fp64) of the 2 output columns;
+//   per output row: the three row sums added top to bottom, the eigenvalue, the running maximum of the lane.
+// Covariance positions outside the image take the value at the REFLECTED position (see the tiled kernel): a column by a
+// register copy inside the lane (-1 <- 1; w <- w - 2 lies at most two columns left of it), a row by substituting the
+// other neighbour's row sums in the vertical sum (-1 <- 1, h <- h - 2).  A wavefront covers 64 x (2 * ME_R) pixels; the
+// per-cell maximum is ONE atomic per wavefront when its tile lies in one grid cell (wave-uniform test; else four
+// registers for the <= 2 x 2 cells a tile can touch, or per-pixel atomics for cells smaller than a tile).
+// Measured against the tiled kernel (tools/prep_bench.py, profiles/r04_*_prep.json; SQ_INSTS_VALU per pixel: r04_*_pipeline_by_kernel_pmc.json).
+// ------------------------------------------------------------------------------------------------
+constexpr int ME_R = 8;                       // output rows per lane
+constexpr int ME_TW = 64, ME_TH = 2 * ME_R;   // pixels per wavefront: 32 column pairs x 2 bands
+
+template <bool SOBEL_FMA>
+__global__ __launch_bounds__(256) void min_eig_fused_kernel(const uint8_t* __restrict__ img, int pitch, int w, int h,
+                                                            float* __restrict__ eig, GfttGrid g,
+                                                            uint32_t* __restrict__ cell_max, float f1, float f0, int hi_prio) {
+    helper_priority(hi_prio);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the four wavefronts of a workgroup: 2 x 2 tiles
+    const int tx0 = (blockIdx.x * 2 + (wave & 1)) * ME_TW, ty0 = (blockIdx.y * 2 + (wave >> 1)) * ME_TH;
+    if (tx0 >= w || ty0 >= h) return;          // wave-uniform
+    const int x = tx0 + 2 * (lane & 31), y0 = ty0 + ME_R * (lane >> 5);
+    const bool lane_on = x < w && y0 < h;
+    // grid cells of the tile's corners (wave-uniform)
+    const int cx_lo = tx0 / g.cell_w, cx_hi = min(tx0 + ME_TW - 1, w - 1) / g.cell_w;
+    const int cy_lo = ty0 / g.cell_h, cy_hi = min(ty0 + ME_TH - 1, h - 1) / g.cell_h;
+    const bool one_cell = cx_lo == cx_hi && cy_lo == cy_hi;
+    const bool four_regs = !one_cell && g.cell_w >= ME_TW && g.cell_h >= ME_TH;   // <= 2 cells per axis
+    const int bx = (cx_lo + 1) * g.cell_w, by = (cy_lo + 1) * g.cell_h;          // the next cell boundaries
+    uint32_t kmax[4] = {0u, 0u, 0u, 0u};
+    // does the tile touch the image border?  (wave-uniform: the interior tiles skip every fix-up)
+    const bool edge = tx0 == 0 || ty0 == 0 || tx0 + ME_TW + 1 > w || ty0 + ME_TH + 1 > h;
+
+    if (lane_on) {
+        // columns x - 2 .. x + 3 of a gray row as bytes o .. o + 5 of two aligned dwords
+        const int a = (x - 2) & ~3;
+        const uint32_t o8 = (uint32_t)(x - 2 - a) * 8u;     // 0 or 16
+        const uint8_t* col = img + a;
+        // right image edge inside this lane's covariance columns (index 0..3 = columns x - 1 .. x + 2): column w takes w - 2
+        const int cw = w - (x - 1);                          // index of column w; 2 or 3 when it matters (x <= w - 1)
+        float rx[3][4], ry[3][4];
+        // Vertical sums without keeping three rows of row sums: when the row sums h of covariance row ay arrive they
+        // complete output row ay - 1 (acc + h, acc = h[ay - 2] + h[ay - 1]) and form the next acc = hprev + h.  Rows outside
+        // the image: output 0 is (h[1] + h[0]) + h[1] = (acc + h) + h with acc = h[0] alone; output h - 1 is
+        // (h[h - 2] + h[h - 1]) + h[h - 2] = acc + hprev, emitted one step early (at ay = h - 1, where h[h - 2] is still here).
+        double hprev[3][2], acc[3][2];
+        auto emit = [&](int y, const double (&sv)[3][2]) {
+            float e[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const float a2 = (float)sv[0][j] * 0.5f;
+                const float b2 = (float)sv[1][j];
+                const float c2 = (float)sv[2][j] * 0.5f;
+                const float t = a2 - c2;
+                e[j] = (a2 + c2) - sqrtf(t * t + b2 * b2);
+            }
+            float* out = eig + (size_t)y * w + x;
+            const bool two = x + 1 < w;
+            if (two && ((w & 1) == 0)) {
+                *reinterpret_cast<float2*>(out) = make_float2(e[0], e[1]);   // y * w + x is even
+            } else {
+                out[0] = e[0];
+                if (two) out[1] = e[1];
+            }
+            const uint32_t k0 = float_to_ordered(e[0]), k1 = two ? float_to_ordered(e[1]) : 0u;
+            if (one_cell) {
+                kmax[0] = max(kmax[0], max(k0, k1));
+            } else if (four_regs) {
+                const int qy = y >= by ? 2 : 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t v0 = (qy + (x >= bx ? 1 : 0)) == q ? k0 : 0u;
+                    const uint32_t v1 = (qy + (x + 1 >= bx ? 1 : 0)) == q ? k1 : 0u;
+                    kmax[q] = max(kmax[q], max(v0, v1));
+                }
+            } else {
+                atomicMax(&cell_max[(y / g.cell_h) * g.cols + x / g.cell_w], k0);
+                if (two) atomicMax(&cell_max[(y / g.cell_h) * g.cols + (x + 1) / g.cell_w], k1);
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < ME_R + 4; k++) {
+            const int gy = min(y0 - 2 + k, h);               // rows past h feed nothing that is stored
+            const uint32_t d0 = *reinterpret_cast<const uint32_t*>(col + (ptrdiff_t)gy * pitch);
+            const uint32_t d1 = *reinterpret_cast<const uint32_t*>(col + (ptrdiff_t)gy * pitch + 4);
+            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, o8), hi = d1 >> o8;
+            float gv[6];
+            gv[0] = (float)(lo & 0xffu);
+            gv[1] = (float)((lo >> 8) & 0xffu);
+            gv[2] = (float)((lo >> 16) & 0xffu);
+            gv[3] = (float)(lo >> 24);
+            gv[4] = (float)(hi & 0xffu);
+            gv[5] = (float)((hi >> 8) & 0xffu);
+            float p1[6], p0[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) p1[i] = f1 * gv[i];
+#pragma unroll
+            for (int i = 1; i < 5; i++) p0[i] = f0 * gv[i];
+            const int cur = k % 3, prev = (k + 2) % 3, pp = (k + 1) % 3;   // gray rows gy, gy - 1, gy - 2
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                rx[cur][c] = gv[c + 2] - gv[c];              // == (0 - g[-1]) + g[+1]: exact either way
+                float t = p1[c];                             // t = f1 * s[-1]; t += f0 * s[0]; t += f1 * s[+1]
+                t += p0[c + 1];
+                t += p1[c + 2];
+                ry[cur][c] = t;
+            }
+            if (k < 2) continue;
+            // covariance row ay (the middle one of the three gray rows)
+            const int ay = y0 + k - 3;
+            float cxx[4], cxy[4], cyy[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float dx = SOBEL_FMA ? __fmaf_rn(rx[pp][c] + rx[cur][c], f1, rx[prev][c] * f0)
+                                           : (rx[pp][c] + rx[cur][c]) * f1 + rx[prev][c] * f0;
+                const float dy = ry[cur][c] - ry[pp][c];
+                cxx[c] = dx * dx;
+                cxy[c] = dx * dy;
+                cyy[c] = dy * dy;
+            }
+            if (edge) {
+                if (x == 0) {                                // column -1 <- column 1
+                    cxx[0] = cxx[2];
+                    cxy[0] = cxy[2];
+                    cyy[0] = cyy[2];
+                }
+#pragma unroll
+                for (int c = 2; c < 4; c++) {                // column w <- column w - 2
+                    if (cw == c) {
+                        cxx[c] = cxx[c - 2];
+                        cxy[c] = cxy[c - 2];
+                        cyy[c] = cyy[c - 2];
+                    }
+                }
+            }
+            double hc[3][2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                hc[0][j] = ((double)cxx[j] + (double)cxx[j + 1]) + (double)cxx[j + 2];
+                hc[1][j] = ((double)cxy[j] + (double)cxy[j + 1]) + (double)cxy[j + 2];
+                hc[2][j] = ((double)cyy[j] + (double)cyy[j + 1]) + (double)cyy[j + 2];
+            }
+            if (k >= 4) {
+                // output row y = ay - 1: its rows y - 1, y are in acc, row y + 1 is hc
+                const int y = ay - 1;
+                if (y < h && !(edge && y == h - 1 && y > 0)) {
+                    double sv[3][2];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            double v = acc[ch][j] + hc[ch][j];
+                            if (edge && y == 0) v = v + hc[ch][j];      // acc holds h[0] alone: (h[0] + h[1]) + h[1]
+                            sv[ch][j] = v;
+                        }
+                    emit(y, sv);
+                }
+            }
+            if (k >= 3) {
+                // acc for output row ay = rows ay - 1 (hprev) + ay (hc); a bottom row h - 1 is complete with h[h - 2] = hprev
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[ch][j] = (edge && ay == 0) ? hc[ch][j] : hprev[ch][j] + hc[ch][j];
+                if (edge && ay == h - 1 && ay > 0) {
+                    double sv[3][2];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++) sv[ch][j] = acc[ch][j] + hprev[ch][j];
+                    emit(ay, sv);
+                }
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) hprev[ch][j] = hc[ch][j];
+        }
+    }
+    // per-cell maxima of the wavefront
+    if (one_cell || four_regs) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (q > 0 && one_cell) break;
+            uint32_t v = kmax[q];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+            const int cx = cx_lo + (q & 1), cy = cy_lo + (q >> 1);
+            if (lane == 0 && v != 0u && cx < g.cols && cy < g.rows) atomicMax(&cell_max[cy * g.cols + cx], v);
+        }
+    }
+}
+
+// POLYCHASE_MINEIG_VARIANT=1: the LDS-tiled kernel of rounds 1-3 (the cross-check of the fused one; tests/test_env_variants_gpu.py)
+static int min_eig_variant() {
+    static const int v = [] {
+        const char* e = getenv("POLYCHASE_MINEIG_VARIANT");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, bool sobel_fma, hipStream_t s) {
     // scale = 1 / (2^(ksize-1) * block_size * 255), folded into the smoothing taps (see oracle)
     const double scale_d = 1.0 / (4.0 * 3.0 * 255.0);
     const float f1 = (float)(1.0 * scale_d), f0 = (float)(2.0 * scale_d);
+    if (min_eig_variant() == 0) {
+        dim3 grid2((l0.w + 2 * ME_TW - 1) / (2 * ME_TW), (l0.h + 2 * ME_TH - 1) / (2 * ME_TH));
+        if (sobel_fma) hipLaunchKernelGGL(min_eig_fused_kernel<true>, grid2, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, helper_prio_arg());
+        else hipLaunchKernelGGL(min_eig_fused_kernel<false>, grid2, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, helper_prio_arg());
+        return;
+    }
     dim3 grid((l0.w + TW - 1) / TW, (l0.h + TH - 1) / TH);
     if (sobel_fma) hipLaunchKernelGGL(min_eig_kernel<true>, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, helper_prio_arg());
     else hipLaunchKernelGGL(min_eig_kernel<false>, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, helper_prio_arg());
@@ -233,15 +437,21 @@ __global__ __launch_bounds__(256) void box_response_kernel(const float* __restri
     if (x >= w || y >= h) return;
     const size_t n = (size_t)w * h;
     const int a0 = block / 2;
-    double sxx = 0, sxy = 0, syy = 0;   // exact for 8-bit inputs: the order of the additions is free
+    // the oracle's order (RowSum then ColumnSum): each window row left to right, the row sums top to bottom.  Exact for
+    // 8-bit inputs in the canonical arithmetic; under PC_ARITH_SOBEL_FMA the order defines the last bit of ~1 pixel in 10^5.
+    double sxx = 0, sxy = 0, syy = 0;
     for (int j = 0; j < block; j++) {
         const size_t row = (size_t)reflect101(y + j - a0, h) * w;
+        double rxx = 0, rxy = 0, ryy = 0;
         for (int i = 0; i < block; i++) {
             const size_t at = row + reflect101(x + i - a0, w);
-            sxx += (double)cov[at];
-            sxy += (double)cov[n + at];
-            syy += (double)cov[2 * n + at];
+            rxx += (double)cov[at];
+            rxy += (double)cov[n + at];
+            ryy += (double)cov[2 * n + at];
         }
+        sxx += rxx;
+        sxy += rxy;
+        syy += ryy;
     }
     float e;
     if (harris) {

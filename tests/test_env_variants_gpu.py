@@ -20,6 +20,8 @@ VARIANTS = [
     {"POLYCHASE_GFTT_SLOW_PATH": "1"},
     {"POLYCHASE_LK_VARIANT": "1"},
     {"POLYCHASE_PYRAMID_VARIANT": "1"},
+    {"POLYCHASE_MINEIG_VARIANT": "1"},
+    {"POLYCHASE_GFTT_GENERAL": "1"},
     {"POLYCHASE_HELPER_PRIO": "0"},
     {"POLYCHASE_HELPER_PRIO": "1"},
     {"POLYCHASE_COPY_STREAM": "0"},
@@ -31,7 +33,7 @@ VARIANTS = [
 def _hash(extra_env, size=(416, 304, 26)):
     env = dict(os.environ)
     for k in ("POLYCHASE_LK_GATE", "POLYCHASE_DETECT_STREAMS", "POLYCHASE_GFTT_SLOW_PATH", "POLYCHASE_LK_VARIANT",
-              "POLYCHASE_PYRAMID_VARIANT", "GPU_MAX_HW_QUEUES", "POLYCHASE_HELPER_PRIO", "POLYCHASE_COPY_STREAM", "POLYCHASE_LK_LANES",
+              "POLYCHASE_PYRAMID_VARIANT", "POLYCHASE_MINEIG_VARIANT", "POLYCHASE_GFTT_GENERAL", "GPU_MAX_HW_QUEUES", "POLYCHASE_HELPER_PRIO", "POLYCHASE_COPY_STREAM", "POLYCHASE_LK_LANES",
               "POLYCHASE_ENGINE_CACHE", "POLYCHASE_ARITH"):
         env.pop(k, None)
     env.update(extra_env)
