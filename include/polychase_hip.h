@@ -479,6 +479,31 @@ int pc_peer_copy_async(int device_index, void* dst, const void* src, size_t byte
 /* blocking device-to-host copy (verification of what the peers wrote) */
 int pc_peer_buffer_download(int device_index, void* dst_host, const void* src_device, size_t bytes);
 
+/* ---- the same exchange over RCCL, for C / C++ hosts (no torch): api_comm.hip ---------------------------------------------
+ * One communicator per rank (= process = GPU).  Rank 0 makes the id (ncclGetUniqueId) and hands its PC_COMM_ID_BYTES bytes
+ * to the other ranks by any means (csrc/host/multi_gpu.cc: a TCP socket); every rank then calls pc_comm_create, which is
+ * collective (ncclCommInitRank).  librccl.so.1 is loaded at the first of these calls: PC_E_NO_DEVICE when it is missing.
+ *   pc_comm_all_gather_log   BASELINE.json's "RCCL all-gather of the flow DB": every rank contributes `bytes` bytes at
+ *                            `piece` (device memory; sizes may differ) and receives all ranks' pieces in `recv` (device
+ *                            memory, world * slot_bytes; rank r's piece at r * slot_bytes, sizes_host[r] bytes of it valid).
+ *                            Two ncclAllGather calls (the sizes as uint64, then the payload padded to slot_bytes) on the
+ *                            communicator's own stream; returns when both are complete.
+ *   pc_comm_send / _recv     the ordered gather of the product: ncclSend / ncclRecv of exactly `bytes` bytes of device
+ *                            memory, blocking until the transfer is complete.
+ * What they replace in the reference: nothing it has (cpp/opticalflow.cc:209-321 is one process) -- the hand-over of
+ * opticalflow.cc:149-151 (flows -> database) when the frames were analysed on another GPU. */
+typedef struct pc_comm pc_comm;
+#define PC_COMM_ID_BYTES 128
+int pc_comm_unique_id(void* id /* [PC_COMM_ID_BYTES] */);
+int pc_comm_create(pc_context* ctx, const void* id /* [PC_COMM_ID_BYTES] */, int world_size, int rank, pc_comm** out);
+void pc_comm_destroy(pc_comm* comm);
+int pc_comm_world_size(const pc_comm* comm);
+int pc_comm_rank(const pc_comm* comm);
+int pc_comm_all_gather_log(pc_comm* comm, const void* piece_device, uint64_t bytes, void* recv_device, uint64_t slot_bytes,
+                           uint64_t* sizes_host /* [world_size] */);
+int pc_comm_send(pc_comm* comm, const void* src_device, uint64_t bytes, int dst_rank);
+int pc_comm_recv(pc_comm* comm, void* dst_device, uint64_t bytes, int src_rank);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ LIB_DIR = os.path.join(PKG, "lib")
 OBJ_DIR = os.path.join(PKG, "lib", "obj")
 HIP_DIR = os.path.join(PKG, "csrc", "hip")
 
-HIP_SOURCES = ["kernels_image.hip", "kernels_pyramid.hip", "kernels_gftt.hip", "kernels_lk.hip", "kernels_lk3.hip", "kernels_tracker.hip", "kernels_refiner.hip", "kernels_bvh.hip", "api.hip", "api_analyzer.hip", "api_tracker.hip"]
+HIP_SOURCES = ["kernels_image.hip", "kernels_pyramid.hip", "kernels_gftt.hip", "kernels_lk.hip", "kernels_lk3.hip", "kernels_tracker.hip", "kernels_refiner.hip", "kernels_bvh.hip", "api.hip", "api_analyzer.hip", "api_tracker.hip", "api_comm.hip"]
 # -ffp-contract=off: the float stages must match the oracle bit-for-bit (no FMA fusion).
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
              "-Wno-unused-function"]
@@ -127,9 +127,28 @@ def build_core(force: bool = False) -> str:
     return out
 
 
+def multi_gpu_tool_path() -> str:
+    return os.path.join(LIB_DIR, "polychase_multi_gpu")
+
+
+def build_multi_gpu_tool(force: bool = False) -> str:
+    """polychase_amd/lib/polychase_multi_gpu: tools/multi_gpu/multi_gpu_analyze.cc + the host driver objects of build_core --
+    the multi-GPU analysis (csrc/host/multi_gpu.cc) as a plain C++ program: no Python, no torch."""
+    src = os.path.join(ROOT, "tools", "multi_gpu", "multi_gpu_analyze.cc")
+    out = multi_gpu_tool_path()
+    need = ["analysis_driver", "flow_database", "frame_pool", "debug_images", "gpu_context", "multi_gpu"]
+    objs = [os.path.join(OBJ_DIR, f"core_{n}.o") for n in need]
+    if not force and _newer(out, [src, hip_library_path()] + objs):
+        return out
+    _run(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", src, *objs, "-o", out, "-L" + LIB_DIR, "-lpolychase_hip", "-l:libsqlite3.so.0",
+          "-l:libz.so.1", "-L/usr/lib/x86_64-linux-gnu", "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
 def build_all(force: bool = False) -> None:
     build_hip(force)
     build_core(force)
+    build_multi_gpu_tool(force)
 
 
 if __name__ == "__main__":

@@ -13,6 +13,7 @@
 #include "../host/analysis.h"
 #include "../host/frame_pool.h"
 #include "../host/analysis_thread.h"
+#include "../host/multi_gpu.h"
 #include "np_helpers.h"
 
 #ifdef PC_WITH_TRACKER
@@ -191,6 +192,53 @@ py::dict GenerateOpticalFlowShardPy(const VideoInfo& video_info, py::object fram
     return out;
 }
 
+// GenerateOpticalFlowDatabaseMultiGpu (csrc/host/multi_gpu.h): this rank's part of the multi-GPU analysis, RCCL + TCP control
+// channel underneath, no torch.  Not in the reference (its analysis is one process).
+py::dict GenerateOpticalFlowDatabaseMultiGpuPy(const VideoInfo& video_info, py::object frame_accessor, py::object callback,
+                                               const std::string& database_path, int world_size, int rank, const std::string& master_addr,
+                                               int master_port, int device, int piece_frames, const std::string& transport,
+                                               size_t keypoints_per_frame, const GFTTOptions& detector_options,
+                                               const OpticalFlowOptions& flow_options) {
+    std::deque<py::object> keep_alive;
+    FrameAccessorFunction accessor;
+    if (!frame_accessor.is_none())
+        accessor = [&](int32_t frame_id) -> std::optional<FrameView> {
+            py::gil_scoped_acquire gil;
+            return FrameFromPython(frame_accessor(frame_id), keep_alive);
+        };
+    OpticalFlowProgressCallback cb;
+    if (!callback.is_none())
+        cb = [&](float progress, const std::string& msg) -> bool {
+            py::gil_scoped_acquire gil;
+            return callback(progress, msg).cast<bool>();
+        };
+    MultiGpuConfig cfg;
+    cfg.world_size = world_size;
+    cfg.rank = rank;
+    cfg.master_addr = master_addr;
+    cfg.master_port = master_port;
+    cfg.device = device;
+    cfg.piece_frames = piece_frames;
+    cfg.transport = transport;
+    cfg.keypoints_per_frame = keypoints_per_frame;
+    MultiGpuResult r;
+    {
+        py::gil_scoped_release release;
+        r = GenerateOpticalFlowDatabaseMultiGpu(video_info, accessor, cb, database_path, cfg, detector_options, flow_options);
+    }
+    keep_alive.clear();
+    py::dict out;
+    out["shard"] = py::make_tuple(r.shard_begin, r.shard_end);
+    out["pieces"] = r.pieces;
+    out["bytes_moved"] = r.bytes_moved;
+    out["cancelled"] = r.cancelled;
+    out["seconds_analysis"] = r.seconds_analysis;
+    out["seconds_total"] = r.seconds_total;
+    out["seconds_blocked"] = r.seconds_blocked;
+    out["stats"] = r.stats;
+    return out;
+}
+
 OpticalFlowRunStats WriteOpticalFlowRecordsPy(const std::string& database_path, const U8Array& log, size_t bytes) {
     if (bytes > static_cast<size_t>(log.size())) throw py::value_error("bytes exceeds the buffer");
     OpticalFlowRunStats stats;
@@ -350,6 +398,11 @@ PYBIND11_MODULE(polychase_core, m) {
           py::arg("callback"), py::arg("database_path"), py::arg("shard_begin"), py::arg("shard_end"), py::arg("device_log") = 0,
           py::arg("capacity_bytes") = 0, py::arg("log_buffers") = 1, py::arg("piece_frames") = 0, py::arg("on_piece") = py::none(),
           py::arg("host_records") = true, py::arg("detector_options") = GFTTOptions{}, py::arg("flow_options") = OpticalFlowOptions{});
+    m.def("generate_optical_flow_database_multi_gpu", &GenerateOpticalFlowDatabaseMultiGpuPy, py::arg("video_info"),
+          py::arg("frame_accessor_function"), py::arg("callback"), py::arg("database_path"), py::arg("world_size"), py::arg("rank"),
+          py::arg("master_addr") = "127.0.0.1", py::arg("master_port") = 29611, py::arg("device") = -1, py::arg("piece_frames") = 16,
+          py::arg("transport") = "rccl", py::arg("keypoints_per_frame") = 0, py::arg("detector_options") = GFTTOptions{},
+          py::arg("flow_options") = OpticalFlowOptions{});
     py::class_<OpticalFlowRecordWriter>(m, "OpticalFlowRecordWriter")
         .def(py::init<const std::string&>(), py::arg("database_path"))
         .def("write",

@@ -36,6 +36,8 @@ SYMBOLS = [
     "pc_analyzer_set_host_records",
     "pc_peer_buffer_alloc", "pc_peer_buffer_free", "pc_peer_buffer_export", "pc_peer_buffer_open", "pc_peer_buffer_close",
     "pc_peer_copy_async", "pc_peer_buffer_download",
+    "pc_comm_unique_id", "pc_comm_create", "pc_comm_destroy", "pc_comm_world_size", "pc_comm_rank", "pc_comm_all_gather_log",
+    "pc_comm_send", "pc_comm_recv",
     "pc_mesh_create", "pc_mesh_set_mask", "pc_mesh_destroy", "pc_raycast_pixels", "pc_raycast_pixels_sweep",
     "pc_corr_set_create", "pc_corr_set_destroy", "pc_corr_set_clear", "pc_corr_set_append", "pc_corr_set_size",
     "pc_corr_set_download", "pc_pnp_problem_from_set",
@@ -161,6 +163,15 @@ def load():
     L.pc_peer_buffer_close.argtypes = [C.c_int, vp]
     L.pc_peer_copy_async.argtypes = [C.c_int, vp, vp, C.c_size_t, vp]
     L.pc_peer_buffer_download.argtypes = [C.c_int, vp, vp, C.c_size_t]
+    L.pc_comm_unique_id.argtypes = [vp]
+    L.pc_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.pc_comm_destroy.argtypes = [vp]
+    L.pc_comm_destroy.restype = None
+    L.pc_comm_world_size.argtypes = [vp]
+    L.pc_comm_rank.argtypes = [vp]
+    L.pc_comm_all_gather_log.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.pc_comm_send.argtypes = [vp, vp, C.c_uint64, C.c_int]
+    L.pc_comm_recv.argtypes = [vp, vp, C.c_uint64, C.c_int]
     _lib = L
     return L
 
