@@ -764,6 +764,7 @@ int pc_debug_lk_x86_stats(pc_context* c, int enable, unsigned long long* out) {
     if (enable) {
         PC_HIP(c->lk_x86_stats.ensure(4));
         PC_HIP(hipMemset(c->lk_x86_stats.p, 0, 4 * sizeof(unsigned long long)));
+        PC_HIP(hipDeviceSynchronize());   // the fill is asynchronous and the LK launches run on non-blocking streams
     } else {
         c->lk_x86_stats.release();
     }

@@ -14,6 +14,7 @@
 // read from the min-eig map itself.
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "kernels.hpp"
@@ -212,9 +213,11 @@ __global__ __launch_bounds__(256) void min_eig_fused_kernel(const uint8_t* __res
     const int bx = (cx_lo + 1) * g.cell_w, by = (cy_lo + 1) * g.cell_h;          // the next cell boundaries
     uint32_t kmax[4] = {0u, 0u, 0u, 0u};
     // does the tile touch the image border?  (wave-uniform: the interior tiles skip every fix-up)
-    const bool edge = tx0 == 0 || ty0 == 0 || tx0 + ME_TW + 1 > w || ty0 + ME_TH + 1 > h;
+    const bool edge_tile = tx0 == 0 || ty0 == 0 || tx0 + ME_TW + 1 > w || ty0 + ME_TH + 1 > h;
 
-    if (lane_on) {
+    // the walk, compiled twice: EDGE = false has no fix-up at all (as selects the fix-ups were a third of the kernel's instructions)
+    auto walk = [&](auto edge_tag) {
+        constexpr bool edge = decltype(edge_tag)::value;
         // columns x - 2 .. x + 3 of a gray row as bytes o .. o + 5 of two aligned dwords
         const int a = (x - 2) & ~3;
         const uint32_t o8 = (uint32_t)(x - 2 - a) * 8u;     // 0 or 16
@@ -359,6 +362,10 @@ __global__ __launch_bounds__(256) void min_eig_fused_kernel(const uint8_t* __res
 #pragma unroll
                 for (int j = 0; j < 2; j++) hprev[ch][j] = hc[ch][j];
         }
+    };
+    if (lane_on) {
+        if (edge_tile) walk(std::true_type{});
+        else walk(std::false_type{});
     }
     // per-cell maxima of the wavefront
     if (one_cell || four_regs) {

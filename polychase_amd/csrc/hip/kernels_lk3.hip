@@ -58,6 +58,27 @@ namespace pc {
 #ifndef PC_LK3_X86_STICK_AFTER
 #define PC_LK3_X86_STICK_AFTER 1
 #endif
+// Experiments for "what would staging through LDS-DMA save at most" (tools/lk_variants.py, profiles/r04_*_lk_staging_cost.jsonl):
+// PC_LK3_STAGE_TWICE stages every J region twice, PC_LK3_ISTAGE_TWICE loads and stores the I-side windows twice -- same
+// results, and the extra time is the whole cost (global loads, permutes, LDS stores, their waits) of one such staging, i.e. an
+// UPPER bound of what a staging without VGPR round trip (global_load_lds) could remove.
+#ifndef PC_LK3_RESTAGE_ALL
+#define PC_LK3_RESTAGE_ALL 0
+#endif
+#ifndef PC_LK3_STAGE_AHEAD
+#define PC_LK3_STAGE_AHEAD 0
+#endif
+// rows in flight of a staging INSIDE the iteration loop.  With PC_LK3_J_EARLY those are the rare restagings of a drifting window,
+// and every row in flight is 7 registers on top of the loop's 50 (bias, Dxy) registers
+#ifndef PC_LK3_RESTAGE_ROWS
+#define PC_LK3_RESTAGE_ROWS (PC_LK3_J_EARLY ? 1 : PC_LK3_STAGE_ROWS)
+#endif
+#ifndef PC_LK3_STAGE_TWICE
+#define PC_LK3_STAGE_TWICE 0
+#endif
+#ifndef PC_LK3_ISTAGE_TWICE
+#define PC_LK3_ISTAGE_TWICE 0
+#endif
 #ifndef PC_LK3_WAVES
 #define PC_LK3_WAVES 1   // wavefronts per workgroup
 #endif
@@ -73,6 +94,18 @@ namespace pc {
 #define PC_PROF_COUNT(k) do { } while (0)
 #endif
 
+// PC_LK3_J_EARLY: a level's FIRST J region -- its origin is known when the level starts -- is loaded right after the I-side
+// windows and stored before the pick-up, so that its memory latency passes behind the I-side evaluation instead of in front of
+// the first iteration (a staging is ~85 instructions but costs as much as 1.5 iterations, most of it waiting:
+// profiles/r04_*_lk_staging_cost.jsonl).  For that the (bias, Dxy) exchange buffers, which the pick-up reads AFTER the regions
+// are written, move out of the area the regions alias: + 2 * X_DW dwords of LDS per wavefront.
+// MEASURED AND NOT TAKEN (round 4, profiles/r04_lk_early_staging.jsonl): isolated launch C2 0.290 -> 0.304 ms, C3 1.34 -> 1.40,
+// pipeline 709 -> 676 frames/s at 4K.  The loads can only be issued after the pixel pass (their 28 registers do not fit beside
+// it), which leaves ~70 instructions to hide them behind; against that stand 1.3 KB more LDS per wavefront and restagings with
+// one row in flight.  Off by default; the code stays as the record of the experiment.
+#ifndef PC_LK3_J_EARLY
+#define PC_LK3_J_EARLY 0
+#endif
 template <int WIN>
 struct LK3Geo {
     static constexpr int GL = 4, NPX = WIN * WIN;
@@ -89,8 +122,10 @@ struct LK3Geo {
     // the LDS pipe's busy time, which itself was 82 % of the launch (rounds 1 and 2 until this was found)
     static constexpr int D_PITCH = WIN + 1, D_DW = (((WIN + 1) * (WIN + 1)) + 1) & ~1;
     static constexpr int X_DW = 2 * NPX;                      // (bias, Dxy) exchange of one keypoint
-    static constexpr int HALF_I_DW = ((I_DW + D_DW + X_DW + 3) / 4) * 4;
-    static constexpr int WAVE_DW = 16 * J_DW > 2 * HALF_I_DW ? 16 * J_DW : 2 * HALF_I_DW;
+    static constexpr bool XSEP = PC_LK3_J_EARLY != 0;         // the exchange buffers live behind the region area
+    static constexpr int HALF_I_DW = ((I_DW + D_DW + (XSEP ? 0 : X_DW) + 3) / 4) * 4;
+    static constexpr int AREA_DW = ((16 * J_DW > 2 * HALF_I_DW ? 16 * J_DW : 2 * HALF_I_DW) + 1) & ~1;   // regions / I-side windows
+    static constexpr int WAVE_DW = AREA_DW + (XSEP ? 2 * X_DW : 0);
     // window pixels of a lane: NCH column chains (columns lg + 4c) + a run of the remaining columns
     static constexpr int WM = (WIN / GL) * GL, NCH = WM / GL, KM = NCH * WIN;
     static constexpr int NEXTRA = (WIN - WM) * WIN, KE = (NEXTRA + GL - 1) / GL, K = KM + KE;
@@ -206,7 +241,7 @@ __device__ __forceinline__ float group4_exact_sum3(int partial) {
 #ifndef PC_LK3_MIN_VGPR
 #define PC_LK3_MIN_VGPR "v135"
 #endif
-template <int WIN>
+template <int WIN, int ROWS_IN_FLIGHT = PC_LK3_STAGE_ROWS>
 __device__ __forceinline__ void stage_region(const uint16_t* __restrict__ J16, int pitch, int rx0, int ry0, uint32_t* jbuf, int lg) {
     using G = LK3Geo<WIN>;
     // The row offsets (lg + 4k) * pitch are loop invariants of the iteration loop this is called from; hoisted out of
@@ -214,7 +249,7 @@ __device__ __forceinline__ void stage_region(const uint16_t* __restrict__ J16, i
     // recompute them here (the empty asm hides the invariance from the optimiser).
     asm volatile("" : "+v"(lg));
     constexpr int TRIPS = (G::RH + G::GL - 1) / G::GL;
-    constexpr int B = TRIPS < PC_LK3_STAGE_ROWS ? TRIPS : PC_LK3_STAGE_ROWS;
+    constexpr int B = TRIPS < ROWS_IN_FLIGHT ? TRIPS : ROWS_IN_FLIGHT;
     const uint16_t* const base = J16 + (ptrdiff_t)__mul24(ry0, pitch) + rx0;   // |ry0|, pitch < 2^23: the 24-bit multiply is full rate
 #pragma unroll
     for (int k0 = 0; k0 < TRIPS; k0 += B) {
@@ -241,6 +276,35 @@ __device__ __forceinline__ void stage_region(const uint16_t* __restrict__ J16, i
     }
 }
 
+// The same staging cut in two (PC_LK3_J_EARLY): load() issues the global loads of a lane's rows (at most four: RH <= 14),
+// store() writes them to the region.
+template <int WIN>
+struct StageRows {
+    using G = LK3Geo<WIN>;
+    static constexpr int TRIPS = (G::RH + G::GL - 1) / G::GL;
+    static_assert(TRIPS <= 4, "a lane stages at most four region rows");
+    RowRegs<G::CH> rows[TRIPS];
+    __device__ __forceinline__ void load(const uint16_t* __restrict__ J16, int pitch, int rx0, int ry0, int lg) {
+        asm volatile("" : "+v"(lg));   // see stage_region
+        const uint16_t* const base = J16 + (ptrdiff_t)__mul24(ry0, pitch) + rx0;
+#pragma unroll
+        for (int k = 0; k < TRIPS; k++) {
+            int r = lg + G::GL * k;
+            if (G::GL * (k + 1) > G::RH) r = min(r, G::RH - 1);
+            rows[k].load(base + (ptrdiff_t)__mul24(r, pitch));
+        }
+    }
+    __device__ __forceinline__ void store(uint32_t* jbuf, int lg) const {
+        asm volatile("" : "+v"(lg));
+#pragma unroll
+        for (int k = 0; k < TRIPS; k++) {
+            int r = lg + G::GL * k;
+            if (G::GL * (k + 1) > G::RH) r = min(r, G::RH - 1);
+            rows[k].store(jbuf + r * G::PITCH);
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------------------------
 // X86 = true (PC_ARITH_LK_X86_ORDER): the sums of the structure tensor and of the mismatch vector as an x86 OpenCV build
 // forms them -- LKTrackerInvoker's CV_SIMD128 path: over the first SIMD_W = (WIN / 8) * 8 columns vector lane j = x & 3
@@ -264,7 +328,7 @@ struct X86Geo {
     static constexpr int KSC0 = SIMD_W == 0 ? G::KM : 0;   // WIN < 8: the canonical column chain belongs to the scalar chain
     static constexpr int NSL = KSC0 + G::KE;               // scalar-chain slots of a lane
     static constexpr int PA_DW = 3 * G::NPX + 16;          // LDS of the ordered structure tensor, per half
-    static_assert(2 * G::HALF_I_DW + 2 * PA_DW <= G::WAVE_DW, "the ordered structure tensor's products fit behind the I-side buffers");
+    static_assert(2 * G::HALF_I_DW + 2 * PA_DW <= G::AREA_DW, "the ordered structure tensor's products fit behind the I-side buffers");
     static_assert(SIMD_W == 0 || (SIMD_W == 8 && G::WM == 8 && G::NCH == 2), "vector lanes = the two column chains");
     // scalar step s (row-major over the scalar columns) -> the lane that owns the pixel and its index among that lane's slots
     static constexpr int sx(int s) { return SIMD_W + s % (NXS > 0 ? NXS : 1); }
@@ -286,6 +350,17 @@ __device__ __forceinline__ float dpp_bcast4(float v, int src_lane) {   // the va
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) { return __int_as_float(dpp_i32<CTRL>(__float_as_int(v))); }
+// acc + (the value of lane `src_lane` of the 4-lane group) as ONE v_add_f32 with a DPP operand, volatile: the steps of a
+// sequential chain stay in place (left to the scheduler, the 2 x NS broadcasts are all formed first -- 40 registers)
+__device__ __forceinline__ float dpp_add4(float acc, float v, int src_lane) {
+    switch (src_lane) {
+        case 0: asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v)); break;
+        case 1: asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v)); break;
+        case 2: asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v)); break;
+        default: asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v)); break;
+    }
+    return acc;
+}
 
 // (ix, iy) of the pixel in slot k as one dword, out of the paired register layout of the iteration loop (PC_LK3_PAIRS)
 // (sel_lo / sel_hi: the v_perm selectors 0x05040100 / 0x07060302 as OPAQUE values of the calling iteration -- with literal
@@ -340,8 +415,22 @@ __device__ __forceinline__ void x86_mismatch_ordered(const uint32_t* jq, int lg,
                 IX = __builtin_amdgcn_perm((uint32_t)Dxy[WIN + r], (uint32_t)Dxy[r], sel_lo);
                 IY = __builtin_amdgcn_perm((uint32_t)Dxy[WIN + r], (uint32_t)Dxy[r], sel_hi);
             }
-            q1 = q1 + (float)sdot2_zero(Rp, IX);   // the int32 pair sum, converted, one term per row
-            q2 = q2 + (float)sdot2_zero(Rp, IY);
+            // q += (float)(int32 pair sum), one term per row.  ONE volatile statement per row: the additions are a dependent
+            // chain per accumulator, and left to itself the scheduler computes all 2 * WIN pair sums ahead of them and holds
+            // them in registers the kernel does not have (177 VGPRs instead of 136).  (s_nop: a dot product's result needs a
+            // wait state before a dependent VALU read on this target; the compiler inserts the same in its own code.)
+            int t1, t2;
+            asm volatile(
+                "v_dot2_i32_i16 %2, %4, %5, 0\n\t"
+                "v_dot2_i32_i16 %3, %4, %6, 0\n\t"
+                "s_nop 1\n\t"
+                "v_cvt_f32_i32 %2, %2\n\t"
+                "v_cvt_f32_i32 %3, %3\n\t"
+                "s_nop 0\n\t"
+                "v_add_f32 %0, %0, %2\n\t"
+                "v_add_f32 %1, %1, %3"
+                : "+v"(q1), "+v"(q2), "=&v"(t1), "=&v"(t2)
+                : "v"(Rp), "v"(IX), "v"(IY));
         }
     }
     // the scalar chain: every lane converts the products of the pixels it owns, then the terms are added in row-major
@@ -385,10 +474,11 @@ __device__ __forceinline__ void x86_mismatch_ordered(const uint32_t* jq, int lg,
         }
     }
     float s1 = 0.f, s2 = 0.f;
+    asm volatile("s_nop 1" ::: "memory");   // a DPP read of a register a VALU instruction has just written needs two wait states
 #pragma unroll
     for (int s = 0; s < X::NS; s++) {
-        s1 = s1 + dpp_bcast4(f1[X::slot_of(s)], X::lane_of(s));
-        s2 = s2 + dpp_bcast4(f2[X::slot_of(s)], X::lane_of(s));
+        s1 = dpp_add4(s1, f1[X::slot_of(s)], X::lane_of(s));
+        s2 = dpp_add4(s2, f2[X::slot_of(s)], X::lane_of(s));
     }
     if constexpr (X::SIMD_W == 8) {
         // bbuf[k] = qb0[k] + qb1[k]: lanes (0, 2) and (1, 3); fb += bbuf[0] + bbuf[2]
@@ -458,7 +548,9 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
     constexpr int GL = G::GL, NPX = G::NPX, NCH = G::NCH, KM = G::KM, KE = G::KE, K = G::K;
     constexpr int KW = (NPX + 31) / 32;   // pixels per lane in the half-wave I-side pass
     // + slack: slots past a lane's run of extra pixels read up to KE rows below the last region (and contribute 0)
-    constexpr int WAVE_DW = G::WAVE_DW + (KE > 0 ? (KE + 1) * G::PITCH : 0);
+    // (with the exchange buffers behind the region area those reads land there: 2 * X_DW dwords are more than the slack)
+    static_assert(!G::XSEP || 2 * G::X_DW >= (KE + 1) * G::PITCH, "the over-read past the last region stays inside the exchange buffers");
+    constexpr int WAVE_DW = G::WAVE_DW + ((KE > 0 && !G::XSEP) ? (KE + 1) * G::PITCH : 0);
     __shared__ __attribute__((aligned(16))) uint32_t s_buf[PC_LK3_WAVES][WAVE_DW];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -481,7 +573,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
     uint32_t* const wbase = &s_buf[wave][0];
     uint32_t* const ibuf = wbase + half * G::HALF_I_DW;                          // I window, position dwords
     int32_t* const dbuf = reinterpret_cast<int32_t*>(ibuf + G::I_DW);            // raw Scharr window
-    uint32_t* const xbuf = ibuf + G::I_DW + G::D_DW;                             // (bias, Dxy) exchange
+    uint32_t* const xbuf = G::XSEP ? wbase + G::AREA_DW + half * G::X_DW : ibuf + G::I_DW + G::D_DW;   // (bias, Dxy) exchange
     uint32_t* const jbuf = wbase + (half * 8 + grp) * G::J_DW;                   // aliases the above
 
     // the lane's run of the columns that do not fill a chain (column-major order of those pixels)
@@ -566,7 +658,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         const int l32_o = lane_o & 31, lg_o = lane_o & 3;
         uint32_t* const ibuf_o = wbase + (lane_o >> 5) * G::HALF_I_DW;
         int32_t* const dbuf_o = reinterpret_cast<int32_t*>(ibuf_o + G::I_DW);
-        uint32_t* const xbuf_o = ibuf_o + G::I_DW + G::D_DW;
+        uint32_t* const xbuf_o = G::XSEP ? wbase + G::AREA_DW + (lane_o >> 5) * G::X_DW : ibuf_o + G::I_DW + G::D_DW;
         int e_q0_o = 0;
         if constexpr (KE > 0 && G::RUNS) {
             const int e0 = lg_o * KE;
@@ -574,6 +666,19 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
             e_q0_o = (len > 0 ? e0 % WIN : 0) * WIN + G::WM + (len > 0 ? e0 / WIN : 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous level's J regions are dead
+#if PC_LK3_ISTAGE_TWICE
+        if (i_in) {
+            DerivWindow<WIN, 32> dw;
+            dw.load(L.der + (ptrdiff_t)(__mul24(ipy, pitch) + ipx), pitch, l32_o);
+            RowRegs<G::I_CH> row;
+            const int r = min(l32_o, G::I_ROWS - 1);
+            row.load(L.img16 + (ptrdiff_t)__mul24(ipy + r, pitch) + ipx);
+            row.store(ibuf_o + r * G::I_PITCH);
+            dw.store(dbuf_o, l32_o);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        asm volatile("" ::: "memory");
+#endif
         if (i_in) {
             DerivWindow<WIN, 32> dw;
             dw.load(L.der + (ptrdiff_t)(__mul24(ipy, pitch) + ipx), pitch, l32_o);
@@ -612,6 +717,26 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 }
             }
         }
+#if PC_LK3_J_EARLY
+        // The first iteration's window origin is floor(q - half_win): the loads of its region are in flight from here on --
+        // behind the reductions, the 2 x 2 system and the level's tests.  (Issued any earlier they live through the pixel
+        // pass, whose registers they do not fit beside: 163 VGPRs; in the X86 kernel they are issued behind the ordered
+        // structure tensor for the same reason.)
+        StageRows<WIN> jpre;
+        int jrx0 = 0, jry0 = 0;
+        bool j_early = false;
+        auto issue_early = [&]() {
+            const int ejx = (int)floorf(qx - half_win), ejy = (int)floorf(qy - half_win);
+            j_early = tgt_active && i_in && p.max_iters > 0 &&
+                      !((unsigned)(ejx + WIN) >= (unsigned)(L.w + WIN) || (unsigned)(ejy + WIN) >= (unsigned)(L.h + WIN));
+            if (j_early) {
+                jrx0 = ejx - G::MX;
+                jry0 = ejy - G::MY;
+                jpre.load(J16, pitch, jrx0, jry0, lg);
+            }
+        };
+        if constexpr (!X86) issue_early();
+#endif
         // per-lane partials fit int32; the half's totals are reduced as exact (hi, lo) halves
 #if PC_LK3_TRIM
         static_assert((long long)NPX * 4080 * 4080 < (1ll << 31), "structure tensor sums fit int32");
@@ -648,6 +773,9 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         const float A12 = half_exact_sum3(sA12) * FLT_SCALE;
         const float A22 = half_exact_sum3(sA22) * FLT_SCALE;
 #endif
+#if PC_LK3_J_EARLY
+        if constexpr (X86) issue_early();
+#endif
         float D = A11 * A22 - A12 * A12;
         const float tdiff = A11 - A22;
         const float min_eig_num = A22 + A11 - sqrtf(tdiff * tdiff + 4.f * A12 * A12);
@@ -670,6 +798,11 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
 
         // every group picks up the pixels it owns
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#if PC_LK3_J_EARLY
+        // the I-side windows (and the ordered structure tensor's products) are consumed: the regions may take their place;
+        // the exchange buffers the pick-up reads lie behind them
+        if (j_early && lvl_ok) jpre.store(jbuf, lg);
+#endif
         PC_PROF(1);
         int Bias[K];  // 2^15 - ival * 2^16: the accumulator init of interp_r
         int Dxy[K];   // (int16 ix) | (int16 iy << 16); 0 for slots without a pixel
@@ -733,6 +866,13 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         float pdx = 0.f, pdy = 0.f;
         int rx0 = 0, ry0 = 0;
         bool staged = false;
+#if PC_LK3_J_EARLY
+        if (j_early) {
+            rx0 = jrx0;
+            ry0 = jry0;
+            staged = true;
+        }
+#endif
         // X86: once the exactness proof of an iteration fails for any pair of the wavefront, the rest of the level runs in
         // the x86 order for all of them (always correct; the proof only saves work) -- wavefront-uniform, so that a
         // wavefront never executes both paths iteration after iteration
@@ -750,15 +890,33 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 break;
             }
             int ox = iqx - rx0, oy = iqy - ry0;
-            if (!staged || (unsigned)ox > (unsigned)(2 * G::MX) || (unsigned)oy > (unsigned)(2 * G::MY)) {
-                rx0 = iqx - G::MX;
-                ry0 = iqy - G::MY;
+            bool restage = !staged || (unsigned)ox > (unsigned)(2 * G::MX) || (unsigned)oy > (unsigned)(2 * G::MY);
+#if PC_LK3_RESTAGE_ALL
+            // a staging costs the WAVEFRONT its ~80 instructions however many of its 16 groups take part: when one group
+            // must restage, every iterating group re-centres its region for free -- and is less likely to ask next
+            restage = __any(restage);
+#endif
+            if (restage) {
                 ox = G::MX;
                 oy = G::MY;
+#if PC_LK3_STAGE_AHEAD
+                // the window keeps moving the way the last step went (the iterations approach their fixed point from one
+                // side far more often than they oscillate): leave the margin's two positions ahead of it, none behind
+                if (j > 0) {
+                    ox = pdx > 0.f ? 0 : (pdx < 0.f ? 2 * G::MX : G::MX);
+                    oy = pdy > 0.f ? 0 : (pdy < 0.f ? 2 * G::MY : G::MY);
+                }
+#endif
+                rx0 = iqx - ox;
+                ry0 = iqy - oy;
                 PC_PROF(4);
                 PC_LK3_SETPRIO_STAGING();
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#if PC_LK3_STAGE_TWICE
                 stage_region<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#endif
+                stage_region<WIN, PC_LK3_RESTAGE_ROWS>(J16, pitch, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 PC_LK3_SETPRIO_ITER();
                 staged = true;
@@ -778,6 +936,10 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 ry0 = iqy - G::MY;
                 PC_PROF(4);   // the timer reads are slow (scalar memory path): only around the rare staging, not per iteration
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#if PC_LK3_STAGE_TWICE
+                stage_region<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#endif
                 stage_region<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 staged = true;
@@ -1026,7 +1188,11 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 rx0 = iex - G::MX;
                 ry0 = iey - G::MY;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                stage_region<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
+#if PC_LK3_STAGE_TWICE
+                stage_region<WIN, PC_LK3_RESTAGE_ROWS>(J16, pitch, rx0, ry0, jbuf, lg);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#endif
+                stage_region<WIN, PC_LK3_RESTAGE_ROWS>(J16, pitch, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 staged = true;
             }

@@ -53,8 +53,26 @@ struct Engine {
         if (an) pc_analyzer_destroy(an);
         if (ctx) pc_context_destroy(ctx);
     }
+    // settings a context / analyzer reads from the environment when it is CREATED (arithmetic mode, stream layout, gate,
+    // helper priority, kernel variants): an engine parked under other values must not serve this run
+    std::string env_key;
+    static std::string EnvKey() {
+        std::string k;
+        for (const char* name : {"POLYCHASE_ARITH", "POLYCHASE_COPY_STREAM", "POLYCHASE_HELPER_PRIO", "POLYCHASE_LK_GATE", "POLYCHASE_LK_LANES",
+                                 "POLYCHASE_DETECT_STREAMS", "POLYCHASE_GFTT_SLOW_PATH", "POLYCHASE_INGEST_DMA"}) {
+            const char* v = std::getenv(name);
+            k += v ? v : "";
+            k += '\x1f';
+        }
+        return k;
+    }
+    // field by field: the structs have padding, memcmp would compare it
     bool Matches(int dev, uint32_t w, uint32_t h, const pc_gftt_options& g, const pc_flow_options& f) const {
-        return dev == device && w == width && h == height && std::memcmp(&g, &gopt, sizeof g) == 0 && std::memcmp(&f, &fopt, sizeof f) == 0;
+        return dev == device && w == width && h == height && g.quality_level == gopt.quality_level && g.min_distance == gopt.min_distance &&
+               g.block_size == gopt.block_size && g.gradient_size == gopt.gradient_size && g.max_corners == gopt.max_corners &&
+               g.use_harris == gopt.use_harris && g.harris_k == gopt.harris_k && g.grid_rows == gopt.grid_rows && g.grid_cols == gopt.grid_cols &&
+               f.window_size == fopt.window_size && f.max_level == fopt.max_level && f.term_max_iters == fopt.term_max_iters &&
+               f.term_epsilon == fopt.term_epsilon && f.min_eigen_threshold == fopt.min_eigen_threshold && env_key == EnvKey();
     }
 };
 
@@ -285,6 +303,7 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
         engine->height = video_info.height;
         engine->gopt = gopt;
         engine->fopt = fopt;
+        engine->env_key = Engine::EnvKey();
         if (pc_context_create(device, &engine->ctx) != PC_OK) ThrowHip("pc_context_create");
         if (pc_analyzer_create(engine->ctx, static_cast<int>(video_info.width), static_cast<int>(video_info.height), &gopt,
                                &fopt, kRing, kMaxJobs, &engine->an) != PC_OK)

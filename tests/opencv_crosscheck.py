@@ -17,7 +17,10 @@ plain C) this script runs the same calls the reference makes and compares them w
                                                                        order of the build at hand (PCO_EMU_LK_SIMD on x86,
                                                                        PCO_EMU_SOBEL_FMA where the AVX2 filters dispatch)
 
-    python tests/opencv_crosscheck.py [--width 640 --height 360]
+    python tests/opencv_crosscheck.py [--width 640 --height 360] [--write-golden [PATH]]
+
+--write-golden is the PIN KIT (tests/opencv_golden.py): it writes tests/golden/opencv_<version>_<isa>.npz -- inputs and THIS
+library's outputs for two small cases -- which the CPU and GPU test suites then hold oracle and HIP path to.
 
 Exit code 0: everything within tolerance; 1: a mismatch (printed); 2: cv2 is not importable.
 """
@@ -36,6 +39,9 @@ def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=360)
+    ap.add_argument("--write-golden", nargs="?", const="", default=None, metavar="PATH",
+                    help="also write the pin kit's golden file (default path: tests/golden/opencv_<version>_<isa>.npz): inputs + this "
+                         "OpenCV's outputs, consumed by tests/test_opencv_golden_{cpu,gpu}.py (tests/opencv_golden.py)")
     args = ap.parse_args()
     try:
         import cv2
@@ -45,6 +51,16 @@ def main() -> int:
     import oracle
     from polychase_amd import synth
 
+    if args.write_golden is not None:
+        import opencv_golden as og
+        backend = og.Cv2Backend()
+        path = args.write_golden or os.path.join(og.GOLDEN_DIR, f"opencv_{backend.tag}.npz")
+        arith = og.write(path, backend)
+        print(f"wrote {path} ({os.path.getsize(path) / 1e6:.1f} MB): {backend.source}; the oracle reproduces it bit for bit in mode "
+              f"'{arith}'.  Commit it: tests/test_opencv_golden_cpu.py and tests/test_opencv_golden_gpu.py pin oracle and HIP path to it.")
+
+    # the comparisons below name their execution explicitly (the oracle's DEFAULT is the x86 one since round 4)
+    oracle.lib().pco_set_opencv_emulation(oracle.EMU_CANONICAL)
     w, h = args.width, args.height
     clip = synth.NoiseClip(w, h, 30)
     rgb0, rgb1 = clip.frame(10), clip.frame(12)

@@ -189,7 +189,7 @@ def test_x86_order_on_the_two_keypoint_kernel_random(ctx, seed):
                 assert np.array_equal(xy[k][m].view(np.uint32), oxy[m].view(np.uint32)), f"{case}: positions of target {k} {stats}"
                 assert np.array_equal(err[k][m].view(np.uint32), oerr[m].view(np.uint32)), f"{case}: errors of target {k}"
         assert stats["keypoint_levels"] == len(kps) * (min(max_level, f1.num_levels - 1) + 1), (case, stats)
-        if kind == "noise" and win >= 6:
+        if kind == "noise" and win >= 8:      # window sums of white noise exceed 2^24 from 8 x 8 on: both ordered evaluations ran
             assert stats["iterations_x86_order"] > 0 and stats["keypoint_levels_x86_order"] > 0, (case, stats)
         for f in [f1] + frames:
             f.close()

@@ -258,3 +258,30 @@ def test_parked_engine_is_reused_and_replaced(core, tmp_path):
     got = core.Database(p3).read_keypoints(5)
     assert np.array_equal(got, oracle.gftt(grays[4]))
     assert _dump(p4)[1] != _dump(p1)[1]
+
+
+def test_parked_engine_is_not_reused_across_a_change_of_the_arithmetic_mode(core, tmp_path, monkeypatch):
+    """settings read when the engine is created (POLYCHASE_ARITH, stream layout, ...) are part of the key of the
+    parked engine.  On step-edge content the two arithmetic modes give different flow bits: a run under
+    POLYCHASE_ARITH=canonical after a default (opencv_x86) run must produce the canonical database, not the parked engine's."""
+    frames = synth.checkerboard_clip(12, w=320, h=240)
+
+    def run(name):
+        p = str(tmp_path / name)
+        core.generate_optical_flow_database(core.VideoInfo(320, 240, 1, len(frames)), lambda fid: frames[fid - 1], None, p,
+                                            core.GFTTOptions(), core.OpticalFlowOptions())
+        return _dump(p)
+
+    core.release_cached_engine()
+    monkeypatch.delenv("POLYCHASE_ARITH", raising=False)
+    x86 = run("x86.db")
+    monkeypatch.setenv("POLYCHASE_ARITH", "canonical")
+    can = run("can.db")
+    monkeypatch.delenv("POLYCHASE_ARITH")
+    again = run("x86b.db")
+    core.release_cached_engine()
+    assert x86 == again
+    assert x86[1] != can[1], "the canonical run reused the engine parked by the x86 run"
+    with oracle.emulation(oracle.EMU_CANONICAL):
+        assert can == _expect(frames, 1)
+    assert x86 == _expect(frames, 1)

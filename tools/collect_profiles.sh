@@ -26,7 +26,7 @@ fi
 # POLYCHASE_LK_LANES=1: all jobs on one lane, so no two LK launches overlap and a dispatch's duration is the launch's
 # own (with two lanes the tail of a launch overlaps the next one: start-to-end times exceed the GPU time a launch
 # costs, and under the profiler -- which serialises dispatch hand-over -- the gate between the lanes only adds its
-# polling).  The bench line saved beside the CSV is the same profiled run: its roofline.hbm.avg_launch_ms is the
+# polling).  The bench line saved beside the CSV is the same profiled run: its roofline.avg_launch_ms is the
 # number the CSV's average must agree with.
 if want kstats; then
 for c in c2 c3; do

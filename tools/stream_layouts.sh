@@ -6,7 +6,7 @@ run() { # label, config ; env comes from the caller
   timeout 300 python "$ROOT/bench.py" --no-cpu-baseline --no-c3 --no-end-to-end --config $2 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readlines()[-1])
-print(json.dumps({'layout': '$1', 'config': '$2', 'fps': round(d['value'],1), 'ms_per_step': round(d['ms_per_step'],4), 'lk_busy_ms': round(d['roofline']['hbm'].get('busy_ms_per_launch', 0),4), 'kernel_ms_per_frame': {k: round(v,3) for k,v in d['kernel_ms_per_frame'].items()}}))"
+print(json.dumps({'layout': '$1', 'config': '$2', 'fps': round(d['value'],1), 'ms_per_step': round(d['ms_per_step'],4), 'lk_busy_ms': round(d['roofline'].get('busy_ms_per_launch', 0),4), 'kernel_ms_per_frame': {k: round(v,3) for k,v in d['kernel_ms_per_frame'].items()}}))"
 }
 for c in c2 c3; do
   run "default (one preparation stream, 4 queues)" $c
