@@ -243,7 +243,8 @@ def main(argv=None) -> int:
     out = analyze(w, h, args.first_frame, n, accessor, args.database, core.GFTTOptions(), fopt, device=dev,
                   piece_frames=args.piece_frames)
     import json
-    print(json.dumps(out), flush=True)
+    sys.stdout.write(json.dumps(out) + "\n")     # ONE write per rank: the ranks share the launcher's stdout
+    sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
     return 0

@@ -243,7 +243,10 @@ def test_launcher_with_two_ranks_on_one_gpu(tmp_path):
         cmd = cmd + ["--synthetic", "c1", "--frames", str(frames), "--database", db, "--piece-frames", "4", *extra]
         r = subprocess.run(cmd, text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env, cwd=ROOT)
         assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
-        return [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        try:
+            return [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        except json.JSONDecodeError as e:
+            raise AssertionError(f"unparsable result line ({e}):\n{r.stdout[-3000:]}\n--- stderr:\n{r.stderr[-2000:]}")
 
     def torchrun(nproc, port):
         return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
