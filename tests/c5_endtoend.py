@@ -52,6 +52,38 @@ def main(argv=None) -> int:
     return 0
 
 
+def _oracle_pose_check(job):
+    """one sampled frame of the C5 check, in a worker process: the float64 CPU reference of the tracking step (cpp/tracker.cc:36-131
+    restated in oracle/pnp_oracle.py) from the GPU's poses of the frame's sources -> (rotation angle, relative translation error)
+    against the GPU's pose of the frame"""
+    path, f, src_cams, guess, q_gpu, t_gpu, verts, tris = job
+    import pnp_oracle as po
+    sys.path.insert(0, os.path.join(ROOT, "polychase_amd", "core"))
+    import polychase_core as core
+    db = core.Database(path)
+    model = np.eye(4)
+    Xs, xs_ = [], []
+    for src, cam in src_cams.items():
+        kps = db.read_keypoints(src)
+        fl = db.read_image_pair_flow(src, f)
+        view = np.eye(4, dtype=np.float32)                                  # the view matrix is float32 in the reference
+        view[:3, :3], view[:3, 3] = cam.R(), cam.t
+        inv = np.linalg.inv(view.astype(np.float64) @ model)                # GetRayObjectSpace, ray_casting.h:53-63
+        origin, dirs = inv[:3, 3], cam.unproject(kps[fl.src_kps_indices]) @ inv[:3, :3].T
+        hit, _, _, _, _, pos = po.raycast_closest(verts, tris, origin, dirs)
+        Xs.append(pos[hit])
+        xs_.append(fl.tgt_kps[hit])
+    db.close()
+    cam, _ = po.solve_pnp(np.concatenate(Xs).astype(np.float32), np.concatenate(xs_).astype(np.float32), guess, kind="cauchy", scale=1.0)
+    # rotation between the two poses from the NORMALISED quaternions: QuatStepPost (cpp/pnp/quaternion.h:11-20) never
+    # renormalises, so after hundreds of fp32 updates |q| is 1 + 1e-7, and the arccos-of-trace angle of the matrices
+    # turns that into 4e-4 "rad" (it grew linearly with the frame number) although costs and translations agree
+    qa, qb = np.asarray(q_gpu, float), np.asarray(cam.q, float)
+    qa, qb = qa / np.linalg.norm(qa), qb / np.linalg.norm(qb)
+    rel = po.quat_mul(np.array([qa[0], -qa[1], -qa[2], -qa[3]]), qb)
+    return (2.0 * float(np.arctan2(np.linalg.norm(rel[1:]), abs(rel[0]))), float(np.linalg.norm(np.asarray(t_gpu, float) - cam.t) / np.linalg.norm(cam.t)))
+
+
 def run(width=1920, height=1080, frames=300, oracle_frames=6, oracle_stride=0, refine_iterations=30, oracle_workers=1) -> dict:
     """the whole of C5 -> the result object (bench.py's "c5" block calls this; main() prints it)"""
     import types
@@ -192,41 +224,21 @@ def run(width=1920, height=1080, frames=300, oracle_frames=6, oracle_stride=0, r
         for f, (q, t, _) in got.items():
             gpu_cam[f] = po.Camera(fx=-F, fy=-F, cx=W / 2, cy=H / 2, aspect_ratio=1.0, width=float(W), height=float(H), opencv=False,
                                    q=np.asarray(q, float), t=np.asarray(t, float))
-        import threading
-        from concurrent.futures import ThreadPoolExecutor
-        tls = threading.local()
-
-        def check(f):
-            if not hasattr(tls, "db"):
-                tls.db = core.Database(path)          # a connection per thread (SQLITE_OPEN_NOMUTEX, database.cc:71-74)
-            tdb = tls.db
-            Xs, xs_ = [], []
-            for src in tdb.find_optical_flows_to_image(f):
-                if src >= f:            # forward tracking: only frames solved before f were filled (tracker.cc:43-50)
-                    continue
-                kps = tdb.read_keypoints(src)
-                fl = tdb.read_image_pair_flow(src, f)
-                origin, dirs = T.rays_object_space(gpu_cam[src], model, kps[fl.src_kps_indices])
-                hit, _, _, _, _, pos = po.raycast_closest(verts, tris, origin, dirs)
-                Xs.append(pos[hit])
-                xs_.append(fl.tgt_kps[hit])
-            cam, _ = po.solve_pnp(np.concatenate(Xs).astype(np.float32), np.concatenate(xs_).astype(np.float32), gpu_cam[f - 1],
-                                  kind="cauchy", scale=1.0)
-            # rotation between the two poses from the NORMALISED quaternions: QuatStepPost (cpp/pnp/quaternion.h:11-20) never
-            # renormalises, so after hundreds of fp32 updates |q| is 1 + 1e-7, and the arccos-of-trace angle of the matrices
-            # turns that into 4e-4 "rad" (it grew linearly with the frame number) although costs and translations agree
-            qa, qb = np.asarray(got[f][0], float), np.asarray(cam.q, float)
-            qa, qb = qa / np.linalg.norm(qa), qb / np.linalg.norm(qb)
-            rel = po.quat_mul(np.array([qa[0], -qa[1], -qa[2], -qa[3]]), qb)
-            return (2.0 * float(np.arctan2(np.linalg.norm(rel[1:]), abs(rel[0]))),
-                    float(np.linalg.norm(got[f][1] - cam.t) / np.linalg.norm(cam.t)))
+        from concurrent.futures import ProcessPoolExecutor
+        import multiprocessing as mp
 
         checked = list(range(2 + a.oracle_stride - 1, n + 1, a.oracle_stride))
+        jobs = []
+        for f in checked:
+            srcs = [s_ for s_ in db.find_optical_flows_to_image(f) if s_ < f]   # forward tracking: only frames solved before f were filled (tracker.cc:43-50)
+            jobs.append((path, f, {s_: gpu_cam[s_] for s_ in srcs}, gpu_cam[f - 1], got[f][0], got[f][1], verts, tris))
         if a.oracle_workers > 1:
-            with ThreadPoolExecutor(max_workers=a.oracle_workers) as ex:
-                res = list(ex.map(check, checked))
+            # processes, not threads: the restatement is numpy + Python loops (the GIL serialises threads: 10 samples took 15 s);
+            # spawned, so that no child inherits this process's HIP state -- they only read the SQLite file
+            with ProcessPoolExecutor(max_workers=min(a.oracle_workers, len(jobs)), mp_context=mp.get_context("spawn")) as ex:
+                res = list(ex.map(_oracle_pose_check, jobs))
         else:
-            res = [check(f) for f in checked]
+            res = [_oracle_pose_check(j) for j in jobs]
         ang, tr = [r[0] for r in res], [r[1] for r in res]
         db.close()
         out["tracking"]["vs_cpu_reference_sampled"] = {"frames": checked, "rotation_rad_max": max(ang), "translation_rel_max": max(tr),
