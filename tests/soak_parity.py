@@ -43,8 +43,11 @@ def main() -> int:
             if seed % 2 == 0:    # every second: the x86 summation order on the two-keypoint kernel, hard content, windows 4-11
                 A.test_x86_order_on_the_two_keypoint_kernel_random(ctx, seed)
         except AssertionError as e:
-            failures.append({"seed": seed, "what": str(e)[:400]})
-            print(f"MISMATCH seed {seed}: {str(e)[:400]}", flush=True)
+            import traceback
+            tb = traceback.extract_tb(e.__traceback__)[-1]
+            where = f"{os.path.basename(tb.filename)}:{tb.lineno}: {tb.line}"
+            failures.append({"seed": seed, "where": where[:300], "what": str(e)[:1200]})
+            print(f"MISMATCH seed {seed} at {where}: {str(e)[:1200]}", flush=True)
             if len(failures) >= 10:
                 break
     ctx.close()
