@@ -170,7 +170,10 @@ ARITH_NAMES = {v: k for k, v in ARITH_FLAGS.items()}
 LAST_ARITH = None   # the arithmetic mode the latest run_config ran in (every rank)
 
 
-def measure_counters(cfg, arith, timeout_s=75):
+_COUNTERS_BROKEN = False   # a pass hung or failed on this box: no further attempts in this run (worst case: one timeout)
+
+
+def measure_counters(cfg, arith, timeout_s=45):
     """SQ_INSTS_VALU, FETCH_SIZE and WRITE_SIZE of ONE LK launch of this configuration, measured now on this box: three short
     `rocprofv3 --pmc` passes (counters in their own runs, no other trace domain) of tools/lk_bench.py -- the same kernel on a
     frame of the same clip.  Returns None when rocprofv3 is missing or a pass fails (the caller then falls back to the
@@ -180,7 +183,8 @@ def measure_counters(cfg, arith, timeout_s=75):
     import shutil
     import signal
 
-    if not shutil.which("rocprofv3"):
+    global _COUNTERS_BROKEN
+    if _COUNTERS_BROKEN or not shutil.which("rocprofv3"):
         return None
     env = dict(os.environ, TMPDIR="/tmp", POLYCHASE_ARITH=arith)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
@@ -197,6 +201,7 @@ def measure_counters(cfg, arith, timeout_s=75):
             os.killpg(proc.pid, signal.SIGKILL)
             proc.communicate()
             shutil.rmtree(d, ignore_errors=True)
+            _COUNTERS_BROKEN = True
             return None
         total, n = 0.0, 0
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -206,6 +211,7 @@ def measure_counters(cfg, arith, timeout_s=75):
                     n += 1
         shutil.rmtree(d, ignore_errors=True)
         if n == 0:
+            _COUNTERS_BROKEN = True
             return None
         got[counter] = total / n
         got["dispatches_" + counter] = n

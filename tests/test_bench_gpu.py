@@ -161,9 +161,13 @@ def test_one_gpu_line_carries_roofline_counters_arith_modes_and_c5():
         assert blk["config"]["arith"] == "opencv_x86" and blk["arith_modes"]["canonical"]["value"] > 0
         v = blk["valu_roofline"]
         assert v["bound"] == "valu" and v["frac_of_nominal_peak"] < v["frac_of_measured_peak"] <= 1.0
+        # counters: measured by the run itself where rocprofv3 works (a pass that hangs is killed and the committed profile is
+        # used instead: the line then says so)
+        assert rf["traffic"] > rf["algorithmic_bytes_per_launch"], rf
+        assert rf["counters_measured_in_run"] in (True, False) and v["counters_measured_in_run"] == rf["counters_measured_in_run"]
         import shutil
-        if shutil.which("rocprofv3"):
-            assert rf["counters_measured_in_run"] is True and rf["traffic"] > rf["algorithmic_bytes_per_launch"], rf
+        if not shutil.which("rocprofv3"):
+            assert rf["counters_measured_in_run"] is False
     assert out["c3"]["steps"] == 20
     c5 = out["c5"]
     assert "error" not in c5, c5
