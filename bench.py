@@ -108,11 +108,19 @@ def cpu_baseline(fetch_host, f1_candidates, gopt_kw, fopt_kw, target_seconds=12.
     def run(f1s):
         lo, hi = f1s[0] - 8, f1s[-1] + 8
         host = [fetch_host(f) for f in range(lo, hi + 1)]
-        t0 = time.perf_counter()
-        oracle.analyze_clip(host, first_frame=lo, f1_range=(f1s[0], f1s[-1] + 1), gopt=oracle.gftt_options(**gopt_kw),
-                            fopt=oracle.flow_options(**fopt_kw), threads=pair_threads, feature_threads=feat_threads,
-                            libpath=so)
-        return time.perf_counter() - t0
+        # timed in the canonical arithmetic: the emulation of the x86 order keeps a second set of accumulators beside the
+        # integer ones and would make the port ~25 % slower than it has to be (a real OpenCV pays nothing for its own order)
+        native = oracle.lib(so) if so else oracle.lib()
+        before = native.pco_get_opencv_emulation()
+        native.pco_set_opencv_emulation(oracle.EMU_CANONICAL)
+        try:
+            t0 = time.perf_counter()
+            oracle.analyze_clip(host, first_frame=lo, f1_range=(f1s[0], f1s[-1] + 1), gopt=oracle.gftt_options(**gopt_kw),
+                                fopt=oracle.flow_options(**fopt_kw), threads=pair_threads, feature_threads=feat_threads,
+                                libpath=so)
+            return time.perf_counter() - t0
+        finally:
+            native.pco_set_opencv_emulation(before)
 
     probe = run(f1_candidates[:2])
     n = int(max(2, min(len(f1_candidates), round(target_seconds / max(probe / 2, 1e-3)))))
@@ -120,7 +128,7 @@ def cpu_baseline(fetch_host, f1_candidates, gopt_kw, fopt_kw, target_seconds=12.
     out = {"value": n / dt, "unit": "frames/s", "cores": pair_threads * feat_threads, "kind": "port",
            "sample": f"{n} interior frame1 x 8 pairs of the same clip, oracle/pc_oracle.c (-O3 -march=native), "
                      f"{pair_threads} pair-threads x {feat_threads} feature-threads (all {cores} host cores), "
-                     f"per-pair gray+pyramid rebuild as in opticalflow.cc:298-302; {dt:.1f} s"}
+                     f"per-pair gray+pyramid rebuild as in opticalflow.cc:298-302, canonical arithmetic; {dt:.1f} s"}
     # the reference's own threading: TBB capped at 4 threads over the pairs (opticalflow.cc:271), features serial
     pair_threads, feat_threads = min(4, cores), 1
     dt4 = run(f1_candidates[:1])
