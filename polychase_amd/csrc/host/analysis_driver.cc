@@ -100,7 +100,34 @@ class EngineCache {
             std::lock_guard<std::mutex> lk(Mutex());
             old = std::move(Slot());
             Slot() = std::move(e);
+            ParkedAt() = std::chrono::steady_clock::now();
         }
+        StartReaper();
+    }
+    // A parked engine holds ~20 frame slabs of GPU memory (several GB at 4K) inside the HOST's process -- Blender -- for a call
+    // that may never come.  It is given back after POLYCHASE_ENGINE_CACHE_IDLE_S seconds without a taker (default 120; 0: keep it
+    // until release_cached_engine()): one detached thread that wakes once a second while an engine is parked.
+    static void StartReaper() {
+        static const double idle_s = [] {
+            const char* v = std::getenv("POLYCHASE_ENGINE_CACHE_IDLE_S");
+            return v ? std::atof(v) : 120.0;
+        }();
+        if (idle_s <= 0) return;
+        static std::once_flag once;
+        std::call_once(once, [] {
+            std::thread([] {
+                for (;;) {
+                    std::this_thread::sleep_for(std::chrono::seconds(1));
+                    std::unique_ptr<Engine> idle;
+                    {
+                        std::lock_guard<std::mutex> lk(Mutex());
+                        if (Slot() && std::chrono::duration<double>(std::chrono::steady_clock::now() - ParkedAt()).count() > idle_s)
+                            idle = std::move(Slot());
+                    }
+                    // destroyed here, outside the lock
+                }
+            }).detach();
+        });
     }
     static void Clear() {
         std::unique_ptr<Engine> old;
@@ -110,8 +137,12 @@ class EngineCache {
 
    private:
     static std::mutex& Mutex() {
-        static std::mutex m;
-        return m;
+        static std::mutex* m = new std::mutex();   // leaked like the slot: the reaper thread may outlive the static destructors
+        return *m;
+    }
+    static std::chrono::steady_clock::time_point& ParkedAt() {
+        static std::chrono::steady_clock::time_point t;
+        return t;
     }
     static std::unique_ptr<Engine>& Slot() {
         // leaked on purpose: at process exit the HIP runtime may be gone before a static destructor would run

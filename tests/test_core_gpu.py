@@ -285,3 +285,27 @@ def test_parked_engine_is_not_reused_across_a_change_of_the_arithmetic_mode(core
     with oracle.emulation(oracle.EMU_CANONICAL):
         assert can == _expect(frames, 1)
     assert x86 == _expect(frames, 1)
+
+
+def test_parked_engine_is_given_back_after_the_idle_time(tmp_path):
+    """the parked engine must not sit on GBs of the host process's GPU memory for ever.  With
+    POLYCHASE_ENGINE_CACHE_IDLE_S=1 (read once per process: a subprocess) a call 3 s after the previous one creates its engine
+    again, a call right after it does not."""
+    import subprocess
+    code = (
+        "import os, sys, time\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'polychase_amd', 'core'))\n"
+        "import torch, polychase_core as core\n"
+        "from polychase_amd import synth\n"
+        "clip = synth.NoiseClip(320, 240, 12); fr = [clip.frame(t) for t in range(12)]\n"
+        "def run():\n"
+        "    return core.generate_optical_flow_database(core.VideoInfo(320, 240, 1, 12), lambda f: fr[f - 1], None, '', core.GFTTOptions(), core.OpticalFlowOptions()).seconds_setup\n"
+        "a = run(); b = run(); time.sleep(3.0); c = run(); d = run()\n"
+        "print('SETUP', a, b, c, d)\n")
+    env = dict(os.environ, POLYCHASE_ENGINE_CACHE_IDLE_S="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    line = [l for l in r.stdout.splitlines() if l.startswith("SETUP")]
+    assert r.returncode == 0 and line, r.stderr[-2000:]
+    a, b, c, d = map(float, line[0].split()[1:])
+    assert b < a / 5 and d < c / 5, (a, b, c, d)          # taken from the slot
+    assert c > 5 * b, (a, b, c, d)                        # created again: the reaper had destroyed the idle engine
