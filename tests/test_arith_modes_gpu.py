@@ -217,3 +217,37 @@ def test_x86_order_is_decided_by_the_proof_on_benchmark_content(ctx):
     total = stats["iterations_proven_exact"] + stats["iterations_x86_order"]
     print("x86 stats on C2 content:", stats)
     assert total > 0 and stats["iterations_x86_order"] <= 0.2 * total, stats
+
+
+def test_hard_edged_clip_through_the_analyzer_in_the_default_mode():
+    """Blurred step edges over a fine texture -- the content class on which a third of the LK iterations and nine tenths of the
+    structure tensors take the ORDERED x86 evaluation (tools/x86_cost_probe.py) -- as a whole clip through pc_analyzer in the
+    library's default arithmetic: every record equals the oracle's in its default emulation."""
+    from polychase_amd.pipeline import ClipAnalyzer
+    rng = np.random.default_rng(11)
+    w, h, n = 384, 256, 14
+    cells = rng.integers(0, 2, (h // 24 + 6, w // 24 + 6))
+    tex_all = rng.integers(-20, 21, (h + 64, w + 64)).astype(np.float64)
+    frames = []
+    for t in range(n):
+        big = 160.0 * np.kron(cells, np.ones((24, 24)))[t:t + h + 2, 2 * t:2 * t + w + 2]
+        big = sum(big[dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)) / 9
+        g = np.clip(40 + big + tex_all[t:t + h, 2 * t:2 * t + w], 0, 255).astype(np.uint8)
+        frames.append(np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2)))
+    ctx = hip.Context(0)
+    assert ctx.arithmetic == hip.ARITH_OPENCV_X86
+    ctx.lk_x86_stats(True)
+    an = ClipAnalyzer(ctx, w, h, 1, n, lambda fid: frames[fid - 1])
+    got = {}
+    an.run(range(1, n + 1), lambda f1, k, det, flows: got.__setitem__(f1, (k.copy(), {t: [a.copy() for a in v] for t, v in flows.items()})))
+    an.close()
+    stats = ctx.lk_x86_stats(False)
+    ctx.close()
+    assert stats["iterations_x86_order"] > 0.05 * stats["iterations_proven_exact"] and stats["keypoint_levels_x86_order"] > 0, stats
+    kps_o, flows_o = oracle.analyze_clip(frames, first_frame=1, threads=4)
+    assert sorted(got) == sorted(kps_o)
+    for f1 in kps_o:
+        assert np.array_equal(got[f1][0], kps_o[f1]), f"keypoints of frame {f1}"
+        for f2, rec in got[f1][1].items():
+            for a, b in zip(rec, flows_o[(f1, f2)]):
+                assert a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"flow {f1} -> {f2}"
