@@ -544,6 +544,17 @@ int pc_context_create(int device_index, pc_context** out) {
     {
         const char* g = getenv("POLYCHASE_LK_GATE");
         c->lk_gate_on = !(g && atoi(g) == 0);
+        // Under rocprofv3 the hand-over of dispatches is serialised: the gate's polling wavefront then sits in front of the
+        // launch it waits for until its 50-ms bail-out (seen in round 2).  A profiled process runs without the gate unless it
+        // is asked for explicitly (POLYCHASE_LK_GATE=1).
+        if (!g) {
+            extern char** environ;
+            for (char** e2 = environ; e2 && *e2; ++e2)
+                if (strncmp(*e2, "ROCPROFILER_", 12) == 0 || strncmp(*e2, "ROCPROF_", 8) == 0 || strncmp(*e2, "ROCP_TOOL_LIB", 13) == 0) {
+                    c->lk_gate_on = false;
+                    break;
+                }
+        }
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking);
