@@ -831,6 +831,8 @@ int pc_frame_create(pc_context* ctx, int width, int height, int window_size, int
         lh = (lh + 1) / 2;
         if (lw <= window_size || lh <= window_size) break;
     }
+    // tail slack: the LK staging reads 16 uint16 columns per region row, a few past the last row of the last plane
+    total += 256;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&f->slab), total);
     if (e != hipSuccess) {
         delete f;

@@ -276,6 +276,83 @@ __device__ __forceinline__ void stage_region(const uint16_t* __restrict__ J16, i
     }
 }
 
+// PC_LK3_STAGE_PAIRED: the same region staged with TWO LANES PER ROW.  stage_region gives every lane whole rows: each of its
+// 8 loads (10-px window) sends 64 lanes to 64 different rows of 16 different images -- 76 L1 accesses per instruction
+// (TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD, profiles/r04_lk_tcp_counters.txt), 608 per staging, and the texture
+// addresser of the CU, which takes one access per cycle, is busy or stalled 68 % of the launch: the twelve wavefronts of a
+// CU queue up behind each other's stagings.  Here lanes (0, 1) of a group read the two 16-byte halves of row 2k, lanes
+// (2, 3) those of row 2k + 1: one dwordx4 per lane and row pair -- 7 instead of 8 loads, and the two lanes of a row share
+// their cache line(s).  Position 8h + 7 needs the first pixel of the other half: one DPP move.  Positions past the region's
+// pitch are not written (lane h = 1: the upper four for a 12-position pitch, all eight for an 8-position one).
+// The loads read uint16 columns rx0 .. rx0 + 15, at most 16 - (WIN + 3) past the row's last needed one: the next row of the
+// plane, or the tail slack behind the frame's last plane (pc_frame_create).
+#ifndef PC_LK3_STAGE_PAIRED
+#define PC_LK3_STAGE_PAIRED 1
+#endif
+template <int WIN>
+__device__ __forceinline__ void stage_region_paired(const uint16_t* __restrict__ J16, int pitch, int rx0, int ry0, uint32_t* jbuf, int lg) {
+    using G = LK3Geo<WIN>;
+    static_assert(G::RWP + 1 <= 16 && G::PITCH >= 8 && G::PITCH <= 16, "a region row is at most 16 pixels: two dwordx4");
+    asm volatile("" : "+v"(lg));   // see stage_region
+    constexpr int NI = (G::RH + 1) / 2;
+    constexpr bool ODD = (G::RH & 1) != 0;   // the last load of lanes (2, 3) repeats row RH - 1
+    static_assert((2 * (NI - 1) + 1) * G::PITCH + 7 < 256, "ds_write2_b32 offsets are 8 bits of dwords");
+    struct __attribute__((packed, aligned(2))) Raw { uint32_t d[4]; };
+    const int s = lg >> 1, h = lg & 1;
+    const uint16_t* src = J16 + (ptrdiff_t)(__mul24(ry0 + s, pitch) + rx0 + 8 * h);
+    const int last_step = ODD ? (s ? pitch : 2 * pitch) : 2 * pitch;
+    Raw v[NI];
+#pragma unroll
+    for (int k = 0; k < NI; k++) {
+        v[k] = *reinterpret_cast<const Raw*>(src);
+        if (k + 1 < NI) src += (k + 2 == NI) ? last_step : 2 * pitch;
+    }
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(jbuf + s * G::PITCH + 8 * h);
+    // the repeated row of an odd region: lanes (2, 3) write row RH - 1 again (the same values as lanes (0, 1))
+    const uint32_t addr_last = ODD ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(jbuf + (G::RH - 1) * G::PITCH + 8 * h) : 0u;
+    const bool lo_on = G::PITCH >= 12 || h == 0, hi_on = G::PITCH >= 16 || h == 0;
+    if (lo_on) {
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const uint32_t d0 = v[k].d[0], d1 = v[k].d[1], d2 = v[k].d[2];
+            const uint32_t p1 = __builtin_amdgcn_alignbit(d1, d0, 16), p3 = __builtin_amdgcn_alignbit(d2, d1, 16);
+            if (ODD && k == NI - 1) {
+                asm volatile("ds_write2_b32 %0, %1, %2 offset0:0 offset1:1" : : "v"(addr_last), "v"(d0), "v"(p1) : "memory");
+                asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3" : : "v"(addr_last), "v"(d1), "v"(p3) : "memory");
+            } else {
+                asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(addr), "v"(d0), "v"(p1), "n"(2 * k * G::PITCH), "n"(2 * k * G::PITCH + 1) : "memory");
+                asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(addr), "v"(d1), "v"(p3), "n"(2 * k * G::PITCH + 2), "n"(2 * k * G::PITCH + 3) : "memory");
+            }
+        }
+    }
+    // (the DPP moves read the other lane's register whether or not that lane writes: they stay outside the masked block)
+    uint32_t nx[NI];
+#pragma unroll
+    for (int k = 0; k < NI; k++) nx[k] = (uint32_t)dpp_i32<0xF5>((int)v[k].d[0]);   // quad_perm [1, 1, 3, 3]
+    if (hi_on) {
+#pragma unroll
+        for (int k = 0; k < NI; k++) {
+            const uint32_t d2 = v[k].d[2], d3 = v[k].d[3];
+            const uint32_t p5 = __builtin_amdgcn_alignbit(d3, d2, 16), p7 = __builtin_amdgcn_alignbit(nx[k], d3, 16);
+            if (ODD && k == NI - 1) {
+                asm volatile("ds_write2_b32 %0, %1, %2 offset0:4 offset1:5" : : "v"(addr_last), "v"(d2), "v"(p5) : "memory");
+                asm volatile("ds_write2_b32 %0, %1, %2 offset0:6 offset1:7" : : "v"(addr_last), "v"(d3), "v"(p7) : "memory");
+            } else {
+                asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(addr), "v"(d2), "v"(p5), "n"(2 * k * G::PITCH + 4), "n"(2 * k * G::PITCH + 5) : "memory");
+                asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(addr), "v"(d3), "v"(p7), "n"(2 * k * G::PITCH + 6), "n"(2 * k * G::PITCH + 7) : "memory");
+            }
+        }
+    }
+}
+template <int WIN, int ROWS_IN_FLIGHT = PC_LK3_STAGE_ROWS>
+__device__ __forceinline__ void stage_j(const uint16_t* __restrict__ J16, int pitch, int rx0, int ry0, uint32_t* jbuf, int lg) {
+#if PC_LK3_STAGE_PAIRED
+    stage_region_paired<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
+#else
+    stage_region<WIN, ROWS_IN_FLIGHT>(J16, pitch, rx0, ry0, jbuf, lg);
+#endif
+}
+
 // The same staging cut in two (PC_LK3_J_EARLY): load() issues the global loads of a lane's rows (at most four: RH <= 14),
 // store() writes them to the region.
 template <int WIN>
@@ -913,10 +990,10 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 PC_LK3_SETPRIO_STAGING();
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #if PC_LK3_STAGE_TWICE
-                stage_region<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
+                stage_j<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #endif
-                stage_region<WIN, PC_LK3_RESTAGE_ROWS>(J16, pitch, rx0, ry0, jbuf, lg);
+                stage_j<WIN, PC_LK3_RESTAGE_ROWS>(J16, pitch, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 PC_LK3_SETPRIO_ITER();
                 staged = true;
@@ -937,10 +1014,10 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 PC_PROF(4);   // the timer reads are slow (scalar memory path): only around the rare staging, not per iteration
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #if PC_LK3_STAGE_TWICE
-                stage_region<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
+                stage_j<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #endif
-                stage_region<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
+                stage_j<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 staged = true;
                 PC_PROF_COUNT(9);
@@ -1189,10 +1266,10 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 ry0 = iey - G::MY;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #if PC_LK3_STAGE_TWICE
-                stage_region<WIN, PC_LK3_RESTAGE_ROWS>(J16, pitch, rx0, ry0, jbuf, lg);
+                stage_j<WIN, PC_LK3_RESTAGE_ROWS>(J16, pitch, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #endif
-                stage_region<WIN, PC_LK3_RESTAGE_ROWS>(J16, pitch, rx0, ry0, jbuf, lg);
+                stage_j<WIN, PC_LK3_RESTAGE_ROWS>(J16, pitch, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 staged = true;
             }
