@@ -155,8 +155,10 @@ def test_x86_order_on_the_two_keypoint_kernel_random(ctx, seed):
     n_targets = int(rng.integers(1, 9))
     src = _hard(rng, w, h, kind)
     tgts = []
+    moved = False
     for _ in range(n_targets):
         dx, dy = rng.integers(-4, 5, 2)
+        moved = moved or bool(dx or dy)
         t = np.roll(src, (int(dy), int(dx)), axis=(0, 1)).astype(np.int16) + rng.integers(-5, 6, src.shape, dtype=np.int16)
         tgts.append(np.clip(t, 0, 255).astype(np.uint8))
     fk = dict(window_size=win, max_level=max_level, term_max_iters=int(rng.choice([3, 30])))
@@ -190,7 +192,10 @@ def test_x86_order_on_the_two_keypoint_kernel_random(ctx, seed):
                 assert np.array_equal(err[k][m].view(np.uint32), oerr[m].view(np.uint32)), f"{case}: errors of target {k}"
         assert stats["keypoint_levels"] == len(kps) * (min(max_level, f1.num_levels - 1) + 1), (case, stats)
         if kind == "noise" and win >= 8:      # window sums of white noise exceed 2^24 from 8 x 8 on: both ordered evaluations ran
-            assert stats["iterations_x86_order"] > 0 and stats["keypoint_levels_x86_order"] > 0, (case, stats)
+            assert stats["keypoint_levels_x86_order"] > 0, (case, stats)
+            # (a target that is the source plus +-5 grey levels, not moved, differs too little for the proof to fail:
+            # soak seeds 1056340, 1060684, 1068510)
+            assert stats["iterations_x86_order"] > 0 or not moved, (case, stats)
         for f in [f1] + frames:
             f.close()
     finally:
