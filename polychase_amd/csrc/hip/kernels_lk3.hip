@@ -353,6 +353,37 @@ __device__ __forceinline__ void stage_j(const uint16_t* __restrict__ J16, int pi
 #endif
 }
 
+// The I window of one keypoint (WIN + 1 rows x WIN positions, staged by the keypoint's half-wave) the same way: lanes (2r, 2r + 1)
+// read the two 16-byte halves of row r -- one load where a lane per row takes a dwordx4 and a dwordx3 (lanes past the last row
+// repeat it, as there).
+// MEASURED AND NOT TAKEN (profiles/r04_lk_paired_i_window.txt, four A/B runs of the isolated launch): C2 x86 -2.6 %, C2 canonical
+// -0.6 %, C3 x86 +0.9 %, C3 canonical -0.1 % -- inside the run-to-run spread of +-1 %; the I side is a third of the launch's L1
+// accesses but 22 of its 32 lanes per half already share rows with a neighbour.  Off by default.
+#ifndef PC_LK3_ISTAGE_PAIRED
+#define PC_LK3_ISTAGE_PAIRED 0
+#endif
+template <int WIN>
+__device__ __forceinline__ void stage_i_window_paired(const uint16_t* __restrict__ origin, int pitch, uint32_t* ibuf, int l32) {
+    using G = LK3Geo<WIN>;
+    static_assert(2 * G::I_ROWS <= 32 && WIN + 1 <= 16 && G::I_PITCH <= 16, "two lanes per row of a half-wave");
+    struct __attribute__((packed, aligned(2))) Raw { uint32_t d[4]; };
+    const int r = min(l32 >> 1, G::I_ROWS - 1), h = l32 & 1;
+    const Raw v = *reinterpret_cast<const Raw*>(origin + (ptrdiff_t)(__mul24(r, pitch) + 8 * h));
+    const uint32_t nx = (uint32_t)dpp_i32<0xF5>((int)v.d[0]);   // quad_perm [1, 1, 3, 3]: the other half's first pixel
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(ibuf + r * G::I_PITCH + 8 * h);
+    // positions 8h .. 8h + 3 and 8h + 4 .. 8h + 7, where the window's pitch has them
+    if (h == 0 || G::I_PITCH > 8) {
+        const uint32_t p1 = __builtin_amdgcn_alignbit(v.d[1], v.d[0], 16), p3 = __builtin_amdgcn_alignbit(v.d[2], v.d[1], 16);
+        asm volatile("ds_write2_b32 %0, %1, %2 offset0:0 offset1:1" : : "v"(addr), "v"(v.d[0]), "v"(p1) : "memory");
+        asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3" : : "v"(addr), "v"(v.d[1]), "v"(p3) : "memory");
+    }
+    if (h == 0 ? G::I_PITCH > 4 : G::I_PITCH > 12) {
+        const uint32_t p5 = __builtin_amdgcn_alignbit(v.d[3], v.d[2], 16), p7 = __builtin_amdgcn_alignbit(nx, v.d[3], 16);
+        asm volatile("ds_write2_b32 %0, %1, %2 offset0:4 offset1:5" : : "v"(addr), "v"(v.d[2]), "v"(p5) : "memory");
+        asm volatile("ds_write2_b32 %0, %1, %2 offset0:6 offset1:7" : : "v"(addr), "v"(v.d[3]), "v"(p7) : "memory");
+    }
+}
+
 // The same staging cut in two (PC_LK3_J_EARLY): load() issues the global loads of a lane's rows (at most four: RH <= 14),
 // store() writes them to the region.
 template <int WIN>
@@ -759,11 +790,15 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         if (i_in) {
             DerivWindow<WIN, 32> dw;
             dw.load(L.der + (ptrdiff_t)(__mul24(ipy, pitch) + ipx), pitch, l32_o);
+#if PC_LK3_ISTAGE_PAIRED
+            stage_i_window_paired<WIN>(L.img16 + (ptrdiff_t)(__mul24(ipy, pitch) + ipx), pitch, ibuf_o, l32_o);
+#else
             // I window: lane r < WIN + 1 stages row r (the other lanes repeat the last row)
             RowRegs<G::I_CH> row;
             const int r = min(l32_o, G::I_ROWS - 1);
             row.load(L.img16 + (ptrdiff_t)__mul24(ipy + r, pitch) + ipx);
             row.store(ibuf_o + r * G::I_PITCH);
+#endif
             dw.store(dbuf_o, l32_o);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
