@@ -9,6 +9,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -58,6 +59,7 @@ class Socket {
         const char* c = static_cast<const char*>(p);
         while (n > 0) {
             const ssize_t k = ::send(fd_, c, n, MSG_NOSIGNAL);
+            if (k < 0 && errno == EINTR) continue;
             if (k <= 0) Fail("control connection lost while sending");
             c += k;
             n -= static_cast<size_t>(k);
@@ -67,6 +69,7 @@ class Socket {
         char* c = static_cast<char*>(p);
         while (n > 0) {
             const ssize_t k = ::recv(fd_, c, n, 0);
+            if (k < 0 && errno == EINTR) continue;
             if (k <= 0) Fail("control connection lost while receiving (the peer ended)");
             c += k;
             n -= static_cast<size_t>(k);
