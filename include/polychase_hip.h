@@ -46,10 +46,11 @@ typedef struct pc_gftt_options {
     int block_size;       /* 3   (any size >= 1: 3 runs the tiled kernel, others the general pair of kernels) */
     int gradient_size;    /* 3   (Sobel aperture; only 3 on the device, others: PC_E_INVALID -- the addon never sets it) */
     int max_corners;      /* 0 = unlimited */
-    int use_harris;       /* 0   (1: cornerHarris, gftt.cc:31-33 -- bit-exact against the oracle's restatement of calcHarris'
-                                 SCALAR expression (k in double) for every pixel; a real x86 OpenCV computes all but the last
-                                 width % 4 / % 8 columns in its SIMD path, in float with (float)k: that execution is NOT
-                                 emulated in any arithmetic mode -- the reference's addon never takes this branch) */
+    int use_harris;       /* 0   (1: cornerHarris, gftt.cc:31-33 -- calcHarris' scalar expression (k in double) in the canonical
+                                 mode; under PC_ARITH_SOBEL_FMA the first width / 4 * 4 columns of a row as the vector loop of an
+                                 x86 build computes them, in float with (float)k, and the scalar expression for the rest;
+                                 bit-exact against the oracle's restatement of either -- the reference's addon never takes
+                                 this branch) */
     double harris_k;      /* 0.04 */
     int grid_rows;        /* 4 */
     int grid_cols;        /* 4 */
@@ -95,7 +96,8 @@ int pc_context_synchronize(pc_context* ctx);
  *                           (+10-18 % on the LK launch); other windows run the generic kernel
  *   PC_ARITH_SOBEL_FMA      the fused multiply-add of the AVX2-dispatched symmetric column filter of Sobel inside
  *                           cornerMinEigenVal (cpp/feature_detection/gftt.cc:35): same corners, the (value, address)
- *                           order of near-ties -- i.e. keypoint indices -- as a stock x86 build produces them
+ *                           order of near-ties -- i.e. keypoint indices -- as a stock x86 build produces them; with
+ *                           use_harris also calcHarris' vector loop (float, (float)k) over the first width / 4 * 4 columns
  *   PC_ARITH_OPENCV_X86     both
  * Bit for bit what oracle/pc_oracle.c computes under pco_set_opencv_emulation(flags).  Default: PC_ARITH_OPENCV_X86 -- the
  * execution of the OpenCV build the reference links (vcpkg, x86-64: SSE baseline, AVX2 / FMA3 dispatched)

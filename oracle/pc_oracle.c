@@ -74,9 +74,10 @@ int pco_min_eigen_val(const uint8_t* gray, int w, int h, int block_size, int ksi
 /* cv::cornerHarris(gray, dst, block_size, ksize, k)  (cpp/feature_detection/gftt.cc:31-33): the same covariance sums
  * (cornerEigenValsVecs, same scale), then calcHarris' scalar expression
  *     dst = (float)(a * c - b * b - k * (a + c) * (a + c)),   a = cxx, b = cxy, c = cyy (float), k double
- * evaluated as C does: a*c, b*b and their difference in float; k * (a + c) * (a + c) in double.  (OpenCV's SIMD branch
- * of calcHarris computes the same in float with (float)k for the first width / 4 * 4 columns of a row -- an execution
- * order of its own, not emulated here: Harris is the reference's unused branch.)  [recalled] */
+ * evaluated as C does: a*c, b*b and their difference in float; k * (a + c) * (a + c) in double.  An x86 build computes
+ * only the last width % 4 columns of a row that way: the vector loop of calcHarris takes the first width / 4 * 4 columns in
+ * float with (float)k, (a*c - b*b) - ((k*(a + c))*(a + c)), no fused operations -- emulated under PCO_EMU_SOBEL_FMA (the
+ * "detector as an x86 build executes it" bit).  [recalled] */
 int pco_corner_harris(const uint8_t* gray, int w, int h, int block_size, int ksize, double k, float* dst) {
     return corner_response(gray, w, h, block_size, ksize, 1, k, dst);
 }
@@ -153,7 +154,15 @@ static int corner_response(const uint8_t* gray, int w, int h, int block_size, in
                 const float ac = a * c, bb = b * b;
                 const float det = ac - bb;
                 const float tr = a + c;
-                eig[(size_t)y * w + x] = (float)((double)det - harris_k * (double)tr * (double)tr);
+                if ((g_emulation & PCO_EMU_SOBEL_FMA) && x < (w / 4) * 4) {
+                    /* calcHarris' vector loop (128-bit universal intrinsics, and 8 at a time in corner.avx.cpp, compiled
+                     * without FMA): all in float with (float)k: (a*c - b*b) - ((k*(a + c))*(a + c)) */
+                    const float kf = (float)harris_k;
+                    const float kt = kf * tr;
+                    eig[(size_t)y * w + x] = det - kt * tr;
+                } else {
+                    eig[(size_t)y * w + x] = (float)((double)det - harris_k * (double)tr * (double)tr);
+                }
                 continue;
             }
             const float a = (float)sxx * 0.5f;

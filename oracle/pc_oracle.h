@@ -117,7 +117,7 @@ int pco_analyze_clip(const uint8_t* const* frames, int n_frames, int w, int h, i
  * PCO_EMU_OPENCV_X86, like the GPU library's PC_ARITH_OPENCV_X86.  Process-wide, set before calling; not thread safe
  * against running calls. */
 #define PCO_EMU_LK_SIMD 1
-#define PCO_EMU_SOBEL_FMA 2
+#define PCO_EMU_SOBEL_FMA 2   /* the detector as an x86 build executes it: FMA in the Sobel column filter, calcHarris' float vector loop */
 #define PCO_EMU_OPENCV_X86 3
 void pco_set_opencv_emulation(int flags);
 int pco_get_opencv_emulation(void);

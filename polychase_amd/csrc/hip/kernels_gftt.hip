@@ -462,11 +462,18 @@ __global__ __launch_bounds__(256) void box_response_kernel(const float* __restri
     }
     float e;
     if (harris) {
-        // calcHarris' scalar expression: (float)(a * c - b * b - k * (a + c) * (a + c)), the k term in double
+        // calcHarris' scalar expression: (float)(a * c - b * b - k * (a + c) * (a + c)), the k term in double; harris == 2
+        // (PC_ARITH_SOBEL_FMA, the detector as an x86 build executes it): the first w / 4 * 4 columns of a row go through
+        // calcHarris' vector loop -- all in float with (float)k, no fused operations (the build has -ffp-contract=off)
         const float a = (float)sxx, b = (float)sxy, c = (float)syy;
         const float ac = a * c, bb = b * b;
         const float det = ac - bb, tr = a + c;
-        e = (float)((double)det - harris_k * (double)tr * (double)tr);
+        if (harris == 2 && x < (w / 4) * 4) {
+            const float kt = (float)harris_k * tr;
+            e = det - kt * tr;
+        } else {
+            e = (float)((double)det - harris_k * (double)tr * (double)tr);
+        }
     } else {
         const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
         const float t = a - c;
@@ -492,7 +499,7 @@ void launch_corner_response(const Level& l0, float* eig, float* cov, const GfttG
     const float f1 = (float)(1.0 * scale_d), f0 = (float)(2.0 * scale_d);
     dim3 grid((l0.w + 63) / 64, (l0.h + 3) / 4);
     hipLaunchKernelGGL(cov_kernel, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, cov, f1, f0, sobel_fma ? 1 : 0, helper_prio_arg());
-    hipLaunchKernelGGL(box_response_kernel, grid, dim3(256), 0, s, cov, l0.w, l0.h, block_size, harris ? 1 : 0, harris_k, eig, g, cell_max,
+    hipLaunchKernelGGL(box_response_kernel, grid, dim3(256), 0, s, cov, l0.w, l0.h, block_size, harris ? (sobel_fma ? 2 : 1) : 0, harris_k, eig, g, cell_max,
                        helper_prio_arg());
 }
 

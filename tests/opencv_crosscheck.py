@@ -8,6 +8,7 @@ plain C) this script runs the same calls the reference makes and compares them w
 
     cv2.cvtColor(COLOR_RGB2GRAY)             opticalflow.cc:259        bit-exact expected
     cv2.cornerMinEigenVal(gray, 3, 3)        gftt.cc:35                bit-exact expected (float order fixed, no FMA)
+    cv2.cornerHarris(gray, 3, 3, 0.04)       gftt.cc:31-33             bit-exact expected in one of the two modes
     cv2.buildOpticalFlowPyramid              opticalflow.cc:184        bit-exact expected (images + Scharr planes)
     cv2.calcOpticalFlowPyrLK                 opticalflow.cc:119-125    status equal; positions within 1e-3 px of the
                                                                        canonical oracle (the bound
@@ -88,6 +89,18 @@ def main() -> int:
     report("cornerMinEigenVal", same or same_f or rel < 1e-6,
            f"bit-exact vs canonical={same}, vs AVX2-FMA emulation={same_f}, max |diff| / max = {rel:.2e}")
     k_o = oracle.gftt(g0)
+    # the detector's unused branch (gftt.cc:31-33): calcHarris' scalar expression everywhere (canonical) / its float vector
+    # loop over the first w / 4 * 4 columns (the x86 execution, under EMU_SOBEL_FMA).  g0 is cropped to a width that is not a
+    # multiple of 4 so that both loops are exercised
+    gh, ch = np.ascontiguousarray(g0[:, :g0.shape[1] - 3]), np.ascontiguousarray(c0[:, :c0.shape[1] - 3])
+    h_c = cv2.cornerHarris(ch, 3, 3, 0.04)
+    h_same = {}
+    for name, flags in (("canonical", 0), ("sobel_fma", oracle.EMU_SOBEL_FMA)):
+        with oracle.emulation(flags):
+            h_same[name] = bool(np.array_equal(oracle.corner_harris(gh, 3, 3, 0.04).view(np.uint32), h_c.view(np.uint32)))
+    h_rel = np.abs(oracle.corner_harris(gh, 3, 3, 0.04) - h_c).max() / max(float(np.abs(h_c).max()), 1e-30)
+    report("cornerHarris", any(h_same.values()) or h_rel < 1e-5, f"bit-exact vs canonical={h_same['canonical']}, vs x86 emulation={h_same['sobel_fma']}, "
+                                                                    f"max |diff| / max = {h_rel:.2e}")
 
     # A.3 pyramid with derivatives
     win, max_level = 10, 3
