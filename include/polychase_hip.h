@@ -99,12 +99,19 @@ int pc_context_synchronize(pc_context* ctx);
  *                           order of near-ties -- i.e. keypoint indices -- as a stock x86 build produces them; with
  *                           use_harris also calcHarris' vector loop (float, (float)k) over the first width / 4 * 4 columns
  *   PC_ARITH_OPENCV_X86     both
+ *   PC_ARITH_SOBEL_ROW_FMA  (not part of the default) additionally the ROW pass of Dy -- the smoothing taps [1, 2, 1] * scale
+ *                           over the 8-bit pixels -- as a fused chain t = k0 a; t = fma(k1, b, t); t = fma(k0, c, t): what the
+ *                           8u -> 32f vector row filter computes IF the linked OpenCV has one and dispatches it to AVX2 (a
+ *                           second hypothesis about the real build; `tests/opencv_crosscheck.py` on a machine with cv2 tells
+ *                           which one holds and names the POLYCHASE_ARITH value to use)
  * Bit for bit what oracle/pc_oracle.c computes under pco_set_opencv_emulation(flags).  Default: PC_ARITH_OPENCV_X86 -- the
  * execution of the OpenCV build the reference links (vcpkg, x86-64: SSE baseline, AVX2 / FMA3 dispatched)
- * -- or the environment variable POLYCHASE_ARITH = canonical | opencv_x86 | lk_x86 | sobel_fma at context creation. */
+ * -- or the environment variable POLYCHASE_ARITH = canonical | opencv_x86 | lk_x86 | sobel_fma | sobel_fma_rows | opencv_x86_rows at
+ * context creation. */
 #define PC_ARITH_CANONICAL 0
 #define PC_ARITH_LK_X86_ORDER 1
 #define PC_ARITH_SOBEL_FMA 2
+#define PC_ARITH_SOBEL_ROW_FMA 4
 #define PC_ARITH_OPENCV_X86 3
 /* Synchronous copy of `bytes` bytes of this context's device memory to host memory (debug dump of frames that were handed
  * over as device memory, cpp/opticalflow.cc:80-96). */

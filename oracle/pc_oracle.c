@@ -104,8 +104,13 @@ static int corner_response(const uint8_t* gray, int w, int h, int block_size, in
             const float sp = (float)s[reflect101(x + 1, w)];
             rdx[(size_t)y * w + x] = (0.0f - sm) + sp; /* -1*sm + 0*sc + 1*sp, exact */
             float t = f1 * sm;
-            t += f0 * sc;
-            t += f1 * sp;
+            if (g_emulation & PCO_EMU_SOBEL_ROW_FMA) { /* the vector row filter's v_muladd chain from a zero accumulator, fused */
+                t = fmaf(f0, sc, t);
+                t = fmaf(f1, sp, t);
+            } else {
+                t += f0 * sc;
+                t += f1 * sp;
+            }
             rdy[(size_t)y * w + x] = t;
         }
     }

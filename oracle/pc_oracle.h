@@ -119,6 +119,7 @@ int pco_analyze_clip(const uint8_t* const* frames, int n_frames, int w, int h, i
 #define PCO_EMU_LK_SIMD 1
 #define PCO_EMU_SOBEL_FMA 2   /* the detector as an x86 build executes it: FMA in the Sobel column filter, calcHarris' float vector loop */
 #define PCO_EMU_OPENCV_X86 3
+#define PCO_EMU_SOBEL_ROW_FMA 4   /* a second hypothesis: also the 8u -> 32f row smoothing of Dy as a fused chain (not in the default) */
 void pco_set_opencv_emulation(int flags);
 int pco_get_opencv_emulation(void);
 

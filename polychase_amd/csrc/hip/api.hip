@@ -152,7 +152,7 @@ int validate_gftt(const pc_gftt_options* opt, int w, int h, pc::GfttGrid* g) {
 // default, the general pair of kernels otherwise (their covariance scratch is allocated on first use: not the addon's path)
 static int corner_response(pc_context* ctx, const pc_frame* f, DetectScratch& d, const pc::GfttGrid& grid, const pc_gftt_options& opt,
                            uint32_t* cell_max) {
-    const bool fma = (ctx->arith & PC_ARITH_SOBEL_FMA) != 0;
+    const int fma = ((ctx->arith & PC_ARITH_SOBEL_FMA) ? 1 : 0) | ((ctx->arith & PC_ARITH_SOBEL_ROW_FMA) ? 2 : 0);
     // POLYCHASE_GFTT_GENERAL=1: the general kernels for the default options too (cross-check of the tiled kernel)
     static const bool force_general = getenv("POLYCHASE_GFTT_GENERAL") && atoi(getenv("POLYCHASE_GFTT_GENERAL")) == 1;
     if (opt.block_size == 3 && !opt.use_harris && !force_general) {
@@ -586,9 +586,11 @@ int pc_context_create(int device_index, pc_context** out) {
         else if (mode == "lk_x86") c->arith = PC_ARITH_LK_X86_ORDER;
         else if (mode == "sobel_fma") c->arith = PC_ARITH_SOBEL_FMA;
         else if (mode == "canonical") c->arith = PC_ARITH_CANONICAL;
+        else if (mode == "sobel_fma_rows") c->arith = PC_ARITH_SOBEL_FMA | PC_ARITH_SOBEL_ROW_FMA;
+        else if (mode == "opencv_x86_rows") c->arith = PC_ARITH_OPENCV_X86 | PC_ARITH_SOBEL_ROW_FMA;
         else if (!mode.empty()) {
             delete c;
-            return fail(PC_E_INVALID, "POLYCHASE_ARITH=%s: expected canonical, opencv_x86, lk_x86 or sobel_fma", m);
+            return fail(PC_E_INVALID, "POLYCHASE_ARITH=%s: expected canonical, opencv_x86, lk_x86, sobel_fma, sobel_fma_rows or opencv_x86_rows", m);
         }
     }
     if (e != hipSuccess) {
@@ -660,7 +662,7 @@ int pc_peer_buffer_download(int device_index, void* dst_host, const void* src_de
 
 int pc_context_set_arithmetic(pc_context* c, int flags) {
     if (!c) return fail(PC_E_INVALID, "null context");
-    if (flags & ~PC_ARITH_OPENCV_X86) return fail(PC_E_INVALID, "unknown arithmetic flags %d", flags);
+    if (flags & ~(PC_ARITH_OPENCV_X86 | PC_ARITH_SOBEL_ROW_FMA)) return fail(PC_E_INVALID, "unknown arithmetic flags %d", flags);
     c->arith = flags;
     c->eig_owner = nullptr;   // a min-eig map computed under the other mode is not this mode's
     return PC_OK;

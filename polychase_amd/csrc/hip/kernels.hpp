@@ -52,11 +52,12 @@ struct GfttGrid {
 constexpr int kMaxGridCells = 256;
 // K2: cornerMinEigenVal (block 3, Sobel 3) of the level-0 interior + per-cell max (ordered keys,
 // cell_max must be zeroed first).
-// sobel_fma: the column pass of Dx as ONE fused multiply-add (PC_ARITH_SOBEL_FMA: the AVX2 dispatch of OpenCV's filter)
-void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, bool sobel_fma, hipStream_t s);
+// sobel_fma, bit 0: the column pass of Dx as ONE fused multiply-add (PC_ARITH_SOBEL_FMA: the AVX2 dispatch of OpenCV's filter);
+// bit 1: the row pass of Dy as a fused chain (PC_ARITH_SOBEL_ROW_FMA)
+void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, int sobel_fma, hipStream_t s);
 // K2 for any block_size and for cornerHarris (gftt.cc:31-36): two plain kernels; cov = 3 * w * h floats of scratch
 void launch_corner_response(const Level& l0, float* eig, float* cov, const GfttGrid& g, uint32_t* cell_max, int block_size, bool harris,
-                            double harris_k, bool sobel_fma, hipStream_t s);
+                            double harris_k, int sobel_fma, hipStream_t s);
 // K3: per-cell THRESH_TOZERO + 3x3 dilate + strict-interior local maxima -> 64-bit keys
 // (ordered(value) << 32 | y*w+x) appended to `keys` (capacity `cap`), count in *counter; cstate (w*h bytes): 1 at
 // candidates, 0 elsewhere, every pixel written; sort_params[2] / hist[kSortBuckets]: value range and per-bucket counts

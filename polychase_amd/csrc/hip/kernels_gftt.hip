@@ -36,15 +36,32 @@ constexpr int TW = 64, TH = 16;
 constexpr int GH = TH + 4, G_PITCH = 72;  // gray tile: columns x0 - 4 .. x0 + 67 (18 aligned dwords), rows y0 - 2 .. y0 + 17
 constexpr int CW = TW + 2, CH = TH + 2;   // covariance tile: x0 - 1 .. x0 + 64, y0 - 1 .. y0 + 16
 
+// Dy's row pass: the smoothing taps [1, 2, 1] * scale over (a, b, c).  Canonical: the generic row filter's t = f1 a; t += f0 b;
+// t += f1 c.  ROW_FMA (PC_ARITH_SOBEL_ROW_FMA): the same chain fused -- what the 8u -> 32f vector row filter of an
+// AVX2-dispatched build computes (v_muladd from a zero accumulator: the first term is a plain product)
+template <bool ROW_FMA>
+__device__ __forceinline__ float smooth_row(float a, float b, float c, float f1, float f0) {
+    float t = f1 * a;
+    if (ROW_FMA) {
+        t = __fmaf_rn(f0, b, t);
+        t = __fmaf_rn(f1, c, t);
+    } else {
+        t += f0 * b;
+        t += f1 * c;
+    }
+    return t;
+}
+
 // SOBEL_FMA (PC_ARITH_SOBEL_FMA) is a template parameter, not a launch argument: the extra code of that mode took the
 // kernel from 64 to 106 VGPRs, and a helper wavefront with more than 104 does not fit beside three LK wavefronts per SIMD
 // (512 - 3 x 136): the detection then only ran in the gaps of the LK launches -- 4K pipeline 710 -> 537 frames/s, caught by
 // the round's last profile run.  tests/test_kernel_resources_cpu.py now holds every helper kernel to its budget.
-template <bool SOBEL_FMA>
+// SOBEL: bit 0 = the fused column pass of Dx (PC_ARITH_SOBEL_FMA), bit 1 = the fused row pass of Dy (PC_ARITH_SOBEL_ROW_FMA)
+template <int SOBEL>
 __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict__ img, int pitch, int w, int h,
                                                       float* __restrict__ eig, GfttGrid g,
                                                       uint32_t* __restrict__ cell_max, float f1, float f0, int hi_prio) {
-    constexpr bool sobel_fma = SOBEL_FMA;
+    constexpr bool sobel_fma = (SOBEL & 1) != 0, row_fma = (SOBEL & 2) != 0;
     helper_priority(hi_prio);
     __shared__ __attribute__((aligned(16))) uint8_t s_gray[GH][G_PITCH];
     __shared__ float s_cxx[CH][CW + 1];
@@ -78,10 +95,7 @@ __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict_
             const uint8_t* gp = &s_gray[6 * band + k][cx + 2];
             const float a = gp[0], b = gp[1], c = gp[2];
             rx[k] = c - a;
-            float t = f1 * a;
-            t += f0 * b;
-            t += f1 * c;
-            ry[k] = t;
+            ry[k] = smooth_row<row_fma>(a, b, c, f1, f0);
         }
 #pragma unroll
         for (int k = 0; k < 6; k++) {
@@ -89,10 +103,7 @@ __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict_
             const uint8_t* gp = &s_gray[cy + 2][cx + 2];
             const float a = gp[0], b = gp[1], c = gp[2];
             rx[2] = c - a;
-            float t = f1 * a;
-            t += f0 * b;
-            t += f1 * c;
-            ry[2] = t;
+            ry[2] = smooth_row<row_fma>(a, b, c, f1, f0);
             // Dx: row [-1,0,1] then column (S0 + S2)*f1 + S1*f0;  Dy: row [1,2,1]*scale then column S2 - S0
             // PC_ARITH_SOBEL_FMA: v_muladd(S0 + S2, k1, S1 * k0) fused, as the AVX2 build of the filter executes it
             const float dx = sobel_fma ? __fmaf_rn(rx[0] + rx[2], f1, rx[1] * f0) : (rx[0] + rx[2]) * f1 + rx[1] * f0;
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(256) void min_eig_kernel(const uint8_t* __restrict_
 constexpr int ME_R = 8;                       // output rows per lane
 constexpr int ME_TW = 64, ME_TH = 2 * ME_R;   // pixels per wavefront: 32 column pairs x 2 bands
 
-template <bool SOBEL_FMA>
+template <int SOBEL>
 __global__ __launch_bounds__(256) void min_eig_fused_kernel(const uint8_t* __restrict__ img, int pitch, int w, int h,
                                                             float* __restrict__ eig, GfttGrid g,
                                                             uint32_t* __restrict__ cell_max, float f1, float f0, int hi_prio) {
@@ -277,18 +288,26 @@ __global__ __launch_bounds__(256) void min_eig_fused_kernel(const uint8_t* __res
             gv[3] = (float)(lo >> 24);
             gv[4] = (float)(hi & 0xffu);
             gv[5] = (float)((hi >> 8) & 0xffu);
+            constexpr bool SOBEL_FMA = (SOBEL & 1) != 0, ROW_FMA = (SOBEL & 2) != 0;
             float p1[6], p0[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) p1[i] = f1 * gv[i];
+            if (!ROW_FMA) {
 #pragma unroll
-            for (int i = 1; i < 5; i++) p0[i] = f0 * gv[i];
+                for (int i = 1; i < 5; i++) p0[i] = f0 * gv[i];
+            }
             const int cur = k % 3, prev = (k + 2) % 3, pp = (k + 1) % 3;   // gray rows gy, gy - 1, gy - 2
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 rx[cur][c] = gv[c + 2] - gv[c];              // == (0 - g[-1]) + g[+1]: exact either way
                 float t = p1[c];                             // t = f1 * s[-1]; t += f0 * s[0]; t += f1 * s[+1]
-                t += p0[c + 1];
-                t += p1[c + 2];
+                if (ROW_FMA) {                               // ... the same chain fused (smooth_row)
+                    t = __fmaf_rn(f0, gv[c + 1], t);
+                    t = __fmaf_rn(f1, gv[c + 2], t);
+                } else {
+                    t += p0[c + 1];
+                    t += p1[c + 2];
+                }
                 ry[cur][c] = t;
             }
             if (k < 2) continue;
@@ -390,19 +409,26 @@ static int min_eig_variant() {
     return v;
 }
 
-void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, bool sobel_fma, hipStream_t s) {
-    // scale = 1 / (2^(ksize-1) * block_size * 255), folded into the smoothing taps (see oracle)
-    const double scale_d = 1.0 / (4.0 * 3.0 * 255.0);
-    const float f1 = (float)(1.0 * scale_d), f0 = (float)(2.0 * scale_d);
+template <int SOBEL>
+static void launch_min_eig_mode(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, float f1, float f0, hipStream_t s) {
     if (min_eig_variant() == 0) {
         dim3 grid2((l0.w + 2 * ME_TW - 1) / (2 * ME_TW), (l0.h + 2 * ME_TH - 1) / (2 * ME_TH));
-        if (sobel_fma) hipLaunchKernelGGL(min_eig_fused_kernel<true>, grid2, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, helper_prio_arg());
-        else hipLaunchKernelGGL(min_eig_fused_kernel<false>, grid2, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, helper_prio_arg());
+        hipLaunchKernelGGL(min_eig_fused_kernel<SOBEL>, grid2, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, helper_prio_arg());
         return;
     }
     dim3 grid((l0.w + TW - 1) / TW, (l0.h + TH - 1) / TH);
-    if (sobel_fma) hipLaunchKernelGGL(min_eig_kernel<true>, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, helper_prio_arg());
-    else hipLaunchKernelGGL(min_eig_kernel<false>, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, helper_prio_arg());
+    hipLaunchKernelGGL(min_eig_kernel<SOBEL>, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, eig, g, cell_max, f1, f0, helper_prio_arg());
+}
+void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, int sobel_fma, hipStream_t s) {
+    // scale = 1 / (2^(ksize-1) * block_size * 255), folded into the smoothing taps (see oracle)
+    const double scale_d = 1.0 / (4.0 * 3.0 * 255.0);
+    const float f1 = (float)(1.0 * scale_d), f0 = (float)(2.0 * scale_d);
+    switch (sobel_fma & 3) {
+        case 0: launch_min_eig_mode<0>(l0, eig, g, cell_max, f1, f0, s); break;
+        case 1: launch_min_eig_mode<1>(l0, eig, g, cell_max, f1, f0, s); break;
+        case 2: launch_min_eig_mode<2>(l0, eig, g, cell_max, f1, f0, s); break;
+        default: launch_min_eig_mode<3>(l0, eig, g, cell_max, f1, f0, s); break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -424,12 +450,9 @@ __global__ __launch_bounds__(256) void cov_kernel(const uint8_t* __restrict__ im
         const uint8_t* row = img + (ptrdiff_t)(y - 1 + k) * pitch + x;
         const float sm = row[-1], sc = row[0], sp = row[1];
         rdx[k] = (0.0f - sm) + sp;
-        float t = f1 * sm;
-        t += f0 * sc;
-        t += f1 * sp;
-        rdy[k] = t;
+        rdy[k] = (sobel_fma & 2) ? smooth_row<true>(sm, sc, sp, f1, f0) : smooth_row<false>(sm, sc, sp, f1, f0);
     }
-    const float dx = sobel_fma ? __fmaf_rn(rdx[0] + rdx[2], f1, rdx[1] * f0) : (rdx[0] + rdx[2]) * f1 + rdx[1] * f0;
+    const float dx = (sobel_fma & 1) ? __fmaf_rn(rdx[0] + rdx[2], f1, rdx[1] * f0) : (rdx[0] + rdx[2]) * f1 + rdx[1] * f0;
     const float dy = rdy[2] - rdy[0];
     const size_t n = (size_t)w * h, i = (size_t)y * w + x;
     cov[i] = dx * dx;
@@ -494,12 +517,12 @@ __global__ __launch_bounds__(256) void box_response_kernel(const float* __restri
 }
 
 void launch_corner_response(const Level& l0, float* eig, float* cov, const GfttGrid& g, uint32_t* cell_max, int block_size, bool harris,
-                            double harris_k, bool sobel_fma, hipStream_t s) {
+                            double harris_k, int sobel_fma, hipStream_t s) {
     const double scale_d = 1.0 / (4.0 * (double)block_size * 255.0);
     const float f1 = (float)(1.0 * scale_d), f0 = (float)(2.0 * scale_d);
     dim3 grid((l0.w + 63) / 64, (l0.h + 3) / 4);
-    hipLaunchKernelGGL(cov_kernel, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, cov, f1, f0, sobel_fma ? 1 : 0, helper_prio_arg());
-    hipLaunchKernelGGL(box_response_kernel, grid, dim3(256), 0, s, cov, l0.w, l0.h, block_size, harris ? (sobel_fma ? 2 : 1) : 0, harris_k, eig, g, cell_max,
+    hipLaunchKernelGGL(cov_kernel, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, cov, f1, f0, sobel_fma, helper_prio_arg());
+    hipLaunchKernelGGL(box_response_kernel, grid, dim3(256), 0, s, cov, l0.w, l0.h, block_size, harris ? ((sobel_fma & 1) ? 2 : 1) : 0, harris_k, eig, g, cell_max,
                        helper_prio_arg());
 }
 

@@ -48,6 +48,7 @@ SYMBOLS = [
 
 
 ARITH_CANONICAL, ARITH_LK_X86_ORDER, ARITH_SOBEL_FMA, ARITH_OPENCV_X86 = 0, 1, 2, 3
+ARITH_SOBEL_ROW_FMA = 4   # on top of the others (include/polychase_hip.h: PC_ARITH_SOBEL_ROW_FMA)
 
 
 class GfttOptions(C.Structure):
@@ -214,7 +215,7 @@ class Context:
             pass
 
     def set_arithmetic(self, flags: int):
-        """ARITH_CANONICAL | ARITH_LK_X86_ORDER | ARITH_SOBEL_FMA (include/polychase_hip.h: pc_context_set_arithmetic)."""
+        """ARITH_CANONICAL | ARITH_LK_X86_ORDER | ARITH_SOBEL_FMA | ARITH_SOBEL_ROW_FMA (include/polychase_hip.h: pc_context_set_arithmetic)."""
         _check(load().pc_context_set_arithmetic(self._h, int(flags)))
 
     @property

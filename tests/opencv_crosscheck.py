@@ -154,20 +154,21 @@ def main() -> int:
     big = oracle.rgb2gray(synth.NoiseClip(1920, 1080, 4).frame(2))
     e_big = cv2.cornerMinEigenVal(big, 3, ksize=3)
     verdict = {}
-    for name, flags in (("canonical", 0), ("sobel_fma", oracle.EMU_SOBEL_FMA)):
+    for name, flags in (("canonical", 0), ("sobel_fma", oracle.EMU_SOBEL_FMA), ("sobel_fma_rows", oracle.EMU_SOBEL_FMA | oracle.EMU_SOBEL_ROW_FMA)):
         with oracle.emulation(flags):
             verdict[name] = bool(np.array_equal(oracle.min_eigen_val(big, 3, 3).view(np.uint32), e_big.view(np.uint32)))
     with oracle.emulation(oracle.EMU_LK_SIMD):
         xb_e, sb_e, _ = oracle.lk(oracle.Pyramid(gb0, win, max_level), oracle.Pyramid(gb1, win, max_level), kb)
     lk_modes = {"canonical": bool(np.array_equal(sb_o, sb_c) and np.array_equal(xb_o[mb].view(np.uint32), xb_c[mb].view(np.uint32))),
                 "lk_x86": bool(np.array_equal(sb_e, sb_c) and np.array_equal(xb_e[sb_c == 1].view(np.uint32), xb_c[sb_c == 1].view(np.uint32)))}
-    gftt_mode = "sobel_fma" if verdict["sobel_fma"] else ("canonical" if verdict["canonical"] else None)
+    gftt_mode = next((m for m in ("sobel_fma", "sobel_fma_rows", "canonical") if verdict[m]), None)
     lk_mode = "lk_x86" if lk_modes["lk_x86"] else ("canonical" if lk_modes["canonical"] else None)
-    print(f"min-eig map at 1920x1080 bit-exact: canonical={verdict['canonical']} sobel_fma={verdict['sobel_fma']};  "
+    print(f"min-eig map at 1920x1080 bit-exact: canonical={verdict['canonical']} sobel_fma={verdict['sobel_fma']} sobel_fma_rows={verdict['sobel_fma_rows']};  "
           f"LK on the checkerboard bit-exact: canonical={lk_modes['canonical']} lk_x86={lk_modes['lk_x86']}")
     if gftt_mode and lk_mode:
         arith = {("canonical", "canonical"): "canonical", ("sobel_fma", "canonical"): "sobel_fma",
-                 ("canonical", "lk_x86"): "lk_x86", ("sobel_fma", "lk_x86"): "opencv_x86"}[(gftt_mode, lk_mode)]
+                 ("canonical", "lk_x86"): "lk_x86", ("sobel_fma", "lk_x86"): "opencv_x86",
+                 ("sobel_fma_rows", "canonical"): "sobel_fma_rows", ("sobel_fma_rows", "lk_x86"): "opencv_x86_rows"}[(gftt_mode, lk_mode)]
         print(f"==> this OpenCV build is reproduced bit for bit by POLYCHASE_ARITH={arith} (DESIGN.md section 2)")
     else:
         report("an arithmetic mode that reproduces this build", False, "neither mode is bit-exact: the restatement needs another look")

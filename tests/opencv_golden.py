@@ -25,7 +25,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN_DIR = os.path.join(HERE, "golden")
 WIN, MAX_LEVEL = 10, 3
-ARITH_FLAGS = {"canonical": 0, "lk_x86": 1, "sobel_fma": 2, "opencv_x86": 3}
+ARITH_FLAGS = {"canonical": 0, "lk_x86": 1, "sobel_fma": 2, "opencv_x86": 3, "sobel_fma_rows": 6, "opencv_x86_rows": 7}   # = POLYCHASE_ARITH values
 
 
 def cases():
@@ -230,7 +230,7 @@ def compare(G, name, got, exact_float: bool):
 
 def matching_arith(G) -> str | None:
     """the arithmetic mode in which the ORACLE reproduces the file bit for bit (tried: the default opencv_x86 first)"""
-    for mode in ("opencv_x86", "lk_x86", "sobel_fma", "canonical"):
+    for mode in ("opencv_x86", "opencv_x86_rows", "lk_x86", "sobel_fma", "sobel_fma_rows", "canonical"):
         if all(not compare(G, name, oracle_outputs(G, name, ARITH_FLAGS[mode]), True) for name in ("c1", "c2")):
             return mode
     return None

@@ -71,6 +71,7 @@ def lib(path: str | None = None):
 
 
 EMU_CANONICAL, EMU_LK_SIMD, EMU_SOBEL_FMA, EMU_OPENCV_X86 = 0, 1, 2, 3   # the default is EMU_OPENCV_X86 (pc_oracle.c)
+EMU_SOBEL_ROW_FMA = 4   # hypothesis flag on top: Dy's 8u -> 32f row smoothing as a fused chain (pc_oracle.h)
 
 
 class emulation:

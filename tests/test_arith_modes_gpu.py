@@ -90,7 +90,9 @@ def test_sobel_fma_mode_min_eig_map_and_keypoint_order_at_1080p(ctx):
     rgb = clip.frame(2)
     gray = oracle.rgb2gray(rgb)
     got = {}
-    for flags, emu in ((hip.ARITH_SOBEL_FMA, oracle.EMU_SOBEL_FMA), (hip.ARITH_CANONICAL, 0)):
+    # (the third: the second hypothesis about the real build -- Dy's row smoothing fused as well, PC_ARITH_SOBEL_ROW_FMA)
+    for flags, emu in ((hip.ARITH_SOBEL_FMA, oracle.EMU_SOBEL_FMA), (hip.ARITH_CANONICAL, 0),
+                       (hip.ARITH_SOBEL_FMA | hip.ARITH_SOBEL_ROW_FMA, oracle.EMU_SOBEL_FMA | oracle.EMU_SOBEL_ROW_FMA)):
         ctx.set_arithmetic(flags)
         f = hip.Frame(ctx, 1920, 1080)
         f.set_rgb(rgb)

@@ -15,7 +15,8 @@ from polychase_amd import build
 HELPER_VGPR_BUDGET = 104          # 512 - 3 * 136, allocation granularity 8
 HELPER_LDS_BUDGET = 18 * 1024     # two workgroups of a helper kernel per CU beside 12 LK wavefronts (120 of 160 KB)
 # kernels enqueued by the analyzer while LK launches run (substring of the mangled name)
-HELPERS = ["level_kernel", "min_eig_kernelILb0", "min_eig_kernelILb1", "min_eig_fused_kernelILb0", "min_eig_fused_kernelILb1", "nms_kernel", "bucket_scatter_kernel", "bucket_sort_kernel", "suppress_sorted_kernel",
+HELPERS = ["level_kernel", "min_eig_kernelILi0", "min_eig_kernelILi1", "min_eig_kernelILi2", "min_eig_kernelILi3", "min_eig_fused_kernelILi0", "min_eig_fused_kernelILi1",
+           "min_eig_fused_kernelILi2", "min_eig_fused_kernelILi3", "nms_kernel", "bucket_scatter_kernel", "bucket_sort_kernel", "suppress_sorted_kernel",
            "accept_all_kernel", "accepted_scatter_kernel", "bin_scatter_kernel", "compact_count_kernel", "compact_scatter_kernel",
            "copy_keypoints_kernel", "lk_gate_kernel"]
 

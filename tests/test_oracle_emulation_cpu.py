@@ -90,3 +90,27 @@ def test_gftt_gap_to_avx2_sobel(name):
           f"{len(kc)} corners canonical / {len(ke)} emulated, {len(sc ^ se)} not common, {moved} positions of the list hold another corner")
     assert max_rel < 1e-6
     assert len(sc ^ se) <= max(2, len(kc) // 1000)
+
+
+def test_row_fma_hypothesis_is_a_last_bit_change_of_dy():
+    """PCO_EMU_SOBEL_ROW_FMA (the second hypothesis about an AVX2-dispatched build: Dy's 8u -> 32f row smoothing as a fused
+    chain) against a numpy restatement of exactly that chain on one row, and its effect on the map: last bits, the same corners."""
+    rng = np.random.default_rng(12)
+    gray = rng.integers(0, 256, (90, 131), dtype=np.uint8)
+    with oracle.emulation(oracle.EMU_SOBEL_FMA):
+        e1, k1 = oracle.min_eigen_val(gray), oracle.gftt(gray)
+    with oracle.emulation(oracle.EMU_SOBEL_FMA | oracle.EMU_SOBEL_ROW_FMA):
+        e2, k2 = oracle.min_eigen_val(gray), oracle.gftt(gray)
+    assert (e1 != e2).any(), "the flag must reach the row pass"
+    assert float(np.abs(e1 - e2).max() / np.abs(e1).max()) < 1e-6
+    assert len(set(map(tuple, k1.astype(int))) ^ set(map(tuple, k2.astype(int)))) <= 2
+    # the chain itself: fma(a, b, c) of float32 values = the float64 a * b + c (exact product, 53 bits hold the sum of a 24-bit
+    # times 8-bit product and a float of the same magnitude) rounded once to float32
+    scale = 1.0 / (4.0 * 3.0 * 255.0)
+    f1, f0 = np.float32(scale), np.float32(2.0 * scale)
+    a, b, c = (gray[7, 0:-2].astype(np.float32), gray[7, 1:-1].astype(np.float32), gray[7, 2:].astype(np.float32))
+    t = f1 * a
+    fused = (np.float64(f0) * b.astype(np.float64) + t.astype(np.float64)).astype(np.float32)
+    fused = (np.float64(f1) * c.astype(np.float64) + fused.astype(np.float64)).astype(np.float32)
+    plain = (t + f0 * b) + f1 * c
+    assert (fused != plain).any(), "on 129 pixels the two chains differ somewhere"

@@ -144,7 +144,8 @@ def test_random_detector_branch_and_arithmetic_mode(ctx, seed):
     win, max_level = int(rng.integers(3, 17)), int(rng.integers(0, 4))
     block = int(rng.choice([1, 2, 3, 3, 4, 5, 7]))
     harris = bool(rng.random() < 0.35)
-    arith = int(rng.choice([hip.ARITH_CANONICAL, hip.ARITH_LK_X86_ORDER, hip.ARITH_SOBEL_FMA, hip.ARITH_OPENCV_X86]))
+    arith = int(rng.choice([hip.ARITH_CANONICAL, hip.ARITH_LK_X86_ORDER, hip.ARITH_SOBEL_FMA, hip.ARITH_OPENCV_X86,
+                            hip.ARITH_SOBEL_FMA | hip.ARITH_SOBEL_ROW_FMA, hip.ARITH_OPENCV_X86 | hip.ARITH_SOBEL_ROW_FMA, hip.ARITH_SOBEL_ROW_FMA]))
     gk = dict(quality_level=float(rng.choice([0.01, 0.05, 0.3])), min_distance=float(rng.choice([0.0, 2.5, 5.0])), block_size=block,
               use_harris=int(harris), harris_k=float(rng.choice([0.04, 0.06, 0.15])), grid_rows=int(rng.integers(1, 5)),
               grid_cols=int(rng.integers(1, 5)))
@@ -155,7 +156,8 @@ def test_random_detector_branch_and_arithmetic_mode(ctx, seed):
         src = np.where(src > 127, 255, 0).astype(np.uint8)
     tgts = [_shifted(rng, src, int(rng.integers(0, 5))) for _ in range(n_targets)]
     case = f"seed {seed}: {w}x{h} {kind} win {win} L {max_level} gftt {gk} lk {fk} targets {n_targets} arith {arith}"
-    emu = (oracle.EMU_LK_SIMD if arith & hip.ARITH_LK_X86_ORDER else 0) | (oracle.EMU_SOBEL_FMA if arith & hip.ARITH_SOBEL_FMA else 0)
+    emu = (oracle.EMU_LK_SIMD if arith & hip.ARITH_LK_X86_ORDER else 0) | (oracle.EMU_SOBEL_FMA if arith & hip.ARITH_SOBEL_FMA else 0) | \
+          (oracle.EMU_SOBEL_ROW_FMA if arith & hip.ARITH_SOBEL_ROW_FMA else 0)
     before = ctx.arithmetic
     ctx.set_arithmetic(arith)
     try:
