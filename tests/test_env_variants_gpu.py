@@ -52,3 +52,13 @@ def reference_hash():
 @pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
 def test_knob_does_not_change_the_database(reference_hash, variant):
     assert _hash(variant) == reference_hash
+
+
+def test_the_three_min_eig_kernels_agree_in_the_row_fma_mode():
+    """POLYCHASE_ARITH=opencv_x86_rows (PC_ARITH_SOBEL_ROW_FMA on top of the default: the second hypothesis about the AVX2 build):
+    the fused kernel, the LDS-tiled one and the general pair give one database -- and an unknown mode name is refused."""
+    base = _hash({"POLYCHASE_ARITH": "opencv_x86_rows"})
+    assert _hash({"POLYCHASE_ARITH": "opencv_x86_rows", "POLYCHASE_MINEIG_VARIANT": "1"}) == base
+    assert _hash({"POLYCHASE_ARITH": "opencv_x86_rows", "POLYCHASE_GFTT_GENERAL": "1"}) == base
+    with pytest.raises(AssertionError):
+        _hash({"POLYCHASE_ARITH": "no_such_mode"})
