@@ -99,6 +99,8 @@ void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunct
 // Frees the idle engine a finished run has parked for the next one (GPU memory of ~20 resident frames; analysis_driver.cc:
 // EngineCache).  POLYCHASE_ENGINE_CACHE=0 disables the parking altogether.
 void ReleaseCachedEngine();
+// testing aid: true while the idle timer of a parked engine exists (a thread that lives only as long as an engine is parked)
+bool EngineCacheTimerRunning();
 
 // ---- multi-GPU analysis (one process per GPU, frame1 ranges sharded, RCCL only for the stitch) ----------
 

@@ -81,73 +81,114 @@ struct Engine {
 // 0.25 ms per frame of a 300-frame clip at 1080p, more than the analysis of a frame takes.  A run that ends normally
 // parks its engine here (pc_analyzer_reset: allocations kept, no state); the next run with the same device, geometry and
 // options takes it, any other run replaces it.  release_cached_engine() / POLYCHASE_ENGINE_CACHE=0 give the memory back.
+//
+// A parked engine holds ~20 frame slabs of GPU memory (several GB at 4K) inside the HOST's process -- Blender -- for a call
+// that may never come: it is given back after POLYCHASE_ENGINE_CACHE_IDLE_S seconds without a taker (default 120; 0: keep it
+// until release_cached_engine()).  The timer is a thread that EXISTS ONLY WHILE AN ENGINE IS PARKED: it sleeps in one timed
+// condition-variable wait until the deadline, and whoever takes, replaces or releases the engine wakes and JOINS it -- no
+// thread of this library is left running in a host that holds no parked engine, and none polls.  At process exit (an atexit
+// handler registered with the first parked engine, i.e. after the HIP runtime's own and therefore run before them) the timer
+// is told to end without touching the GPU and is joined; an engine still parked then is left to the operating system -- no
+// GPU call is made while the process is going down.
 class EngineCache {
    public:
     static std::unique_ptr<Engine> Take(int dev, uint32_t w, uint32_t h, const pc_gftt_options& g, const pc_flow_options& f) {
-        std::unique_ptr<Engine> e;
-        {
-            std::lock_guard<std::mutex> lk(Mutex());
-            e = std::move(Slot());
-        }
-        if (e && !e->Matches(dev, w, h, g, f)) e.reset();   // destroyed here, outside the lock
+        std::unique_ptr<Engine> e = Exchange(nullptr);
+        if (e && !e->Matches(dev, w, h, g, f)) e.reset();   // destroyed here, outside every lock
         return e;
     }
     static void Park(std::unique_ptr<Engine> e) {
         static const bool enabled = !(std::getenv("POLYCHASE_ENGINE_CACHE") && std::atoi(std::getenv("POLYCHASE_ENGINE_CACHE")) == 0);
         if (!enabled || !e || pc_analyzer_reset(e->an) != PC_OK) return;   // e is destroyed
-        std::unique_ptr<Engine> old;
-        {
-            std::lock_guard<std::mutex> lk(Mutex());
-            old = std::move(Slot());
-            Slot() = std::move(e);
-            ParkedAt() = std::chrono::steady_clock::now();
-        }
-        StartReaper();
+        Exchange(std::move(e));   // the engine it replaces, if any, is destroyed here
     }
-    // A parked engine holds ~20 frame slabs of GPU memory (several GB at 4K) inside the HOST's process -- Blender -- for a call
-    // that may never come.  It is given back after POLYCHASE_ENGINE_CACHE_IDLE_S seconds without a taker (default 120; 0: keep it
-    // until release_cached_engine()): one detached thread that wakes once a second while an engine is parked.
-    static void StartReaper() {
+    static void Clear() { Exchange(nullptr); }
+    // testing aid: is a timer thread alive right now?
+    static bool TimerRunning() {
+        State& st = S();
+        std::lock_guard<std::mutex> lk(st.m);
+        return st.timer_alive;
+    }
+
+   private:
+    struct State {
+        std::mutex lifecycle;            // serialises Take / Park / Clear / exit (rare calls); never held by the timer
+        std::mutex m;                    // slot, deadline, flags
+        std::condition_variable cv;
+        std::unique_ptr<Engine> slot;
+        std::chrono::steady_clock::time_point deadline;
+        std::thread timer;
+        bool stop = false, exiting = false, exit_hook = false, timer_alive = false;
+    };
+    static State& S() {
+        // leaked on purpose: at process exit the HIP runtime may be gone before a static destructor would run
+        static State* s = new State();
+        return *s;
+    }
+    static double IdleSeconds() {
         static const double idle_s = [] {
             const char* v = std::getenv("POLYCHASE_ENGINE_CACHE_IDLE_S");
             return v ? std::atof(v) : 120.0;
         }();
-        if (idle_s <= 0) return;
-        static std::once_flag once;
-        std::call_once(once, [] {
-            std::thread([] {
-                for (;;) {
-                    std::this_thread::sleep_for(std::chrono::seconds(1));
-                    std::unique_ptr<Engine> idle;
-                    {
-                        std::lock_guard<std::mutex> lk(Mutex());
-                        if (Slot() && std::chrono::duration<double>(std::chrono::steady_clock::now() - ParkedAt()).count() > idle_s)
-                            idle = std::move(Slot());
-                    }
-                    // destroyed here, outside the lock
-                }
-            }).detach();
-        });
+        return idle_s;
     }
-    static void Clear() {
+    // puts `e` (or nothing) into the slot and returns what was there; the timer of the old engine is ended and joined,
+    // a new one is started for the new engine
+    static std::unique_ptr<Engine> Exchange(std::unique_ptr<Engine> e) {
+        State& st = S();
+        std::lock_guard<std::mutex> life(st.lifecycle);
         std::unique_ptr<Engine> old;
-        std::lock_guard<std::mutex> lk(Mutex());
-        old = std::move(Slot());
+        std::thread old_timer;
+        {
+            std::lock_guard<std::mutex> lk(st.m);
+            old = std::move(st.slot);
+            old_timer = std::move(st.timer);
+            st.stop = true;
+        }
+        st.cv.notify_all();
+        if (old_timer.joinable()) old_timer.join();   // at most the 50-80 ms of an engine it is just destroying
+        if (e) {
+            std::lock_guard<std::mutex> lk(st.m);
+            st.stop = false;
+            if (st.exiting) return old;   // too late to park anything: `e` is destroyed by the caller's unique_ptr
+            st.slot = std::move(e);
+            const double idle_s = IdleSeconds();
+            if (idle_s > 0) {
+                st.deadline = std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(
+                                                                     std::chrono::duration<double>(idle_s));
+                st.timer_alive = true;
+                st.timer = std::thread(TimerMain);
+                if (!st.exit_hook) {
+                    st.exit_hook = true;
+                    std::atexit(AtExit);
+                }
+            }
+        }
+        return old;
     }
-
-   private:
-    static std::mutex& Mutex() {
-        static std::mutex* m = new std::mutex();   // leaked like the slot: the reaper thread may outlive the static destructors
-        return *m;
+    static void TimerMain() {
+        State& st = S();
+        std::unique_ptr<Engine> idle;
+        {
+            std::unique_lock<std::mutex> lk(st.m);
+            st.cv.wait_until(lk, st.deadline, [&] { return st.stop || st.exiting; });
+            st.timer_alive = false;
+            if (st.stop || st.exiting) return;
+            idle = std::move(st.slot);
+        }
+        // destroyed here, outside the lock; Exchange / AtExit join this thread, so the destruction is complete before a
+        // new engine is parked or the process goes on exiting
     }
-    static std::chrono::steady_clock::time_point& ParkedAt() {
-        static std::chrono::steady_clock::time_point t;
-        return t;
-    }
-    static std::unique_ptr<Engine>& Slot() {
-        // leaked on purpose: at process exit the HIP runtime may be gone before a static destructor would run
-        static std::unique_ptr<Engine>* slot = new std::unique_ptr<Engine>();
-        return *slot;
+    static void AtExit() {
+        State& st = S();
+        std::thread t;
+        {
+            std::lock_guard<std::mutex> lk(st.m);
+            st.exiting = true;
+            t = std::move(st.timer);
+        }
+        st.cv.notify_all();
+        if (t.joinable()) t.join();
     }
 };
 
@@ -599,6 +640,7 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
 }
 
 void ReleaseCachedEngine() { EngineCache::Clear(); }
+bool EngineCacheTimerRunning() { return EngineCache::TimerRunning(); }
 
 void GenerateOpticalFlowDatabase(const VideoInfo& video_info, FrameAccessorFunction frame_accessor,
                                  OpticalFlowProgressCallback callback, const std::string& database_path,

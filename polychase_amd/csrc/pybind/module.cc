@@ -393,6 +393,7 @@ PYBIND11_MODULE(polychase_core, m) {
         SaveImageForDebugging(img.data(), static_cast<int>(rgb.shape(1)), static_cast<int>(rgb.shape(0)), frame_id, dir, kps.data(),
                               static_cast<int>(kps.size() / 2));
     });
+    m.def("_engine_cache_timer_running", &EngineCacheTimerRunning);   // testing aid
     m.def("release_cached_engine", &ReleaseCachedEngine);   // not in the reference: gives the parked GPU engine's memory back
     m.def("generate_optical_flow_shard", &GenerateOpticalFlowShardPy, py::arg("video_info"), py::arg("frame_accessor_function"),
           py::arg("callback"), py::arg("database_path"), py::arg("shard_begin"), py::arg("shard_end"), py::arg("device_log") = 0,

@@ -46,6 +46,9 @@ def main(argv=None) -> int:
     a = ap.parse_args(argv)
     out = run(a.width, a.height, a.frames, a.oracle_frames, a.oracle_stride, a.refine_iterations, a.oracle_workers)
     print(json.dumps(out))
+    sys.path.insert(0, os.path.join(ROOT, "polychase_amd", "core"))
+    import polychase_core
+    polychase_core.release_cached_engine()   # nothing of the library is alive when the interpreter (and a profiler) shut down
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         json.dump(out, open(a.out, "w"), indent=1)

@@ -300,12 +300,19 @@ def test_parked_engine_is_given_back_after_the_idle_time(tmp_path):
         "clip = synth.NoiseClip(320, 240, 12); fr = [clip.frame(t) for t in range(12)]\n"
         "def run():\n"
         "    return core.generate_optical_flow_database(core.VideoInfo(320, 240, 1, 12), lambda f: fr[f - 1], None, '', core.GFTTOptions(), core.OpticalFlowOptions()).seconds_setup\n"
-        "a = run(); b = run(); time.sleep(3.0); c = run(); d = run()\n"
-        "print('SETUP', a, b, c, d)\n")
+        "t0 = core._engine_cache_timer_running()\n"
+        "a = run(); t1 = core._engine_cache_timer_running(); b = run(); time.sleep(3.0); t2 = core._engine_cache_timer_running()\n"
+        "c = run(); d = run(); t3 = core._engine_cache_timer_running(); core.release_cached_engine(); t4 = core._engine_cache_timer_running()\n"
+        "print('SETUP', a, b, c, d)\n"
+        "print('TIMER', int(t0), int(t1), int(t2), int(t3), int(t4))\n")
     env = dict(os.environ, POLYCHASE_ENGINE_CACHE_IDLE_S="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     line = [l for l in r.stdout.splitlines() if l.startswith("SETUP")]
     assert r.returncode == 0 and line, r.stderr[-2000:]
     a, b, c, d = map(float, line[0].split()[1:])
     assert b < a / 5 and d < c / 5, (a, b, c, d)          # taken from the slot
-    assert c > 5 * b, (a, b, c, d)                        # created again: the reaper had destroyed the idle engine
+    assert c > 5 * b, (a, b, c, d)                        # created again: the idle timer had destroyed the parked engine
+    # the timer is a thread that exists only while an engine is parked: none before the first run, one while
+    # parked, gone after the idle time fired, one again, joined by release_cached_engine()
+    timer = [l for l in r.stdout.splitlines() if l.startswith("TIMER")][0].split()[1:]
+    assert timer == ["0", "1", "0", "1", "0"], timer
