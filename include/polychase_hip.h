@@ -44,7 +44,7 @@ typedef struct pc_gftt_options {
     double quality_level; /* 0.01 */
     double min_distance;  /* 5.0 */
     int block_size;       /* 3   (any size >= 1: 3 runs the tiled kernel, others the general pair of kernels) */
-    int gradient_size;    /* 3   (Sobel aperture; only 3 on the device, others: PC_E_INVALID -- the addon never sets it) */
+    int gradient_size;    /* 3   (aperture of cornerEigenValsVecs' derivative: Sobel 3 / 5 / 7, or -1 = Scharr; anything else: PC_E_INVALID) */
     int max_corners;      /* 0 = unlimited */
     int use_harris;       /* 0   (1: cornerHarris, gftt.cc:31-33 -- calcHarris' scalar expression (k in double) in the canonical
                                  mode; under PC_ARITH_SOBEL_FMA the first width / 4 * 4 columns of a row as the vector loop of an
@@ -420,6 +420,58 @@ typedef struct pc_pnp_solve_result {
 } pc_pnp_solve_result;
 int pc_pnp_solve(pc_context* ctx, pc_pnp_problem* prob, const pc_pnp_camera* initial, const pc_pnp_solve_options* options,
                  pc_pnp_solve_result* result);
+/* ---- SolveFrame in one call (cpp/tracker.cc:36-131): the correspondences of EVERY source frame + SolvePnPIterative ----
+ * Two launches and one wait per frame: one ray-cast launch over the matches of all sources (each under its own
+ * camera; world points stay on the GPU, no compaction), then the whole Levenberg-Marquardt loop and the inlier pass as
+ * ONE persistent launch -- the workgroups keep their correspondences, meet at a grid barrier once per evaluated
+ * parameter set, one workgroup takes the solver's decision (lev_marq.h:146-221) and the rounds stop when it is done; the
+ * result is written to pinned host memory by the kernel.  (pc_corr_set_append + pc_pnp_solve -- 12 + 28 launches per
+ * frame -- remain as the building blocks and as the cross-check: same world points bit for bit, poses equal to fp32
+ * summation order.)
+ * sources[k]: camera of source frame k (already solved), its keypoints (cached by keypoints_key like
+ * pc_corr_set_append) and where its matches -- src_keypoints_indices (n_matches x uint32 at idx_offset) and
+ * tgt_keypoints (n_matches x 2 floats at tgt_offset; byte offsets, 4- / 8-aligned) -- lie inside the block `matches`
+ * of matches_bytes bytes: the block travels to the GPU in ONE transfer (host memory; pc_host_buffer_alloc memory is
+ * fetched by the copy engine without a staging copy).
+ * options->optimize_*: what the caller ASKS for; intrinsics are only optimised with more than 3 correspondences
+ * (pnp_problem.h:34-35), decided on the device where the count is known.
+ * result->n_correspondences < 3: "not enough features" (tracker.cc:95-97), nothing was solved. */
+typedef struct pc_track_source {
+    pc_ray_camera cam;
+    long long keypoints_key;
+    const float* keypoints_xy;    /* host, n_keypoints x 2 */
+    int n_keypoints;
+    int n_matches;
+    size_t idx_offset, tgt_offset;
+} pc_track_source;
+typedef struct pc_track_solve_result {
+    pc_pnp_solve_result pnp;
+    int n_matches;                /* rows of all sources */
+    int n_correspondences;        /* ... whose ray hit the (unmasked) mesh */
+    int rounds;                   /* parameter sets evaluated by the persistent launch */
+    /* where the persistent launch spent its time, measured by its deciding workgroup in 100 MHz ticks and summed over the
+     * rounds: [0] residual sweep + publishing the partial sums, [1] waiting for the other workgroups, [2] adding the
+     * partials, [3] the decision (9x9 algebra, one lane), [4] publishing it, [5] fetching the next parameters,
+     * [6] inlier pass, [7] the whole launch */
+    unsigned lm_ticks[8];
+} pc_track_solve_result;
+int pc_track_solve_frame(pc_context* ctx, pc_corr_set* set, const pc_mesh* mesh, const float* model_matrix, int check_mask,
+                         const pc_track_source* sources, int n_sources, const void* matches, size_t matches_bytes,
+                         const pc_pnp_camera* initial, const pc_pnp_solve_options* options, pc_track_solve_result* result);
+/* The same in three steps, so that a caller overlaps the host's part and the transfer of frame f + 1 with the launches of
+ * frame f (csrc/host/track_sequence.cc): upload = the matches block (and the keypoints of sources the set has not cached yet)
+ * on the set's own copy stream, into the second of two device blocks -- callable while a frame is in flight, before the
+ * cameras of its sources are known; launch = the two launches behind that upload, for the block uploaded last; finish =
+ * wait + result.  `matches` and the keypoint arrays must stay untouched until the frame's finish. */
+int pc_track_frame_upload(pc_context* ctx, pc_corr_set* set, const void* matches, size_t matches_bytes, const pc_track_source* sources,
+                          int n_sources);
+int pc_track_frame_launch(pc_context* ctx, pc_corr_set* set, const pc_mesh* mesh, const float* model_matrix, int check_mask,
+                          const pc_track_source* sources, int n_sources, const pc_pnp_camera* initial, const pc_pnp_solve_options* options);
+int pc_track_frame_finish(pc_context* ctx, pc_corr_set* set, pc_track_solve_result* result);
+/* debugging / tests: (world x, y, z, hit ? 1 : 0) of the first n matches of the last pc_track_solve_frame, in match order
+ * (source after source). */
+int pc_track_download_points(pc_context* ctx, pc_corr_set* set, int n, float* world_xyzw);
+
 /* LevMarqDenseSolver::TotalCost (lev_marq.h:316-356) and the inlier count of SolvePnPIterative
  * (cpp/pnp/solvers.cc:31-47) in one pass. */
 int pc_pnp_total_cost(pc_context* ctx, const pc_pnp_problem* prob, const pc_pnp_params* params,

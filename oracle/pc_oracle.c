@@ -81,15 +81,43 @@ int pco_min_eigen_val(const uint8_t* gray, int w, int h, int block_size, int ksi
 int pco_corner_harris(const uint8_t* gray, int w, int h, int block_size, int ksize, double k, float* dst) {
     return corner_response(gray, w, h, block_size, ksize, 1, k, dst);
 }
+/* The derivative filters of cornerEigenValsVecs (imgproc/corner.cpp) for every aperture the reference's GFTTOptions can
+ * carry (cpp/feature_detection/gftt.cc:31-36, bound at cpp/polychase_pybind.cc:128-136):  [recalled]
+ *   ksize 3, 5, 7  Sobel: getSobelKernels' binomial taps -- smoothing [1,2,1] / [1,4,6,4,1] / [1,6,15,20,15,6,1], derivative
+ *                  [-1,0,1] / [-1,-2,0,2,1] / [-1,-4,-5,0,5,4,1]; scale = 1 / (2^(ksize-1) * block_size * 255)
+ *   ksize -1       Scharr (cornerEigenValsVecs calls Scharr() for aperture_size < 0): smoothing [3,10,3], derivative [-1,0,1];
+ *                  scale = 1 / (2^2 * block_size * 255) / 2
+ * Sobel() / Scharr() fold the scale into the SMOOTHING kernel of each image: `kx *= scale` is Mat::convertTo on a CV_32F
+ * kernel, i.e. tap_f = (float)tap * (float)scale (cvtScale32f works in float).  sepFilter2D, 8U -> 32F through a 32F buffer:
+ *   row pass     the generic RowFilter<uchar, float>: s = k[0]*S[0]; s += k[i]*S[i] in tap order (exact for the integer
+ *                derivative taps; one rounding per tap for the scaled smoothing taps -- PCO_EMU_SOBEL_ROW_FMA: the vector row
+ *                filter's fused chain from a zero accumulator)
+ *   column pass  symmetric (smoothing) kernel: s = k[c]*S[c]; s = muladd(S[c+j] + S[c-j], k[c+j], s), j = 1 .. r -- the
+ *                order of SymmColumnSmallVec_32f (ksize 3: (S0 + S2)*k1 + S1*k0, the same sum) and SymmColumnVec_32f /
+ *                SymmColumnFilter's scalar tail (5, 7); PCO_EMU_SOBEL_FMA fuses each muladd (AVX2 dispatch).
+ *                anti-symmetric (derivative) kernel: ksize 3 / Scharr S[c+1] - S[c-1] (the |k1| == 1 special case); 5 and 7:
+ *                s = k[c+1]*(S[c+1] - S[c-1]); s = muladd(S[c+j] - S[c-j], k[c+j], s) -- the taps 2, 1 / 5, 4, 1 make every
+ *                product but the first exact and the first is rounded either way: fused and unfused give the same bits.
+ * All BORDER_REFLECT_101. */
 static int corner_response(const uint8_t* gray, int w, int h, int block_size, int ksize, int harris, double harris_k, float* eig) {
-    if (ksize != 3 || block_size < 1 || w < 1 || h < 1) return -1;
-    const double scale_d = 1.0 / ((double)(1 << (ksize - 1)) * block_size * 255.0);
-    const float f1 = (float)(1.0 * scale_d);
-    const float f0 = (float)(2.0 * scale_d);
+    if ((ksize != 3 && ksize != 5 && ksize != 7 && ksize != -1) || block_size < 1 || w < 1 || h < 1) return -1;
+    static const int sm3[3] = {1, 2, 1}, dv3[3] = {-1, 0, 1};
+    static const int sm5[5] = {1, 4, 6, 4, 1}, dv5[5] = {-1, -2, 0, 2, 1};
+    static const int sm7[7] = {1, 6, 15, 20, 15, 6, 1}, dv7[7] = {-1, -4, -5, 0, 5, 4, 1};
+    static const int smS[3] = {3, 10, 3};
+    const int taps = ksize > 0 ? ksize : 3, r = taps / 2;
+    const int* sm = ksize == 3 ? sm3 : ksize == 5 ? sm5 : ksize == 7 ? sm7 : smS;
+    const int* dv = ksize == 5 ? dv5 : ksize == 7 ? dv7 : dv3;
+    double scale_d = (double)(1 << (taps - 1)) * block_size;
+    if (ksize < 0) scale_d *= 2.0;
+    scale_d = 1.0 / (scale_d * 255.0);
+    const float scale_f = (float)scale_d;
+    float smf[7];
+    for (int k = 0; k < taps; k++) smf[k] = (float)sm[k] * scale_f;
     const size_t n = (size_t)w * (size_t)h;
 
     /* row pass */
-    float* rdx = (float*)malloc(n * sizeof(float)); /* src(x+1) - src(x-1) */
+    float* rdx = (float*)malloc(n * sizeof(float)); /* derivative taps along x: exact integers */
     float* rdy = (float*)malloc(n * sizeof(float)); /* smoothed along x, scaled */
     float* cov = (float*)malloc(n * 3 * sizeof(float));
     if (!rdx || !rdy || !cov) {
@@ -99,31 +127,41 @@ static int corner_response(const uint8_t* gray, int w, int h, int block_size, in
     for (int y = 0; y < h; y++) {
         const uint8_t* s = gray + (size_t)y * w;
         for (int x = 0; x < w; x++) {
-            const float sm = (float)s[reflect101(x - 1, w)];
-            const float sc = (float)s[x];
-            const float sp = (float)s[reflect101(x + 1, w)];
-            rdx[(size_t)y * w + x] = (0.0f - sm) + sp; /* -1*sm + 0*sc + 1*sp, exact */
-            float t = f1 * sm;
-            if (g_emulation & PCO_EMU_SOBEL_ROW_FMA) { /* the vector row filter's v_muladd chain from a zero accumulator, fused */
-                t = fmaf(f0, sc, t);
-                t = fmaf(f1, sp, t);
-            } else {
-                t += f0 * sc;
-                t += f1 * sp;
+            float d = 0.0f, t = 0.0f;
+            for (int k = 0; k < taps; k++) {
+                const float v = (float)s[reflect101(x + k - r, w)];
+                if (k == 0) {
+                    d = (float)dv[0] * v;
+                    t = smf[0] * v;
+                } else {
+                    d += (float)dv[k] * v;
+                    if (g_emulation & PCO_EMU_SOBEL_ROW_FMA) t = fmaf(smf[k], v, t); /* the vector row filter's v_muladd chain, fused */
+                    else t += smf[k] * v;
+                }
             }
+            rdx[(size_t)y * w + x] = d;
             rdy[(size_t)y * w + x] = t;
         }
     }
     /* column pass + covariance products */
     for (int y = 0; y < h; y++) {
-        const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
+        int yy[7];
+        for (int k = 0; k < taps; k++) yy[k] = reflect101(y + k - r, h);
         for (int x = 0; x < w; x++) {
-            float dx;
-            if (g_emulation & PCO_EMU_SOBEL_FMA)
-                dx = fmaf(rdx[(size_t)ym * w + x] + rdx[(size_t)yp * w + x], f1, rdx[(size_t)y * w + x] * f0);
-            else
-                dx = (rdx[(size_t)ym * w + x] + rdx[(size_t)yp * w + x]) * f1 + rdx[(size_t)y * w + x] * f0;
-            const float dy = rdy[(size_t)yp * w + x] - rdy[(size_t)ym * w + x];
+            float dx = rdx[(size_t)yy[r] * w + x] * smf[r];
+            for (int j = 1; j <= r; j++) {
+                const float pair = rdx[(size_t)yy[r + j] * w + x] + rdx[(size_t)yy[r - j] * w + x];
+                if (g_emulation & PCO_EMU_SOBEL_FMA) dx = fmaf(pair, smf[r + j], dx);
+                else dx = pair * smf[r + j] + dx;
+            }
+            float dy;
+            if (taps == 3) {
+                dy = rdy[(size_t)yy[2] * w + x] - rdy[(size_t)yy[0] * w + x];
+            } else {
+                dy = (float)dv[r + 1] * (rdy[(size_t)yy[r + 1] * w + x] - rdy[(size_t)yy[r - 1] * w + x]);
+                for (int j = 2; j <= r; j++)
+                    dy = (rdy[(size_t)yy[r + j] * w + x] - rdy[(size_t)yy[r - j] * w + x]) * (float)dv[r + j] + dy;
+            }
             float* c = cov + ((size_t)y * w + x) * 3;
             c[0] = dx * dx;
             c[1] = dx * dy;

@@ -137,7 +137,9 @@ int validate_gftt(const pc_gftt_options* opt, int w, int h, pc::GfttGrid* g) {
     // CHECKs of gftt.cc:18-19
     if (!(opt->quality_level > 0 && opt->min_distance >= 0 && opt->max_corners >= 0))
         return fail(PC_E_INVALID, "GFTT options violate quality_level > 0 && min_distance >= 0 && max_corners >= 0");
-    if (opt->gradient_size != 3) return fail(PC_E_INVALID, "only gradient_size == 3 (the 3x3 Sobel) is implemented on the HIP path");
+    // cornerEigenValsVecs: Sobel apertures 3 / 5 / 7 or Scharr (-1) (gftt.cc:31-36)
+    if (opt->gradient_size != 3 && opt->gradient_size != 5 && opt->gradient_size != 7 && opt->gradient_size != -1)
+        return fail(PC_E_INVALID, "gradient_size must be 3, 5, 7 (Sobel) or -1 (Scharr)");
     if (opt->block_size < 1 || opt->block_size > 31) return fail(PC_E_INVALID, "block_size must be in [1,31] on the HIP path");
     if (opt->min_distance > 64.0) return fail(PC_E_INVALID, "min_distance > 64 is not supported on the HIP path");
     g->rows = std::max(1, opt->grid_rows);
@@ -155,12 +157,14 @@ static int corner_response(pc_context* ctx, const pc_frame* f, DetectScratch& d,
     const int fma = ((ctx->arith & PC_ARITH_SOBEL_FMA) ? 1 : 0) | ((ctx->arith & PC_ARITH_SOBEL_ROW_FMA) ? 2 : 0);
     // POLYCHASE_GFTT_GENERAL=1: the general kernels for the default options too (cross-check of the tiled kernel)
     static const bool force_general = getenv("POLYCHASE_GFTT_GENERAL") && atoi(getenv("POLYCHASE_GFTT_GENERAL")) == 1;
-    if (opt.block_size == 3 && !opt.use_harris && !force_general) {
+    if (opt.block_size == 3 && opt.gradient_size == 3 && !opt.use_harris && !force_general) {
         pc::launch_min_eig(f->levels[0], d.eig.p, grid, cell_max, fma, ctx->work);
         return PC_OK;
     }
     PC_HIP(d.cov.ensure((size_t)3 * f->w * f->h));
-    pc::launch_corner_response(f->levels[0], d.eig.p, d.cov.p, grid, cell_max, opt.block_size, opt.use_harris != 0, opt.harris_k, fma, ctx->work);
+    if (!pc::launch_corner_response(f->levels[0], d.eig.p, d.cov.p, grid, cell_max, opt.block_size, opt.gradient_size, opt.use_harris != 0, opt.harris_k,
+                                    fma, ctx->work))
+        return fail(PC_E_INVALID, "gradient_size must be 3, 5, 7 (Sobel) or -1 (Scharr)");
     return PC_OK;
 }
 

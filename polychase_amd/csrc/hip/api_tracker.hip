@@ -14,6 +14,7 @@ struct pc_mesh {
     int n_vertices = 0, n_triangles = 0;
     DevBuf<float> verts;
     DevBuf<uint32_t> tris, mask;
+    std::vector<uint32_t> mask_sent;   // what `mask` holds (all zero after creation): an unchanged mask is not sent again
     // LBVH (bvh.hpp): n_triangles - 1 internal nodes + the sorted leaf order
     DevBuf<pc::BvhNode> bvh_nodes;
     DevBuf<uint32_t> bvh_leaf_tri;
@@ -73,13 +74,27 @@ struct pc_corr_set {
         DevBuf<float2> xy;
     };
     Cached cache[16];
-    DevBuf<float2> uncached_kps;
+    DevBuf<float2> uncached_kps[pc::kTrackMaxSources];
     uint64_t clock = 0;
     // PnP scratch shared by the problems made from this set
     DevBuf<float> partials, out, lm_partials4;
     PinBuf<float> h_out;
     DevBuf<pc::LmState> lm_state;
     PinBuf<pc::LmState> lm_host;
+    // pc_track_solve_frame: all matches of the frame (device copies), their world points, the solver's barrier words
+    DevBuf<uint8_t> t_block[2];   // the matches of the frame being solved and of the next one (uploaded while the first is solved)
+    int t_cur = 0;                // the block of the last pc_track_frame_upload
+    size_t t_block_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t upload_done = nullptr;
+    int t_stage = 0;              // 0 idle, 1 uploaded, 2 launched
+    int t_n = 0;                  // matches of the launched frame
+    DevBuf<uint32_t> t_sync;
+    DevBuf<float2> t_obs;
+    DevBuf<float4> t_pts;
+    DevBuf<float> t_partials;
+    PinBuf<pc::TrackLmOut> t_out;
+    bool t_sync_zero = false;
 };
 
 extern "C" {
@@ -98,6 +113,7 @@ int pc_mesh_create(pc_context* ctx, const float* vertices, int n_vertices, const
     m->ctx = ctx;
     m->n_vertices = n_vertices;
     m->n_triangles = n_triangles;
+    m->mask_sent.assign((size_t)((n_triangles + 31) / 32), 0u);
     const int words = (n_triangles + 31) / 32 + 4;
     hipError_t e = m->verts.ensure((size_t)std::max(1, n_vertices) * 3);
     if (e == hipSuccess) e = m->tris.ensure((size_t)std::max(1, n_triangles) * 3);
@@ -169,8 +185,14 @@ int pc_mesh_set_mask(pc_context* ctx, pc_mesh* mesh, const uint32_t* mask_words,
     const int need = (mesh->n_triangles + 31) / 32;
     if (n_words < need) return fail(PC_E_INVALID, "mask has %d words, %d needed", n_words, need);
     if (need > 0) {
+        // the tracker sends the mask before every frame (it can be edited through inner_mut() at any time): a transfer and
+        // a wait only when a bit has changed
+        if (mesh->mask_sent.size() == (size_t)need && std::memcmp(mesh->mask_sent.data(), mask_words, (size_t)need * sizeof(uint32_t)) == 0)
+            return PC_OK;
+        PC_HIP(hipSetDevice(ctx->device));
         PC_HIP(hipMemcpyAsync(mesh->mask.p, mask_words, (size_t)need * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         PC_HIP(hipStreamSynchronize(ctx->stream));
+        mesh->mask_sent.assign(mask_words, mask_words + need);
     }
     return PC_OK;
 }
@@ -267,6 +289,7 @@ void pc_corr_set_destroy(pc_corr_set* s) {
     if (s->ctx) {
         (void)hipSetDevice(s->ctx->device);
         (void)hipStreamSynchronize(s->ctx->stream);
+        if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
     }
     s->X.release();
     s->x.release();
@@ -279,13 +302,21 @@ void pc_corr_set_destroy(pc_corr_set* s) {
     s->d_idx.release();
     s->d_tgt.release();
     for (auto& c : s->cache) c.xy.release();
-    s->uncached_kps.release();
+    for (auto& b : s->uncached_kps) b.release();
     s->partials.release();
     s->out.release();
     s->h_out.release();
     s->lm_partials4.release();
     s->lm_state.release();
     s->lm_host.release();
+    for (auto& b : s->t_block) b.release();
+    if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+    if (s->upload_done) (void)hipEventDestroy(s->upload_done);
+    s->t_sync.release();
+    s->t_obs.release();
+    s->t_pts.release();
+    s->t_partials.release();
+    s->t_out.release();
     delete s;
 }
 
@@ -322,6 +353,36 @@ static int corr_reserve(pc_context* ctx, pc_corr_set* s, size_t need) {
     return PC_OK;
 }
 
+// device copy of a source frame's keypoints: cached by key (a frame is a source for up to 8 targets), else uploaded
+static int corr_keypoints(pc_context* ctx, pc_corr_set* s, long long keypoints_key, const float* keypoints_xy, int n_keypoints,
+                          const float2** out, int uncached_slot = 0, hipStream_t stream = nullptr) {
+    if (!stream) stream = ctx->stream;
+    const float2* d_kps = nullptr;
+    if (keypoints_key >= 0) {
+        pc_corr_set::Cached* slot = nullptr;
+        for (auto& c : s->cache)
+            if (c.key == keypoints_key && c.n == n_keypoints) slot = &c;
+        if (!slot) {
+            slot = &s->cache[0];
+            for (auto& c : s->cache)
+                if (c.stamp < slot->stamp) slot = &c;
+            PC_HIP(slot->xy.ensure((size_t)std::max(n_keypoints, 1)));
+            PC_HIP(hipMemcpyAsync(slot->xy.p, keypoints_xy, (size_t)n_keypoints * sizeof(float2), hipMemcpyHostToDevice, stream));
+            slot->key = keypoints_key;
+            slot->n = n_keypoints;
+        }
+        slot->stamp = ++s->clock;
+        d_kps = slot->xy.p;
+    } else {
+        DevBuf<float2>& buf = s->uncached_kps[uncached_slot];
+        PC_HIP(buf.ensure((size_t)std::max(n_keypoints, 1)));
+        PC_HIP(hipMemcpyAsync(buf.p, keypoints_xy, (size_t)n_keypoints * sizeof(float2), hipMemcpyHostToDevice, stream));
+        d_kps = buf.p;
+    }
+    *out = d_kps;
+    return PC_OK;
+}
+
 int pc_corr_set_append(pc_context* ctx, pc_corr_set* s, const pc_mesh* mesh, const pc_ray_camera* cam, const float* model_matrix,
                        long long keypoints_key, const float* keypoints_xy, int n_keypoints, const uint32_t* src_idx,
                        const float* tgt_xy, int n_matches, int check_mask) {
@@ -338,28 +399,9 @@ int pc_corr_set_append(pc_context* ctx, pc_corr_set* s, const pc_mesh* mesh, con
     PC_HIP(s->block_offsets.ensure((size_t)nb));
     PC_HIP(s->d_idx.ensure((size_t)n_matches));
     PC_HIP(s->d_tgt.ensure((size_t)n_matches));
-    // keypoints: cached by key (a frame is a source for up to 8 targets)
     const float2* d_kps = nullptr;
-    if (keypoints_key >= 0) {
-        pc_corr_set::Cached* slot = nullptr;
-        for (auto& c : s->cache)
-            if (c.key == keypoints_key && c.n == n_keypoints) slot = &c;
-        if (!slot) {
-            slot = &s->cache[0];
-            for (auto& c : s->cache)
-                if (c.stamp < slot->stamp) slot = &c;
-            PC_HIP(slot->xy.ensure((size_t)std::max(n_keypoints, 1)));
-            PC_HIP(hipMemcpyAsync(slot->xy.p, keypoints_xy, (size_t)n_keypoints * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
-            slot->key = keypoints_key;
-            slot->n = n_keypoints;
-        }
-        slot->stamp = ++s->clock;
-        d_kps = slot->xy.p;
-    } else {
-        PC_HIP(s->uncached_kps.ensure((size_t)std::max(n_keypoints, 1)));
-        PC_HIP(hipMemcpyAsync(s->uncached_kps.p, keypoints_xy, (size_t)n_keypoints * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
-        d_kps = s->uncached_kps.p;
-    }
+    rc = corr_keypoints(ctx, s, keypoints_key, keypoints_xy, n_keypoints, &d_kps);
+    if (rc != PC_OK) return rc;
     PC_HIP(hipMemcpyAsync(s->d_idx.p, src_idx, (size_t)n_matches * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     PC_HIP(hipMemcpyAsync(s->d_tgt.p, tgt_xy, (size_t)n_matches * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
     pc::RayCamera rcam;
@@ -517,6 +559,52 @@ int pc_pnp_normal_equations_cost(pc_context* ctx, const pc_pnp_problem* prob, co
     return PC_OK;
 }
 
+static void fill_lm_config(const pc_pnp_solve_options* o, pc::LmConfig* c) {
+    c->max_iterations = o->max_iterations;
+    c->initial_lambda = o->initial_lambda;
+    c->min_lambda = o->min_lambda;
+    c->max_lambda = o->max_lambda;
+    c->gradient_tol = o->gradient_tol;
+    c->step_tol = o->step_tol;
+    c->f_low = o->f_low;
+    c->f_high = o->f_high;
+    c->cx_low = o->cx_low;
+    c->cx_high = o->cx_high;
+    c->cy_low = o->cy_low;
+    c->cy_high = o->cy_high;
+    c->optimize_focal = o->optimize_focal_length ? 1 : 0;
+    c->optimize_pp = o->optimize_principal_point ? 1 : 0;
+    c->loss_type = o->loss_type;
+    c->loss_scale = o->loss_scale;
+    c->max_inlier_err_sq = o->max_inlier_error > 0.0f ? o->max_inlier_error * o->max_inlier_error : 0.0f;
+}
+static void fill_lm_camera(const pc_pnp_camera* in, pc::LmCamera* c) {
+    c->qx = in->q_xyzw[0];
+    c->qy = in->q_xyzw[1];
+    c->qz = in->q_xyzw[2];
+    c->qw = in->q_xyzw[3];
+    for (int i = 0; i < 3; i++) c->t[i] = in->t[i];
+    c->fx = in->fx;
+    c->fy = in->fy;
+    c->cx = in->cx;
+    c->cy = in->cy;
+    c->aspect_ratio = in->aspect_ratio;
+    c->convention_opencv = in->convention_opencv;
+}
+static void read_lm_camera(const pc::LmCamera& c, pc_pnp_camera* out) {
+    out->q_xyzw[0] = c.qx;
+    out->q_xyzw[1] = c.qy;
+    out->q_xyzw[2] = c.qz;
+    out->q_xyzw[3] = c.qw;
+    for (int i = 0; i < 3; i++) out->t[i] = c.t[i];
+    out->fx = c.fx;
+    out->fy = c.fy;
+    out->cx = c.cx;
+    out->cy = c.cy;
+    out->aspect_ratio = c.aspect_ratio;
+    out->convention_opencv = c.convention_opencv;
+}
+
 int pc_pnp_solve(pc_context* ctx, pc_pnp_problem* prob, const pc_pnp_camera* initial, const pc_pnp_solve_options* o,
                  pc_pnp_solve_result* result) {
     if (!ctx || !prob || !initial || !o || !result) return fail(PC_E_INVALID, "null argument");
@@ -533,34 +621,8 @@ int pc_pnp_solve(pc_context* ctx, pc_pnp_problem* prob, const pc_pnp_camera* ini
     }
     pc::LmState& h = *prob->lm_host;
     std::memset(&h, 0, sizeof(h));
-    h.cfg.max_iterations = o->max_iterations;
-    h.cfg.initial_lambda = o->initial_lambda;
-    h.cfg.min_lambda = o->min_lambda;
-    h.cfg.max_lambda = o->max_lambda;
-    h.cfg.gradient_tol = o->gradient_tol;
-    h.cfg.step_tol = o->step_tol;
-    h.cfg.f_low = o->f_low;
-    h.cfg.f_high = o->f_high;
-    h.cfg.cx_low = o->cx_low;
-    h.cfg.cx_high = o->cx_high;
-    h.cfg.cy_low = o->cy_low;
-    h.cfg.cy_high = o->cy_high;
-    h.cfg.optimize_focal = o->optimize_focal_length ? 1 : 0;
-    h.cfg.optimize_pp = o->optimize_principal_point ? 1 : 0;
-    h.cfg.loss_type = o->loss_type;
-    h.cfg.loss_scale = o->loss_scale;
-    h.cfg.max_inlier_err_sq = o->max_inlier_error > 0.0f ? o->max_inlier_error * o->max_inlier_error : 0.0f;
-    h.cam.qx = initial->q_xyzw[0];
-    h.cam.qy = initial->q_xyzw[1];
-    h.cam.qz = initial->q_xyzw[2];
-    h.cam.qw = initial->q_xyzw[3];
-    for (int i = 0; i < 3; i++) h.cam.t[i] = initial->t[i];
-    h.cam.fx = initial->fx;
-    h.cam.fy = initial->fy;
-    h.cam.cx = initial->cx;
-    h.cam.cy = initial->cy;
-    h.cam.aspect_ratio = initial->aspect_ratio;
-    h.cam.convention_opencv = initial->convention_opencv;
+    fill_lm_config(o, &h.cfg);
+    fill_lm_camera(initial, &h.cam);
     h.cam_new = h.cam;
     h.lambda = o->initial_lambda;
     h.v = 2.0f;
@@ -586,17 +648,7 @@ int pc_pnp_solve(pc_context* ctx, pc_pnp_problem* prob, const pc_pnp_camera* ini
         if (enqueued >= limit) return fail(PC_E_STATE, "the PnP solver did not finish within %d rounds", enqueued);
         rounds = 6;
     }
-    result->camera.q_xyzw[0] = h.cam.qx;
-    result->camera.q_xyzw[1] = h.cam.qy;
-    result->camera.q_xyzw[2] = h.cam.qz;
-    result->camera.q_xyzw[3] = h.cam.qw;
-    for (int i = 0; i < 3; i++) result->camera.t[i] = h.cam.t[i];
-    result->camera.fx = h.cam.fx;
-    result->camera.fy = h.cam.fy;
-    result->camera.cx = h.cam.cx;
-    result->camera.cy = h.cam.cy;
-    result->camera.aspect_ratio = h.cam.aspect_ratio;
-    result->camera.convention_opencv = h.cam.convention_opencv;
+    read_lm_camera(h.cam, &result->camera);
     result->iterations = h.iterations;
     result->invalid_steps = h.invalid_steps;
     result->initial_cost = h.initial_cost;
@@ -605,6 +657,194 @@ int pc_pnp_solve(pc_context* ctx, pc_pnp_problem* prob, const pc_pnp_camera* ini
     result->step_norm = h.step_norm;
     result->grad_norm = h.grad_norm;
     result->inliers = o->max_inlier_error > 0.0f ? (int)prob->h_out[2] : 0;
+    return PC_OK;
+}
+
+static void to_ray_camera(const pc_ray_camera* cam, pc::RayCamera* rc) {
+    std::memcpy(rc->m, cam->dir_matrix, sizeof(rc->m));
+    std::memcpy(rc->origin, cam->origin, sizeof(rc->origin));
+    rc->fx = cam->fx;
+    rc->fy = cam->fy;
+    rc->cx = cam->cx;
+    rc->cy = cam->cy;
+    rc->sign = cam->unproject_sign;
+}
+
+static int check_track_sources(const pc_track_source* sources, int n_sources, size_t matches_bytes, size_t* total_out) {
+    if (n_sources < 0 || (n_sources > 0 && !sources)) return fail(PC_E_INVALID, "bad argument");
+    if (n_sources > pc::kTrackMaxSources) return fail(PC_E_INVALID, "%d source frames, at most %d", n_sources, pc::kTrackMaxSources);
+    size_t total = 0;
+    for (int k = 0; k < n_sources; k++) {
+        const pc_track_source& q = sources[k];
+        if (q.n_matches < 0 || q.n_keypoints < 0 || (q.n_matches > 0 && !q.keypoints_xy)) return fail(PC_E_INVALID, "bad source %d", k);
+        const size_t rows = (size_t)q.n_matches;
+        if (rows && ((q.idx_offset & 3u) || (q.tgt_offset & 7u) || q.idx_offset > matches_bytes || rows * 4 > matches_bytes - q.idx_offset ||
+                     q.tgt_offset > matches_bytes || rows * 8 > matches_bytes - q.tgt_offset))
+            return fail(PC_E_INVALID, "the matches of source %d do not lie inside the block", k);
+        total += rows;
+    }
+    if (total > (size_t)1 << 30) return fail(PC_E_INVALID, "too many matches");
+    *total_out = total;
+    return PC_OK;
+}
+
+int pc_track_frame_upload(pc_context* ctx, pc_corr_set* s, const void* matches, size_t matches_bytes, const pc_track_source* sources,
+                          int n_sources) {
+    if (!ctx || !s || (matches_bytes > 0 && !matches)) return fail(PC_E_INVALID, "bad argument");
+    size_t total = 0;
+    int rc = check_track_sources(sources, n_sources, matches_bytes, &total);
+    if (rc != PC_OK) return rc;
+    PC_HIP(hipSetDevice(ctx->device));
+    if (!s->copy_stream) {
+        PC_HIP(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+        PC_HIP(hipEventCreateWithFlags(&s->upload_done, hipEventDisableTiming));
+    }
+    // the other block: the launch that reads the current one may still be running
+    s->t_cur ^= 1;
+    s->t_block_bytes = matches_bytes;
+    PC_HIP(s->t_block[s->t_cur].ensure(std::max<size_t>(matches_bytes, 16)));
+    if (matches_bytes) PC_HIP(hipMemcpyAsync(s->t_block[s->t_cur].p, matches, matches_bytes, hipMemcpyHostToDevice, s->copy_stream));
+    // the keypoints of sources the set has not seen yet (normally ONE: the frame solved last), into the set's cache
+    for (int k = 0; k < n_sources; k++) {
+        if (sources[k].keypoints_key < 0 || sources[k].n_matches == 0) continue;
+        const float2* unused = nullptr;
+        rc = corr_keypoints(ctx, s, sources[k].keypoints_key, sources[k].keypoints_xy, sources[k].n_keypoints, &unused, 0, s->copy_stream);
+        if (rc != PC_OK) return rc;
+    }
+    PC_HIP(hipEventRecord(s->upload_done, s->copy_stream));
+    if (s->t_stage == 0) s->t_stage = 1;   // (an upload while a frame is in flight leaves it in flight)
+    return PC_OK;
+}
+
+int pc_track_frame_launch(pc_context* ctx, pc_corr_set* s, const pc_mesh* mesh, const float* model_matrix, int check_mask,
+                          const pc_track_source* sources, int n_sources, const pc_pnp_camera* initial, const pc_pnp_solve_options* o) {
+    if (!ctx || !s || !mesh || !model_matrix || !initial || !o) return fail(PC_E_INVALID, "bad argument");
+    if (o->loss_type < 0 || o->loss_type > 2) return fail(PC_E_INVALID, "Unknown loss type: %d", o->loss_type);
+    if (s->t_stage == 2) return fail(PC_E_STATE, "a frame is in flight: pc_track_frame_finish first");
+    if (!s->copy_stream) return fail(PC_E_STATE, "pc_track_frame_upload first");
+    size_t total = 0;
+    int rc = check_track_sources(sources, n_sources, s->t_block_bytes, &total);
+    if (rc != PC_OK) return rc;
+    s->t_n = (int)total;
+    s->t_stage = 2;
+    if (total == 0) return PC_OK;   // no correspondences: finish reports "not enough features"
+    PC_HIP(hipSetDevice(ctx->device));
+    const int n = (int)total;
+    const int nb = pc::track_lm_blocks(n);
+    PC_HIP(s->t_obs.ensure(total));
+    PC_HIP(s->t_pts.ensure(total));
+    PC_HIP(s->t_partials.ensure((size_t)nb * 56));
+    PC_HIP(s->t_out.ensure(1));
+    PC_HIP(s->t_sync.ensure((size_t)pc::kTrackSyncWords));
+    if (!s->t_sync_zero) {
+        PC_HIP(hipMemsetAsync(s->t_sync.p, 0, pc::kTrackSyncWords * sizeof(uint32_t), ctx->stream));
+        s->t_sync_zero = true;   // from here on every launch leaves the words zero
+    }
+    PC_HIP(hipStreamWaitEvent(ctx->stream, s->upload_done, 0));
+    const uint8_t* block = s->t_block[s->t_cur].p;
+    pc::TrackCastArgs ca;
+    std::memset(&ca, 0, sizeof(ca));
+    ca.bvh = mesh->bvh();
+    ca.mask = mesh->mask.p;
+    ca.check_mask = check_mask;
+    std::memcpy(ca.model.m, model_matrix, sizeof(ca.model.m));
+    int blocks = 0, begin = 0, used = 0;
+    for (int k = 0; k < n_sources; k++) {
+        const pc_track_source& q = sources[k];
+        if (q.n_matches == 0) continue;
+        pc::TrackSource& t = ca.src[used];
+        to_ray_camera(&q.cam, &t.cam);
+        rc = corr_keypoints(ctx, s, q.keypoints_key, q.keypoints_xy, q.n_keypoints, &t.kps, used);   // cached by the upload, else sent now
+        if (rc != PC_OK) return rc;
+        t.idx = reinterpret_cast<const uint32_t*>(block + q.idx_offset);
+        t.tgt = reinterpret_cast<const float2*>(block + q.tgt_offset);
+        t.n_kps = q.n_keypoints;
+        t.begin = begin;
+        t.n_matches = q.n_matches;
+        t.block_begin = blocks;
+        begin += q.n_matches;
+        blocks += pc::track_cast_blocks(q.n_matches);
+        used++;
+    }
+    ca.n_sources = used;
+    ca.pts = s->t_pts.p;
+    ca.obs = s->t_obs.p;
+    ca.bad_index = s->counter.p + 1;
+    pc::launch_track_cast(ca, blocks, ctx->stream);
+    pc::TrackLmArgs la;
+    std::memset(&la, 0, sizeof(la));
+    la.pts = s->t_pts.p;
+    la.obs = s->t_obs.p;
+    la.n = n;
+    fill_lm_config(o, &la.cfg);
+    fill_lm_camera(initial, &la.cam);
+    la.partials = s->t_partials.p;
+    la.sync = s->t_sync.p;
+    la.out = s->t_out.p;
+    la.max_rounds = o->max_iterations + 3;   // the initial sweep, one per iteration, one more for the 3-point case
+    la.bad_index = s->counter.p + 1;         // zero unless an earlier call found a bad index and has not been cleared
+    s->t_out.p->status = -1;
+    s->t_out.p->bad_index = 0;
+    pc::launch_track_lm(la, ctx->stream);
+    return PC_OK;
+}
+
+int pc_track_frame_finish(pc_context* ctx, pc_corr_set* s, pc_track_solve_result* result) {
+    if (!ctx || !s || !result) return fail(PC_E_INVALID, "null argument");
+    if (s->t_stage != 2) return fail(PC_E_STATE, "no frame is in flight");
+    s->t_stage = 0;
+    std::memset(result, 0, sizeof(*result));
+    result->n_matches = s->t_n;
+    if (s->t_n == 0) return PC_OK;
+    PC_HIP(hipSetDevice(ctx->device));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    const pc::TrackLmOut& out = *s->t_out.p;
+    if (out.status == 2 || out.status < 0) {
+        s->t_sync_zero = false;   // the barrier words are in an unknown state
+        return fail(PC_E_STATE, "the PnP solver's workgroups did not all become resident (status %d)", out.status);
+    }
+    if (out.bad_index) {
+        (void)hipMemsetAsync(s->counter.p, 0, 2 * sizeof(int), ctx->stream);
+        return fail(PC_E_INVALID, "a source keypoint index is out of range");
+    }
+    if (out.status == 3) return fail(PC_E_STATE, "the PnP solver did not finish within %d rounds", out.rounds);
+    result->n_correspondences = out.n_valid;
+    result->rounds = out.rounds;
+    for (int k = 0; k < 8; k++) result->lm_ticks[k] = out.ticks[k];
+    if (out.status == 1) return PC_OK;   // fewer than 3 correspondences: nothing solved
+    read_lm_camera(out.cam, &result->pnp.camera);
+    result->pnp.iterations = out.iterations;
+    result->pnp.invalid_steps = out.invalid_steps;
+    result->pnp.initial_cost = out.initial_cost;
+    result->pnp.cost = out.cost;
+    result->pnp.lambda = out.lambda;
+    result->pnp.step_norm = out.step_norm;
+    result->pnp.grad_norm = out.grad_norm;
+    result->pnp.inliers = out.inliers;
+    return PC_OK;
+}
+
+int pc_track_solve_frame(pc_context* ctx, pc_corr_set* s, const pc_mesh* mesh, const float* model_matrix, int check_mask,
+                         const pc_track_source* sources, int n_sources, const void* matches, size_t matches_bytes,
+                         const pc_pnp_camera* initial, const pc_pnp_solve_options* o, pc_track_solve_result* result) {
+    if (!result) return fail(PC_E_INVALID, "null argument");
+    std::memset(result, 0, sizeof(*result));
+    if (s && s->t_stage == 2) return fail(PC_E_STATE, "a frame is in flight: pc_track_frame_finish first");
+    int rc = pc_track_frame_upload(ctx, s, matches, matches_bytes, sources, n_sources);
+    if (rc == PC_OK) rc = pc_track_frame_launch(ctx, s, mesh, model_matrix, check_mask, sources, n_sources, initial, o);
+    if (rc != PC_OK) {
+        if (s) s->t_stage = 0;
+        return rc;
+    }
+    return pc_track_frame_finish(ctx, s, result);
+}
+
+int pc_track_download_points(pc_context* ctx, pc_corr_set* s, int n, float* world_xyzw) {
+    if (!ctx || !s || n < 0 || (n > 0 && !world_xyzw)) return fail(PC_E_INVALID, "bad argument");
+    if ((size_t)n > s->t_pts.cap) return fail(PC_E_INVALID, "the last pc_track_solve_frame had fewer matches");
+    PC_HIP(hipSetDevice(ctx->device));
+    if (n) PC_HIP(hipMemcpyAsync(world_xyzw, s->t_pts.p, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
     return PC_OK;
 }
 

@@ -55,9 +55,10 @@ constexpr int kMaxGridCells = 256;
 // sobel_fma, bit 0: the column pass of Dx as ONE fused multiply-add (PC_ARITH_SOBEL_FMA: the AVX2 dispatch of OpenCV's filter);
 // bit 1: the row pass of Dy as a fused chain (PC_ARITH_SOBEL_ROW_FMA)
 void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, int sobel_fma, hipStream_t s);
-// K2 for any block_size and for cornerHarris (gftt.cc:31-36): two plain kernels; cov = 3 * w * h floats of scratch
-void launch_corner_response(const Level& l0, float* eig, float* cov, const GfttGrid& g, uint32_t* cell_max, int block_size, bool harris,
-                            double harris_k, int sobel_fma, hipStream_t s);
+// K2 for any block_size, any gradient_size (3, 5, 7: Sobel; -1: Scharr) and for cornerHarris (gftt.cc:31-36): two plain kernels;
+// cov = 3 * w * h floats of scratch.  false: not an aperture OpenCV has
+bool launch_corner_response(const Level& l0, float* eig, float* cov, const GfttGrid& g, uint32_t* cell_max, int block_size, int gradient_size,
+                            bool harris, double harris_k, int sobel_fma, hipStream_t s);
 // K3: per-cell THRESH_TOZERO + 3x3 dilate + strict-interior local maxima -> 64-bit keys
 // (ordered(value) << 32 | y*w+x) appended to `keys` (capacity `cap`), count in *counter; cstate (w*h bytes): 1 at
 // candidates, 0 elsewhere, every pixel written; sort_params[2] / hist[kSortBuckets]: value range and per-bucket counts
@@ -216,6 +217,39 @@ void launch_pnp_lm_rounds(const float* X, const float* x, const float* w, int n,
 void launch_pnp_cost(const float* X, const float* x, const float* w, int n, const PnPParams& p, float max_err_sq,
                      float* partials, float* out4, hipStream_t s);
 
+
+// ---- SolveFrame in two launches (kernels_tracker.hip: track_cast_kernel, track_lm_kernel) ----
+constexpr int kTrackMaxSources = 8;     // flows into a frame: the skips -8 .. +8 (cpp/opticalflow.cc:76-77)
+constexpr int kTrackSyncWords = 64 + 512; // barrier words of track_lm_kernel: zero before the launch, left zero by it
+struct TrackSource {                    // one source frame of the frame being solved
+    RayCamera cam;                      // the source's camera, object space (GetRayObjectSpace, ray_casting.h:53-63)
+    const float2* kps;                  // its keypoints (device)
+    const uint32_t* idx;                // its matches (device): src_keypoints_indices ...
+    const float2* tgt;                  // ... and tgt_keypoints of the flow source -> frame
+    int n_kps;
+    int begin, n_matches;               // its rows of the frame's arrays pts / obs
+    int block_begin;                    // first workgroup of track_cast_kernel that works on them
+};
+struct TrackCastArgs {
+    BvhView bvh;
+    const uint32_t* mask;
+    int check_mask;
+    CorrModel model;
+    int n_sources;
+    TrackSource src[kTrackMaxSources];
+    float4* pts;                        // out, per match: world point + 1, or zeros for a miss
+    float2* obs;                        // out, per match: its tracked position (the sources' tgt arrays, one after the other)
+    int* bad_index;                     // set when an index lies past its source's keypoints (tracker.cc:61)
+};
+int track_cast_blocks(int n_matches);
+void launch_track_cast(const TrackCastArgs& a, int total_blocks, hipStream_t s);
+
+struct LmConfig;
+struct LmCamera;
+struct TrackLmOut;
+struct TrackLmArgs;
+int track_lm_blocks(int n);
+void launch_track_lm(const TrackLmArgs& a, hipStream_t s);
 
 // lm_cholesky9 + lm_cholesky9_solve (pnp_lm.hpp) of one system on the device; all pointers device memory
 void launch_llt9_debug(const float* a81, const float* b9, float* l81, float* x9, int* ok, hipStream_t s);

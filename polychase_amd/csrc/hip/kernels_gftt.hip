@@ -432,28 +432,89 @@ void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* ce
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2, general form: any block_size, cornerMinEigenVal or cornerHarris (gftt.cc:31-36).  The detector's default
-// (block 3, min-eig) has the LDS-tiled kernel above; everything else -- never used by the addon -- takes two plain
+// K2, general form: any block_size, any gradient_size (Sobel 3 / 5 / 7, Scharr = -1), cornerMinEigenVal or cornerHarris
+// (gftt.cc:31-36).  The detector's default (block 3, Sobel 3, min-eig) has the fused kernel above; everything else -- never used
+// by the addon -- takes two plain
 // kernels with the same arithmetic as oracle/pc_oracle.c: the covariance products of every pixel into three float planes,
 // then block x block box sums of those planes in fp64 (BORDER_REFLECT_101 applies to the covariance image, anchor
 // block / 2) and the response.  Scale 1 / (2^(ksize-1) * block * 255) folded into the smoothing taps.
 // ------------------------------------------------------------------------------------------------
+// Taps of the derivative filters (cornerEigenValsVecs, imgproc/corner.cpp; oracle/pc_oracle.c: corner_response): the
+// binomial Sobel kernels of getSobelKernels for apertures 3 / 5 / 7 and Scharr's 3 / 10 / 3 for aperture -1, the scale
+// 1 / (2^(taps-1) * block * 255) (x 1/2 for Scharr) folded into the SMOOTHING taps as float x float like `kx *= scale`.
+struct SobelTaps {
+    float sm[7];   // smoothing taps x scale
+    float dv[7];   // derivative taps (small integers)
+};
+static bool make_sobel_taps(int gradient_size, int block_size, SobelTaps* t, int* taps_out) {
+    static const int sm3[3] = {1, 2, 1}, dv3[3] = {-1, 0, 1};
+    static const int sm5[5] = {1, 4, 6, 4, 1}, dv5[5] = {-1, -2, 0, 2, 1};
+    static const int sm7[7] = {1, 6, 15, 20, 15, 6, 1}, dv7[7] = {-1, -4, -5, 0, 5, 4, 1};
+    static const int smS[3] = {3, 10, 3};
+    if (gradient_size != 3 && gradient_size != 5 && gradient_size != 7 && gradient_size != -1) return false;
+    const int taps = gradient_size > 0 ? gradient_size : 3;
+    const int* sm = gradient_size == 3 ? sm3 : gradient_size == 5 ? sm5 : gradient_size == 7 ? sm7 : smS;
+    const int* dv = gradient_size == 5 ? dv5 : gradient_size == 7 ? dv7 : dv3;
+    double scale_d = (double)(1 << (taps - 1)) * block_size;
+    if (gradient_size < 0) scale_d *= 2.0;
+    scale_d = 1.0 / (scale_d * 255.0);
+    const float scale_f = (float)scale_d;
+    for (int k = 0; k < 7; k++) {
+        t->sm[k] = k < taps ? (float)sm[k] * scale_f : 0.f;
+        t->dv[k] = k < taps ? (float)dv[k] : 0.f;
+    }
+    *taps_out = taps;
+    return true;
+}
+
+// Covariance products of one pixel for a TAPS x TAPS aperture.  The row pass is sepFilter2D's generic row filter (taps in
+// order, one rounding per smoothing tap; bit 1 of sobel_fma: the fused chain of the vector row filter), the column pass the
+// symmetric / anti-symmetric column filter's order: centre tap first, then the pairs outwards (bit 0 of sobel_fma: each
+// v_muladd fused, the AVX2 dispatch).  Borders by index reflection (BORDER_REFLECT_101): no reliance on the plane's padding,
+// whose width follows the LK window.
+template <int TAPS>
 __global__ __launch_bounds__(256) void cov_kernel(const uint8_t* __restrict__ img, int pitch, int w, int h, float* __restrict__ cov,
-                                                  float f1, float f0, int sobel_fma, int hi_prio) {
+                                                  SobelTaps T, int sobel_fma, int hi_prio) {
     helper_priority(hi_prio);
+    constexpr int R = TAPS / 2;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
-    // the level-0 plane carries REFLECT_101 padding: rows y - 1 .. y + 1, columns x - 1 .. x + 1 are addressable
-    float rdx[3], rdy[3];
+    int xs[TAPS];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const uint8_t* row = img + (ptrdiff_t)(y - 1 + k) * pitch + x;
-        const float sm = row[-1], sc = row[0], sp = row[1];
-        rdx[k] = (0.0f - sm) + sp;
-        rdy[k] = (sobel_fma & 2) ? smooth_row<true>(sm, sc, sp, f1, f0) : smooth_row<false>(sm, sc, sp, f1, f0);
+    for (int i = 0; i < TAPS; i++) xs[i] = reflect101(x + i - R, w);
+    float rdx[TAPS], rdy[TAPS];
+#pragma unroll
+    for (int k = 0; k < TAPS; k++) {
+        const uint8_t* row = img + (ptrdiff_t)reflect101(y + k - R, h) * pitch;
+        float d = 0.f, t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TAPS; i++) {
+            const float v = row[xs[i]];
+            if (i == 0) {
+                d = T.dv[0] * v;
+                t = T.sm[0] * v;
+            } else {
+                d += T.dv[i] * v;
+                t = (sobel_fma & 2) ? __fmaf_rn(T.sm[i], v, t) : t + T.sm[i] * v;
+            }
+        }
+        rdx[k] = d;
+        rdy[k] = t;
     }
-    const float dx = (sobel_fma & 1) ? __fmaf_rn(rdx[0] + rdx[2], f1, rdx[1] * f0) : (rdx[0] + rdx[2]) * f1 + rdx[1] * f0;
-    const float dy = rdy[2] - rdy[0];
+    float dx = rdx[R] * T.sm[R];
+#pragma unroll
+    for (int j = 1; j <= R; j++) {
+        const float pair = rdx[R + j] + rdx[R - j];
+        dx = (sobel_fma & 1) ? __fmaf_rn(pair, T.sm[R + j], dx) : pair * T.sm[R + j] + dx;
+    }
+    float dy;
+    if (TAPS == 3) {
+        dy = rdy[2] - rdy[0];
+    } else {
+        dy = T.dv[R + 1] * (rdy[R + 1] - rdy[R - 1]);
+#pragma unroll
+        for (int j = 2; j <= R; j++) dy = (rdy[R + j] - rdy[R - j]) * T.dv[R + j] + dy;
+    }
     const size_t n = (size_t)w * h, i = (size_t)y * w + x;
     cov[i] = dx * dx;
     cov[n + i] = dx * dy;
@@ -516,14 +577,21 @@ __global__ __launch_bounds__(256) void box_response_kernel(const float* __restri
     }
 }
 
-void launch_corner_response(const Level& l0, float* eig, float* cov, const GfttGrid& g, uint32_t* cell_max, int block_size, bool harris,
-                            double harris_k, int sobel_fma, hipStream_t s) {
-    const double scale_d = 1.0 / (4.0 * (double)block_size * 255.0);
-    const float f1 = (float)(1.0 * scale_d), f0 = (float)(2.0 * scale_d);
+bool launch_corner_response(const Level& l0, float* eig, float* cov, const GfttGrid& g, uint32_t* cell_max, int block_size, int gradient_size,
+                            bool harris, double harris_k, int sobel_fma, hipStream_t s) {
+    SobelTaps T;
+    int taps = 0;
+    if (!make_sobel_taps(gradient_size, block_size, &T, &taps)) return false;
     dim3 grid((l0.w + 63) / 64, (l0.h + 3) / 4);
-    hipLaunchKernelGGL(cov_kernel, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, cov, f1, f0, sobel_fma, helper_prio_arg());
+    if (taps == 3)
+        hipLaunchKernelGGL(cov_kernel<3>, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, cov, T, sobel_fma, helper_prio_arg());
+    else if (taps == 5)
+        hipLaunchKernelGGL(cov_kernel<5>, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, cov, T, sobel_fma, helper_prio_arg());
+    else
+        hipLaunchKernelGGL(cov_kernel<7>, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, cov, T, sobel_fma, helper_prio_arg());
     hipLaunchKernelGGL(box_response_kernel, grid, dim3(256), 0, s, cov, l0.w, l0.h, block_size, harris ? ((sobel_fma & 1) ? 2 : 1) : 0, harris_k, eig, g, cell_max,
                        helper_prio_arg());
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -319,6 +319,56 @@ __device__ __forceinline__ void block_reduce(float (&v)[NV], float (*s_part)[NV]
         for (int k = 0; k < NV; k++) v[k] = (s_part[0][k] + s_part[1][k]) + (s_part[2][k] + s_part[3][k]);
 }
 
+// one correspondence's terms of the 56 sums (cpp/pnp/pnp_problem.h:63-99, lev_marq.h:231-297): Z world point, (ox, oy) its
+// observation, `weight` != 0
+__device__ __forceinline__ void pnp_accumulate(float Zx, float Zy, float Zz, float ox, float oy, float weight, const PnPParams& p,
+                                               float (&acc)[PNP_ACC]) {
+    // RtZ = R Z + t  (Pose::ApplyWithJac, cpp/pose.h:60-78)
+    const float ax = p.R[0] * Zx + p.R[1] * Zy + p.R[2] * Zz + p.t[0];
+    const float ay = p.R[3] * Zx + p.R[4] * Zy + p.R[5] * Zz + p.t[1];
+    const float az = p.R[6] * Zx + p.R[7] * Zy + p.R[8] * Zz + p.t[2];
+    // ProjectWithJac (cpp/pnp/types.h:69-93)
+    const float zx = p.fx * ax / az + p.cx, zy = p.fy * ay / az + p.cy;
+    const float rx = zx - ox, ry = zy - oy;
+    const float d00 = p.fx / az, d02 = -p.fx * ax / (az * az);
+    const float d11 = p.fy / az, d12 = -p.fy * ay / (az * az);
+    // dRtZ_dR = R * Skew(-Z):  Skew(-Z) = [[0, Zz, -Zy], [-Zz, 0, Zx], [Zy, -Zx, 0]]
+    float M[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const float r0 = p.R[3 * r], r1 = p.R[3 * r + 1], r2 = p.R[3 * r + 2];
+        M[3 * r] = -r1 * Zz + r2 * Zy;
+        M[3 * r + 1] = r0 * Zz - r2 * Zx;
+        M[3 * r + 2] = -r0 * Zy + r1 * Zx;
+    }
+    float J0[9], J1[9];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        J0[c] = d00 * M[c] + d02 * M[6 + c];
+        J1[c] = d11 * M[3 + c] + d12 * M[6 + c];
+    }
+    J0[3] = d00; J0[4] = 0.f; J0[5] = d02;
+    J1[3] = 0.f; J1[4] = d11; J1[5] = d12;
+    J0[6] = p.optimize_focal ? p.aspect_ratio * ax / az : 0.f;
+    J1[6] = p.optimize_focal ? ay / az : 0.f;
+    J0[7] = p.optimize_pp ? 1.f : 0.f; J0[8] = 0.f;
+    J1[7] = 0.f; J1[8] = p.optimize_pp ? 1.f : 0.f;
+    const float r2n = rx * rx + ry * ry;
+    const float tw = weight * loss_weight(p.loss_type, p.loss_scale, r2n);
+    int o = 0;
+#pragma unroll
+    for (int a = 0; a < 9; a++)
+#pragma unroll
+        for (int b = 0; b <= a; b++) acc[o++] += tw * (J0[a] * J0[b] + J1[a] * J1[b]);
+#pragma unroll
+    for (int a = 0; a < 9; a++) acc[45 + a] += J0[a] * (tw * rx) + J1[a] * (tw * ry);
+    acc[54] += 1.0f;
+    // the cost of these parameters, term for term what pnp_cost_kernel adds (same per-thread order, same
+    // reduction tree): the LM loop gets the candidate's cost and its normal equations from ONE sweep
+    const bool behind = p.convention_opencv ? (az < 0.0f) : (az > 0.0f);
+    acc[55] += weight * loss_value(p.loss_type, p.loss_scale, behind ? __builtin_inff() : r2n);
+}
+
 __device__ __forceinline__ void pnp_normal_eq_body(const float* __restrict__ X, const float* __restrict__ x,
                                                    const float* __restrict__ w, int n, const PnPParams& p,
                                                    float* __restrict__ partials) {
@@ -329,51 +379,7 @@ __device__ __forceinline__ void pnp_normal_eq_body(const float* __restrict__ X, 
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float weight = w ? w[i] : 1.0f;
         if (weight == 0.0f) continue;
-        const float Zx = X[3 * i], Zy = X[3 * i + 1], Zz = X[3 * i + 2];
-        // RtZ = R Z + t  (Pose::ApplyWithJac, cpp/pose.h:60-78)
-        const float ax = p.R[0] * Zx + p.R[1] * Zy + p.R[2] * Zz + p.t[0];
-        const float ay = p.R[3] * Zx + p.R[4] * Zy + p.R[5] * Zz + p.t[1];
-        const float az = p.R[6] * Zx + p.R[7] * Zy + p.R[8] * Zz + p.t[2];
-        // ProjectWithJac (cpp/pnp/types.h:69-93)
-        const float zx = p.fx * ax / az + p.cx, zy = p.fy * ay / az + p.cy;
-        const float rx = zx - x[2 * i], ry = zy - x[2 * i + 1];
-        const float d00 = p.fx / az, d02 = -p.fx * ax / (az * az);
-        const float d11 = p.fy / az, d12 = -p.fy * ay / (az * az);
-        // dRtZ_dR = R * Skew(-Z):  Skew(-Z) = [[0, Zz, -Zy], [-Zz, 0, Zx], [Zy, -Zx, 0]]
-        float M[9];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const float r0 = p.R[3 * r], r1 = p.R[3 * r + 1], r2 = p.R[3 * r + 2];
-            M[3 * r] = -r1 * Zz + r2 * Zy;
-            M[3 * r + 1] = r0 * Zz - r2 * Zx;
-            M[3 * r + 2] = -r0 * Zy + r1 * Zx;
-        }
-        float J0[9], J1[9];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            J0[c] = d00 * M[c] + d02 * M[6 + c];
-            J1[c] = d11 * M[3 + c] + d12 * M[6 + c];
-        }
-        J0[3] = d00; J0[4] = 0.f; J0[5] = d02;
-        J1[3] = 0.f; J1[4] = d11; J1[5] = d12;
-        J0[6] = p.optimize_focal ? p.aspect_ratio * ax / az : 0.f;
-        J1[6] = p.optimize_focal ? ay / az : 0.f;
-        J0[7] = p.optimize_pp ? 1.f : 0.f; J0[8] = 0.f;
-        J1[7] = 0.f; J1[8] = p.optimize_pp ? 1.f : 0.f;
-        const float r2n = rx * rx + ry * ry;
-        const float tw = weight * loss_weight(p.loss_type, p.loss_scale, r2n);
-        int o = 0;
-#pragma unroll
-        for (int a = 0; a < 9; a++)
-#pragma unroll
-            for (int b = 0; b <= a; b++) acc[o++] += tw * (J0[a] * J0[b] + J1[a] * J1[b]);
-#pragma unroll
-        for (int a = 0; a < 9; a++) acc[45 + a] += J0[a] * (tw * rx) + J1[a] * (tw * ry);
-        acc[54] += 1.0f;
-        // the cost of these parameters, term for term what pnp_cost_kernel adds (same per-thread order, same
-        // reduction tree): the LM loop gets the candidate's cost and its normal equations from ONE sweep
-        const bool behind = p.convention_opencv ? (az < 0.0f) : (az > 0.0f);
-        acc[55] += weight * loss_value(p.loss_type, p.loss_scale, behind ? __builtin_inff() : r2n);
+        pnp_accumulate(X[3 * i], X[3 * i + 1], X[3 * i + 2], x[2 * i], x[2 * i + 1], weight, p, acc);
     }
     block_reduce<PNP_ACC>(acc, s_part);
     if (threadIdx.x == 0)
@@ -513,6 +519,393 @@ void launch_pnp_cost(const float* X, const float* x, const float* w, int n, cons
     const int nb = pnp_num_blocks(n);
     hipLaunchKernelGGL(pnp_cost_kernel, dim3(nb), dim3(256), 0, s, X, x, w, n, p, max_err_sq, partials);
     hipLaunchKernelGGL(pnp_finalize_kernel, dim3(1), dim3(1024), 0, s, partials, nb, 4, out4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SolveFrame in two launches (reference cpp/tracker.cc:36-131 = correspondences of every source + SolvePnPIterative)
+//
+//   track_cast_kernel   ONE launch for all source frames of the frame being solved: lane = one match of one source;
+//                       gather the source keypoint, closest hit under THAT source's camera, model transform -- the code of
+//                       corr_cast_kernel -- and pts[i] = (world point, 1) for a hit, (0, 0, 0, 0) for a miss.  No
+//                       compaction: the solver skips invalid entries, their count is one of its sums.
+//   track_lm_kernel     the WHOLE Levenberg-Marquardt loop (lev_marq.h:132-228) + the inlier pass (solvers.cc:31-47) as one
+//                       persistent launch: every workgroup keeps its share of the correspondences, sweeps them with the
+//                       parameters of the round, publishes its 56 partial sums and arrives at a grid barrier; workgroup 0
+//                       -- which holds the solver's state in LDS for the whole launch -- adds the partials in a fixed
+//                       order, takes the decision (lm_consume: one lane, 9x9 algebra in registers), publishes the next
+//                       parameters and releases the others.  Rounds stop at `done`; the result goes straight to pinned
+//                       host memory.  Round 4 enqueued 13 x (sweep, reduce + decide) + 2 launches per frame, each round
+//                       15 + 15 us of a mostly idle GPU (profiles/r05_head_c5_timeline.json).
+//
+// Cross-workgroup data follows common.hpp's rules for this chip (the XCDs' L2s are not coherent with one another): what
+// another workgroup will read is written with agent-scope atomic stores and read either with agent-scope atomic loads (the
+// round word, the parameters) or with plain loads behind ONE acquire fence in the reading workgroup (the partials).
+// Co-residency: at most 512 workgroups of 256 lanes, ~2 KB of LDS each -- two per CU at any register count -- so every
+// workgroup of the launch is resident however little of the GPU is free, and nothing else on the GPU waits for this
+// kernel; the spin loops sleep between polls and give up after kTrackSpinLimit ticks (status 2) instead of hanging.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RC_BLOCK) void track_cast_kernel(TrackCastArgs a) {
+    __shared__ int s_stack[kBvhStack][RC_BLOCK];
+    // the block's source: the last one whose first block is <= blockIdx (blocks of a source are consecutive)
+    int sel = 0;
+    for (int k = 1; k < a.n_sources; k++)
+        if ((int)blockIdx.x >= a.src[k].block_begin) sel = k;
+    sel = __builtin_amdgcn_readfirstlane(sel);
+    const TrackSource& S = a.src[sel];
+    const int local = ((int)blockIdx.x - S.block_begin) * RC_BLOCK + (int)threadIdx.x;
+    if (local >= S.n_matches) return;
+    const size_t i = (size_t)S.begin + (size_t)local;
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t k = S.idx[local];
+    a.obs[i] = S.tgt[local];
+    if (k >= (uint32_t)S.n_kps) {
+        atomicExch(a.bad_index, 1);   // CHECK_LT(idx, keypoints.size()), tracker.cc:61
+    } else {
+        const RayCamera& cam = S.cam;
+        const float2 p = S.kps[k];
+        const float ux = cam.sign * ((p.x - cam.cx) / cam.fx), uy = cam.sign * ((p.y - cam.cy) / cam.fy), uz = cam.sign;
+        const float dx = cam.m[0] * ux + cam.m[1] * uy + cam.m[2] * uz;
+        const float dy = cam.m[3] * ux + cam.m[4] * uy + cam.m[5] * uz;
+        const float dz = cam.m[6] * ux + cam.m[7] * uy + cam.m[8] * uz;
+        float best_t, best_u, best_v;
+        const int best = bvh_closest_hit(a.bvh, cam.origin[0], cam.origin[1], cam.origin[2], dx, dy, dz, &s_stack[0][threadIdx.x],
+                                         RC_BLOCK, &best_t, &best_u, &best_v);
+        bool ok = best >= 0;
+        if (ok && a.check_mask && ((a.mask[best >> 5] >> (best & 31)) & 1u)) ok = false;   // ray_casting.cc:104-106
+        if (ok) {
+            const BvhView& B = a.bvh;
+            const uint32_t va = B.tris[3 * best], vb = B.tris[3 * best + 1], vc = B.tris[3 * best + 2];
+            const float w0 = 1.0f - best_u - best_v;
+            float pos[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++)  // Triangle::Barycentric (geometry.h:17-19)
+                pos[q] = w0 * B.verts[3 * va + q] + best_u * B.verts[3 * vb + q] + best_v * B.verts[3 * vc + q];
+            const float* m = a.model.m;   // model_matrix * hit (tracker.cc:80-82), left to right like the host code
+            out.x = m[0] * pos[0] + m[1] * pos[1] + m[2] * pos[2] + m[3];
+            out.y = m[4] * pos[0] + m[5] * pos[1] + m[6] * pos[2] + m[7];
+            out.z = m[8] * pos[0] + m[9] * pos[1] + m[10] * pos[2] + m[11];
+            out.w = 1.0f;
+        }
+    }
+    a.pts[i] = out;
+}
+
+int track_cast_blocks(int n_matches) { return (n_matches + RC_BLOCK - 1) / RC_BLOCK; }
+void launch_track_cast(const TrackCastArgs& a, int total_blocks, hipStream_t s) {
+    if (total_blocks <= 0) return;
+    hipLaunchKernelGGL(track_cast_kernel, dim3(total_blocks), dim3(RC_BLOCK), 0, s, a);
+}
+
+namespace {
+
+constexpr int kParamWords = (int)(sizeof(PnPParams) / sizeof(uint32_t));
+static_assert(sizeof(PnPParams) % sizeof(uint32_t) == 0, "PnPParams travels word by word");
+// Words of TrackLmArgs::sync (all zero before a launch, left zero by it):
+//   [kSyncAbort]                a lane's wait ran out: everybody leaves
+//   [kSyncParams .. + 2 * (kParamWords + 1))   the decision of a round as 64-bit words (tag << 32 | value), tag = the round it
+//                               is FOR: the parameters to evaluate and `done`.  A tagged word is its own flag: a reader needs
+//                               ONE round trip to learn that the round has begun and what to evaluate (a round word polled
+//                               first and the parameters fetched after cost two).
+//   [kSyncFlags + b]            workgroup b has published its partial sums of round r: r + 1
+constexpr int kSyncAbort = 0, kSyncParams = 2, kSyncFlags = 64;
+static_assert(kSyncParams + 2 * (kParamWords + 1) <= kSyncFlags && kSyncFlags + 512 <= kTrackSyncWords, "sync layout");
+constexpr long long kTrackSpinLimit = 500000000ll;   // wall_clock64 ticks (100 MHz): 5 s
+
+__device__ __forceinline__ uint32_t peek(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long peek64(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void publish64(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Polls until `ready()` holds in every lane that called; false when the launch was aborted or the limit ran out.  Called by
+// whole wavefronts (all lanes take part in the loop; lanes with nothing to wait for pass ready() = true).
+template <typename Ready>
+__device__ __forceinline__ bool spin_until(Ready ready, uint32_t* sync) {
+    const long long t0 = wall_clock64();
+    for (uint32_t it = 0;; it++) {
+        if (__all(ready())) return true;
+        __builtin_amdgcn_s_sleep(2);
+        if ((it & 63u) == 63u) {
+            if (peek(sync + kSyncAbort)) return false;
+            if (wall_clock64() - t0 > kTrackSpinLimit) {
+                publish(sync + kSyncAbort, 1u);
+                return false;
+            }
+        }
+    }
+}
+
+// wave sums -> LDS -> lanes k < NV publish the workgroup's sum of value k (value-major like pnp_normal_eq_body)
+template <int NV>
+__device__ __forceinline__ void block_reduce_publish(float (&v)[NV], float (*s_part)[NV], float* __restrict__ partials) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();   // the previous round's readers of s_part are done
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NV; k++) s_part[wave][k] = v[k];
+    __syncthreads();
+    if ((int)threadIdx.x < NV) {
+        const int k = threadIdx.x;
+        const float sum = (s_part[0][k] + s_part[1][k]) + (s_part[2][k] + s_part[3][k]);
+        __hip_atomic_store(partials + (size_t)k * gridDim.x + blockIdx.x, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// this workgroup's partial sums of round `arrival - 1` are published: each lane waits until the memory system has
+// acknowledged its own stores, the barrier collects the workgroup, one lane raises the workgroup's flag
+__device__ __forceinline__ void grid_arrive(uint32_t* sync, uint32_t arrival) {
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) publish(sync + kSyncFlags + blockIdx.x, arrival);
+}
+// workgroup 0: until every workgroup's flag says `arrival` (lane t watches the flags t, t + 256); the result in s_ok
+__device__ __forceinline__ void wait_for_all(uint32_t* sync, uint32_t arrival, int* s_ok) {
+    const int G = gridDim.x, t = threadIdx.x;
+    bool a = t >= G, b = t + 256 >= G;
+    const bool ok = spin_until(
+        [&]() {
+            if (!a) a = peek(sync + kSyncFlags + t) == arrival;
+            if (!b) b = peek(sync + kSyncFlags + t + 256) == arrival;
+            return a && b;
+        },
+        sync);
+    if (t == 0) *s_ok = 1;
+    __syncthreads();
+    if (!ok) *s_ok = 0;   // any wavefront that gave up
+    __syncthreads();
+}
+
+// Sum of `nblocks` (<= 512) partials of each of NV values by one 256-lane workgroup: wave w takes the values w, w + 4, ...;
+// lane l adds the partials l, l + 64, ... (8 of them), then a fixed shuffle tree.  ALL loads of a lane are issued before the
+// first is consumed: behind the acquire fence every one of them misses the L2, and a loop that waits for each load in turn
+// (round 4's second stage, and the first version of this kernel: 14 values x 8 dependent misses per lane) took longer than
+// the sweep it follows.
+template <int NV>
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ partials, int nblocks, float* s_out) {
+    constexpr int PER_WAVE = (NV + 3) / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float v[PER_WAVE][8];
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; q++) {
+        const int k = wave + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int b = lane + 64 * j;
+            v[q][j] = (k < NV && b < nblocks) ? partials[(size_t)k * nblocks + b] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; q++) {
+        const int k = wave + 4 * q;
+        float s = ((v[q][0] + v[q][1]) + (v[q][2] + v[q][3])) + ((v[q][4] + v[q][5]) + (v[q][6] + v[q][7]));
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+        if (lane == 0 && k < NV) s_out[k] = s;
+    }
+}
+
+}  // namespace
+
+// the decision of one round on top of lm_consume: the correspondence count is only known once the first sweep has
+// counted the valid entries (PnPProblem's n: pnp_problem.h:34-35, solvers.cc:54-55, tracker.cc:95-97)
+__device__ __forceinline__ void track_consume(LmState& s, const float* out56, int round, int max_rounds) {
+    if (s.phase == 0) {
+        s.n_valid = (int)out56[54];
+        if (s.n_valid < 3) {   // "Not enough features" (tracker.cc:95-97): nothing is solved
+            s.status = 1;
+            lm_finish(s);
+            return;
+        }
+        if (s.n_valid == 3 && (s.cfg.optimize_focal || s.cfg.optimize_pp)) {
+            // intrinsics are only optimised with more than 3 points: evaluate the initial parameters again without
+            // their columns (the round stays phase 0)
+            s.cfg.optimize_focal = 0;
+            s.cfg.optimize_pp = 0;
+            lm_make_params(s.cam, s.cfg, &s.sweep);
+            return;
+        }
+    }
+    lm_consume(s, out56);
+    if (!s.done && round + 1 >= max_rounds) {
+        s.status = 3;
+        lm_finish(s);
+    }
+}
+
+__global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
+    __shared__ float s_part[4][PNP_ACC];
+    __shared__ float s_out[PNP_ACC];
+    __shared__ LmState s_state;                  // workgroup 0: the solver's state for the whole launch
+    __shared__ uint32_t s_pw[kParamWords + 1];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x, G = gridDim.x;
+    const size_t T = (size_t)G * 256, gtid = (size_t)blockIdx.x * 256 + tid;
+    PnPParams p;
+    lm_make_params(a.cam, a.cfg, &p);   // round 0: the initial parameters, from the launch arguments
+    {
+        uint32_t* pw = reinterpret_cast<uint32_t*>(&p);
+#pragma unroll
+        for (int k = 0; k < kParamWords; k++) pw[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)pw[k]);   // uniform: scalar registers
+    }
+    uint32_t round = 0;
+    bool aborted = false;
+    // where the launch's time goes, measured by workgroup 0 (100 MHz ticks, TrackLmOut::ticks): its own sweep + publish,
+    // waiting for the other workgroups, adding the partials, the decision, publishing it, fetching the parameters
+    long long tk[kTrackTickPhases] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long t_begin = wall_clock64();
+    long long t_mark = t_begin;
+    auto tick = [&](int phase) {
+        if (blockIdx.x == 0 && tid == 0) {
+            const long long now = wall_clock64();
+            tk[phase] += now - t_mark;
+            t_mark = now;
+        }
+    };
+    for (;;) {
+        // ---- the sweep of this workgroup's correspondences (pnp_normal_eq_body's per-lane order) ----
+        float acc[PNP_ACC];
+#pragma unroll
+        for (int k = 0; k < PNP_ACC; k++) acc[k] = 0.f;
+        for (size_t i = gtid; i < (size_t)a.n; i += T) {
+            const float4 P = a.pts[i];
+            if (P.w == 0.0f) continue;
+            const float2 o = a.obs[i];
+            pnp_accumulate(P.x, P.y, P.z, o.x, o.y, 1.0f, p, acc);
+        }
+        block_reduce_publish<PNP_ACC>(acc, s_part, a.partials);
+        grid_arrive(a.sync, round + 1u);
+        tick(0);
+        unsigned long long* pub = reinterpret_cast<unsigned long long*>(a.sync + kSyncParams);
+        if (blockIdx.x == 0) {
+            wait_for_all(a.sync, round + 1u, &s_ok);
+            if (!s_ok) { aborted = true; break; }
+            tick(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            reduce_partials<PNP_ACC>(a.partials, G, s_out);
+            __syncthreads();
+            tick(2);
+            if (tid == 0) {
+                if (round == 0) {
+                    LmState& h = s_state;
+                    uint32_t* z = reinterpret_cast<uint32_t*>(&h);
+                    for (int i = 0; i < (int)(sizeof(LmState) / sizeof(uint32_t)); i++) z[i] = 0u;
+                    h.cfg = a.cfg;
+                    h.cam = a.cam;
+                    h.cam_new = a.cam;
+                    h.lambda = a.cfg.initial_lambda;
+                    h.v = 2.0f;
+                    h.grad_norm = -1.0f;
+                    h.step_norm = -1.0f;
+                    h.rebuild = 1;
+                    lm_make_params(h.cam, h.cfg, &h.sweep);
+                }
+                track_consume(s_state, s_out, (int)round, a.max_rounds);
+            }
+            __syncthreads();
+            tick(3);
+            // the decision, tagged with the round it is for
+            const uint32_t* sw = reinterpret_cast<const uint32_t*>(&s_state.sweep);
+            const unsigned long long tag = (unsigned long long)(round + 1u) << 32;
+            if (tid < kParamWords) publish64(pub + tid, tag | sw[tid]);
+            if (tid == kParamWords) publish64(pub + kParamWords, tag | (uint32_t)s_state.done);
+            tick(4);
+        }
+        // ---- everyone: the parameters of the next round (or the accepted ones once done), as soon as they are there ----
+        if (tid < 64) {
+            unsigned long long v = 0;
+            const bool mine = tid <= kParamWords;
+            const bool ok = spin_until(
+                [&]() {
+                    if (mine) v = peek64(pub + tid);
+                    return !mine || (uint32_t)(v >> 32) == round + 1u;
+                },
+                a.sync);
+            if (mine) s_pw[tid] = (uint32_t)v;
+            if (tid == 0) s_ok = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (!s_ok) { aborted = true; break; }
+        uint32_t* pw = reinterpret_cast<uint32_t*>(&p);
+#pragma unroll
+        for (int k = 0; k < kParamWords; k++) pw[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_pw[k]);
+        const int done = __builtin_amdgcn_readfirstlane((int)s_pw[kParamWords]);
+        round++;
+        tick(5);
+        if (done) break;
+    }
+    if (aborted) {
+        if (blockIdx.x == 0 && tid == 0) a.out->status = 2;
+        return;
+    }
+    // ---- inlier pass on the accepted parameters (solvers.cc:31-47; pnp_cost_body's terms) ----
+    {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (size_t i = gtid; i < (size_t)a.n; i += T) {
+            const float4 P = a.pts[i];
+            if (P.w == 0.0f) continue;
+            const float2 o = a.obs[i];
+            const float ax = p.R[0] * P.x + p.R[1] * P.y + p.R[2] * P.z + p.t[0];
+            const float ay = p.R[3] * P.x + p.R[4] * P.y + p.R[5] * P.z + p.t[1];
+            const float az = p.R[6] * P.x + p.R[7] * P.y + p.R[8] * P.z + p.t[2];
+            const bool behind = p.convention_opencv ? (az < 0.0f) : (az > 0.0f);
+            float r2n;
+            if (behind) {
+                r2n = __builtin_inff();
+            } else {
+                const float rx = p.fx * ax / az + p.cx - o.x, ry = p.fy * ay / az + p.cy - o.y;
+                r2n = rx * rx + ry * ry;
+            }
+            if (r2n < a.cfg.max_inlier_err_sq) acc[2] += 1.0f;
+            acc[0] += loss_value(p.loss_type, p.loss_scale, r2n);
+            acc[1] += 1.0f;
+        }
+        block_reduce_publish<4>(acc, reinterpret_cast<float(*)[4]>(&s_part[0][0]), a.partials);
+        grid_arrive(a.sync, round + 1u);
+    }
+    if (blockIdx.x != 0) return;
+    wait_for_all(a.sync, round + 1u, &s_ok);
+    if (!s_ok) {
+        if (tid == 0) a.out->status = 2;
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    reduce_partials<4>(a.partials, G, s_out);
+    __syncthreads();
+    // every workgroup has arrived for the last time and reads nothing more: the words go back to zero for the next launch
+    for (int i = tid; i < kTrackSyncWords; i += 256) publish(a.sync + i, 0u);
+    if (tid == 0) {
+        const LmState& h = s_state;
+        TrackLmOut* o = a.out;
+        o->cam = h.cam;
+        o->iterations = h.iterations;
+        o->invalid_steps = h.invalid_steps;
+        o->initial_cost = h.initial_cost;
+        o->cost = h.cost;
+        o->lambda = h.lambda;
+        o->step_norm = h.step_norm;
+        o->grad_norm = h.grad_norm;
+        o->n_valid = h.n_valid;
+        o->inliers = a.cfg.max_inlier_err_sq > 0.0f ? (int)s_out[2] : 0;
+        o->rounds = (int)round;
+        tick(6);
+        tk[7] = wall_clock64() - t_begin;
+        for (int k = 0; k < kTrackTickPhases; k++) o->ticks[k] = (uint32_t)tk[k];
+        o->status = h.status;
+        o->bad_index = *a.bad_index;
+    }
+}
+
+int track_lm_blocks(int n) { return pnp_num_blocks(n); }
+void launch_track_lm(const TrackLmArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(track_lm_kernel, dim3(track_lm_blocks(a.n)), dim3(256), 0, s, a);
 }
 
 // The damped 9x9 solve of the device-resident LM on its own (pc_debug_llt9: the reference's float32 known-answer test,

@@ -42,6 +42,35 @@ struct LmState {
     float JtJ[81], diag[9], Jtr[9], step[9];
     float cost, initial_cost, lambda, v, grad_norm, step_norm;
     int iterations, invalid_steps, rebuild, phase, done;
+    int n_valid, status;      // track_lm_kernel: correspondences counted by the first sweep; 0 ok, 1 fewer than 3, 3 round limit
+};
+
+// track_lm_kernel (kernels_tracker.hip): the launch arguments and what it leaves in pinned host memory
+constexpr int kTrackTickPhases = 8;
+struct TrackLmOut {
+    LmCamera cam;
+    int iterations, invalid_steps;
+    float initial_cost, cost, lambda, step_norm, grad_norm;
+    int n_valid;              // correspondences (matches whose ray hit the mesh)
+    int inliers;
+    int rounds;               // sweeps evaluated
+    int status;               // 0 solved, 1 fewer than 3 correspondences, 2 a grid barrier timed out, 3 round limit
+    int bad_index;            // a match named a keypoint past its source's array (tracker.cc:61)
+    // 100 MHz ticks of workgroup 0, summed over the rounds: [0] sweep + publish, [1] waiting for the other workgroups, [2] adding
+    // the partials, [3] the decision (one lane), [4] publishing it, [5] fetching the next parameters, [6] inlier pass, [7] launch
+    uint32_t ticks[kTrackTickPhases];
+};
+struct TrackLmArgs {
+    const float4* pts;        // track_cast_kernel's output
+    const float2* obs;        // tracked positions, same rows
+    int n;
+    LmConfig cfg;
+    LmCamera cam;             // initial guess
+    float* partials;          // 56 x track_lm_blocks(n)
+    uint32_t* sync;           // kTrackSyncWords
+    TrackLmOut* out;          // device-visible host memory
+    const int* bad_index;     // track_cast_kernel's flag, passed on to `out`
+    int max_rounds;
 };
 
 PC_HD float lm_clamp(float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); }   // std::clamp
@@ -69,31 +98,44 @@ PC_HD void lm_make_params(const LmCamera& c, const LmConfig& cfg, PnPParams* p) 
 }
 
 // In-place lower Cholesky of a 9x9 row-major matrix, left-looking like Eigen's unblocked llt_inplace
+// Every loop of the 9x9 algebra is fully unrolled: all indices are compile-time constants, so the work arrays live in
+// registers.  (Round 4's decision kernel kept L[81] in scratch memory -- 116 bytes per lane, every access a trip to
+// memory -- and took 15 us per LM round, as long as the residual sweep it follows: profiles/r05_head_c5_timeline.json.)
+// A failed pivot does not return from inside the unrolled loop (that would keep the array addressable): the flag is
+// carried to the end; the entries computed after a failure are never used.
 PC_HD bool lm_cholesky9(float* a) {
+    bool ok = true;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         float x = a[k * 9 + k];
+#pragma unroll
         for (int j = 0; j < k; j++) x -= a[k * 9 + j] * a[k * 9 + j];
-        if (!(x > 0.0f)) return false;
+        ok = ok && (x > 0.0f);
         x = sqrtf(x);
         a[k * 9 + k] = x;
+#pragma unroll
         for (int i = k + 1; i < 9; i++) {
             float s = a[i * 9 + k];
+#pragma unroll
             for (int j = 0; j < k; j++) s -= a[i * 9 + j] * a[k * 9 + j];
             a[i * 9 + k] = s / x;
         }
     }
-    return true;
+    return ok;
 }
 PC_HD void lm_cholesky9_solve(const float* l, const float* b, float* x) {
     float y[9];
+#pragma unroll
     for (int i = 0; i < 9; i++) {
         float s = b[i];
+#pragma unroll
         for (int j = 0; j < i; j++) s -= l[i * 9 + j] * y[j];
         y[i] = s / l[i * 9 + i];
     }
+#pragma unroll
     for (int i = 8; i >= 0; i--) {
         float s = y[i];
+#pragma unroll
         for (int j = i + 1; j < 9; j++) s -= l[j * 9 + i] * x[j];
         x[i] = s / l[i * 9 + i];
     }
@@ -137,21 +179,30 @@ PC_HD void lm_advance(LmState& s) {
     while (s.iterations < s.cfg.max_iterations) {
         if (s.rebuild) {
             int o = 0;
+#pragma unroll
             for (int a = 0; a < 9; a++)
+#pragma unroll
                 for (int b = 0; b <= a; b++) s.JtJ[9 * a + b] = s.cur_lower[o++];
+#pragma unroll
             for (int a = 0; a < 9; a++) s.Jtr[a] = s.cur_Jtr[a];
             // JtJ_diag = diag.cwiseMax(1e-6).cwiseMin(1e32)  (:296)
+#pragma unroll
             for (int a = 0; a < 9; a++) s.diag[a] = fminf(fmaxf(s.JtJ[10 * a], 1e-6f), 1e32f);
             float g2 = 0;
+#pragma unroll
             for (int a = 0; a < 9; a++) g2 += s.Jtr[a] * s.Jtr[a];
             s.grad_norm = sqrtf(g2);
             if (s.grad_norm < s.cfg.gradient_tol) break;
         }
         // ComputeStep (:299-314): multiplicative damping, LLT of the lower triangle
         float L[81];
+#pragma unroll
         for (int a = 0; a < 9; a++)
+#pragma unroll
             for (int b = 0; b <= a; b++) L[9 * a + b] = s.JtJ[9 * a + b];
+#pragma unroll
         for (int a = 0; a < 9; a++) L[10 * a] = s.diag[a] * (1.0f + s.lambda);
+#pragma unroll
         for (int a = 0; a < 9; a++) s.JtJ[10 * a] = s.diag[a];  // "remove dampening" leaves the clamped diagonal
         if (!lm_cholesky9(L)) {
             s.invalid_steps++;
@@ -163,8 +214,10 @@ PC_HD void lm_advance(LmState& s) {
             continue;
         }
         lm_cholesky9_solve(L, s.Jtr, s.step);
+#pragma unroll
         for (int a = 0; a < 9; a++) s.step[a] = -s.step[a];
         float s2 = 0;
+#pragma unroll
         for (int a = 0; a < 9; a++) s2 += s.step[a] * s.step[a];
         s.step_norm = sqrtf(s2);
         if (s.step_norm < s.cfg.step_tol) break;
@@ -180,7 +233,9 @@ PC_HD void lm_advance(LmState& s) {
 PC_HD void lm_consume(LmState& s, const float* out56) {
     if (s.done) return;
     if (s.phase == 0) {   // the initial parameters (lev_marq.h:139-144)
+#pragma unroll
         for (int k = 0; k < 45; k++) s.cur_lower[k] = out56[k];
+#pragma unroll
         for (int k = 0; k < 9; k++) s.cur_Jtr[k] = out56[45 + k];
         s.cost = out56[55];
         s.initial_cost = s.cost;
@@ -193,8 +248,10 @@ PC_HD void lm_consume(LmState& s, const float* out56) {
         const float actual = cost_new - s.cost;
         // step^T (2 Jtr + JtJ_sym step)   (:183-186), fp32 like the reference
         float expected = 0;
+#pragma unroll
         for (int a = 0; a < 9; a++) {
             float row = 0;
+#pragma unroll
             for (int b = 0; b < 9; b++) row += (b <= a ? s.JtJ[9 * a + b] : s.JtJ[9 * b + a]) * s.step[b];
             expected += s.step[a] * (2.0f * s.Jtr[a] + row);
         }
@@ -206,7 +263,9 @@ PC_HD void lm_consume(LmState& s, const float* out56) {
             s.lambda = lm_clamp((float)((double)s.lambda * factor), s.cfg.min_lambda, s.cfg.max_lambda);
         }
         s.cam = s.cam_new;
+#pragma unroll
         for (int k = 0; k < 45; k++) s.cur_lower[k] = out56[k];
+#pragma unroll
         for (int k = 0; k < 9; k++) s.cur_Jtr[k] = out56[45 + k];
         s.cost = cost_new;
         s.v = 2;

@@ -126,6 +126,7 @@ struct OpticalFlowShard {
     int piece_frames = 0;
     std::function<void(int piece, size_t offset_bytes, size_t bytes, int32_t first_frame1, int n_frames)> on_piece;
     bool host_records = true;   // false (and no database): the records are not downloaded to host memory as well
+    int device = -1;            // HIP device of the run; -1: $POLYCHASE_DEVICE, else 0
     // results
     size_t used_bytes = 0;      // bytes of the last piece (a run with one piece: of the run)
     int pieces = 0;

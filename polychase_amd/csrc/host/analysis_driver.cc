@@ -203,7 +203,12 @@ double Now() {
 class RecordWriter {
    public:
     RecordWriter(Database* db, std::mutex* db_mtx, OpticalFlowRunStats* stats)
-        : db_(db), db_mtx_(db_mtx), stats_(stats), thread_([this] { Run(); }) {}
+        : db_(db), db_mtx_(db_mtx), stats_(stats), batch_(BatchFrames()), thread_([this] { Run(); }) {}
+    static int BatchFrames() {
+        const char* env = std::getenv("POLYCHASE_DB_BATCH_FRAMES");   // read per run
+        const int n = env ? std::atoi(env) : 8;
+        return n < 1 ? 1 : n;
+    }
     ~RecordWriter() {
         {
             std::lock_guard<std::mutex> lk(mtx_);
@@ -232,17 +237,40 @@ class RecordWriter {
     void Rethrow() {
         if (error_) std::rethrow_exception(error_);
     }
+    // Records go in as transactions of up to batch_ frames (POLYCHASE_DB_BATCH_FRAMES, default 8; 1 = one transaction per
+    // frame, round 4's behaviour): a commit costs the journal's fsync-free bookkeeping plus the page-cache flush of what the
+    // transaction touched, ~8 % of the insert at one frame per commit (profiles/r03_dbfloor.json: one transaction per clip
+    // +8 %).  A transaction also ends whenever the queue runs empty -- a slow frame source (a renderer) has every frame
+    // committed as it arrives -- and at Flush() / destruction.  What a crash or an exception loses is at most the batch's
+    // finished frames: the file is rolled back to the last commit and a resumed run recomputes exactly those rows
+    // (cpp/opticalflow.cc:168-178, :286: rows that exist are skipped), bit for bit.
     void Run() {
+        bool in_transaction = false;
+        int in_batch = 0;
+        auto fail = [&](std::exception_ptr e) {
+            if (in_transaction) {
+                try {
+                    std::lock_guard<std::mutex> dblk(*db_mtx_);
+                    db_->Rollback();   // or every later Begin fails with "cannot start a transaction within a transaction"
+                } catch (...) {
+                }
+                in_transaction = false;
+                in_batch = 0;
+            }
+            std::lock_guard<std::mutex> lk(mtx_);
+            if (!error_) error_ = e;   // the first error is the cause; later ones are its echo
+        };
         for (;;) {
             pc_frame_result r;
+            bool last_of_burst = false;
             {
                 std::unique_lock<std::mutex> lk(mtx_);
                 cv_.wait(lk, [&] { return !queue_.empty() || quit_; });
-                if (queue_.empty()) return;
+                if (queue_.empty()) break;
                 r = queue_.front();
+                last_of_burst = queue_.size() == 1;
                 busy_ = true;
             }
-            bool in_transaction = false;
             try {
                 const double t0 = Now();
                 std::lock_guard<std::mutex> dblk(*db_mtx_);
@@ -250,8 +278,10 @@ class RecordWriter {
                     std::lock_guard<std::mutex> lk(mtx_);
                     if (error_) throw WriterStopped{};   // an earlier record failed: nothing more is written
                 }
-                db_->Begin();
-                in_transaction = true;
+                if (!in_transaction) {
+                    db_->Begin();
+                    in_transaction = true;
+                }
                 if (r.keypoints_detected && !db_->KeypointsExist(r.frame1)) {
                     db_->WriteKeypoints(r.frame1, r.keypoints_xy, static_cast<size_t>(r.n_keypoints));
                     stats_->keypoint_rows_written++;
@@ -262,27 +292,30 @@ class RecordWriter {
                                             static_cast<size_t>(b - a));
                     stats_->flow_rows_written++;
                 }
-                db_->Commit();
-                in_transaction = false;
+                if (++in_batch >= batch_ || last_of_burst) {
+                    db_->Commit();
+                    in_transaction = false;
+                    in_batch = 0;
+                }
                 seconds_ += Now() - t0;
             } catch (const WriterStopped&) {
             } catch (...) {
-                if (in_transaction) {
-                    try {
-                        std::lock_guard<std::mutex> dblk(*db_mtx_);
-                        db_->Rollback();   // or every later Begin fails with "cannot start a transaction within a transaction"
-                    } catch (...) {
-                    }
-                }
-                std::lock_guard<std::mutex> lk(mtx_);
-                if (!error_) error_ = std::current_exception();   // the first error is the cause; later ones are its echo
+                fail(std::current_exception());
             }
             {
                 std::lock_guard<std::mutex> lk(mtx_);
-                queue_.pop_front();  // only now may the pinned buffers of this record be reused
+                queue_.pop_front();  // only now may the pinned buffers of this record be reused (SQLite has copied the blobs)
                 busy_ = false;
             }
             cv_.notify_all();
+        }
+        if (in_transaction) {   // (only when the last record's write threw before its commit and the rollback failed too)
+            try {
+                std::lock_guard<std::mutex> dblk(*db_mtx_);
+                db_->Commit();
+            } catch (...) {
+                fail(std::current_exception());
+            }
         }
     }
 
@@ -295,7 +328,8 @@ class RecordWriter {
     bool quit_ = false, busy_ = false;
     std::exception_ptr error_;
     double seconds_ = 0;
-    std::thread thread_;
+    int batch_ = 8;
+    std::thread thread_;   // last: it starts in the constructor's initialiser list
 };
 
 }  // namespace
@@ -366,7 +400,8 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
     // out (exceptions included) the analyzer has synchronised its streams before a buffer goes back to the pool
     std::deque<std::pair<int32_t, std::shared_ptr<void>>> frames_in_flight;
     int device = 0;
-    if (const char* env = std::getenv("POLYCHASE_DEVICE")) device = std::atoi(env);
+    if (shard && shard->device >= 0) device = shard->device;   // a rank of the multi-GPU analysis names its GPU itself
+    else if (const char* env = std::getenv("POLYCHASE_DEVICE")) device = std::atoi(env);
     std::unique_ptr<Engine> engine = EngineCache::Take(device, video_info.width, video_info.height, gopt, fopt);
     if (!engine) {
         engine = std::make_unique<Engine>();

@@ -212,6 +212,21 @@ void Database::ReadKeypoints(int32_t image_id, Keypoints& out) const {
     BlobToVector(stmt, 1, static_cast<size_t>(rows), out);
 }
 
+bool Database::ReadKeypointsInto(int32_t image_id, const std::function<float*(size_t rows)>& place, size_t* rows_out) const {
+    sqlite3_stmt* stmt = Stmt(kReadKeypoints);
+    Resetter reset{stmt};
+    SQL_OK(sqlite3_bind_int(stmt, 1, image_id));
+    if (SQL_OK(sqlite3_step(stmt)) != SQLITE_ROW) return false;
+    const int rows = sqlite3_column_int(stmt, 0);
+    CHECK(rows >= 0);
+    const size_t bytes = static_cast<size_t>(sqlite3_column_bytes(stmt, 1));
+    CHECK_EQ(static_cast<size_t>(rows) * sizeof(Keypoint), bytes);
+    float* dst = place(static_cast<size_t>(rows));
+    if (bytes) std::memcpy(dst, sqlite3_column_blob(stmt, 1), bytes);
+    if (rows_out) *rows_out = static_cast<size_t>(rows);
+    return true;
+}
+
 Keypoints Database::ReadKeypoints(int32_t image_id) const {
     Keypoints k;
     ReadKeypoints(image_id, k);
@@ -259,6 +274,27 @@ void Database::ReadImagePairMatches(int32_t from, int32_t to, KeypointsIndices& 
     const size_t rows = static_cast<size_t>(sqlite3_column_int(stmt, 0));
     BlobToVector(stmt, 1, rows, idx);
     BlobToVector(stmt, 2, rows, tgt);
+}
+
+bool Database::ReadImagePairMatchesInto(int32_t from, int32_t to,
+                                        const std::function<void(size_t rows, uint32_t** idx, float** tgt_xy)>& place,
+                                        size_t* rows_out) const {
+    sqlite3_stmt* stmt = Stmt(kReadMatches);
+    Resetter reset{stmt};
+    SQL_OK(sqlite3_bind_int(stmt, 1, from));
+    SQL_OK(sqlite3_bind_int(stmt, 2, to));
+    if (SQL_OK(sqlite3_step(stmt)) != SQLITE_ROW) return false;
+    const size_t rows = static_cast<size_t>(sqlite3_column_int(stmt, 0));
+    const size_t idx_bytes = static_cast<size_t>(sqlite3_column_bytes(stmt, 1)), tgt_bytes = static_cast<size_t>(sqlite3_column_bytes(stmt, 2));
+    CHECK_EQ(rows * sizeof(uint32_t), idx_bytes);
+    CHECK_EQ(rows * sizeof(Keypoint), tgt_bytes);
+    uint32_t* idx = nullptr;
+    float* tgt = nullptr;
+    place(rows, &idx, &tgt);
+    if (idx_bytes) std::memcpy(idx, sqlite3_column_blob(stmt, 1), idx_bytes);
+    if (tgt_bytes) std::memcpy(tgt, sqlite3_column_blob(stmt, 2), tgt_bytes);
+    if (rows_out) *rows_out = rows;
+    return true;
 }
 
 ImagePairFlow Database::ReadImagePairFlow(int32_t from, int32_t to) const {

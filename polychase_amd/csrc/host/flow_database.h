@@ -10,6 +10,7 @@
 
 #include <array>
 #include <cstdint>
+#include <functional>
 #include <limits>
 #include <string>
 #include <vector>
@@ -51,6 +52,9 @@ class Database {
     bool KeypointsExist(int32_t image_id) const;
     Keypoints ReadKeypoints(int32_t image_id) const;
     void ReadKeypoints(int32_t image_id, Keypoints& out) const;  // leaves `out` untouched if absent
+    // Not in the reference: the blob straight into memory the caller chooses once the row count is known (the tracker's
+    // page-locked staging buffers: one copy from SQLite's page cache instead of two).  false if the row is absent.
+    bool ReadKeypointsInto(int32_t image_id, const std::function<float*(size_t rows)>& place, size_t* rows_out) const;
     void WriteKeypoints(int32_t image_id, const Keypoints& keypoints);
     void WriteKeypoints(int32_t image_id, const float* xy, size_t rows);
     int32_t GetMinImageIdWithKeypoints() const;
@@ -63,6 +67,9 @@ class Database {
     // Not in the reference: the two columns the tracker consumes (tracker.cc:56-86), without flow_errors
     void ReadImagePairMatches(int32_t image_id_from, int32_t image_id_to, KeypointsIndices& src_kps_indices,
                               Keypoints& tgt_kps) const;
+    // ... and straight into caller-chosen memory: place(rows, &idx, &tgt) names where the two columns go
+    bool ReadImagePairMatchesInto(int32_t image_id_from, int32_t image_id_to,
+                                  const std::function<void(size_t rows, uint32_t** idx, float** tgt_xy)>& place, size_t* rows_out) const;
     void WriteImagePairFlow(const ImagePairFlow& flow);
     void WriteImagePairFlow(int32_t image_id_from, int32_t image_id_to, const KeypointsIndices& src_kps_indices,
                             const Keypoints& tgt_kps, const FlowErrors& flow_errors);

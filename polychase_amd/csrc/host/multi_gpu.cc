@@ -5,9 +5,11 @@
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <chrono>
@@ -70,6 +72,7 @@ class Socket {
         while (n > 0) {
             const ssize_t k = ::recv(fd_, c, n, 0);
             if (k < 0 && errno == EINTR) continue;
+            if (k < 0 && (errno == EAGAIN || errno == EWOULDBLOCK)) Fail("control connection: a receive timed out");   // (no socket of this file has a timeout)
             if (k <= 0) Fail("control connection lost while receiving (the peer ended)");
             c += k;
             n -= static_cast<size_t>(k);
@@ -120,17 +123,36 @@ std::vector<Socket> AcceptRanks(const std::string& host, int port, int world, do
         ::close(lfd);
         Fail("rank 0 cannot listen on " + host + ":" + std::to_string(port));
     }
-    timeval tv{};
-    tv.tv_sec = static_cast<long>(timeout_s);
-    setsockopt(lfd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    // The deadline applies to the RENDEZVOUS only: poll() on the listening socket and on a fresh connection's rank
+    // announcement.  (Round 4 set SO_RCVTIMEO on the listening socket, which Linux hands down to every accepted socket: all
+    // of rank 0's later receives -- headers, payloads, the final flag -- then failed after connect_timeout_s of silence, i.e.
+    // whenever a rank needed longer than that between two pieces.)  The accepted sockets block without a limit: a peer that
+    // dies closes its end and the receive returns 0.
+    const auto t0 = Clock::now();
+    auto wait_readable = [&](int fd) {
+        for (;;) {
+            const double left = timeout_s - Since(t0);
+            if (left <= 0) return false;
+            pollfd p{};
+            p.fd = fd;
+            p.events = POLLIN;
+            const int rc = ::poll(&p, 1, static_cast<int>(std::min(left * 1000.0 + 1.0, 1000.0)));
+            if (rc > 0) return true;
+            if (rc < 0 && errno != EINTR) return false;
+        }
+    };
     std::vector<Socket> out(static_cast<size_t>(world));
     for (int k = 1; k < world; k++) {
-        const int fd = ::accept(lfd, nullptr, nullptr);
+        const int fd = wait_readable(lfd) ? ::accept(lfd, nullptr, nullptr) : -1;
         if (fd < 0) {
             ::close(lfd);
             Fail("rank 0 waited for " + std::to_string(world - 1) + " ranks, " + std::to_string(k - 1) + " connected");
         }
         Socket s(fd);
+        if (!wait_readable(fd)) {
+            ::close(lfd);
+            Fail("a connection did not announce its rank");
+        }
         const int32_t r = s.RecvValue<int32_t>();
         if (r < 1 || r >= world || out[static_cast<size_t>(r)].Ok()) {
             ::close(lfd);
@@ -158,9 +180,11 @@ class BoundedQueue {
         cv_.notify_all();
         return true;
     }
-    bool Pop(T* v) {
+    bool Pop(T* v, double* seconds_blocked = nullptr) {
         std::unique_lock<std::mutex> lk(m_);
+        const auto t0 = Clock::now();
         cv_.wait(lk, [&] { return !q_.empty() || closed_; });
+        if (seconds_blocked) *seconds_blocked += Since(t0);
         if (q_.empty()) return false;
         *v = std::move(q_.front());
         q_.pop_front();
@@ -231,8 +255,8 @@ MultiGpuResult GenerateOpticalFlowDatabaseMultiGpu(const VideoInfo& video_info, 
     if (cfg.transport != "rccl" && cfg.transport != "tcp") Fail("transport must be rccl or tcp");
     if (cfg.piece_frames < 1) Fail("piece_frames must be >= 1");
     const bool rccl = cfg.transport == "rccl";
-    const int device = cfg.device >= 0 ? cfg.device : rank;
-    setenv("POLYCHASE_DEVICE", std::to_string(device).c_str(), 1);   // the driver's and the shared context's device
+    const int device = cfg.device >= 0 ? cfg.device : rank;   // handed to the driver and to the communicator explicitly: no
+                                                              // process-global state is touched (round 4 set POLYCHASE_DEVICE)
     const auto t0 = Clock::now();
     MultiGpuResult res;
     res.shard_begin = video_info.first_frame + static_cast<int32_t>(static_cast<int64_t>(video_info.num_frames) * rank / world);
@@ -241,6 +265,7 @@ MultiGpuResult GenerateOpticalFlowDatabaseMultiGpu(const VideoInfo& video_info, 
     OpticalFlowShard shard;
     shard.begin = res.shard_begin;
     shard.end = res.shard_end;
+    shard.device = device;
     if (world == 1) {
         GenerateOpticalFlowShard(video_info, frame_accessor, callback, database_path, shard, detector_options, flow_options, &res.stats);
         res.cancelled = shard.cancelled;
@@ -248,13 +273,20 @@ MultiGpuResult GenerateOpticalFlowDatabaseMultiGpu(const VideoInfo& video_info, 
         return res;
     }
 
+    // the communicator lives on a context of its own ON THIS RANK'S DEVICE: the staging / log buffers are allocated there, and
+    // the process-wide shared context (csrc/host/gpu_context.h) may already exist on another device in a host that has used
+    // AcceleratedMesh or track_sequence before
+    pc_context* comm_ctx = nullptr;
     pc_comm* comm = nullptr;
     struct CommGuard {
         pc_comm*& c;
+        pc_context*& ctx;
         ~CommGuard() {
             if (c) pc_comm_destroy(c);
+            if (ctx) pc_context_destroy(ctx);
         }
-    } comm_guard{comm};
+    } comm_guard{comm, comm_ctx};
+    if (rccl) CheckAbi(pc_context_create(device, &comm_ctx), "pc_context_create");
 
     if (rank == 0) {
         // ---- the owner of the database ----
@@ -263,7 +295,7 @@ MultiGpuResult GenerateOpticalFlowDatabaseMultiGpu(const VideoInfo& video_info, 
             unsigned char id[PC_COMM_ID_BYTES];
             CheckAbi(pc_comm_unique_id(id), "pc_comm_unique_id");
             for (int r = 1; r < world; r++) peers[static_cast<size_t>(r)].Send(id, sizeof(id));
-            CheckAbi(pc_comm_create(SharedGpuContext(), id, world, 0, &comm), "pc_comm_create");
+            CheckAbi(pc_comm_create(comm_ctx, id, world, 0, &comm), "pc_comm_create");
         }
         BoundedQueue<Incoming> arrived(2);
         std::atomic<bool> abort{false};
@@ -351,7 +383,7 @@ MultiGpuResult GenerateOpticalFlowDatabaseMultiGpu(const VideoInfo& video_info, 
     if (rccl) {
         unsigned char id[PC_COMM_ID_BYTES];
         master.Recv(id, sizeof(id));
-        CheckAbi(pc_comm_create(SharedGpuContext(), id, world, rank, &comm), "pc_comm_create");
+        CheckAbi(pc_comm_create(comm_ctx, id, world, rank, &comm), "pc_comm_create");
     }
     const size_t part = LogPartBytes(video_info, cfg);
     DeviceBuffer log(device, 2 * part);
@@ -397,7 +429,7 @@ MultiGpuResult GenerateOpticalFlowDatabaseMultiGpu(const VideoInfo& video_info, 
         o.h = Header{static_cast<int64_t>(bytes), n_frames, first_frame1};
         const uint8_t* src = static_cast<const uint8_t*>(log.p) + offset;
         if (rccl) {
-            if (!free_slots.Pop(&o.slot)) Fail("the sender ended (see its error)");    // waits while two pieces are staged
+            if (!free_slots.Pop(&o.slot, &res.seconds_blocked)) Fail("the sender ended (see its error)");    // waits while two pieces are staged
             CheckAbi(pc_peer_copy_async(device, staging[o.slot]->p, src, bytes, nullptr), "staging copy");
             // the copy runs on the null stream: a blocking one-byte download behind it on the same stream waits for it
             unsigned char probe;

@@ -33,11 +33,18 @@ class StageClock {
         const char* label_;
         std::chrono::steady_clock::time_point t0_;
     };
+    // a duration measured elsewhere (e.g. by a kernel) under the same report
+    static void Add(const char* label, double ms) {
+        if (!Enabled()) return;
+        auto& e = Totals()[label];
+        e.first += ms;
+        e.second += 1;
+    }
     static void Report(const char* title) {
         if (!Enabled()) return;
         std::fprintf(stderr, "[polychase stages] %s\n", title);
         for (const auto& kv : Totals())
-            std::fprintf(stderr, "  %-28s %10.2f ms  %8ld calls\n", kv.first.c_str(), kv.second.first, kv.second.second);
+            std::fprintf(stderr, "  %-44s %10.2f ms  %8ld calls\n", kv.first.c_str(), kv.second.first, kv.second.second);
         Totals().clear();
     }
 

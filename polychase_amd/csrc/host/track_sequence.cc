@@ -8,8 +8,10 @@
 // (pnp.cc).  Sequential over frames by construction: frame k needs the poses solved before it.
 #include "track_sequence.h"
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <mutex>
 #include <optional>
@@ -24,24 +26,111 @@ namespace {
 
 constexpr float kMaxInlierError = 12.0f;  // tracker.cc:123 ("FIXME: Make this customizable")
 
-// Reads the blobs the NEXT frame will need -- the matches of every flow into it from a source that has, or is about to
-// get, a pose, and the keypoints of the frame being solved right now (the one new source) -- on a second read
-// connection while the GPU works on the current frame.  SQLite reads were a third of a frame's time.
-class FlowPrefetcher {
+[[noreturn]] void ThrowHip(const char* what) { throw std::runtime_error(std::string(what) + ": " + pc_last_error()); }
+
+// Page-locked host memory (pc_host_buffer_alloc): what the database reader fills is fetched by the GPU's copy engine as
+// it is -- a pageable std::vector costs a staging copy on the calling thread for every transfer (round 4: 31 us per
+// source frame, a fifth of a tracked frame).
+class PinnedBuffer {
    public:
+    PinnedBuffer() = default;
+    PinnedBuffer(const PinnedBuffer&) = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    ~PinnedBuffer() { pc_host_buffer_free(p_); }
+    // at least `bytes`; `keep` bytes of the old contents survive a reallocation
+    void Reserve(size_t bytes, size_t keep = 0) {
+        if (bytes <= cap_) return;
+        const size_t want = bytes + bytes / 2 + 65536;   // pinned allocations take tens of milliseconds: grow rarely
+        void* q = nullptr;
+        if (pc_host_buffer_alloc(want, &q) != PC_OK) ThrowHip("pc_host_buffer_alloc");
+        if (keep) std::memcpy(q, p_, keep);
+        pc_host_buffer_free(p_);
+        p_ = q;
+        cap_ = want;
+    }
+    uint8_t* data() const { return static_cast<uint8_t*>(p_); }
+    void swap(PinnedBuffer& o) {
+        std::swap(p_, o.p_);
+        std::swap(cap_, o.cap_);
+    }
+
+   private:
+    void* p_ = nullptr;
+    size_t cap_ = 0;
+};
+
+size_t Align16(size_t v) { return (v + 15u) & ~static_cast<size_t>(15u); }
+
+// The matches of every flow INTO one frame, one after the other in a page-locked block: per source the
+// src_keypoints_indices (uint32) followed by the tgt_keypoints (2 floats), each 16-byte aligned.  This is the block
+// pc_track_solve_frame sends to the GPU in one transfer.
+struct MatchBlock {
     struct Flow {
         int32_t source = 0;
-        KeypointsIndices indices;
-        Keypoints targets;
+        size_t rows = 0, idx_offset = 0, tgt_offset = 0;
     };
+    PinnedBuffer buffer;
+    size_t bytes = 0;
+    std::vector<Flow> flows;
+    void Clear() {
+        bytes = 0;
+        flows.clear();
+    }
+    // reads the flow source -> target behind what the block already holds; false if the database has no such row
+    bool Append(const Database& db, int32_t source, int32_t target) {
+        Flow f;
+        f.source = source;
+        const bool found = db.ReadImagePairMatchesInto(
+            source, target,
+            [&](size_t rows, uint32_t** idx, float** tgt) {
+                f.rows = rows;
+                f.idx_offset = Align16(bytes);
+                f.tgt_offset = Align16(f.idx_offset + rows * sizeof(uint32_t));
+                const size_t end = f.tgt_offset + rows * sizeof(Keypoint);
+                buffer.Reserve(end, bytes);
+                *idx = reinterpret_cast<uint32_t*>(buffer.data() + f.idx_offset);
+                *tgt = reinterpret_cast<float*>(buffer.data() + f.tgt_offset);
+                bytes = end;
+            },
+            nullptr);
+        if (found) flows.push_back(f);
+        return found;
+    }
+    const Flow* Find(int32_t source) const {
+        for (const Flow& f : flows)
+            if (f.source == source) return &f;
+        return nullptr;
+    }
+};
+
+struct PinnedKeypoints {
+    PinnedBuffer buffer;
+    size_t rows = 0;
+    const float* xy() const { return reinterpret_cast<const float*>(buffer.data()); }
+    bool Read(const Database& db, int32_t frame) {
+        rows = 0;
+        return db.ReadKeypointsInto(
+            frame,
+            [&](size_t n) {
+                buffer.Reserve(std::max<size_t>(n, 1) * sizeof(Keypoint));
+                return reinterpret_cast<float*>(buffer.data());
+            },
+            &rows);
+    }
+};
+
+// Reads the blobs the NEXT frame will need -- the matches of every flow into it from a source that has, or is about to
+// get, a pose, and the keypoints of the frame being solved right now (the one new source) -- on a second read
+// connection while the GPU works on the current frame, straight into page-locked memory.
+class FlowPrefetcher {
+   public:
     struct Batch {
         int32_t frame = 0;
         bool valid = false;
-        std::vector<Flow> flows;     // entries [0, n_flows) are meaningful (the vectors are recycled)
-        size_t n_flows = 0;
+        MatchBlock matches;
         int32_t keypoints_frame = 0;
         bool has_keypoints = false;
-        Keypoints keypoints;
+        PinnedKeypoints keypoints;
     };
 
     explicit FlowPrefetcher(const std::string& path) {
@@ -78,7 +167,9 @@ class FlowPrefetcher {
         }
         cv_.notify_all();
     }
-    // the batch of the last request if it was for `frame` (waits for the reader), else nullptr
+    // the batch of the last request if it was for `frame` (waits for the reader), else nullptr.  The batch stays untouched
+    // until two more requests have been made: the tracker holds one batch for the frame on the GPU and one for the frame it
+    // is preparing while the reader fills the third.
     Batch* Take(int32_t frame) {
         if (!Enabled()) return nullptr;
         std::unique_lock<std::mutex> lk(mtx_);
@@ -102,29 +193,22 @@ class FlowPrefetcher {
                 sources = std::move(req_sources_);
                 has_request_ = false;
             }
-            Batch& b = batches_[1 - ready_];   // the consumer may still be reading batches_[ready_]
+            Batch& b = batches_[(ready_ + 1) % kBatches];   // the consumer may still hold batches_[ready_] and the one before it
             b.frame = frame;
             b.valid = false;
-            b.n_flows = 0;
+            b.matches.Clear();
             b.has_keypoints = false;
             try {
-                for (int32_t src : sources) {
-                    if (b.flows.size() <= b.n_flows) b.flows.emplace_back();
-                    Flow& f = b.flows[b.n_flows++];
-                    f.source = src;
-                    db_->ReadImagePairMatches(src, frame, f.indices, f.targets);
-                }
+                for (int32_t src : sources) b.matches.Append(*db_, src, frame);
                 b.keypoints_frame = kp_frame;
-                b.keypoints.clear();
-                db_->ReadKeypoints(kp_frame, b.keypoints);
-                b.has_keypoints = true;
+                b.has_keypoints = b.keypoints.Read(*db_, kp_frame);
                 b.valid = true;
             } catch (...) {
                 b.valid = false;   // the consumer falls back to its own connection and reports the error there
             }
             {
                 std::lock_guard<std::mutex> lk(mtx_);
-                ready_ = 1 - ready_;
+                ready_ = (ready_ + 1) % kBatches;
                 done_ = true;
             }
             cv_.notify_all();
@@ -138,12 +222,14 @@ class FlowPrefetcher {
     bool stop_ = false, has_request_ = false, done_ = false;
     int32_t req_frame_ = 0, req_keypoints_frame_ = 0;
     std::vector<int32_t> req_sources_;
-    Batch batches_[2];
+    static constexpr int kBatches = 3;
+    Batch batches_[kBatches];
     int ready_ = 0;
 };
 
 // Host-side state that outlives one frame: the device-resident correspondence set, the keypoints of recently used
-// source frames (a frame is a source for up to 8 targets: read from SQLite once) and the blobs of the current flow.
+// source frames (a frame is a source for up to 8 targets: read from SQLite once; page-locked, the GPU's copy of an array
+// is made from it once and cached by frame id inside the set) and the match block of the frame when nothing was prefetched.
 struct Scratch {
     pc_context* ctx = nullptr;
     pc_corr_set* set = nullptr;
@@ -152,12 +238,12 @@ struct Scratch {
         int32_t frame = 0;
         bool valid = false;
         uint64_t stamp = 0;
-        Keypoints keypoints;
+        PinnedKeypoints keypoints;
     };
     CachedKeypoints cache[16];
     uint64_t clock = 0;
-    KeypointsIndices indices;
-    Keypoints targets;
+    MatchBlock own_matches[2];   // alternating: the block of the frame on the GPU stays untouched while the next one is read
+    int own_turn = 0;
 
     Scratch() : ctx(SharedGpuContext()) {
         GpuSection section;
@@ -170,7 +256,7 @@ struct Scratch {
         pc_corr_set_destroy(set);
     }
 
-    const Keypoints& KeypointsOf(const Database& db, int32_t frame, FlowPrefetcher::Batch* batch) {
+    const PinnedKeypoints& KeypointsOf(const Database& db, int32_t frame, FlowPrefetcher::Batch* batch) {
         CachedKeypoints* slot = &cache[0];
         for (auto& c : cache) {
             if (c.valid && c.frame == frame) {
@@ -180,11 +266,11 @@ struct Scratch {
             if (c.stamp < slot->stamp) slot = &c;
         }
         if (batch && batch->has_keypoints && batch->keypoints_frame == frame) {
-            slot->keypoints.swap(batch->keypoints);   // read ahead by the prefetcher
+            slot->keypoints.buffer.swap(batch->keypoints.buffer);   // read ahead by the prefetcher
+            slot->keypoints.rows = batch->keypoints.rows;
             batch->has_keypoints = false;
         } else {
-            slot->keypoints.clear();   // a recycled slot: a frame without a keypoints row must not inherit the old ones
-            db.ReadKeypoints(frame, slot->keypoints);
+            slot->keypoints.Read(db, frame);   // a frame without a keypoints row has none (rows = 0)
         }
         slot->frame = frame;
         slot->valid = true;
@@ -193,44 +279,15 @@ struct Scratch {
     }
 };
 
-[[noreturn]] void ThrowHip(const char* what) { throw std::runtime_error(std::string(what) + ": " + pc_last_error()); }
-
-// correspondences contributed by one source frame (tracker.cc:52-92): the gather, the ray cast, the model
-// transform and the append run on the GPU (pc_corr_set_append); the host only feeds the database blobs
-void AppendFromSource(const Database& db, int32_t source_frame, int32_t target_frame, const CameraState& source_camera,
-                      const Mat4f& model_matrix, const AcceleratedMesh& mesh, Scratch& s, FlowPrefetcher::Batch* batch) {
-    const Keypoints* keypoints;
-    const KeypointsIndices* indices = &s.indices;
-    const Keypoints* targets = &s.targets;
-    {
-        StageClock::Scope sc("track/db read");
-        keypoints = &s.KeypointsOf(db, source_frame, batch);
-        bool prefetched = false;
-        if (batch)
-            for (size_t k = 0; k < batch->n_flows && !prefetched; k++)
-                if (batch->flows[k].source == source_frame) {
-                    indices = &batch->flows[k].indices;
-                    targets = &batch->flows[k].targets;
-                    prefetched = true;
-                }
-        if (!prefetched) db.ReadImagePairMatches(source_frame, target_frame, s.indices, s.targets);
-    }
-    CHECK_EQ(indices->size(), targets->size());
-    if (indices->empty()) return;
-    StageClock::Scope sc("track/append (enqueue)");
+void SourceCamera(const CameraState& source_camera, const Mat4f& model_matrix, pc_ray_camera* cam) {
     SceneTransformations scene;
     scene.model_matrix = model_matrix;
     scene.view_matrix = source_camera.pose.Rt4x4();
     scene.intrinsics = source_camera.intrinsics;
-    pc_ray_camera cam;
-    MakeRayCamera(scene, &cam);
-    static const float kNoKeypoint[2] = {0.f, 0.f};
-    if (pc_corr_set_append(s.ctx, s.set, mesh.Gpu(), &cam, model_matrix.data(), source_frame,
-                           keypoints->empty() ? kNoKeypoint : keypoints->front().data(), static_cast<int>(keypoints->size()),
-                           indices->data(), targets->front().data(), static_cast<int>(indices->size()),
-                           /*check_mask=*/1) != PC_OK)
-        ThrowHip("pc_corr_set_append");
+    MakeRayCamera(scene, cam);
 }
+
+const float kNoKeypoint[2] = {0.f, 0.f};
 
 // "The solution should be very close to the previous/next pose" (tracker.cc:111-119)
 CameraState InitialGuess(const CameraTrajectory& traj, int32_t frame) {
@@ -239,21 +296,50 @@ CameraState InitialGuess(const CameraTrajectory& traj, int32_t frame) {
     return CameraState{};
 }
 
-// fills s.set with the correspondences of `frame`; returns their number
+// the flows into `frame` whose source already has a pose (:43-50), in the database's order; their matches in `block`
+// (the prefetched one, or read now)
+// `pending`: a frame whose solve is in flight counts as filled (its pose is there before anything that uses it is launched)
+const MatchBlock& GatherMatches(const Database& db, const CameraTrajectory& traj, int32_t frame, Scratch& s,
+                                FlowPrefetcher::Batch* batch, std::vector<int32_t>& used_sources, const int32_t* pending = nullptr) {
+    StageClock::Scope sc("track/db read");
+    s.sources.clear();
+    db.FindOpticalFlowsToImage(frame, s.sources);
+    used_sources.clear();
+    for (int32_t source : s.sources) {
+        CHECK_NE(source, frame);
+        if (traj.IsFrameFilled(source) || (pending && source == *pending)) used_sources.push_back(source);   // only frames that already have a pose (:48)
+    }
+    if (batch) {
+        bool complete = true;
+        for (int32_t source : used_sources) complete = complete && batch->matches.Find(source) != nullptr;
+        if (complete) return batch->matches;
+    }
+    MatchBlock& own = s.own_matches[s.own_turn ^= 1];
+    own.Clear();
+    for (int32_t source : used_sources) own.Append(db, source, frame);
+    return own;
+}
+
+// ---- the cross-check path (POLYCHASE_TRACK_FUSED=0) and FrameCorrespondences: one pc_corr_set_append per source frame
+// (gather, ray cast, model transform, ordered compaction: tracker.cc:52-92), then pc_pnp_solve ----
 int GatherCorrespondences(const Database& db, const CameraTrajectory& traj, const Mat4f& model_matrix, int32_t frame,
                           const AcceleratedMesh& mesh, Scratch& s, FlowPrefetcher::Batch* batch = nullptr) {
     if (pc_corr_set_clear(s.ctx, s.set) != PC_OK) ThrowHip("pc_corr_set_clear");
-    s.sources.clear();
-    db.FindOpticalFlowsToImage(frame, s.sources);
-    bool mask_sent = false;
-    for (int32_t source : s.sources) {
-        CHECK_NE(source, frame);
-        if (!traj.IsFrameFilled(source)) continue;  // only frames that already have a pose (:48)
-        if (!mask_sent) {   // the mask can be edited between frames through inner_mut(): send the current bits
-            mesh.SyncMask();
-            mask_sent = true;
-        }
-        AppendFromSource(db, source, frame, *traj.Get(source), model_matrix, mesh, s, batch);
+    std::vector<int32_t> used;
+    const MatchBlock& block = GatherMatches(db, traj, frame, s, batch, used);
+    if (!used.empty()) mesh.SyncMask();   // the mask can be edited between frames through inner_mut(): send the current bits
+    for (int32_t source : used) {
+        const MatchBlock::Flow* f = block.Find(source);
+        if (!f || f->rows == 0) continue;
+        const PinnedKeypoints& kps = s.KeypointsOf(db, source, batch);
+        StageClock::Scope sc("track/append (enqueue)");
+        pc_ray_camera cam;
+        SourceCamera(*traj.Get(source), model_matrix, &cam);
+        if (pc_corr_set_append(s.ctx, s.set, mesh.Gpu(), &cam, model_matrix.data(), source, kps.rows ? kps.xy() : kNoKeypoint,
+                               static_cast<int>(kps.rows), reinterpret_cast<const uint32_t*>(block.buffer.data() + f->idx_offset),
+                               reinterpret_cast<const float*>(block.buffer.data() + f->tgt_offset), static_cast<int>(f->rows),
+                               /*check_mask=*/1) != PC_OK)
+            ThrowHip("pc_corr_set_append");
     }
     int n = 0;
     {
@@ -267,11 +353,9 @@ int GatherCorrespondences(const Database& db, const CameraTrajectory& traj, cons
     return n;
 }
 
-std::optional<PnPResult> SolveFrame(const Database& db, const CameraTrajectory& traj, const Mat4f& model_matrix,
-                                    int32_t frame, const AcceleratedMesh& mesh, const PnPOptions& pnp_opts, Scratch& s,
-                                    FlowPrefetcher::Batch* batch) {
-    // the GPU part of one frame -- correspondences appended, counted, solved, read back -- is one section on the shared
-    // context; between frames other threads (ray_cast from Python, a refinement) get their turn
+std::optional<PnPResult> SolveFrameUnfused(const Database& db, const CameraTrajectory& traj, const Mat4f& model_matrix,
+                                           int32_t frame, const AcceleratedMesh& mesh, const PnPOptions& pnp_opts, Scratch& s,
+                                           FlowPrefetcher::Batch* batch) {
     GpuSection section;
     const int n = GatherCorrespondences(db, traj, model_matrix, frame, mesh, s, batch);
     if (n < 3) return std::nullopt;  // :95-97
@@ -288,6 +372,169 @@ std::optional<PnPResult> SolveFrame(const Database& db, const CameraTrajectory& 
         SolvePnPIterativeOnGpu(prob, static_cast<size_t>(n), pnp_opts, result);
     }
     return result;
+}
+
+// ---- the product path: SolveFrame (tracker.cc:36-131) = one transfer of the frame's matches, one ray-cast launch over all
+// sources, the whole LM loop as one persistent launch, one wait (pc_track_frame_upload / _launch / _finish).  In three steps,
+// because only the LAUNCH needs the pose of the frame before: while the GPU solves frame f the host plans frame f + 1 (which
+// flows, where their blobs are) and its matches travel to the GPU on the copy stream; when the pose of f arrives the launches
+// of f + 1 are enqueued at once, and the caller's callback for f runs beside them. ----
+class FrameSolver {
+   public:
+    FrameSolver(const Database& db, const CameraTrajectory& traj, const Mat4f& model_matrix, const AcceleratedMesh& mesh,
+                const PnPOptions& opts, Scratch& scratch)
+        : db_(db), traj_(traj), model_(model_matrix), mesh_(mesh), opts_(opts), s_(scratch) {
+        const int lt = static_cast<int>(opts.bundle_opts.loss_type);
+        if (lt < 0 || lt > 2) throw std::runtime_error("Unknown loss type: " + std::to_string(lt));
+    }
+    ~FrameSolver() {
+        if (!launched_) return;
+        GpuSection section;   // an exception on the way: nothing stays in flight on the shared context
+        pc_track_solve_result unused;
+        (void)pc_track_frame_finish(s_.ctx, s_.set, &unused);
+    }
+
+    // host-only part + transfer: which flows end in `frame`, where their matches and the sources' keypoints are
+    void Plan(int32_t frame, FlowPrefetcher::Batch* batch, const int32_t* pending) {
+        frame_ = frame;
+        n_sources_ = 0;
+        std::vector<int32_t>& used = used_;
+        const MatchBlock& block = GatherMatches(db_, traj_, frame, s_, batch, used, pending);
+        for (int32_t source : used) {
+            const MatchBlock::Flow* f = block.Find(source);
+            if (!f || f->rows == 0) continue;
+            CHECK(n_sources_ < 8);   // the skips of cpp/opticalflow.cc:76-77: at most 8 flows end in a frame
+            const PinnedKeypoints& kps = s_.KeypointsOf(db_, source, batch);
+            source_frames_[n_sources_] = source;
+            pc_track_source& q = sources_[n_sources_++];
+            std::memset(&q.cam, 0, sizeof(q.cam));
+            q.keypoints_key = source;
+            q.keypoints_xy = kps.rows ? kps.xy() : kNoKeypoint;
+            q.n_keypoints = static_cast<int>(kps.rows);
+            q.n_matches = static_cast<int>(f->rows);
+            q.idx_offset = f->idx_offset;
+            q.tgt_offset = f->tgt_offset;
+        }
+        if (n_sources_ == 0) return;
+        StageClock::Scope sc("track/upload (enqueue)");
+        GpuSection section;
+        if (pc_track_frame_upload(s_.ctx, s_.set, block.buffer.data(), block.bytes, sources_, n_sources_) != PC_OK)
+            ThrowHip("pc_track_frame_upload");
+    }
+
+    // the sources' poses are all there now: cameras, initial guess (tracker.cc:111-119), the two launches
+    void Launch() {
+        if (n_sources_ == 0) return;
+        StageClock::Scope sc("track/launch (enqueue)");
+        for (int k = 0; k < n_sources_; k++) SourceCamera(*traj_.Get(source_frames_[k]), model_, &sources_[k].cam);
+        guess_ = InitialGuess(traj_, frame_);
+        const BundleOptions& bo = opts_.bundle_opts;
+        const CameraIntrinsics::Bounds bounds = guess_.intrinsics.GetBounds();
+        pc_pnp_camera init;
+        init.q_xyzw[0] = guess_.pose.q.x;
+        init.q_xyzw[1] = guess_.pose.q.y;
+        init.q_xyzw[2] = guess_.pose.q.z;
+        init.q_xyzw[3] = guess_.pose.q.w;
+        for (int i = 0; i < 3; i++) init.t[i] = guess_.pose.t[i];
+        init.fx = guess_.intrinsics.fx;
+        init.fy = guess_.intrinsics.fy;
+        init.cx = guess_.intrinsics.cx;
+        init.cy = guess_.intrinsics.cy;
+        init.aspect_ratio = guess_.intrinsics.aspect_ratio;
+        init.convention_opencv = guess_.intrinsics.convention == CameraConvention::OpenCV ? 1 : 0;
+        pc_pnp_solve_options so;
+        so.max_iterations = static_cast<int>(bo.max_iterations);
+        so.initial_lambda = bo.initial_lambda;
+        so.min_lambda = bo.min_lambda;
+        so.max_lambda = bo.max_lambda;
+        so.gradient_tol = bo.gradient_tol;
+        so.step_tol = bo.step_tol;
+        so.loss_type = static_cast<int>(bo.loss_type);
+        so.loss_scale = bo.loss_scale;
+        so.optimize_focal_length = opts_.optimize_focal_length ? 1 : 0;        // "with more than 3 points" is decided on the device
+        so.optimize_principal_point = opts_.optimize_principal_point ? 1 : 0;
+        so.f_low = bounds.f_low;
+        so.f_high = bounds.f_high;
+        so.cx_low = bounds.cx_low;
+        so.cx_high = bounds.cx_high;
+        so.cy_low = bounds.cy_low;
+        so.cy_high = bounds.cy_high;
+        so.max_inlier_error = opts_.max_inlier_error;
+        so.rounds_hint = 0;
+        GpuSection section;
+        mesh_.SyncMask();   // the mask can be edited between frames through inner_mut(): the current bits (sent when they changed)
+        if (pc_track_frame_launch(s_.ctx, s_.set, mesh_.Gpu(), model_.data(), /*check_mask=*/1, sources_, n_sources_, &init, &so) != PC_OK)
+            ThrowHip("pc_track_frame_launch");
+        launched_ = true;
+    }
+
+    // waits for the frame launched last; nullopt: fewer than 3 correspondences (:95-97)
+    std::optional<PnPResult> Finish() {
+        if (!launched_) return std::nullopt;
+        launched_ = false;
+        pc_track_solve_result sr;
+        {
+            StageClock::Scope sc("track/wait for the GPU");
+            GpuSection section;
+            if (pc_track_frame_finish(s_.ctx, s_.set, &sr) != PC_OK) {
+                // an index past the source's keypoints: the reference's CHECK_LT (tracker.cc:61)
+                CHECK(std::string(pc_last_error()).find("out of range") == std::string::npos);
+                ThrowHip("pc_track_frame_finish");
+            }
+        }
+        if (StageClock::Enabled()) {
+            static const char* kPhase[8] = {"track/lm kernel: sweep + publish", "track/lm kernel: wait for workgroups", "track/lm kernel: add partials",
+                                            "track/lm kernel: decision", "track/lm kernel: publish decision", "track/lm kernel: fetch parameters",
+                                            "track/lm kernel: inlier pass", "track/lm kernel: whole launch"};
+            for (int k = 0; k < 8; k++) StageClock::Add(kPhase[k], sr.lm_ticks[k] * 1e-5);   // 100 MHz ticks -> ms
+            StageClock::Add("track/lm kernel: rounds (count, not ms)", sr.rounds);
+        }
+        if (sr.n_correspondences < 3) return std::nullopt;  // :95-97
+        PnPResult result;
+        result.camera = guess_;
+        CameraState& c = result.camera;
+        c.pose.q.x = sr.pnp.camera.q_xyzw[0];
+        c.pose.q.y = sr.pnp.camera.q_xyzw[1];
+        c.pose.q.z = sr.pnp.camera.q_xyzw[2];
+        c.pose.q.w = sr.pnp.camera.q_xyzw[3];
+        for (int i = 0; i < 3; i++) c.pose.t[i] = sr.pnp.camera.t[i];
+        c.intrinsics.fx = sr.pnp.camera.fx;
+        c.intrinsics.fy = sr.pnp.camera.fy;
+        c.intrinsics.cx = sr.pnp.camera.cx;
+        c.intrinsics.cy = sr.pnp.camera.cy;
+        BundleStats st;
+        st.iterations = static_cast<size_t>(sr.pnp.iterations);
+        st.invalid_steps = static_cast<size_t>(sr.pnp.invalid_steps);
+        st.initial_cost = sr.pnp.initial_cost;
+        st.cost = sr.pnp.cost;
+        st.lambda = sr.pnp.lambda;
+        st.step_norm = sr.pnp.step_norm;
+        st.grad_norm = sr.pnp.grad_norm;
+        result.bundle_stats = st;
+        result.inlier_ratio = static_cast<Float>(sr.pnp.inliers) / static_cast<Float>(sr.n_correspondences);
+        return result;
+    }
+    int32_t frame() const { return frame_; }
+
+   private:
+    const Database& db_;
+    const CameraTrajectory& traj_;
+    const Mat4f& model_;
+    const AcceleratedMesh& mesh_;
+    const PnPOptions& opts_;
+    Scratch& s_;
+    int32_t frame_ = 0;
+    int n_sources_ = 0;
+    pc_track_source sources_[8];
+    int32_t source_frames_[8];
+    std::vector<int32_t> used_;
+    CameraState guess_;
+    bool launched_ = false;
+};
+
+bool FusedSolve() {
+    const char* env = std::getenv("POLYCHASE_TRACK_FUSED");   // read per call: the tests flip it
+    return !(env && env[0] == '0');
 }
 
 }  // namespace
@@ -321,33 +568,89 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
     Scratch scratch;
     FlowPrefetcher prefetcher(database.Path());
     std::vector<int32_t> next_sources, wanted;
-    for (int32_t frame = frame_from + step; frame != frame_to_inclusive + step; frame += step) {
-        FlowPrefetcher::Batch* batch = prefetcher.Take(frame);
-        // while this frame is solved: read what the next one needs -- flows from the frames that have a pose by
-        // then (this one included) and this frame's keypoints, the one array the host cache does not hold yet
-        const int32_t next = frame + step;
-        if (prefetcher.Enabled() && next != frame_to_inclusive + step) {
-            next_sources.clear();
-            wanted.clear();
-            database.FindOpticalFlowsToImage(next, next_sources);
-            for (int32_t src : next_sources)
-                if (src == frame || camera_traj.IsFrameFilled(src)) wanted.push_back(src);
-            prefetcher.Request(next, wanted, frame);
+    // what frame `next` will need, read ahead: flows from the frames that have a pose by then -- filled now, or tracked
+    // before it in this run -- and the keypoints of the frame tracked just before it (the one array no cache holds yet)
+    auto request = [&](int32_t next) {
+        if (!prefetcher.Enabled() || next == frame_to_inclusive + step) return;
+        next_sources.clear();
+        wanted.clear();
+        database.FindOpticalFlowsToImage(next, next_sources);
+        for (int32_t src : next_sources) {
+            const bool tracked_before = step > 0 ? (src > frame_from && src < next) : (src < frame_from && src > next);
+            if (tracked_before || camera_traj.IsFrameFilled(src)) wanted.push_back(src);
         }
-        const std::optional<PnPResult> solved =
-            SolveFrame(database, camera_traj, model_matrix, frame, accel_mesh, pnp_opts, scratch, batch);
-        if (!solved)
-            throw std::runtime_error("Could not track to frame: " + std::to_string(frame) + ". Not enough features.");
+        prefetcher.Request(next, wanted, next - step);
+    };
+    auto report_and_store = [&](int32_t frame, const PnPResult& solved) {
         if (callback) {
             FrameTrackingResult report;
             report.frame = frame;
-            report.pose = solved->camera.pose;
-            report.intrinsics = solved->camera.intrinsics;
-            report.bundle_stats = solved->bundle_stats;
-            report.inlier_ratio = solved->inlier_ratio;
-            if (!callback(report)) return;  // the pose of a frame the user stopped at is not stored (:179-186)
+            report.pose = solved.camera.pose;
+            report.intrinsics = solved.camera.intrinsics;
+            report.bundle_stats = solved.bundle_stats;
+            report.inlier_ratio = solved.inlier_ratio;
+            return callback(report);
         }
-        camera_traj.Set(frame, solved->camera);
+        return true;
+    };
+    const int32_t first = frame_from + step, end = frame_to_inclusive + step;
+    if (!FusedSolve()) {
+        // the cross-check: round 4's path, one frame after the other
+        request(first);
+        for (int32_t frame = first; frame != end; frame += step) {
+            FlowPrefetcher::Batch* batch = prefetcher.Take(frame);
+            request(frame + step);
+            const std::optional<PnPResult> solved = SolveFrameUnfused(database, camera_traj, model_matrix, frame, accel_mesh, pnp_opts, scratch, batch);
+            if (!solved) throw std::runtime_error("Could not track to frame: " + std::to_string(frame) + ". Not enough features.");
+            if (!report_and_store(frame, *solved)) return;  // the pose of a frame the user stopped at is not stored (:179-186)
+            camera_traj.Set(frame, solved->camera);
+        }
+        StageClock::Report("TrackCameraTrajectory");
+        return;
+    }
+    if (first != end) {
+        // two solvers take turns: one holds the frame on the GPU, the other plans the next
+        FrameSolver solvers[2] = {FrameSolver(database, camera_traj, model_matrix, accel_mesh, pnp_opts, scratch),
+                                  FrameSolver(database, camera_traj, model_matrix, accel_mesh, pnp_opts, scratch)};
+        int cur = 0;
+        request(first);
+        {
+            FlowPrefetcher::Batch* batch = prefetcher.Take(first);
+            request(first + step);
+            solvers[cur].Plan(first, batch, nullptr);
+            solvers[cur].Launch();
+        }
+        for (int32_t frame = first; frame != end; frame += step) {
+            const int32_t next = frame + step;
+            FrameSolver& now = solvers[cur];
+            FrameSolver& then = solvers[cur ^ 1];
+            if (next != end) {   // while the GPU solves `frame`
+                FlowPrefetcher::Batch* batch = prefetcher.Take(next);
+                request(next + step);
+                then.Plan(next, batch, &frame);
+            }
+            const std::optional<PnPResult> solved = now.Finish();
+            if (!solved) throw std::runtime_error("Could not track to frame: " + std::to_string(frame) + ". Not enough features.");
+            // the pose goes in at once -- the next frame's launches need it -- and comes out again if the callback stops the run:
+            // the pose of a frame the user stopped at is not stored (:179-186)
+            const std::optional<CameraState> before = camera_traj.Get(frame);
+            camera_traj.Set(frame, solved->camera);
+            struct Restore {
+                CameraTrajectory& traj;
+                int32_t frame;
+                const std::optional<CameraState>& before;
+                bool armed = true;
+                ~Restore() {
+                    if (!armed) return;
+                    if (before) traj.Set(frame, *before);
+                    else traj.Clear(frame);
+                }
+            } restore{camera_traj, frame, before};
+            if (next != end) then.Launch();
+            if (!report_and_store(frame, *solved)) return;   // (`then`'s destructor waits for the launches that are no longer wanted)
+            restore.armed = false;
+            cur ^= 1;
+        }
     }
     StageClock::Report("TrackCameraTrajectory");
 }

@@ -664,7 +664,12 @@ class OrderedPieceGather:
         if self.rank != 0:
             return
         self._aborted = True
-        if self._thread is not None:          # the receiver owns the control channel: it sends the negative credits itself
+        if self._thread is not None:
+            # the receiver owns the control channel: it sends the negative credits itself.  It may be parked in a put() on the
+            # full output queue (nobody consumes while rank 0 works on its own shard): every put() of the loop is a timed one
+            # that re-checks _aborted, so it gets there within a tick -- wait for it, so that the other ranks have their
+            # answer before the caller's exception travels on (a caller that catches it keeps the process alive)
+            self._thread.join(timeout=30.0)
             return
         for r in range(1, self.world):
             try:
@@ -707,6 +712,17 @@ class OrderedPieceGather:
         out = self._out = queue.Queue(maxsize=self.depth)
         dist = self.dist
 
+        def hand_over(item) -> bool:
+            """queue a received piece for pieces(); False when the run was aborted meanwhile (the piece is dropped).  Never a
+            blocking put: after rank 0's own failure nobody drains the queue any more"""
+            while not getattr(self, "_aborted", False):
+                try:
+                    out.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
         def recv_loop():
             try:
                 if not self.on_host:
@@ -738,10 +754,20 @@ class OrderedPieceGather:
                             host.copy_(dev_buf[:n])
                             torch.cuda.current_stream(dev_buf.device).synchronize()
                         self.bytes_moved += n
-                        out.put((r, first, frames, host.numpy()))
-                out.put(None)
+                        hand_over((r, first, frames, host.numpy()))   # (aborted: the next turn of the loop sends the negative credits)
+                if not hand_over(None):
+                    raise RuntimeError("aborted by rank 0")
             except BaseException as e:
-                out.put(e)
+                # the consumer must see the error, but must not be waited for: make room if the queue is full
+                while True:
+                    try:
+                        out.put_nowait(e)
+                        break
+                    except queue.Full:
+                        try:
+                            out.get_nowait()
+                        except queue.Empty:
+                            pass
 
         self._thread = self._threading.Thread(target=recv_loop, daemon=True)
         self._thread.start()

@@ -93,6 +93,9 @@ def reference_keypoints(eig: np.ndarray, quality_level=0.01, min_distance=5.0, g
     return np.array(out, np.float32).reshape(-1, 2)
 
 
+OTHER_APERTURES = (5, 7, -1)     # Sobel 5 / 7, Scharr
+
+
 class Cv2Backend:
     def __init__(self):
         import cv2
@@ -106,8 +109,8 @@ class Cv2Backend:
     def gray(self, rgb):
         return self.cv2.cvtColor(rgb, self.cv2.COLOR_RGB2GRAY)
 
-    def min_eig(self, gray):
-        return self.cv2.cornerMinEigenVal(gray, 3, ksize=3)
+    def min_eig(self, gray, ksize=3):
+        return self.cv2.cornerMinEigenVal(gray, 3, ksize=ksize)      # ksize -1: Scharr (cornerEigenValsVecs, aperture_size < 0)
 
     def pyramid(self, gray):
         n, pyr = self.cv2.buildOpticalFlowPyramid(gray, (WIN, WIN), MAX_LEVEL)
@@ -136,8 +139,8 @@ class OracleBackend:
     def gray(self, rgb):
         return self.o.rgb2gray(rgb)
 
-    def min_eig(self, gray):
-        return self.o.min_eigen_val(gray, 3, 3)
+    def min_eig(self, gray, ksize=3):
+        return self.o.min_eigen_val(gray, 3, ksize)
 
     def pyramid(self, gray):
         p = self.o.Pyramid(gray, WIN, MAX_LEVEL)
@@ -156,6 +159,8 @@ def make(backend) -> dict:
         out[f"{name}_frames"] = np.stack(frames)
         out[f"{name}_gray"] = np.stack(grays)
         out[f"{name}_min_eig"] = eig
+        for ks in OTHER_APERTURES:       # GFTTOptions.gradient_size the addon never sets (gftt.cc:31-36): the response map only
+            out[f"{name}_min_eig_k{ks}"] = backend.min_eig(grays[0], ks)
         out[f"{name}_keypoints"] = kps
         for l, (img, der) in enumerate(backend.pyramid(grays[0])):
             out[f"{name}_level{l}"] = img
@@ -175,6 +180,8 @@ def oracle_outputs(G, name, emu):
         grays = [oracle.rgb2gray(np.ascontiguousarray(f)) for f in frames]
         res["gray"] = np.stack(grays)
         res["min_eig"] = oracle.min_eigen_val(grays[0], 3, 3)
+        for ks in OTHER_APERTURES:
+            res[f"min_eig_k{ks}"] = oracle.min_eigen_val(grays[0], 3, ks)
         res["keypoints"] = oracle.gftt(grays[0])
         p0 = oracle.Pyramid(grays[0], WIN, MAX_LEVEL)
         for l in range(p0.num_levels):
@@ -206,6 +213,16 @@ def compare(G, name, got, exact_float: bool):
         a, b = set(map(tuple, got["keypoints"].astype(int))), set(map(tuple, G[f"{name}_keypoints"].astype(int)))
         if len(a ^ b) > max(2, len(b) // 1000):
             bad.append(f"{name}/keypoints: {len(a ^ b)} corners not common")
+    for ks in OTHER_APERTURES:
+        key = f"min_eig_k{ks}"
+        if f"{name}_{key}" not in G or key not in got:      # files written before round 5 do not hold them
+            continue
+        e2, g2 = got[key], G[f"{name}_{key}"]
+        if exact_float:
+            if not np.array_equal(e2.view(np.uint32), g2.view(np.uint32)):
+                bad.append(f"{name}/{key}: {(e2.view(np.uint32) != g2.view(np.uint32)).sum()} pixels differ in bits")
+        elif float(np.abs(e2 - g2).max() / max(float(np.abs(g2).max()), 1e-30)) > 1e-6:
+            bad.append(f"{name}/{key}: max |diff| / max = {float(np.abs(e2 - g2).max() / max(float(np.abs(g2).max()), 1e-30)):.2e}")
     for k in range(1, n_targets + 1):
         st, gst = got[f"lk_status_{k}"], G[f"{name}_lk_status_{k}"]
         if not np.array_equal(st, gst):

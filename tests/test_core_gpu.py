@@ -88,7 +88,12 @@ def test_c1_checkerboard_through_thread_protocol(core, tmp_path):
     assert len(f) == 8 * 30 - 30
 
 
-def test_cancel_then_resume_gives_identical_database(core, tmp_path):
+@pytest.mark.parametrize("batch", ["1", "8", "5"])
+def test_cancel_then_resume_gives_identical_database(core, tmp_path, monkeypatch, batch):
+    """... for every size of the writer's transactions (POLYCHASE_DB_BATCH_FRAMES: 1 = a transaction per frame as in rounds
+    1-4, 8 = the default, 5 = a size that does not divide the clip): a cancelled run commits what it finished, the resumed run
+    recomputes the rest, the file is the uninterrupted run's."""
+    monkeypatch.setenv("POLYCHASE_DB_BATCH_FRAMES", batch)
     clip = synth.NoiseClip(320, 240, 24)
     frames = [clip.frame(t) for t in range(24)]
     full, part = str(tmp_path / "full.db"), str(tmp_path / "part.db")

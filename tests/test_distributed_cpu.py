@@ -329,11 +329,17 @@ def _abort_worker(rank, world, port, mode):
     g = D.OrderedPieceGather(depth=2)
     t0 = time.time()
     if rank == 0:
-        if mode == "abort_running":
+        if mode in ("abort_running", "abort_full_queue"):
             g.start()
-            time.sleep(0.3)
+            # "abort_full_queue" (ADVICE r04): long enough for the receiver to have queued `depth` pieces and to be parked
+            # in the put() of the next one -- nobody consumes while rank 0 is busy with its own shard
+            time.sleep(1.5 if mode == "abort_full_queue" else 0.3)
+        if mode == "abort_full_queue":
+            assert g._out.full(), "the receiver should be blocked on the full output queue by now"
+        t_abort = time.time()
         g.abort()
-        if mode == "abort_running":
+        assert time.time() - t_abort < 5 and not g._thread.is_alive() if g._thread is not None else True
+        if mode in ("abort_running", "abort_full_queue"):
             with pytest.raises(RuntimeError):
                 for _ in g.pieces():
                     pass
@@ -350,7 +356,7 @@ def _abort_worker(rank, world, port, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["abort_before_start", "abort_running"])
+@pytest.mark.parametrize("mode", ["abort_before_start", "abort_running", "abort_full_queue"])
 def test_ordered_piece_gather_rank0_failure_releases_the_other_ranks(mode):
     """rank 0's shard throws while the other ranks wait for credits / sit on a full queue -- nobody may hang."""
     import torch.multiprocessing as mp

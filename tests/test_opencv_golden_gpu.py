@@ -28,6 +28,9 @@ def hip_outputs(ctx, G, name):
     fr[0].detect()
     res["min_eig"] = fr[0].min_eig()
     res["keypoints"] = fr[0].keypoints()
+    for ks in og.OTHER_APERTURES:
+        fr[0].detect(hip.gftt_options(gradient_size=ks))
+        res[f"min_eig_k{ks}"] = fr[0].min_eig()
     win = og.WIN
     for l in range(fr[0].num_levels):
         res[f"level{l}"] = fr[0].level(l)[win:-win, win:-win]

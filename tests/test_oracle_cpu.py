@@ -71,6 +71,57 @@ def test_min_eigen_val_vs_float64(gray):
     assert np.abs(got - ref).max() < 2e-7 * max(1.0, np.abs(ref).max()) + 1e-9
 
 
+@pytest.mark.parametrize("ksize,block", [(5, 3), (7, 3), (-1, 3), (5, 2), (7, 5), (-1, 4)])
+def test_min_eigen_val_other_apertures_vs_float64(gray, ksize, block):
+    """gradient_size 5 / 7 (Sobel, binomial taps from getSobelKernels' recurrence -- rebuilt here by convolution, not copied
+    from the C tables) and -1 (Scharr 3 / 10 / 3), cornerEigenValsVecs' scale 1 / (2^(ksize-1) * block * 255) (x 1/2 for
+    Scharr), any block size with anchor block / 2: the C restatement against float64 scipy, both arithmetic hypotheses."""
+    g = gray.astype(np.float64)
+    if ksize > 0:
+        sm = np.array([1.0])
+        for _ in range(ksize - 1):
+            sm = np.convolve(sm, [1, 1])
+        dv = np.array([1.0])
+        for _ in range(ksize - 2):
+            dv = np.convolve(dv, [1, 1])
+        dv = np.convolve(dv, [1, -1])[::-1]            # correlation taps: minus on the left
+        s = 1.0 / (2 ** (ksize - 1) * block * 255)
+    else:
+        sm, dv, s = np.array([3.0, 10.0, 3.0]), np.array([-1.0, 0.0, 1.0]), 1.0 / (4 * block * 255) / 2
+    assert dv[0] < 0 and dv[-1] > 0 and abs(dv.sum()) < 1e-12
+    dx = ndimage.correlate1d(ndimage.correlate1d(g, dv, axis=1, mode="mirror"), sm * s, axis=0, mode="mirror")
+    dy = ndimage.correlate1d(ndimage.correlate1d(g, sm * s, axis=1, mode="mirror"), dv, axis=0, mode="mirror")
+    # unnormalised box sum, window rows y - block//2 .. y - block//2 + block - 1 (anchor = block / 2), REFLECT_101 on the products
+    def box(a):
+        a0 = block // 2
+        p = np.pad(a, ((a0, block - 1 - a0), (a0, block - 1 - a0)), mode="reflect")
+        out = np.zeros_like(a)
+        for j in range(block):
+            for i in range(block):
+                out += p[j:j + a.shape[0], i:i + a.shape[1]]
+        return out
+    a, b, c = box(dx * dx) * 0.5, box(dx * dy), box(dy * dy) * 0.5
+    ref = (a + c) - np.sqrt((a - c) ** 2 + b * b)
+    for emu in (oracle.EMU_CANONICAL, oracle.EMU_OPENCV_X86, oracle.EMU_OPENCV_X86 | oracle.EMU_SOBEL_ROW_FMA):
+        with oracle.emulation(emu):
+            got = oracle.min_eigen_val(gray, block, ksize)
+        assert np.abs(got - ref).max() < 1e-6 * max(1.0, np.abs(ref).max()) + 1e-9, (emu, np.abs(got - ref).max(), np.abs(ref).max())
+    # Harris takes the same covariance sums
+    ref_h = (4 * a * c - b * b) - 0.04 * (2 * a + 2 * c) ** 2
+    with oracle.emulation(oracle.EMU_CANONICAL):
+        got_h = oracle.corner_harris(gray, block, ksize, 0.04)
+    assert np.abs(got_h - ref_h).max() < 1e-5 * max(1e-12, np.abs(ref_h).max())
+    assert lib_refuses(gray)
+
+
+def lib_refuses(gray):
+    """apertures OpenCV's getSobelKernels would also reject (even, > 7 in this restatement) are an error, not a guess"""
+    import ctypes as C
+    out = np.empty(gray.shape, np.float32)
+    g = np.ascontiguousarray(gray)
+    return all(oracle.lib().pco_min_eigen_val(g.ctypes.data, g.shape[1], g.shape[0], 3, k, out.ctypes.data) != 0 for k in (0, 1, 2, 4, 6, 9, -2))
+
+
 def test_gftt_invariants_and_grid(gray):
     xy, eig, ncand = oracle.gftt(gray, want_eig=True)
     assert len(xy) > 20 and ncand >= len(xy)

@@ -146,3 +146,165 @@ def test_pnp_solve_on_a_set_and_bad_options(env):
     L.pc_pnp_problem_destroy(prob)
     L.pc_corr_set_destroy.argtypes = [VP]
     L.pc_corr_set_destroy(s)
+
+
+class TrackSource(C.Structure):
+    _fields_ = [("cam", RayCamera), ("keypoints_key", C.c_longlong), ("keypoints_xy", VP), ("n_keypoints", C.c_int),
+                ("n_matches", C.c_int), ("idx_offset", C.c_size_t), ("tgt_offset", C.c_size_t)]
+
+
+class TrackResult(C.Structure):
+    _fields_ = [("pnp", SolveResult), ("n_matches", C.c_int), ("n_correspondences", C.c_int), ("rounds", C.c_int), ("lm_ticks", C.c_uint * 8)]
+
+
+def _block(flows):
+    """[(idx, tgt), ...] -> one byte block with 16-byte aligned columns + the offsets (what csrc/host/track_sequence.cc builds)"""
+    parts, offs, at = [], [], 0
+    for idx, tgt in flows:
+        io = (at + 15) // 16 * 16
+        to = (io + idx.nbytes + 15) // 16 * 16
+        offs.append((io, to))
+        at = to + tgt.nbytes
+        parts.append((io, idx.tobytes()))
+        parts.append((to, tgt.tobytes()))
+    blob = np.zeros(max(at, 16), np.uint8)
+    for o, b in parts:
+        blob[o:o + len(b)] = np.frombuffer(b, np.uint8)
+    return blob, offs
+
+
+def _solve_frame(L, ctx, s, mesh, cams, kps_list, flows, init, o, keys=None, model=None):
+    model = np.eye(4, dtype=np.float32) if model is None else model
+    blob, offs = _block(flows)
+    src = (TrackSource * len(flows))()
+    for k, ((idx, tgt), (io, to)) in enumerate(zip(flows, offs)):
+        src[k].cam = cams[k]
+        src[k].keypoints_key = -1 if keys is None else keys[k]
+        src[k].keypoints_xy = _p(kps_list[k])
+        src[k].n_keypoints = len(kps_list[k])
+        src[k].n_matches = len(idx)
+        src[k].idx_offset, src[k].tgt_offset = io, to
+    r = TrackResult()
+    L.pc_track_solve_frame.argtypes = [VP, VP, VP, VP, C.c_int, C.POINTER(TrackSource), C.c_int, VP, C.c_size_t, C.POINTER(PnPCamera),
+                                       C.POINTER(SolveOptions), C.POINTER(TrackResult)]
+    rc = L.pc_track_solve_frame(ctx._h, s, mesh, _p(model), 1, src, len(flows), _p(blob), blob.nbytes, C.byref(init), C.byref(o), C.byref(r))
+    return rc, r
+
+
+def test_solve_frame_in_one_call_against_its_building_blocks(env):
+    """pc_track_solve_frame (one transfer, one ray-cast launch over all sources, the LM loop as ONE persistent launch) against
+    pc_corr_set_append per source + pc_pnp_solve (round 4's 40 launches): the same world points bit for bit, the same
+    correspondence count / inliers / iteration count, poses equal up to the order of the fp32 sums; misses, a 3-point frame,
+    too few points, a bad index, loss types, repeated calls on one set (the barrier words come back zero)."""
+    L, ctx, mesh, cam = env
+    s = VP()
+    assert L.pc_corr_set_create(ctx._h, C.byref(s)) == 0
+    rng = np.random.default_rng(5)
+    # three "source frames" with their own keypoints, two seen by a second camera shifted along x
+    cam2 = RayCamera()
+    cam2.dir_matrix[:] = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+    cam2.origin[:] = [0.4, -0.1, -5.2]
+    cam2.fx = cam2.fy = 500.0
+    cam2.cx, cam2.cy, cam2.unproject_sign = 320.0, 240.0, 1.0
+    cams = [cam, cam2, cam]
+    kps_list, flows, truth_X = [], [], []
+    for k, n in enumerate((700, 133, 4099)):
+        kps = rng.uniform([60, 40], [580, 440], (n, 2)).astype(np.float32)
+        kps[::97] = [5000, 240]                                   # rays that miss the quad
+        idx = rng.permutation(n).astype(np.uint32)[: n - 7]
+        c = cams[k]
+        # the target frame's camera is `cam` at origin (0, 0, -5): observation of the world point the source ray hits
+        d = np.stack([(kps[idx, 0] - 320) / 500, (kps[idx, 1] - 240) / 500, np.ones(len(idx))], 1)
+        o_ = np.array(list(c.origin), np.float64)
+        X = o_ + d * (-o_[2] / d[:, 2:3])
+        tgt = np.stack([500 * X[:, 0] / (X[:, 2] + 5) + 320, 500 * X[:, 1] / (X[:, 2] + 5) + 240], 1) + rng.normal(0, 0.2, (len(idx), 2))
+        kps_list.append(kps)
+        flows.append((idx, tgt.astype(np.float32)))
+    init = PnPCamera()
+    init.q_xyzw[:] = [0.004, -0.003, 0.002, 1.0]
+    init.t[:] = [0.03, -0.02, 5.05]
+    init.fx = init.fy = 500.0
+    init.cx, init.cy, init.aspect_ratio, init.convention_opencv = 320.0, 240.0, 1.0, 1
+    L.pc_pnp_solve.argtypes = [VP, VP, C.POINTER(PnPCamera), C.POINTER(SolveOptions), C.POINTER(SolveResult)]
+    L.pc_pnp_problem_destroy.argtypes = [VP]
+    L.pc_corr_set_download.argtypes = [VP, VP, VP, VP]
+    L.pc_track_download_points.argtypes = [VP, VP, C.c_int, VP]
+    for loss, opt_f in ((0, 0), (2, 0), (1, 1)):
+        o = SolveOptions(max_iterations=100, initial_lambda=1e-5, min_lambda=1e-10, max_lambda=1e10, gradient_tol=1e-10,
+                         step_tol=1e-8, loss_type=loss, loss_scale=1.0, optimize_focal_length=opt_f, optimize_principal_point=opt_f,
+                         f_low=10, f_high=5000, cx_low=0, cx_high=640, cy_low=0, cy_high=480, max_inlier_error=2.0, rounds_hint=0)
+        rc, r = _solve_frame(L, ctx, s, mesh, cams, kps_list, flows, init, o, keys=[11, 12, 13])
+        assert rc == 0, L.pc_last_error()
+        total = sum(len(i) for i, _ in flows)
+        pts = np.zeros((total, 4), np.float32)
+        assert L.pc_track_download_points(ctx._h, s, total, _p(pts)) == 0
+        # the building blocks on a second set
+        s2 = VP()
+        assert L.pc_corr_set_create(ctx._h, C.byref(s2)) == 0
+        for k, (idx, tgt) in enumerate(flows):
+            assert _append(L, ctx, s2, mesh, cams[k], kps_list[k], idx, tgt, key=11 + k) == 0
+        n = C.c_int()
+        assert L.pc_corr_set_size(ctx._h, s2, C.byref(n)) == 0
+        assert r.n_matches == total and r.n_correspondences == n.value == int(pts[:, 3].sum()) and 0 < total - n.value < 200
+        w, x = np.zeros((n.value, 3), np.float32), np.zeros((n.value, 2), np.float32)
+        assert L.pc_corr_set_download(ctx._h, s2, _p(w), _p(x)) == 0
+        assert np.array_equal(w, pts[pts[:, 3] == 1, :3])                          # the same rays, the same arithmetic
+        assert np.array_equal(x, np.concatenate([t for _, t in flows])[pts[:, 3] == 1])
+        prob = VP()
+        assert L.pc_pnp_problem_from_set(ctx._h, s2, C.byref(prob)) == 0
+        r2 = SolveResult()
+        assert L.pc_pnp_solve(ctx._h, prob, C.byref(init), C.byref(o), C.byref(r2)) == 0
+        L.pc_pnp_problem_destroy(prob)
+        L.pc_corr_set_destroy.argtypes = [VP]
+        L.pc_corr_set_destroy(s2)
+        a, b = r.pnp, r2
+        # the two paths add the same terms in different orders: near convergence a step may be accepted in one and rejected in
+        # the other, so the iteration counts may differ by a few -- the minimum they reach may not
+        assert abs(a.iterations - b.iterations) <= 4 and a.inliers == b.inliers, (loss, a.iterations, b.iterations)
+        assert abs(a.cost - b.cost) <= 2e-5 * b.cost and abs(a.initial_cost - b.initial_cost) <= 2e-5 * b.initial_cost
+        # (a plane seen head-on leaves focal length and distance nearly interchangeable: with the intrinsics free the two
+        # summation orders stop at different points of that flat valley -- same cost, poses within its width)
+        tol = 100.0 if opt_f else 1.0
+        assert np.allclose(list(a.camera.t), list(b.camera.t), atol=2e-5 * tol) and np.allclose(list(a.camera.q_xyzw), list(b.camera.q_xyzw), atol=2e-6 * tol)
+        assert np.allclose([a.camera.fx, a.camera.fy, a.camera.cx, a.camera.cy], [b.camera.fx, b.camera.fy, b.camera.cx, b.camera.cy], rtol=2e-5 * tol)
+        assert 2 <= r.rounds <= a.iterations + 1                                   # one sweep per evaluated parameter set, none after `done`
+        assert np.allclose(list(a.camera.t), [0, 0, 5], atol=5e-2 if opt_f else 5e-3)
+        # the same call again on the same set: bit-identical (the barrier words came back zero, sums in a fixed order)
+        rc, rr = _solve_frame(L, ctx, s, mesh, cams, kps_list, flows, init, o, keys=[11, 12, 13])
+        assert rc == 0 and bytes(rr)[:C.sizeof(TrackResult) - 32] == bytes(r)[:C.sizeof(TrackResult) - 32]   # all but the tick counters
+    o = SolveOptions(max_iterations=100, initial_lambda=1e-5, min_lambda=1e-10, max_lambda=1e10, gradient_tol=1e-10, step_tol=1e-8,
+                     loss_type=0, loss_scale=1.0, optimize_focal_length=1, optimize_principal_point=1, f_low=10, f_high=5000, cx_low=0,
+                     cx_high=640, cy_low=0, cy_high=480, max_inlier_error=2.0, rounds_hint=0)
+    # exactly 3 correspondences: solved, intrinsics NOT optimised although asked for (pnp_problem.h:34-35)
+    kp3 = np.array([[100, 100], [500, 120], [300, 400], [5000, 5000]], np.float32)
+    rc, r = _solve_frame(L, ctx, s, mesh, [cam], [kp3], [(np.array([0, 1, 2, 3], np.uint32), kp3.copy())], init, o)
+    assert rc == 0 and r.n_matches == 4 and r.n_correspondences == 3
+    assert (r.pnp.camera.fx, r.pnp.camera.cx, r.pnp.camera.cy) == (500.0, 320.0, 240.0) and r.pnp.cost < 1e-6
+    # 2 correspondences / none / no sources: nothing solved, no error
+    rc, r = _solve_frame(L, ctx, s, mesh, [cam], [kp3], [(np.array([0, 3, 1], np.uint32), kp3[:3].copy())], init, o)
+    assert rc == 0 and r.n_correspondences == 2 and r.pnp.iterations == 0
+    rc, r = _solve_frame(L, ctx, s, mesh, [cam], [kp3], [(np.array([3], np.uint32), kp3[:1].copy())], init, o)
+    assert rc == 0 and r.n_correspondences == 0
+    rc, r = _solve_frame(L, ctx, s, mesh, [], [], [], init, o)
+    assert rc == 0 and r.n_correspondences == 0 and r.n_matches == 0
+    # an index past the keypoints is reported (tracker.cc:61 CHECK_LT), and the next call is clean again
+    rc, r = _solve_frame(L, ctx, s, mesh, [cam], [kp3], [(np.array([0, 1, 4], np.uint32), kp3[:3].copy())], init, o)
+    assert rc != 0 and b"out of range" in L.pc_last_error()
+    rc, r = _solve_frame(L, ctx, s, mesh, [cam], [kp3], [(np.array([0, 1, 2], np.uint32), kp3[:3].copy())], init, o)
+    assert rc == 0 and r.n_correspondences == 3
+    # argument checks: offsets outside the block, bad loss type, too many sources
+    src = (TrackSource * 1)()
+    src[0].cam, src[0].keypoints_key, src[0].keypoints_xy, src[0].n_keypoints, src[0].n_matches = cam, -1, _p(kp3), 4, 3
+    src[0].idx_offset, src[0].tgt_offset = 0, 16
+    blob = np.zeros(32, np.uint8)
+    r = TrackResult()
+    assert L.pc_track_solve_frame(ctx._h, s, mesh, _p(np.eye(4, dtype=np.float32)), 1, src, 1, _p(blob), 32, C.byref(init), C.byref(o), C.byref(r)) != 0
+    assert b"inside the block" in L.pc_last_error()
+    o.loss_type = 9
+    rc, r = _solve_frame(L, ctx, s, mesh, [cam], [kp3], [(np.array([0, 1, 2], np.uint32), kp3[:3].copy())], init, o)
+    assert rc != 0 and b"loss type" in L.pc_last_error()
+    o.loss_type = 0
+    rc, r = _solve_frame(L, ctx, s, mesh, [cam] * 9, [kp3] * 9, [(np.array([0], np.uint32), kp3[:1].copy())] * 9, init, o)
+    assert rc != 0 and b"at most" in L.pc_last_error()
+    L.pc_corr_set_destroy.argtypes = [VP]
+    L.pc_corr_set_destroy(s)

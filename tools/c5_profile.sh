@@ -13,7 +13,7 @@ cd /tmp
 POLYCHASE_TRACE_STAGES=1 timeout -k 10 600 python "$ROOT/tests/c5_endtoend.py" --frames $FRAMES --oracle-frames 0 \
   --out "$OUT/${TAG}_c5_endtoend.json" > /tmp/c5_plain.log 2> "$OUT/${TAG}_c5_stages.txt"
 # the kernel trace; the copy trace is tried first and dropped if the profiler does not survive it
-for extra in "--memory-copy-trace" ""; do
+for extra in ""; do   # (--memory-copy-trace: rocprofv3 segfaults at exit with it on this image)
   rm -rf /tmp/c5k
   timeout -k 10 900 rocprofv3 --kernel-trace $extra --stats --output-format csv -d /tmp/c5k -- \
     python "$ROOT/tests/c5_endtoend.py" --frames $FRAMES --oracle-frames 0 --out "$OUT/${TAG}_c5_endtoend_under_rocprofv3.json" > /tmp/c5k.log 2>&1
