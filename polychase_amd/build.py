@@ -37,28 +37,8 @@ def _run(cmd: list[str]) -> None:
 
 
 def hip_library_path() -> str:
-    # POLYCHASE_HIP_LIB: an alternative build of the same C ABI (tools/lk_variants.py compares kernel variants)
+    # POLYCHASE_HIP_LIB: an alternative build of the same C ABI (tools/lk_variants/: kernel experiments on a patched tree)
     return os.environ.get("POLYCHASE_HIP_LIB") or os.path.join(LIB_DIR, "libpolychase_hip.so")
-
-
-def build_hip_variant(tag: str, extra_flags: list[str]) -> str:
-    """lib/variants/libpolychase_hip_<tag>.so: the same sources compiled with extra -D flags (experiments only)."""
-    vdir = os.path.join(LIB_DIR, "variants")
-    odir = os.path.join(LIB_DIR, "obj_" + tag)
-    os.makedirs(vdir, exist_ok=True)
-    os.makedirs(odir, exist_ok=True)
-    out = os.path.join(vdir, f"libpolychase_hip_{tag}.so")
-    srcs = [os.path.join(HIP_DIR, s) for s in HIP_SOURCES]
-    objs = [os.path.join(odir, os.path.splitext(s)[0] + ".o") for s in HIP_SOURCES]
-
-    def compile_one(pair):
-        src, obj = pair
-        _run(["hipcc", *HIP_FLAGS, *extra_flags, "-c", src, "-o", obj])
-
-    with ThreadPoolExecutor(max_workers=8) as ex:
-        list(ex.map(compile_one, zip(srcs, objs)))
-    _run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs])
-    return out
 
 
 def build_hip(force: bool = False) -> str:

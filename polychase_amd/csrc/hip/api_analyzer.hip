@@ -92,6 +92,7 @@ struct pc_analyzer {
     std::vector<Job> jobs;
     size_t job_head = 0, job_count = 0;  // ring of in-flight jobs
     uint64_t submitted = 0;              // jobs submitted so far: job k runs on lane k & 1 (stream, LK output set, pack)
+    bool one_lane = false;               // POLYCHASE_LK_LANES=1 when the analyzer was created: every job on lane 0
     // "the LK launch of a job finished", per lane, handed out round-robin.  Slots remember the event of the last job
     // that read them; an event that has been re-recorded since marks a LATER launch of the same lane, which the
     // lane's stream order puts behind the remembered one -- waiting for it is still correct.
@@ -166,6 +167,10 @@ int pc_analyzer_create(pc_context* ctx, int width, int height, const pc_gftt_opt
     pc_analyzer* a = new (std::nothrow) pc_analyzer();
     if (!a) return fail(PC_E_INVALID, "out of host memory");
     a->ctx = ctx;
+    // POLYCHASE_LK_LANES=1 (read per analyzer): every job on lane 0, i.e. no two LK launches in flight -- a launch's
+    // start-to-end time is then its own duration (the recipe of tools/collect_profiles.sh under rocprofv3 and of bench.py's
+    // roofline time base); the product runs two lanes
+    a->one_lane = getenv("POLYCHASE_LK_LANES") && atoi(getenv("POLYCHASE_LK_LANES")) == 1;
     a->w = width;
     a->h = height;
     a->gopt = *gftt;
@@ -403,8 +408,7 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     // detection of frames that were made resident for later
     // POLYCHASE_LK_LANES=1: every job on lane 0, i.e. no two LK launches in flight -- the recipe for per-dispatch durations under
     // rocprofv3 (tools/collect_profiles.sh); the product runs two lanes
-    static const bool one_lane = getenv("POLYCHASE_LK_LANES") && atoi(getenv("POLYCHASE_LK_LANES")) == 1;
-    const int lane = one_lane ? 0 : (int)(a->submitted & 1);
+    const int lane = a->one_lane ? 0 : (int)(a->submitted & 1);
     hipStream_t const ls = ctx->lane_stream(lane);
     {
         SlowSection ss("submit/waits");
@@ -481,7 +485,7 @@ int pc_analyzer_submit(pc_analyzer* a, int32_t frame1, const int32_t* targets, i
     pc::launch_copy_keypoints(s1->frame->d_kps, reinterpret_cast<float2*>(pack + j.o_kps), n, ls);
     // Everything that reads the resident frames is enqueued: the pyramids (LK), frame1's keypoints (LK, the copy
     // above) and its inverse visiting order (compaction).  A slot may be overwritten once this event has fired.
-    hipEvent_t const lk_done = a->lk_done[lane][(one_lane ? a->submitted : (a->submitted >> 1)) % pc_analyzer::kLaneEvents];
+    hipEvent_t const lk_done = a->lk_done[lane][(a->one_lane ? a->submitted : (a->submitted >> 1)) % pc_analyzer::kLaneEvents];
     PC_HIP(hipEventRecord(lk_done, ls));
     s1->last_read[lane] = lk_done;
     for (int t = 0; t < n_targets; t++) find_slot(a, targets[t])->last_read[lane] = lk_done;

@@ -831,15 +831,68 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const unsigned long
 
 constexpr int kBucketsPerWave = 4;
 
-// one wavefront per workgroup (small workgroups with 4 KB of LDS find room beside the LK wavefronts, which hold 120 of a
-// CU's 160 KB), four consecutive buckets each, one after the other in the same LDS buffer
-__global__ __launch_bounds__(64) void bucket_sort_kernel(const unsigned long long* __restrict__ in, const uint32_t* __restrict__ offsets,
+// Four wavefronts per workgroup, each on its own four consecutive buckets in its own 4 KB of LDS (no barrier between them; 16 KB
+// per workgroup stays inside the helpers' LDS budget beside the LK wavefronts, which hold 120 of a CU's 160 KB).  (Rounds 2-4:
+// one wavefront per workgroup = 2048 workgroups per launch.)
+constexpr int kSortWaves = 4;
+__global__ __launch_bounds__(64 * kSortWaves) void bucket_sort_kernel(const unsigned long long* __restrict__ in, const uint32_t* __restrict__ offsets,
                                                          unsigned long long* __restrict__ out, uint32_t* __restrict__ overflow, int hi_prio) {
     helper_priority(hi_prio);
-    __shared__ unsigned long long s_keys[kBucketLds];
-    const int lane = threadIdx.x;
-    const int b0 = blockIdx.x * kBucketsPerWave;
-    if (offsets[b0] == offsets[min(b0 + kBucketsPerWave, kSortBuckets)]) return;   // nothing in these buckets
+    __shared__ unsigned long long s_all[kSortWaves][kBucketLds];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long* const s_keys = s_all[wave];
+    const int b0 = (blockIdx.x * kSortWaves + wave) * kBucketsPerWave;
+    if (b0 >= kSortBuckets) return;
+    uint32_t o[kBucketsPerWave + 1];
+#pragma unroll
+    for (int k = 0; k <= kBucketsPerWave; k++) o[k] = offsets[min(b0 + k, kSortBuckets)];
+    const uint32_t lo = o[0], n4 = o[kBucketsPerWave] - lo;
+    if (n4 == 0) return;   // nothing in these buckets
+    if (n4 <= (uint32_t)kBucketLds) {
+        // The four buckets TOGETHER (round 5): one trip to memory for all their keys, and every lane ranks a key inside ITS
+        // bucket -- at 4K a bucket holds 43 keys on average, so a bucket at a time left a third of the lanes idle and paid
+        // four dependent memory latencies per wavefront (158 us per frame, 476 at worst: profiles/r04_c3_rocprofv3_kernel_stats.csv).
+        // (all loads of a lane in flight together: kBucketLds / 64 of them at most)
+        unsigned long long ld[kBucketLds / 64];
+#pragma unroll
+        for (int q = 0; q < kBucketLds / 64; q++) {
+            const uint32_t i = lane + 64 * q;
+            ld[q] = i < n4 ? in[lo + i] : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < kBucketLds / 64; q++) {
+            const uint32_t i = lane + 64 * q;
+            if (i < n4) s_keys[i] = ld[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t longest = 0;
+#pragma unroll
+        for (int k = 0; k < kBucketsPerWave; k++) longest = max(longest, o[k + 1] - o[k]);
+        for (uint32_t i = lane; i < n4; i += 64) {
+            const unsigned long long mine = s_keys[i];
+            uint32_t a = lo, b = o[1];
+#pragma unroll
+            for (int k = 1; k < kBucketsPerWave; k++)
+                if (lo + i >= o[k]) {
+                    a = o[k];
+                    b = o[k + 1];
+                }
+            // The rank of the key inside its bucket.  A UNIFORM trip count (the longest of the four buckets; a lane past the end
+            // of its own re-reads its last key and adds nothing) so that the loop unrolls and eight LDS reads are in flight at a
+            // time: with per-lane bounds every iteration sat out one LDS latency -- the 222-key buckets of a 4K frame took 100 us
+            // that way, in a kernel whose comparisons are worth 5.
+            const uint32_t first = a - lo, len = b - a;
+            uint32_t rank = 0;
+#pragma unroll 8
+            for (uint32_t j = 0; j < longest; j++) {
+                const unsigned long long other = s_keys[first + min(j, len - 1u)];
+                rank += (j < len && other > mine) ? 1u : 0u;   // keys are distinct (the address part)
+            }
+            out[a + rank] = mine;
+        }
+        return;
+    }
+    // more keys than the buffer holds at once: bucket by bucket
     for (int b = b0; b < b0 + kBucketsPerWave && b < kSortBuckets; b++) {
         const uint32_t base = offsets[b], n = offsets[b + 1] - base;
         if (n == 0) continue;
@@ -856,6 +909,7 @@ __global__ __launch_bounds__(64) void bucket_sort_kernel(const unsigned long lon
         for (uint32_t i = lane; i < n; i += 64) {
             const unsigned long long mine = s_keys[i];
             uint32_t rank = 0;
+#pragma unroll 8
             for (uint32_t j = 0; j < n; j++) rank += s_keys[j] > mine ? 1u : 0u;   // keys are distinct (the address part)
             out[base + rank] = mine;
         }
@@ -867,7 +921,8 @@ void launch_bucket_sort(const unsigned long long* keys, uint32_t cap, uint32_t n
                         uint32_t* overflow, hipStream_t s) {
     const unsigned blocks = std::max(1u, std::min<unsigned>(1024u, (n_launch + 255u) / 256u));
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3(blocks), dim3(256), 0, s, keys, cap, counter, sort_params, offsets, cursor, scratch, helper_prio_arg());
-    hipLaunchKernelGGL(bucket_sort_kernel, dim3(kSortBuckets / kBucketsPerWave), dim3(64), 0, s, scratch, offsets, out, overflow, helper_prio_arg());
+    hipLaunchKernelGGL(bucket_sort_kernel, dim3((kSortBuckets / kBucketsPerWave + kSortWaves - 1) / kSortWaves), dim3(64 * kSortWaves), 0, s, scratch, offsets,
+                       out, overflow, helper_prio_arg());
 }
 
 // ------------------------------------------------------------------------------------------------

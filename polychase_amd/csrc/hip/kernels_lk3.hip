@@ -28,60 +28,17 @@
 
 namespace pc {
 
-#ifndef PC_LK3_ATTR
-#define PC_LK3_ATTR
-#endif
-// PC_LK3_PAIRS=1: the b-vector accumulation takes the pixels of two runs at a time: (hi16 R_a, hi16 R_b) packed by one
-// v_perm_b32, then b1 += R_a * ix_a + R_b * ix_b as ONE v_dot2_i32_i16 (and one for b2) -- 3 instructions per two
-// pixels where the v_mad_i32_i16 form takes 4.
-#ifndef PC_LK3_PAIRS
-#define PC_LK3_PAIRS 1
-#endif
-// PC_LK3_TRIM=1: the per-iteration arithmetic around the pixel loop with fewer instructions (same values bit for bit):
-// weights rounded by the 1.5 * 2^23 addition and packed with v_perm_b32 (packed_weights), the fractional parts from
-// the floor values, image / region tests as unsigned compares, the oscillation test in fp32.
-#ifndef PC_LK3_TRIM
-#define PC_LK3_TRIM 1
-#endif
-#ifndef PC_LK3_PREFETCH
-#define PC_LK3_PREFETCH 1   // LDS reads of the pixel loop one step ahead of the arithmetic
-#endif
-// PC_LK3_PRIO (experiment, tools/lk_ab.sh): 1 = a wavefront raises its issue priority (s_setprio 2) while it loads and evaluates
-// the I side and stages its J regions -- the latency-bound phases -- and drops it for the iterations; 2 = the other way round.
-#ifndef PC_LK3_PRIO
-#define PC_LK3_PRIO 0
-#endif
-#define PC_LK3_SETPRIO_STAGING() do { if (PC_LK3_PRIO == 1) __builtin_amdgcn_s_setprio(2); else if (PC_LK3_PRIO == 2) __builtin_amdgcn_s_setprio(0); } while (0)
-#define PC_LK3_SETPRIO_ITER() do { if (PC_LK3_PRIO == 1) __builtin_amdgcn_s_setprio(0); else if (PC_LK3_PRIO == 2) __builtin_amdgcn_s_setprio(2); } while (0)
-// X86: failed exactness proofs of a wavefront within one level before the rest of the level runs in the x86 order without
-// trying the proof first (measured: tools/lk_variants.py, profiles/r04_x86_lk3_sticky.jsonl)
-#ifndef PC_LK3_X86_STICK_AFTER
-#define PC_LK3_X86_STICK_AFTER 1
-#endif
-// Experiments for "what would staging through LDS-DMA save at most" (tools/lk_variants.py, profiles/r04_*_lk_staging_cost.jsonl):
-// PC_LK3_STAGE_TWICE stages every J region twice, PC_LK3_ISTAGE_TWICE loads and stores the I-side windows twice -- same
-// results, and the extra time is the whole cost (global loads, permutes, LDS stores, their waits) of one such staging, i.e. an
-// UPPER bound of what a staging without VGPR round trip (global_load_lds) could remove.
-#ifndef PC_LK3_RESTAGE_ALL
-#define PC_LK3_RESTAGE_ALL 0
-#endif
-#ifndef PC_LK3_STAGE_AHEAD
-#define PC_LK3_STAGE_AHEAD 0
-#endif
-// rows in flight of a staging INSIDE the iteration loop.  With PC_LK3_J_EARLY those are the rare restagings of a drifting window,
-// and every row in flight is 7 registers on top of the loop's 50 (bias, Dxy) registers
-#ifndef PC_LK3_RESTAGE_ROWS
-#define PC_LK3_RESTAGE_ROWS (PC_LK3_J_EARLY ? 1 : PC_LK3_STAGE_ROWS)
-#endif
-#ifndef PC_LK3_STAGE_TWICE
-#define PC_LK3_STAGE_TWICE 0
-#endif
-#ifndef PC_LK3_ISTAGE_TWICE
-#define PC_LK3_ISTAGE_TWICE 0
-#endif
-#ifndef PC_LK3_WAVES
-#define PC_LK3_WAVES 1   // wavefronts per workgroup
-#endif
+// What the inner loop is made of (all of it measured, DESIGN_HISTORY.md "The LK kernel"): the b-vector accumulation takes the
+// pixels of two runs at a time -- (hi16 R_a, hi16 R_b) packed by one v_perm_b32, then b1 += R_a * ix_a + R_b * ix_b as ONE
+// v_dot2_i32_i16 (and one for b2): 3 instructions per two pixels where the v_mad_i32_i16 form takes 4; the weights are rounded by
+// the 1.5 * 2^23 addition and packed with v_perm_b32 (packed_weights), the fractional parts come from the floor values, image /
+// region tests are unsigned compares, the oscillation test runs in fp32; LDS reads run one step ahead of the arithmetic.
+// The experiments that were measured and NOT taken -- staging twice (the LDS-DMA ceiling), early loads of a level's first region,
+// restaging all groups together, staging ahead of the motion, two lanes per row for the I windows, issue priorities, 2 / 4
+// wavefronts per SIMD, two wavefronts per workgroup, the unpaired / untrimmed data paths -- are no longer in this file: the
+// patch that holds them is tools/lk_variants/r04_experiments.patch (applies to the round-4 kernel, git tag-less: commit 8b4ea23),
+// their numbers are in profiles/r03_*_lk_variants.jsonl, r04_*_lk_staging_cost.jsonl, r04_lk_early_staging.jsonl,
+// r04_*_lk_restage.jsonl, r04_lk_paired_*.{jsonl,txt}.
 
 // -DPC_LK_PROFILE: per-phase shader-clock sums (pc_debug_lk_profile); costs ~10 % of the launch
 #ifdef PC_LK_PROFILE
@@ -94,18 +51,6 @@ namespace pc {
 #define PC_PROF_COUNT(k) do { } while (0)
 #endif
 
-// PC_LK3_J_EARLY: a level's FIRST J region -- its origin is known when the level starts -- is loaded right after the I-side
-// windows and stored before the pick-up, so that its memory latency passes behind the I-side evaluation instead of in front of
-// the first iteration (a staging is ~85 instructions but costs as much as 1.5 iterations, most of it waiting:
-// profiles/r04_*_lk_staging_cost.jsonl).  For that the (bias, Dxy) exchange buffers, which the pick-up reads AFTER the regions
-// are written, move out of the area the regions alias: + 2 * X_DW dwords of LDS per wavefront.
-// MEASURED AND NOT TAKEN (round 4, profiles/r04_lk_early_staging.jsonl): isolated launch C2 0.290 -> 0.304 ms, C3 1.34 -> 1.40,
-// pipeline 709 -> 676 frames/s at 4K.  The loads can only be issued after the pixel pass (their 28 registers do not fit beside
-// it), which leaves ~70 instructions to hide them behind; against that stand 1.3 KB more LDS per wavefront and restagings with
-// one row in flight.  Off by default; the code stays as the record of the experiment.
-#ifndef PC_LK3_J_EARLY
-#define PC_LK3_J_EARLY 0
-#endif
 template <int WIN>
 struct LK3Geo {
     static constexpr int GL = 4, NPX = WIN * WIN;
@@ -122,10 +67,9 @@ struct LK3Geo {
     // the LDS pipe's busy time, which itself was 82 % of the launch (rounds 1 and 2 until this was found)
     static constexpr int D_PITCH = WIN + 1, D_DW = (((WIN + 1) * (WIN + 1)) + 1) & ~1;
     static constexpr int X_DW = 2 * NPX;                      // (bias, Dxy) exchange of one keypoint
-    static constexpr bool XSEP = PC_LK3_J_EARLY != 0;         // the exchange buffers live behind the region area
-    static constexpr int HALF_I_DW = ((I_DW + D_DW + (XSEP ? 0 : X_DW) + 3) / 4) * 4;
+    static constexpr int HALF_I_DW = ((I_DW + D_DW + X_DW + 3) / 4) * 4;
     static constexpr int AREA_DW = ((16 * J_DW > 2 * HALF_I_DW ? 16 * J_DW : 2 * HALF_I_DW) + 1) & ~1;   // regions / I-side windows
-    static constexpr int WAVE_DW = AREA_DW + (XSEP ? 2 * X_DW : 0);
+    static constexpr int WAVE_DW = AREA_DW;
     // window pixels of a lane: NCH column chains (columns lg + 4c) + a run of the remaining columns
     static constexpr int WM = (WIN / GL) * GL, NCH = WM / GL, KM = NCH * WIN;
     static constexpr int NEXTRA = (WIN - WM) * WIN, KE = (NEXTRA + GL - 1) / GL, K = KM + KE;
@@ -143,7 +87,6 @@ struct RowRegs {
 #pragma unroll
         for (int c = 0; c < CHN; c++) {
             const uint32_t a = v.d[2 * c], b = v.d[2 * c + 1], e = v.d[2 * c + 2];
-#if PC_LK3_TRIM
             // ds_write2_b32 stores two ARBITRARY registers to two dwords; the 16-byte store the compiler forms wants
             // four consecutive registers and pays a v_mov for each loaded dword (LDS operations of a wavefront
             // complete in order, so the compiler's lgkmcnt waits stay sufficient with these in the queue)
@@ -151,10 +94,6 @@ struct RowRegs {
             const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(dst);
             asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(addr), "v"(a), "v"(p1), "n"(4 * c), "n"(4 * c + 1) : "memory");
             asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(addr), "v"(b), "v"(p3), "n"(4 * c + 2), "n"(4 * c + 3) : "memory");
-#else
-            *reinterpret_cast<uint4*>(dst + 4 * c) =
-                make_uint4(a, __builtin_amdgcn_alignbit(b, a, 16), b, __builtin_amdgcn_alignbit(e, b, 16));
-#endif
         }
     }
 };
@@ -226,57 +165,7 @@ __device__ __forceinline__ float group4_exact_sum3(int partial) {
     }
 }
 
-// Stage the J region of one group: rows lg, lg + 4, ... (a lane past the last row repeats it).  PC_LK3_STAGE_ROWS rows
-// of a lane are in flight at a time (7 VGPRs each for the 10-px window): all four cost one memory latency per region.
-// (Affordable since the lane-derived addresses stopped being hoisted across the iteration loop: the 10-px kernel needs
-// 121 VGPRs with four rows in flight, it needed 142 with one.)
-#ifndef PC_LK3_STAGE_ROWS
-#define PC_LK3_STAGE_ROWS 4
-#endif
-// Occupancy cap.  121 registers would let four wavefronts share a SIMD (15 per CU, then LDS-bound): 3 % faster alone,
-// but those 15 hold 153 of the CU's 160 KB of LDS and the frame-preparation kernels (16 KB tiles) starve beside them --
-// at 4K the min-eig kernel took 0.83 ms instead of 0.33 and the pipeline dropped from 640 to 557 fps.  A wavefront that
-// ALLOCATES 136 registers leaves room for three per SIMD, and with them 104 VGPRs per lane and 37 KB of LDS per CU to
-// whatever runs beside LK.  The clobber below is the whole mechanism.
-#ifndef PC_LK3_MIN_VGPR
-#define PC_LK3_MIN_VGPR "v135"
-#endif
-template <int WIN, int ROWS_IN_FLIGHT = PC_LK3_STAGE_ROWS>
-__device__ __forceinline__ void stage_region(const uint16_t* __restrict__ J16, int pitch, int rx0, int ry0, uint32_t* jbuf, int lg) {
-    using G = LK3Geo<WIN>;
-    // The row offsets (lg + 4k) * pitch are loop invariants of the iteration loop this is called from; hoisted out of
-    // it they sit in 8 VGPRs (64-bit each) across the kernel's most register-hungry stretch.  Staging is rare:
-    // recompute them here (the empty asm hides the invariance from the optimiser).
-    asm volatile("" : "+v"(lg));
-    constexpr int TRIPS = (G::RH + G::GL - 1) / G::GL;
-    constexpr int B = TRIPS < ROWS_IN_FLIGHT ? TRIPS : ROWS_IN_FLIGHT;
-    const uint16_t* const base = J16 + (ptrdiff_t)__mul24(ry0, pitch) + rx0;   // |ry0|, pitch < 2^23: the 24-bit multiply is full rate
-#pragma unroll
-    for (int k0 = 0; k0 < TRIPS; k0 += B) {
-        RowRegs<G::CH> rows[B];
-#pragma unroll
-        for (int b = 0; b < B; b++) {
-            const int k = k0 + b;
-            if (k < TRIPS) {
-                int r = lg + G::GL * k;
-                if (G::GL * (k + 1) > G::RH) r = min(r, G::RH - 1);
-                rows[b].load(base + (ptrdiff_t)__mul24(r, pitch));
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < B; b++) {
-            const int k = k0 + b;
-            if (k < TRIPS) {
-                int r = lg + G::GL * k;
-                if (G::GL * (k + 1) > G::RH) r = min(r, G::RH - 1);
-                rows[b].store(jbuf + r * G::PITCH);
-            }
-        }
-        if (k0 + B < TRIPS) __builtin_amdgcn_sched_barrier(0);   // or the next batch's loads are hoisted up here
-    }
-}
-
-// PC_LK3_STAGE_PAIRED: the same region staged with TWO LANES PER ROW.  stage_region gives every lane whole rows: each of its
+// The J region of one group, staged with TWO LANES PER ROW.  Giving every lane whole rows (rounds 2-4) means each of a lane's
 // 8 loads (10-px window) sends 64 lanes to 64 different rows of 16 different images -- 76 L1 accesses per instruction
 // (TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD, profiles/r04_lk_tcp_counters.txt), 608 per staging, and the texture
 // addresser of the CU, which takes one access per cycle, is busy or stalled 68 % of the launch: the twelve wavefronts of a
@@ -286,14 +175,14 @@ __device__ __forceinline__ void stage_region(const uint16_t* __restrict__ J16, i
 // pitch are not written (lane h = 1: the upper four for a 12-position pitch, all eight for an 8-position one).
 // The loads read uint16 columns rx0 .. rx0 + 15, at most 16 - (WIN + 3) past the row's last needed one: the next row of the
 // plane, or the tail slack behind the frame's last plane (pc_frame_create).
-#ifndef PC_LK3_STAGE_PAIRED
-#define PC_LK3_STAGE_PAIRED 1
-#endif
 template <int WIN>
 __device__ __forceinline__ void stage_region_paired(const uint16_t* __restrict__ J16, int pitch, int rx0, int ry0, uint32_t* jbuf, int lg) {
     using G = LK3Geo<WIN>;
     static_assert(G::RWP + 1 <= 16 && G::PITCH >= 8 && G::PITCH <= 16, "a region row is at most 16 pixels: two dwordx4");
-    asm volatile("" : "+v"(lg));   // see stage_region
+    // The row offsets derived from lg are invariants of the iteration loop this is called from; hoisted out of it they sit in
+    // registers across the kernel's most register-hungry stretch.  Staging is rare: recompute them here (the empty asm hides
+    // the invariance from the optimiser).
+    asm volatile("" : "+v"(lg));
     constexpr int NI = (G::RH + 1) / 2;
     constexpr bool ODD = (G::RH & 1) != 0;   // the last load of lanes (2, 3) repeats row RH - 1
     static_assert((2 * (NI - 1) + 1) * G::PITCH + 7 < 256, "ds_write2_b32 offsets are 8 bits of dwords");
@@ -344,75 +233,6 @@ __device__ __forceinline__ void stage_region_paired(const uint16_t* __restrict__
         }
     }
 }
-template <int WIN, int ROWS_IN_FLIGHT = PC_LK3_STAGE_ROWS>
-__device__ __forceinline__ void stage_j(const uint16_t* __restrict__ J16, int pitch, int rx0, int ry0, uint32_t* jbuf, int lg) {
-#if PC_LK3_STAGE_PAIRED
-    stage_region_paired<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
-#else
-    stage_region<WIN, ROWS_IN_FLIGHT>(J16, pitch, rx0, ry0, jbuf, lg);
-#endif
-}
-
-// The I window of one keypoint (WIN + 1 rows x WIN positions, staged by the keypoint's half-wave) the same way: lanes (2r, 2r + 1)
-// read the two 16-byte halves of row r -- one load where a lane per row takes a dwordx4 and a dwordx3 (lanes past the last row
-// repeat it, as there).
-// MEASURED AND NOT TAKEN (profiles/r04_lk_paired_i_window.txt, four A/B runs of the isolated launch): C2 x86 -2.6 %, C2 canonical
-// -0.6 %, C3 x86 +0.9 %, C3 canonical -0.1 % -- inside the run-to-run spread of +-1 %; the I side is a third of the launch's L1
-// accesses but 22 of its 32 lanes per half already share rows with a neighbour.  Off by default.
-#ifndef PC_LK3_ISTAGE_PAIRED
-#define PC_LK3_ISTAGE_PAIRED 0
-#endif
-template <int WIN>
-__device__ __forceinline__ void stage_i_window_paired(const uint16_t* __restrict__ origin, int pitch, uint32_t* ibuf, int l32) {
-    using G = LK3Geo<WIN>;
-    static_assert(2 * G::I_ROWS <= 32 && WIN + 1 <= 16 && G::I_PITCH <= 16, "two lanes per row of a half-wave");
-    struct __attribute__((packed, aligned(2))) Raw { uint32_t d[4]; };
-    const int r = min(l32 >> 1, G::I_ROWS - 1), h = l32 & 1;
-    const Raw v = *reinterpret_cast<const Raw*>(origin + (ptrdiff_t)(__mul24(r, pitch) + 8 * h));
-    const uint32_t nx = (uint32_t)dpp_i32<0xF5>((int)v.d[0]);   // quad_perm [1, 1, 3, 3]: the other half's first pixel
-    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)(ibuf + r * G::I_PITCH + 8 * h);
-    // positions 8h .. 8h + 3 and 8h + 4 .. 8h + 7, where the window's pitch has them
-    if (h == 0 || G::I_PITCH > 8) {
-        const uint32_t p1 = __builtin_amdgcn_alignbit(v.d[1], v.d[0], 16), p3 = __builtin_amdgcn_alignbit(v.d[2], v.d[1], 16);
-        asm volatile("ds_write2_b32 %0, %1, %2 offset0:0 offset1:1" : : "v"(addr), "v"(v.d[0]), "v"(p1) : "memory");
-        asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3" : : "v"(addr), "v"(v.d[1]), "v"(p3) : "memory");
-    }
-    if (h == 0 ? G::I_PITCH > 4 : G::I_PITCH > 12) {
-        const uint32_t p5 = __builtin_amdgcn_alignbit(v.d[3], v.d[2], 16), p7 = __builtin_amdgcn_alignbit(nx, v.d[3], 16);
-        asm volatile("ds_write2_b32 %0, %1, %2 offset0:4 offset1:5" : : "v"(addr), "v"(v.d[2]), "v"(p5) : "memory");
-        asm volatile("ds_write2_b32 %0, %1, %2 offset0:6 offset1:7" : : "v"(addr), "v"(v.d[3]), "v"(p7) : "memory");
-    }
-}
-
-// The same staging cut in two (PC_LK3_J_EARLY): load() issues the global loads of a lane's rows (at most four: RH <= 14),
-// store() writes them to the region.
-template <int WIN>
-struct StageRows {
-    using G = LK3Geo<WIN>;
-    static constexpr int TRIPS = (G::RH + G::GL - 1) / G::GL;
-    static_assert(TRIPS <= 4, "a lane stages at most four region rows");
-    RowRegs<G::CH> rows[TRIPS];
-    __device__ __forceinline__ void load(const uint16_t* __restrict__ J16, int pitch, int rx0, int ry0, int lg) {
-        asm volatile("" : "+v"(lg));   // see stage_region
-        const uint16_t* const base = J16 + (ptrdiff_t)__mul24(ry0, pitch) + rx0;
-#pragma unroll
-        for (int k = 0; k < TRIPS; k++) {
-            int r = lg + G::GL * k;
-            if (G::GL * (k + 1) > G::RH) r = min(r, G::RH - 1);
-            rows[k].load(base + (ptrdiff_t)__mul24(r, pitch));
-        }
-    }
-    __device__ __forceinline__ void store(uint32_t* jbuf, int lg) const {
-        asm volatile("" : "+v"(lg));
-#pragma unroll
-        for (int k = 0; k < TRIPS; k++) {
-            int r = lg + G::GL * k;
-            if (G::GL * (k + 1) > G::RH) r = min(r, G::RH - 1);
-            rows[k].store(jbuf + r * G::PITCH);
-        }
-    }
-};
-
 // ------------------------------------------------------------------------------------------------------------------
 // X86 = true (PC_ARITH_LK_X86_ORDER): the sums of the structure tensor and of the mismatch vector as an x86 OpenCV build
 // forms them -- LKTrackerInvoker's CV_SIMD128 path: over the first SIMD_W = (WIN / 8) * 8 columns vector lane j = x & 3
@@ -470,7 +290,7 @@ __device__ __forceinline__ float dpp_add4(float acc, float v, int src_lane) {
     return acc;
 }
 
-// (ix, iy) of the pixel in slot k as one dword, out of the paired register layout of the iteration loop (PC_LK3_PAIRS)
+// (ix, iy) of the pixel in slot k as one dword, out of the paired register layout of the iteration loop
 // (sel_lo / sel_hi: the v_perm selectors 0x05040100 / 0x07060302 as OPAQUE values of the calling iteration -- with literal
 // selectors these permutations are invariants of the iteration loop, and hoisted out of it they occupy a register each)
 template <int WIN, int K>
@@ -650,26 +470,28 @@ __device__ __forceinline__ void x86_structure_tensor(uint32_t* wbase, const uint
 }
 
 template <int WIN, bool X86>
-__global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(const LKParams p) {
+__global__ __launch_bounds__(64) void lk3_kernel(const LKParams p) {
     using G = LK3Geo<WIN>;
-    static_assert(!X86 || (PC_LK3_PAIRS * PC_LK3_TRIM) != 0, "the x86 summation order is written on the paired, trimmed data path");
     constexpr int GL = G::GL, NPX = G::NPX, NCH = G::NCH, KM = G::KM, KE = G::KE, K = G::K;
     constexpr int KW = (NPX + 31) / 32;   // pixels per lane in the half-wave I-side pass
     // + slack: slots past a lane's run of extra pixels read up to KE rows below the last region (and contribute 0)
-    // (with the exchange buffers behind the region area those reads land there: 2 * X_DW dwords are more than the slack)
-    static_assert(!G::XSEP || 2 * G::X_DW >= (KE + 1) * G::PITCH, "the over-read past the last region stays inside the exchange buffers");
-    constexpr int WAVE_DW = G::WAVE_DW + ((KE > 0 && !G::XSEP) ? (KE + 1) * G::PITCH : 0);
-    __shared__ __attribute__((aligned(16))) uint32_t s_buf[PC_LK3_WAVES][WAVE_DW];
+    constexpr int WAVE_DW = G::WAVE_DW + (KE > 0 ? (KE + 1) * G::PITCH : 0);
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[1][WAVE_DW];   // one wavefront per workgroup
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int half = lane >> 5, l32 = lane & 31, grp = (lane >> 2) & 7, lg = lane & 3;
     // Workgroup b runs on XCD b % 8; each XCD takes one contiguous eighth of the (spatially binned) keypoint order
     lk_signal_dispatched(p);
-    asm volatile("; occupancy cap" ::: PC_LK3_MIN_VGPR);
+    // Occupancy cap.  121 registers would let four wavefronts share a SIMD (15 per CU, then LDS-bound): 3 % faster alone,
+    // but those 15 hold 153 of the CU's 160 KB of LDS and the frame-preparation kernels (16 KB tiles) starve beside them --
+    // at 4K the min-eig kernel took 0.83 ms instead of 0.33 and the pipeline dropped from 640 to 557 fps.  A wavefront that
+    // ALLOCATES 136 registers leaves room for three per SIMD, and with them 104 VGPRs per lane and 37 KB of LDS per CU to
+    // whatever runs beside LK.  The clobber below is the whole mechanism.
+    asm volatile("; occupancy cap" ::: "v135");
     // (dealing the order to the XCDs in tile-sized chunks instead of contiguous eighths was tried: 2-6 % slower, the
     // launch's tail is not an imbalance between XCDs)
     const int lb = (int)(blockIdx.x & 7u) * p.blocks_per_xcd + (int)(blockIdx.x >> 3);
-    const int first = (lb * PC_LK3_WAVES + wave) * 2;  // first of this wave's two keypoint slots
+    const int first = (lb + wave) * 2;  // first of this wave's two keypoint slots
     if ((int)(blockIdx.x >> 3) >= p.blocks_per_xcd || first >= p.n) return;   // whole waves exit together
     const int slot = first + half;
     const bool kp_valid = slot < p.n;                 // n odd: the last wave's second half idles
@@ -681,7 +503,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
     uint32_t* const wbase = &s_buf[wave][0];
     uint32_t* const ibuf = wbase + half * G::HALF_I_DW;                          // I window, position dwords
     int32_t* const dbuf = reinterpret_cast<int32_t*>(ibuf + G::I_DW);            // raw Scharr window
-    uint32_t* const xbuf = G::XSEP ? wbase + G::AREA_DW + half * G::X_DW : ibuf + G::I_DW + G::D_DW;   // (bias, Dxy) exchange
+    uint32_t* const xbuf = ibuf + G::I_DW + G::D_DW;                             // (bias, Dxy) exchange
     uint32_t* const jbuf = wbase + (half * 8 + grp) * G::J_DW;                   // aliases the above
 
     // the lane's run of the columns that do not fill a chain (column-major order of those pixels)
@@ -723,11 +545,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         const Level L = p.src[level];
         const uint16_t* __restrict__ J16 = p.tgt16[tgt][level];
         const int pitch = L.pitch;
-#if PC_LK3_TRIM
         const float lscale = __uint_as_float((uint32_t)(127 - level) << 23);   // 2^-level, the value of 1.f / (1 << level)
-#else
-        const float lscale = 1.f / (float)(1 << level);
-#endif
         float px = pt.x * lscale, py = pt.y * lscale;
         float qx, qy;
         if (level == p.max_level) {
@@ -741,7 +559,6 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         ny = qy;
 
         // ---- I side: identical for all targets of a keypoint -> computed once by its half-wave ----
-        PC_LK3_SETPRIO_STAGING();
         px -= half_win;
         py -= half_win;
         const int ipx = (int)floorf(px), ipy = (int)floorf(py);
@@ -750,11 +567,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
             status = false;
             err = 0.f;
         }
-#if PC_LK3_TRIM
         const Weights wI = packed_weights(px - (float)ipx, py - (float)ipy);
-#else
-        const Weights wI = bilinear_weights(px - (float)ipx, py - (float)ipy);
-#endif
         const uint32_t wrow0 = wI.r0, wrow1 = wI.r1;
 
         // Lane-derived LDS addresses of the I side and the pick-up are invariants of this level loop; hoisted out of it
@@ -766,7 +579,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         const int l32_o = lane_o & 31, lg_o = lane_o & 3;
         uint32_t* const ibuf_o = wbase + (lane_o >> 5) * G::HALF_I_DW;
         int32_t* const dbuf_o = reinterpret_cast<int32_t*>(ibuf_o + G::I_DW);
-        uint32_t* const xbuf_o = G::XSEP ? wbase + G::AREA_DW + (lane_o >> 5) * G::X_DW : ibuf_o + G::I_DW + G::D_DW;
+        uint32_t* const xbuf_o = ibuf_o + G::I_DW + G::D_DW;
         int e_q0_o = 0;
         if constexpr (KE > 0 && G::RUNS) {
             const int e0 = lg_o * KE;
@@ -774,31 +587,14 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
             e_q0_o = (len > 0 ? e0 % WIN : 0) * WIN + G::WM + (len > 0 ? e0 / WIN : 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous level's J regions are dead
-#if PC_LK3_ISTAGE_TWICE
         if (i_in) {
             DerivWindow<WIN, 32> dw;
             dw.load(L.der + (ptrdiff_t)(__mul24(ipy, pitch) + ipx), pitch, l32_o);
-            RowRegs<G::I_CH> row;
-            const int r = min(l32_o, G::I_ROWS - 1);
-            row.load(L.img16 + (ptrdiff_t)__mul24(ipy + r, pitch) + ipx);
-            row.store(ibuf_o + r * G::I_PITCH);
-            dw.store(dbuf_o, l32_o);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        asm volatile("" ::: "memory");
-#endif
-        if (i_in) {
-            DerivWindow<WIN, 32> dw;
-            dw.load(L.der + (ptrdiff_t)(__mul24(ipy, pitch) + ipx), pitch, l32_o);
-#if PC_LK3_ISTAGE_PAIRED
-            stage_i_window_paired<WIN>(L.img16 + (ptrdiff_t)(__mul24(ipy, pitch) + ipx), pitch, ibuf_o, l32_o);
-#else
             // I window: lane r < WIN + 1 stages row r (the other lanes repeat the last row)
             RowRegs<G::I_CH> row;
             const int r = min(l32_o, G::I_ROWS - 1);
             row.load(L.img16 + (ptrdiff_t)__mul24(ipy + r, pitch) + ipx);
             row.store(ibuf_o + r * G::I_PITCH);
-#endif
             dw.store(dbuf_o, l32_o);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -829,28 +625,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 }
             }
         }
-#if PC_LK3_J_EARLY
-        // The first iteration's window origin is floor(q - half_win): the loads of its region are in flight from here on --
-        // behind the reductions, the 2 x 2 system and the level's tests.  (Issued any earlier they live through the pixel
-        // pass, whose registers they do not fit beside: 163 VGPRs; in the X86 kernel they are issued behind the ordered
-        // structure tensor for the same reason.)
-        StageRows<WIN> jpre;
-        int jrx0 = 0, jry0 = 0;
-        bool j_early = false;
-        auto issue_early = [&]() {
-            const int ejx = (int)floorf(qx - half_win), ejy = (int)floorf(qy - half_win);
-            j_early = tgt_active && i_in && p.max_iters > 0 &&
-                      !((unsigned)(ejx + WIN) >= (unsigned)(L.w + WIN) || (unsigned)(ejy + WIN) >= (unsigned)(L.h + WIN));
-            if (j_early) {
-                jrx0 = ejx - G::MX;
-                jry0 = ejy - G::MY;
-                jpre.load(J16, pitch, jrx0, jry0, lg);
-            }
-        };
-        if constexpr (!X86) issue_early();
-#endif
         // per-lane partials fit int32; the half's totals are reduced as exact (hi, lo) halves
-#if PC_LK3_TRIM
         static_assert((long long)NPX * 4080 * 4080 < (1ll << 31), "structure tensor sums fit int32");
         const int S11 = half_sum3_i32(sA11), S22 = half_sum3_i32(sA22);
         float A11 = (float)S11 * FLT_SCALE;
@@ -880,14 +655,6 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         // 0 / 255 edges (S = 100 * 4080^2) takes the fp64 route.  Wavefront-uniform: both keypoints must qualify.
         constexpr long long kSmallS = (1ll << 62) / ((long long)NPX * 8160 * 8160);
         const bool int_sums = __all((!i_in) || ((long long)S11 < kSmallS && (long long)S22 < kSmallS));
-#else
-        const float A11 = half_exact_sum3(sA11) * FLT_SCALE;
-        const float A12 = half_exact_sum3(sA12) * FLT_SCALE;
-        const float A22 = half_exact_sum3(sA22) * FLT_SCALE;
-#endif
-#if PC_LK3_J_EARLY
-        if constexpr (X86) issue_early();
-#endif
         float D = A11 * A22 - A12 * A12;
         const float tdiff = A11 - A22;
         const float min_eig_num = A22 + A11 - sqrtf(tdiff * tdiff + 4.f * A12 * A12);
@@ -900,21 +667,14 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
             lvl_ok = false;
         }
         D = 1.f / D;
-#if PC_LK3_TRIM
         // b = sum * 2^-20 enters the solve only through products that are then multiplied by D: the power of two commutes
         // with every rounding on the way (nothing gets near the denormals), so it is applied to D once per level instead
         // of to both sums in every iteration
         D *= FLT_SCALE;
-#endif
         lvl_ok = lvl_ok && tgt_active;   // idle groups only help with the I side
 
         // every group picks up the pixels it owns
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#if PC_LK3_J_EARLY
-        // the I-side windows (and the ordered structure tensor's products) are consumed: the regions may take their place;
-        // the exchange buffers the pick-up reads lie behind them
-        if (j_early && lvl_ok) jpre.store(jbuf, lg);
-#endif
         PC_PROF(1);
         int Bias[K];  // 2^15 - ival * 2^16: the accumulator init of interp_r
         int Dxy[K];   // (int16 ix) | (int16 iy << 16); 0 for slots without a pixel
@@ -932,7 +692,6 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                     Bias[c * WIN + r] = (int)v.x;
                     Dxy[c * WIN + r] = (int)v.y;
                 }
-#if PC_LK3_PAIRS
             // rows r and H1 + r of a chain (the same step of its two runs) share their registers: slot r holds
             // (ix_a, ix_b), slot H1 + r holds (iy_a, iy_b); an odd window's middle row keeps the (ix, iy) form
 #pragma unroll
@@ -943,7 +702,6 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                     Dxy[c * WIN + r] = (int)__builtin_amdgcn_perm(b, a, 0x05040100u);
                     Dxy[c * WIN + (WIN + 1) / 2 + r] = (int)__builtin_amdgcn_perm(b, a, 0x07060302u);
                 }
-#endif
 #pragma unroll
             for (int e = 0; e < KE; e++) {
                 uint2 v = make_uint2(0u, 0u);
@@ -955,7 +713,6 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 Bias[KM + e] = (int)v.x;
                 Dxy[KM + e] = (int)v.y;
             }
-#if PC_LK3_PAIRS
             if constexpr (KE > 1 && G::RUNS) {
                 // the run of the remaining columns: pixels 2m and 2m + 1 share slots 2m (ix pair) and 2m + 1 (iy pair)
 #pragma unroll
@@ -965,7 +722,6 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                     Dxy[KM + e + 1] = (int)__builtin_amdgcn_perm(b, a, 0x07060302u);
                 }
             }
-#endif
         }
         // the J regions alias the I-side buffers of BOTH halves: no group may stage before every group has read
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -978,23 +734,13 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
         float pdx = 0.f, pdy = 0.f;
         int rx0 = 0, ry0 = 0;
         bool staged = false;
-#if PC_LK3_J_EARLY
-        if (j_early) {
-            rx0 = jrx0;
-            ry0 = jry0;
-            staged = true;
-        }
-#endif
         // X86: once the exactness proof of an iteration fails for any pair of the wavefront, the rest of the level runs in
         // the x86 order for all of them (always correct; the proof only saves work) -- wavefront-uniform, so that a
         // wavefront never executes both paths iteration after iteration
         bool x86_ordered = false;
-        int x86_fails = 0;
         (void)x86_ordered;
-        (void)x86_fails;
         for (int j = 0; j < p.max_iters; j++) {
             PC_PROF_COUNT(8);
-#if PC_LK3_TRIM
             const float fqx = floorf(qx), fqy = floorf(qy);
             const int iqx = (int)fqx, iqy = (int)fqy;
             if ((unsigned)(iqx + WIN) >= (unsigned)(L.w + WIN) || (unsigned)(iqy + WIN) >= (unsigned)(L.h + WIN)) {
@@ -1003,64 +749,21 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
             }
             int ox = iqx - rx0, oy = iqy - ry0;
             bool restage = !staged || (unsigned)ox > (unsigned)(2 * G::MX) || (unsigned)oy > (unsigned)(2 * G::MY);
-#if PC_LK3_RESTAGE_ALL
-            // a staging costs the WAVEFRONT its ~80 instructions however many of its 16 groups take part: when one group
-            // must restage, every iterating group re-centres its region for free -- and is less likely to ask next
-            restage = __any(restage);
-#endif
             if (restage) {
                 ox = G::MX;
                 oy = G::MY;
-#if PC_LK3_STAGE_AHEAD
-                // the window keeps moving the way the last step went (the iterations approach their fixed point from one
-                // side far more often than they oscillate): leave the margin's two positions ahead of it, none behind
-                if (j > 0) {
-                    ox = pdx > 0.f ? 0 : (pdx < 0.f ? 2 * G::MX : G::MX);
-                    oy = pdy > 0.f ? 0 : (pdy < 0.f ? 2 * G::MY : G::MY);
-                }
-#endif
                 rx0 = iqx - ox;
                 ry0 = iqy - oy;
                 PC_PROF(4);
-                PC_LK3_SETPRIO_STAGING();
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#if PC_LK3_STAGE_TWICE
-                stage_j<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
+                stage_region_paired<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#endif
-                stage_j<WIN, PC_LK3_RESTAGE_ROWS>(J16, pitch, rx0, ry0, jbuf, lg);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                PC_LK3_SETPRIO_ITER();
                 staged = true;
                 PC_PROF_COUNT(9);
                 PC_PROF(3);
             }
             const Weights wJ = packed_weights(qx - fqx, qy - fqy);   // (float)iqx == fqx
             const uint32_t* jq = jbuf + __mul24(oy, G::PITCH) + ox;
-#else
-            const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
-            if (iqx < -WIN || iqx >= L.w || iqy < -WIN || iqy >= L.h) {
-                if (level == 0) status = false;
-                break;
-            }
-            if (!staged || iqx < rx0 || iqx > rx0 + 2 * G::MX || iqy < ry0 || iqy > ry0 + 2 * G::MY) {
-                rx0 = iqx - G::MX;
-                ry0 = iqy - G::MY;
-                PC_PROF(4);   // the timer reads are slow (scalar memory path): only around the rare staging, not per iteration
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#if PC_LK3_STAGE_TWICE
-                stage_j<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#endif
-                stage_j<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                staged = true;
-                PC_PROF_COUNT(9);
-                PC_PROF(3);
-            }
-            const Weights wJ = bilinear_weights(qx - (float)iqx, qy - (float)iqy);
-            const uint32_t* jq = jbuf + (iqy - ry0) * G::PITCH + (iqx - rx0);
-#endif
             int sb1 = 0, sb2 = 0;  // per-lane partials: <= K * 8160 * 4080
             int dd0 = 0, dd1 = 0;  // X86: the lane's sum of squared differences (<= K * 8160^2 < 2^31), for the exactness proof
             (void)dd0;
@@ -1081,7 +784,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 uint32_t top[NR > 0 ? NR : 1];
                 const uint32_t* rb[NR > 0 ? NR : 1];
                 int tb1 = 0, tb2 = 0;
-                int r_even = 0;   // PC_LK3_PAIRS: the extra run's result of the even step, waiting for its partner
+                int r_even = 0;   // the extra run's result of the even step, waiting for its partner
                 (void)r_even;
 #pragma unroll
                 for (int u = 0; u < NRC; u++) {
@@ -1102,11 +805,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
 #pragma unroll
                     for (int u = 0; u < NR; u++) {
                         const int len = u < NRC ? ((u & 1) ? H2 : H1) : KE;
-#if PC_LK3_PREFETCH
                         if (st + 1 < len) nxt[u] = rb[u][(st + 2) * G::PITCH];
-#else
-                        if (st > 0 && st < len) bot[u] = rb[u][(st + 1) * G::PITCH];
-#endif
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1126,14 +825,13 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-#if PC_LK3_PAIRS
                     if (st < H2) {
                         uint32_t Rp[NCH > 0 ? NCH : 1];
 #pragma unroll
                         for (int c = 0; c < NCH; c++) Rp[c] = __builtin_amdgcn_perm((uint32_t)R[2 * c + 1], (uint32_t)R[2 * c], 0x07060302u);
 #pragma unroll
                         for (int c = 0; c < NCH; c++) {
-                            if (PC_LK3_TRIM && st == 0 && c < 2) {   // the first term of an accumulator
+                            if (st == 0 && c < 2) {   // the first term of an accumulator
                                 (c ? tb1 : sb1) = sdot2_zero(Rp[c], (uint32_t)Dxy[c * WIN + st]);
                                 (c ? tb2 : sb2) = sdot2_zero(Rp[c], (uint32_t)Dxy[c * WIN + H1 + st]);
                             } else if (c & 1) {
@@ -1182,27 +880,8 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                             }
                         }
                     }
-#else
-#pragma unroll
-                    for (int u = 0; u < NR; u++) {
-                        const int len = u < NRC ? ((u & 1) ? H2 : H1) : KE;
-                        const int k = u < NRC ? (u >> 1) * WIN + ((u & 1) ? H1 : 0) + st : KM + st;
-                        if (st < len) {   // slots past a lane's run of extra pixels: Dxy == 0
-                            // two accumulator pairs, alternating: a mad reading the previous mad's result needs a wait state
-                            if (u & 1) {
-                                tb1 = mad16_hl(R[u], (uint32_t)Dxy[k], tb1);
-                                tb2 = mad16_hh(R[u], (uint32_t)Dxy[k], tb2);
-                            } else {
-                                sb1 = mad16_hl(R[u], (uint32_t)Dxy[k], sb1);
-                                sb2 = mad16_hh(R[u], (uint32_t)Dxy[k], sb2);
-                            }
-                        }
-                    }
-#endif
-#if PC_LK3_PREFETCH
 #pragma unroll
                     for (int u = 0; u < NR; u++) bot[u] = nxt[u];
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 sb1 += tb1;   // integer sums: any order gives the same bits
@@ -1226,7 +905,6 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 }
             }
             }   // !x86_ordered
-#if PC_LK3_TRIM
             float b1 = 0.f, b2 = 0.f;
             bool run_ordered = X86 && x86_ordered;
             if (!run_ordered) {
@@ -1249,7 +927,7 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                     ddf += dpp_f32<0x4E>(ddf);
                     const bool proven = ddf * cert_s <= 281474976710656.f * (1.f - 1.f / 1024.f);
                     if (__any(!proven)) {
-                        x86_ordered = ++x86_fails >= PC_LK3_X86_STICK_AFTER;
+                        x86_ordered = true;
                         run_ordered = true;
                     }
                 }
@@ -1262,10 +940,6 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                     x86_iters += 1;
                 }
             }
-#else
-            const float b1 = group4_exact_sum3<K>(sb1) * FLT_SCALE;
-            const float b2 = group4_exact_sum3<K>(sb2) * FLT_SCALE;
-#endif
             const float dx = (A12 * b2 - A22 * b1) * D;
             const float dy = (A12 * b1 - A11 * b2) * D;
             qx += dx;
@@ -1273,12 +947,8 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
             nx = qx + half_win;
             ny = qy + half_win;
             if ((double)dx * (double)dx + (double)dy * (double)dy <= p.eps_sq) break;
-#if PC_LK3_TRIM
             // |float| < 0.01 (a double) <=> |float| <= 0.01f: 0.01f = 0x1.47ae14p-7 is the largest float below 0.01
             if (j > 0 && fabsf(dx + pdx) <= 0x1.47ae14p-7f && fabsf(dy + pdy) <= 0x1.47ae14p-7f) {
-#else
-            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
-#endif
                 nx -= dx * 0.5f;
                 ny -= dy * 0.5f;
                 break;
@@ -1300,19 +970,11 @@ __global__ __launch_bounds__(64 * PC_LK3_WAVES) PC_LK3_ATTR void lk3_kernel(cons
                 rx0 = iex - G::MX;
                 ry0 = iey - G::MY;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#if PC_LK3_STAGE_TWICE
-                stage_j<WIN, PC_LK3_RESTAGE_ROWS>(J16, pitch, rx0, ry0, jbuf, lg);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#endif
-                stage_j<WIN, PC_LK3_RESTAGE_ROWS>(J16, pitch, rx0, ry0, jbuf, lg);
+                stage_region_paired<WIN>(J16, pitch, rx0, ry0, jbuf, lg);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 staged = true;
             }
-#if PC_LK3_TRIM
             const Weights wE = packed_weights(ex - (float)iex, ey - (float)iey);
-#else
-            const Weights wE = bilinear_weights(ex - (float)iex, ey - (float)iey);
-#endif
             const uint32_t* jq = jbuf + (iey - ry0) * G::PITCH + (iex - rx0);
             int se = 0;
 #pragma unroll
@@ -1398,12 +1060,12 @@ template <int WIN>
 static void launch_lk3_t(const LKParams& p0, hipStream_t s) {
     LKParams p = p0;
     p.min_eig_num_thr = division_threshold(p.min_eig_thr, (float)(2 * WIN * WIN));
-    const int per_block = 2 * PC_LK3_WAVES;   // two keypoints per wavefront
+    const int per_block = 2;   // two keypoints per wavefront, one wavefront per workgroup
     const int blocks = (p.n + per_block - 1) / per_block;
     if (blocks == 0) return;
     p.blocks_per_xcd = (blocks + 7) / 8;
-    if (p.x86_order) hipLaunchKernelGGL((lk3_kernel<WIN, true>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(64 * PC_LK3_WAVES), 0, s, p);
-    else hipLaunchKernelGGL((lk3_kernel<WIN, false>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(64 * PC_LK3_WAVES), 0, s, p);
+    if (p.x86_order) hipLaunchKernelGGL((lk3_kernel<WIN, true>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((lk3_kernel<WIN, false>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(64), 0, s, p);
 }
 
 bool lk_profile_enabled() {

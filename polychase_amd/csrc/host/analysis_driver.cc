@@ -740,7 +740,22 @@ void OpticalFlowRecordWriter::Write(const uint8_t* log, size_t bytes, OpticalFlo
     Keypoints known;
     const double t0 = Now();
     auto up16 = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
+    const char* batch_env = std::getenv("POLYCHASE_DB_BATCH_FRAMES");
+    const int batch = std::max(1, batch_env ? std::atoi(batch_env) : 8);
+    int in_batch = 0;
     size_t o = 0;
+    struct RollbackOnThrow {   // an exception between Begin and Commit must not leave the connection inside a transaction
+        Database& db;
+        int& open;
+        ~RollbackOnThrow() {
+            if (open > 0 && std::uncaught_exceptions() > 0) {
+                try {
+                    db.Rollback();
+                } catch (...) {
+                }
+            }
+        }
+    } rollback_guard{db, in_batch};
     while (o < bytes) {
         // header (128 B): magic, frame1, keypoints, targets, target ids [8], rows; then the packed record:
         // row offsets (128 B) | keypoints | src indices | tgt xy | errors, every part 16-byte aligned
@@ -755,7 +770,7 @@ void OpticalFlowRecordWriter::Write(const uint8_t* log, size_t bytes, OpticalFlo
         const size_t o_kps = o + 256, o_idx = up16(o_kps + n * 8), o_xy = up16(o_idx + rows * 4), o_err = up16(o_xy + rows * 8);
         const size_t end = up16(o_err + rows * 4);
         if (end > bytes) throw std::runtime_error("truncated optical-flow record log");
-        db.Begin();
+        if (in_batch == 0) db.Begin();
         if (!db.KeypointsExist(frame1)) {
             db.WriteKeypoints(frame1, reinterpret_cast<const float*>(log + o_kps), n);
             local.keypoint_rows_written++;
@@ -766,7 +781,9 @@ void OpticalFlowRecordWriter::Write(const uint8_t* log, size_t bytes, OpticalFlo
             known.clear();
             db.ReadKeypoints(frame1, known);
             if (known.size() != n || (n > 0 && std::memcmp(known[0].data(), log + o_kps, n * 8) != 0)) {
-                db.Rollback();
+                if (in_batch > 0) db.Commit();   // the records before this one are complete: they stay
+                else db.Rollback();              // this record opened the transaction: nothing in it
+                in_batch = 0;
                 throw std::runtime_error("keypoints of frame " + std::to_string(frame1) +
                                          " stored in the database differ from the record's: refusing to mix two analyses");
             }
@@ -780,10 +797,16 @@ void OpticalFlowRecordWriter::Write(const uint8_t* log, size_t bytes, OpticalFlo
                                   reinterpret_cast<const float*>(log + o_xy) + 2 * a, reinterpret_cast<const float*>(log + o_err) + a, b - a);
             local.flow_rows_written++;
         }
-        db.Commit();
+        // transactions of up to POLYCHASE_DB_BATCH_FRAMES records (default 8, like the single-process writer thread); every
+        // Write() ends with a commit, so a piece that has been stored is on disk when the call returns
+        if (++in_batch >= batch) {
+            db.Commit();
+            in_batch = 0;
+        }
         local.frames_processed++;
         o = end;
     }
+    if (in_batch > 0) db.Commit();
     local.seconds_db = local.seconds_total = Now() - t0;
     if (stats) *stats = local;
 }

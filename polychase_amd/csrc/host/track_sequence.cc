@@ -482,12 +482,14 @@ class FrameSolver {
                 ThrowHip("pc_track_frame_finish");
             }
         }
-        if (StageClock::Enabled()) {
+        {
             static const char* kPhase[8] = {"track/lm kernel: sweep + publish", "track/lm kernel: wait for workgroups", "track/lm kernel: add partials",
                                             "track/lm kernel: decision", "track/lm kernel: publish decision", "track/lm kernel: fetch parameters",
                                             "track/lm kernel: inlier pass", "track/lm kernel: whole launch"};
             for (int k = 0; k < 8; k++) StageClock::Add(kPhase[k], sr.lm_ticks[k] * 1e-5);   // 100 MHz ticks -> ms
             StageClock::Add("track/lm kernel: rounds (count, not ms)", sr.rounds);
+            StageClock::Add("track/matches (count, not ms)", sr.n_matches);
+            StageClock::Add("track/correspondences (count, not ms)", sr.n_correspondences);
         }
         if (sr.n_correspondences < 3) return std::nullopt;  // :95-97
         PnPResult result;

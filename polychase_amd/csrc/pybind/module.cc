@@ -14,6 +14,7 @@
 #include "../host/frame_pool.h"
 #include "../host/analysis_thread.h"
 #include "../host/multi_gpu.h"
+#include "../host/stage_clock.h"
 #include "np_helpers.h"
 
 #ifdef PC_WITH_TRACKER
@@ -394,6 +395,13 @@ PYBIND11_MODULE(polychase_core, m) {
                               static_cast<int>(kps.size() / 2));
     });
     m.def("_engine_cache_timer_running", &EngineCacheTimerRunning);   // testing aid
+    // measurement aid (not in the reference): the stage totals of the last finished call of that kind -- "TrackCameraTrajectory",
+    // "RefineTrajectory" -- as {label: (milliseconds or count, calls)} (csrc/host/stage_clock.h)
+    m.def("_stage_report", [](const std::string& title) {
+        py::dict d;
+        for (const auto& kv : StageClock::Last(title)) d[py::str(kv.first)] = py::make_tuple(kv.second.first, kv.second.second);
+        return d;
+    });
     m.def("release_cached_engine", &ReleaseCachedEngine);   // not in the reference: gives the parked GPU engine's memory back
     m.def("generate_optical_flow_shard", &GenerateOpticalFlowShardPy, py::arg("video_info"), py::arg("frame_accessor_function"),
           py::arg("callback"), py::arg("database_path"), py::arg("shard_begin"), py::arg("shard_end"), py::arg("device_log") = 0,

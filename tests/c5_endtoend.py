@@ -42,9 +42,12 @@ def main(argv=None) -> int:
                          "its source frames and the GPU's pose of the frame before it as the initial guess")
     ap.add_argument("--oracle-workers", type=int, default=1, help="threads over the sampled frames of --oracle-stride")
     ap.add_argument("--refine-iterations", type=int, default=30)
+    ap.add_argument("--refine-oracle-frames", type=int, default=0,
+                    help="> 2: the float64 CPU restatement of the refinement sweeps (oracle/refine_oracle.py) is timed on a "
+                         "sub-segment of that many frames in the middle of the clip (a CPU baseline; checker leg)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args(argv)
-    out = run(a.width, a.height, a.frames, a.oracle_frames, a.oracle_stride, a.refine_iterations, a.oracle_workers)
+    out = run(a.width, a.height, a.frames, a.oracle_frames, a.oracle_stride, a.refine_iterations, a.oracle_workers, a.refine_oracle_frames)
     print(json.dumps(out))
     sys.path.insert(0, os.path.join(ROOT, "polychase_amd", "core"))
     import polychase_core
@@ -87,11 +90,12 @@ def _oracle_pose_check(job):
     return (2.0 * float(np.arctan2(np.linalg.norm(rel[1:]), abs(rel[0]))), float(np.linalg.norm(np.asarray(t_gpu, float) - cam.t) / np.linalg.norm(cam.t)))
 
 
-def run(width=1920, height=1080, frames=300, oracle_frames=6, oracle_stride=0, refine_iterations=30, oracle_workers=1) -> dict:
+def run(width=1920, height=1080, frames=300, oracle_frames=6, oracle_stride=0, refine_iterations=30, oracle_workers=1,
+        refine_oracle_frames=0) -> dict:
     """the whole of C5 -> the result object (bench.py's "c5" block calls this; main() prints it)"""
     import types
     a = types.SimpleNamespace(width=width, height=height, frames=frames, oracle_frames=oracle_frames, oracle_stride=oracle_stride,
-                              refine_iterations=refine_iterations, oracle_workers=oracle_workers)
+                              refine_iterations=refine_iterations, oracle_workers=oracle_workers, refine_oracle_frames=refine_oracle_frames)
 
     import torch
     import torch.nn.functional as Fn
@@ -187,7 +191,9 @@ def run(width=1920, height=1080, frames=300, oracle_frames=6, oracle_stride=0, r
     db.close()
     out["tracking"] = {"seconds": round(dt, 3), "frames_per_s": (n - 1) / dt, "mean_lm_iterations": float(np.mean(lm_iters)),
                        "min_inlier_ratio": min(v[2] for v in got.values()), "keypoints_per_frame": n_kp,
-                       "vs_truth": errors({f: (q, t) for f, (q, t, _) in got.items()})}
+                       "vs_truth": errors({f: (q, t) for f, (q, t, _) in got.items()}),
+                       # where the call's time went (csrc/host/stage_clock.h): host stages in ms, the LM kernel's own phases, counts
+                       "stages": {k: [round(v[0], 3), v[1]] for k, v in core._stage_report("TrackCameraTrajectory").items()}}
 
     # ---- the CPU reference of the tracking step on the same database (first frames) ----
     k = min(a.oracle_frames, n - 1)
@@ -245,7 +251,8 @@ def run(width=1920, height=1080, frames=300, oracle_frames=6, oracle_stride=0, r
         ang, tr = [r[0] for r in res], [r[1] for r in res]
         db.close()
         out["tracking"]["vs_cpu_reference_sampled"] = {"frames": checked, "rotation_rad_max": max(ang), "translation_rel_max": max(tr),
-                                                       "cpu_seconds_per_frame": (time.time() - t0) / max(1, len(checked))}
+                                                       "cpu_seconds_per_frame": (time.time() - t0) / max(1, len(checked)),
+                                                       "cpu_wall_seconds": time.time() - t0, "cpu_processes": max(1, min(a.oracle_workers, len(jobs)))}
 
     # ---- refinement ----
     traj_c = core.CameraTrajectory(1, n)
@@ -266,7 +273,39 @@ def run(width=1920, height=1080, frames=300, oracle_frames=6, oracle_stride=0, r
     dt = time.time() - t0
     refined = {f: (np.array(traj_c.get(f).pose.q, float), np.array(traj_c.get(f).pose.t, float)) for f in range(2, n + 1)}
     out["refinement"] = {"seconds": round(dt, 3), "iterations": last[-1].iterations if last else 0,
-                         "cost": [last[-1].initial_cost, last[-1].cost] if last else None, "vs_truth": errors(refined)}
+                         "cost": [last[-1].initial_cost, last[-1].cost] if last else None, "vs_truth": errors(refined),
+                         "stages": {k: [round(v[0], 3), v[1]] for k, v in core._stage_report("RefineTrajectory").items()}}
+    # ---- CPU baseline of the refinement sweeps: the float64 restatement on a sub-segment (checker leg) ----
+    if a.refine_oracle_frames > 2:
+        import refine_oracle as ro
+        m = min(a.refine_oracle_frames, n)
+        f0 = max(1, n // 2 - m // 2)
+        db = core.Database(path)
+        kps_d, flows_d = {}, {}
+        for f in range(f0, f0 + m):
+            kps_d[f] = db.read_keypoints(f)
+            fl = []
+            for to in db.find_optical_flows_from_image(f):
+                if f0 <= to < f0 + m:
+                    pf = db.read_image_pair_flow(f, to)
+                    fl.append((to, pf.src_kps_indices, pf.tgt_kps))
+            flows_d[f] = fl
+        db.close()
+        cams_o = [po.Camera(fx=-F, fy=-F, cx=W / 2, cy=H / 2, aspect_ratio=1.0, width=float(W), height=float(H), opencv=False,
+                            q=refined[f][0] if f in refined else po.R_to_quat(true_pose(f)[0]), t=refined[f][1] if f in refined else true_pose(f)[1])
+                  for f in range(f0, f0 + m)]
+        model64 = np.eye(4)
+        seg = ro.load_segment(kps_d, flows_d, cams_o, f0, verts, model64)
+        n_res = int(sum(len(e[2]) for e in seg.edges))
+        t0 = time.time()
+        ro.total_cost(seg, cams_o, verts.astype(np.float64), tris, None, model64, "cauchy", 1.0)
+        t_cost = time.time() - t0
+        t0 = time.time()
+        ro.normal_equations(seg, cams_o, verts.astype(np.float64), tris, model64, "cauchy", 1.0, False, False)
+        t_ne = time.time() - t0
+        out["refinement"]["cpu_reference"] = {"frames": m, "edges": len(seg.edges), "residuals": n_res, "cost_sweep_seconds": t_cost,
+                                              "normal_equations_seconds": t_ne, "processes": 1,
+                                              "what": "float64 numpy restatement of refiner.cc's sweeps (oracle/refine_oracle.py)"}
     for fn in os.listdir(td):
         os.remove(os.path.join(td, fn))
     os.rmdir(td)

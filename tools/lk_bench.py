@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--frame", type=int, default=100)
     ap.add_argument("--window", type=int, default=10)
     ap.add_argument("--arith", default="canonical", choices=["canonical", "lk_x86", "sobel_fma", "opencv_x86"])
+    ap.add_argument("--max-iters", type=int, default=30, help="term_max_iters (30 = the reference's default); smaller values CUT the "
+                    "stragglers' iterations off -- wrong results, but the time saved is the ceiling of what deferring them could gain")
     args = ap.parse_args()
 
     import torch
@@ -46,7 +48,7 @@ def main():
     ctx = hip.Context(0)
     ctx.set_arithmetic({"canonical": hip.ARITH_CANONICAL, "lk_x86": hip.ARITH_LK_X86_ORDER, "sobel_fma": hip.ARITH_SOBEL_FMA,
                         "opencv_x86": hip.ARITH_OPENCV_X86}[args.arith])
-    fopt = hip.flow_options(max_level=max_level, window_size=args.window)
+    fopt = hip.flow_options(max_level=max_level, window_size=args.window, term_max_iters=args.max_iters)
     frames = {}
     for s in (0,) + SKIPS:
         f = hip.Frame(ctx, w, h, args.window, max_level)
@@ -84,7 +86,7 @@ def main():
         ctx.lk_x86_stats(True)
         hip.lk_track(ctx, f1, targets, fopt)
         x86_stats = ctx.lk_x86_stats(False)
-    out = {"config": args.config, "window": args.window, "arith": args.arith, "keypoints": n, "launches": launches,
+    out = {"config": args.config, "window": args.window, "arith": args.arith, "max_iters": args.max_iters, "keypoints": n, "launches": launches,
            "lk_ms_per_launch": ms / max(1, launches), "tracked_rows": int((st == 1).sum()),
            "sha256": hsh.hexdigest()[:16], "lib": os.environ.get("POLYCHASE_HIP_LIB", "default")}
     if x86_stats is not None:

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Run ON the GPU box: isolated LK launch and bench.py frames/s for the default library and every variant under
-# polychase_amd/lib/variants/ (tools/lk_variants.py build ...).   tools/gpu_ab.sh [config] [variant ...]
-ROOT=$(cd "$(dirname "$0")/.." && pwd)
+# polychase_amd/lib/variants/ (tools/lk_variants/lk_variants.py build ...).   tools/gpu_ab.sh [config] [variant ...]
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 CFG=${1:-c2}; shift
 cd "$ROOT"
-python tools/lk_variants.py run --config $CFG --reps 20 "$@" 2>&1 | cut -c1-260
+python tools/lk_variants/lk_variants.py run --config $CFG --reps 20 "$@" 2>&1 | cut -c1-260
 LIBS="default $@"
 [ $# -eq 0 ] && LIBS="default $(ls polychase_amd/lib/variants 2>/dev/null | sed 's/libpolychase_hip_//; s/.so//')"
 for l in $LIBS; do

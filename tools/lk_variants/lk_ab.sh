@@ -1,11 +1,11 @@
 #!/bin/bash
-# Run ON the GPU box: the LK kernel variants of polychase_amd/lib/variants (tools/lk_variants.py build ...) and the other
+# Run ON the GPU box: the LK kernel variants of polychase_amd/lib/variants (tools/lk_variants/lk_variants.py build ...) and the other
 # LK kernels of the library, each measured three ways -- the launch alone (tools/lk_bench.py), the job lanes alone and the
 # whole pipeline (tools/lane_probe.py: modes lk, full).  One JSON line per variant -> gpurun_out/<tag>_lk_variants.jsonl
 #   tools/lk_ab.sh <tag> [config]
 TAG=${1:-r03}
 CFG=${2:-c2}
-ROOT=$(cd "$(dirname "$0")/.." && pwd)
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=$ROOT/gpurun_out/${TAG}_${CFG}_lk_variants.jsonl
 : > "$OUT"
 STEPS=200; [ "$CFG" = "c3" ] && STEPS=80

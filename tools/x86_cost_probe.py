@@ -35,45 +35,62 @@ def content(kind, w, h, t, rng_seed=7):
     return np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2))
 
 
-def main():
+def measure(contents=("c2 texture", "edges + texture", "binary blocks", "checkerboard"), w=1920, h=1080, reps=10, emit=None):
+    """one row per content; `sha256` covers every tracked row of the x86 launch (it must not move when the kernel is worked on)"""
+    import hashlib
     from polychase_amd import hip, synth
-    w, h = 1920, 1080
-    ctx = hip.Context(0)
     clip = synth.NoiseClip(w, h, 24)
-    out = []
-    for kind in ("c2 texture", "edges + texture", "binary blocks", "checkerboard"):
-        frames = []
-        for t in (10, 2, 6, 8, 9, 11, 12, 14, 18):
-            rgb = clip.frame(t) if kind == "c2 texture" else content(kind, w, h, t)
-            f = hip.Frame(ctx, w, h, 10, 3)
-            f.set_rgb(rgb)
-            frames.append(f)
-        row = {"content": kind}
-        for mode, flag in (("canonical", hip.ARITH_CANONICAL), ("lk_x86", hip.ARITH_LK_X86_ORDER)):
-            ctx.set_arithmetic(flag)
-            frames[0].detect()
-            hip.lk_track(ctx, frames[0], frames[1:], hip.flow_options())
-            ctx.enable_timing(["lk"])
-            ctx.reset_timing()
-            for _ in range(10):
-                hip.lk_track(ctx, frames[0], frames[1:], hip.flow_options())
-            n, ms = ctx.timing()["lk"]
-            ctx.enable_timing(False)
-            row[mode + "_ms"] = ms / n
-            if flag:
-                ctx.lk_x86_stats(True)
-                hip.lk_track(ctx, frames[0], frames[1:], hip.flow_options())
-                st = ctx.lk_x86_stats(False)
-                tot = st["iterations_proven_exact"] + st["iterations_x86_order"]
-                row["keypoints"] = frames[0].num_keypoints
-                row["iterations_in_x86_order"] = st["iterations_x86_order"] / max(1, tot)
-                row["levels_with_ordered_structure_tensor"] = st["keypoint_levels_x86_order"] / max(1, st["keypoint_levels"])
-        row["x86_over_canonical"] = row["lk_x86_ms"] / row["canonical_ms"]
-        out.append(row)
-        print(json.dumps(row), flush=True)
-        for f in frames:
-            f.close()
-    ctx.close()
+    rows = []
+    for kind in contents:
+        rgbs = [clip.frame(t) if kind == "c2 texture" else content(kind, w, h, t) for t in (10, 2, 6, 8, 9, 11, 12, 14, 18)]
+        for _once in (0,):
+            ctx = hip.Context(0)
+            frames = []
+            for rgb in rgbs:
+                f = hip.Frame(ctx, w, h, 10, 3)
+                f.set_rgb(rgb)
+                frames.append(f)
+            row = {"content": kind}
+            for mode, flag in (("canonical", hip.ARITH_CANONICAL), ("lk_x86", hip.ARITH_LK_X86_ORDER)):
+                ctx.set_arithmetic(flag)
+                frames[0].detect()
+                xy, st, err = hip.lk_track(ctx, frames[0], frames[1:], hip.flow_options())
+                ctx.enable_timing(["lk"])
+                ctx.reset_timing()
+                for _ in range(reps):
+                    hip.lk_track(ctx, frames[0], frames[1:], hip.flow_options())
+                n, ms = ctx.timing()["lk"]
+                ctx.enable_timing(False)
+                row[mode + "_ms"] = ms / n
+                if flag:
+                    hsh = hashlib.sha256()
+                    m = st == 1
+                    for arr in (st, xy[m], err[m]):
+                        hsh.update(np.ascontiguousarray(arr).tobytes())
+                    row["sha256"] = hsh.hexdigest()[:16]
+                    ctx.lk_x86_stats(True)
+                    hip.lk_track(ctx, frames[0], frames[1:], hip.flow_options())
+                    stt = ctx.lk_x86_stats(False)
+                    tot = stt["iterations_proven_exact"] + stt["iterations_x86_order"]
+                    row["keypoints"] = frames[0].num_keypoints
+                    row["iterations_in_x86_order"] = stt["iterations_x86_order"] / max(1, tot)
+                    row["levels_with_ordered_structure_tensor"] = stt["keypoint_levels_x86_order"] / max(1, stt["keypoint_levels"])
+            row["x86_over_canonical"] = row["lk_x86_ms"] / row["canonical_ms"]
+            rows.append(row)
+            if emit:
+                emit(row)
+            for f in frames:
+                f.close()
+            ctx.close()
+    return rows
+
+
+def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--contents", default="c2 texture,edges + texture,binary blocks,checkerboard")
+    a = ap.parse_args()
+    measure(tuple(a.contents.split(",")), emit=lambda row: print(json.dumps(row), flush=True))
 
 
 if __name__ == "__main__":
