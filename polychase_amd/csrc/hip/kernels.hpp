@@ -220,7 +220,7 @@ void launch_pnp_cost(const float* X, const float* x, const float* w, int n, cons
 
 // ---- SolveFrame in two launches (kernels_tracker.hip: track_cast_kernel, track_lm_kernel) ----
 constexpr int kTrackMaxSources = 8;     // flows into a frame: the skips -8 .. +8 (cpp/opticalflow.cc:76-77)
-constexpr int kTrackSyncWords = 64 + 512; // barrier words of track_lm_kernel: zero before the launch, left zero by it
+constexpr int kTrackSyncWords = 64 + 256; // barrier words of track_lm_kernel: zero before the launch, left zero by it
 struct TrackSource {                    // one source frame of the frame being solved
     RayCamera cam;                      // the source's camera, object space (GetRayObjectSpace, ray_casting.h:53-63)
     const float2* kps;                  // its keypoints (device)

@@ -540,9 +540,10 @@ void launch_pnp_cost(const float* X, const float* x, const float* w, int n, cons
 // Cross-workgroup data follows common.hpp's rules for this chip (the XCDs' L2s are not coherent with one another): what
 // another workgroup will read is written with agent-scope atomic stores and read either with agent-scope atomic loads (the
 // round word, the parameters) or with plain loads behind ONE acquire fence in the reading workgroup (the partials).
-// Co-residency: at most 512 workgroups of 256 lanes, ~2 KB of LDS each -- two per CU at any register count -- so every
-// workgroup of the launch is resident however little of the GPU is free, and nothing else on the GPU waits for this
-// kernel; the spin loops sleep between polls and give up after kTrackSpinLimit ticks (status 2) instead of hanging.
+// Co-residency: at most 256 workgroups of 256 lanes (one per CU of this chip), 12 KB of LDS each: every workgroup of the launch
+// is resident as long as half of every CU's registers are free, and nothing else on the GPU waits for this kernel.  The spin
+// loops sleep between polls and give up after kTrackSpinLimit ticks (status 2) instead of hanging: the host then solves the
+// frame -- and the rest of the run -- with the per-source building blocks (csrc/host/track_sequence.cc).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RC_BLOCK) void track_cast_kernel(TrackCastArgs a) {
     __shared__ int s_stack[kBvhStack][RC_BLOCK];
@@ -608,7 +609,7 @@ static_assert(sizeof(PnPParams) % sizeof(uint32_t) == 0, "PnPParams travels word
 //                               first and the parameters fetched after cost two).
 //   [kSyncFlags + b]            workgroup b has published its partial sums of round r: r + 1
 constexpr int kSyncAbort = 0, kSyncParams = 2, kSyncFlags = 64;
-static_assert(kSyncParams + 2 * (kParamWords + 1) <= kSyncFlags && kSyncFlags + 512 <= kTrackSyncWords, "sync layout");
+static_assert(kSyncParams + 2 * (kParamWords + 1) <= kSyncFlags && kSyncFlags + 256 <= kTrackSyncWords, "sync layout");
 constexpr long long kTrackSpinLimit = 500000000ll;   // wall_clock64 ticks (100 MHz): 5 s
 
 __device__ __forceinline__ uint32_t peek(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -668,13 +669,12 @@ __device__ __forceinline__ void grid_arrive(uint32_t* sync, uint32_t arrival) {
 }
 // workgroup 0: until every workgroup's flag says `arrival` (lane t watches the flags t, t + 256); the result in s_ok
 __device__ __forceinline__ void wait_for_all(uint32_t* sync, uint32_t arrival, int* s_ok) {
-    const int G = gridDim.x, t = threadIdx.x;
-    bool a = t >= G, b = t + 256 >= G;
+    const int G = gridDim.x, t = threadIdx.x;   // G <= 256 = the lanes of this workgroup: lane t watches the flag of workgroup t
+    bool a = t >= G;
     const bool ok = spin_until(
         [&]() {
             if (!a) a = peek(sync + kSyncFlags + t) == arrival;
-            if (!b) b = peek(sync + kSyncFlags + t + 256) == arrival;
-            return a && b;
+            return a;
         },
         sync);
     if (t == 0) *s_ok = 1;
@@ -683,8 +683,8 @@ __device__ __forceinline__ void wait_for_all(uint32_t* sync, uint32_t arrival, i
     __syncthreads();
 }
 
-// Sum of `nblocks` (<= 512) partials of each of NV values by one 256-lane workgroup: wave w takes the values w, w + 4, ...;
-// lane l adds the partials l, l + 64, ... (8 of them), then a fixed shuffle tree.  ALL loads of a lane are issued before the
+// Sum of `nblocks` (<= 256) partials of each of NV values by one 256-lane workgroup: wave w takes the values w, w + 4, ...;
+// lane l adds the partials l, l + 64, ... (4 of them), then a fixed shuffle tree.  ALL loads of a lane are issued before the
 // first is consumed: behind the acquire fence every one of them misses the L2, and a loop that waits for each load in turn
 // (round 4's second stage, and the first version of this kernel: 14 values x 8 dependent misses per lane) took longer than
 // the sweep it follows.
@@ -692,12 +692,12 @@ template <int NV>
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ partials, int nblocks, float* s_out) {
     constexpr int PER_WAVE = (NV + 3) / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float v[PER_WAVE][8];
+    float v[PER_WAVE][4];
 #pragma unroll
     for (int q = 0; q < PER_WAVE; q++) {
         const int k = wave + 4 * q;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < 4; j++) {
             const int b = lane + 64 * j;
             v[q][j] = (k < NV && b < nblocks) ? partials[(size_t)k * nblocks + b] : 0.f;
         }
@@ -705,7 +705,7 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ partia
 #pragma unroll
     for (int q = 0; q < PER_WAVE; q++) {
         const int k = wave + 4 * q;
-        float s = ((v[q][0] + v[q][1]) + (v[q][2] + v[q][3])) + ((v[q][4] + v[q][5]) + (v[q][6] + v[q][7]));
+        float s = (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
         if (lane == 0 && k < NV) s_out[k] = s;
@@ -903,7 +903,13 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
     }
 }
 
-int track_lm_blocks(int n) { return pnp_num_blocks(n); }
+// At most ONE workgroup per CU (256 on this chip): the launch needs every workgroup resident at once, and with one per CU that
+// holds as long as half of every CU's registers are free -- two per CU (512 workgroups, 239 VGPRs each) left no room for anything
+// else on the GPU.  Measured on C5 (150 k matches per frame): the sweep gets a third loop trip, the partial sums and flags halve.
+int track_lm_blocks(int n) {
+    const int b = (n + 255) / 256;
+    return b < 1 ? 1 : (b > 256 ? 256 : b);
+}
 void launch_track_lm(const TrackLmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(track_lm_kernel, dim3(track_lm_blocks(a.n)), dim3(256), 0, s, a);
 }

@@ -449,6 +449,18 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
         ~StageClock() { *acc += Now() - t0; }
     };
     std::mutex db_mtx;
+    // The reference asks the database before every piece of work whether it is there already (keypoints :168-178, pairs :286):
+    // that is how a cancelled analysis resumes.  A database that holds NO keypoints row of this clip when the run starts cannot
+    // answer "yes" to any of those questions later either -- the rows this run writes are of frames whose questions have
+    // been asked (a flow row needs its frame's keypoints row: the schema's foreign key) -- so the questions are not asked: ten
+    // lock acquisitions per frame that each waited for the writer thread's current record (0.8 ms at 1080p) and kept its queue
+    // empty, i.e. every record in a transaction of its own whatever POLYCHASE_DB_BATCH_FRAMES said.
+    bool resume = false;
+    if (db) {
+        const int32_t lo = db->GetMinImageIdWithKeypoints(), hi = db->GetMaxImageIdWithKeypoints();
+        resume = lo != kInvalidId && hi != kInvalidId && hi >= video_info.first_frame &&
+                 lo < video_info.first_frame + static_cast<int32_t>(video_info.num_frames);
+    }
     std::unique_ptr<RecordWriter> writer;
     if (db) writer = std::make_unique<RecordWriter>(db.get(), &db_mtx, &local_stats);
 
@@ -586,7 +598,7 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
                     "Exiting optical flow generation prematurely because some frames were not provided");
             }
             bool will_detect = fid >= f1_begin && fid < f1_end;   // the halo of a shard is tracked into, never from
-            if (db && will_detect) {
+            if (db && resume && will_detect) {
                 std::lock_guard<std::mutex> lk(db_mtx);
                 will_detect = !db->KeypointsExist(fid);
             }
@@ -629,7 +641,7 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
             highest_put = fid;
         }
         // ReadOrGenerateKeypoints (:168-178)
-        if (db) {
+        if (db && resume) {
             known.clear();
             {
                 std::lock_guard<std::mutex> lk(db_mtx);
@@ -644,7 +656,7 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
         for (int32_t skip : kImageSkips) {
             const int32_t frame_id2 = frame_id1 + skip;
             if (frame_id2 < from || frame_id2 >= to) continue;               // :282
-            if (db) {
+            if (db && resume) {
                 std::lock_guard<std::mutex> lk(db_mtx);
                 if (db->ImagePairFlowExists(frame_id1, frame_id2)) continue;  // :286
             }

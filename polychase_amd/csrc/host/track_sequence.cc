@@ -379,6 +379,8 @@ std::optional<PnPResult> SolveFrameUnfused(const Database& db, const CameraTraje
 // because only the LAUNCH needs the pose of the frame before: while the GPU solves frame f the host plans frame f + 1 (which
 // flows, where their blobs are) and its matches travel to the GPU on the copy stream; when the pose of f arrives the launches
 // of f + 1 are enqueued at once, and the caller's callback for f runs beside them. ----
+struct CoResidencyLost {};   // pc_track_frame_finish: the persistent launch's workgroups did not all become resident in time
+
 class FrameSolver {
    public:
     FrameSolver(const Database& db, const CameraTrajectory& traj, const Mat4f& model_matrix, const AcceleratedMesh& mesh,
@@ -477,8 +479,10 @@ class FrameSolver {
             StageClock::Scope sc("track/wait for the GPU");
             GpuSection section;
             if (pc_track_frame_finish(s_.ctx, s_.set, &sr) != PC_OK) {
+                const std::string why = pc_last_error();
+                if (why.find("become resident") != std::string::npos) throw CoResidencyLost{};
                 // an index past the source's keypoints: the reference's CHECK_LT (tracker.cc:61)
-                CHECK(std::string(pc_last_error()).find("out of range") == std::string::npos);
+                CHECK(why.find("out of range") == std::string::npos);
                 ThrowHip("pc_track_frame_finish");
             }
         }
@@ -517,6 +521,14 @@ class FrameSolver {
         return result;
     }
     int32_t frame() const { return frame_; }
+    // waits for whatever this solver has in flight and forgets it
+    void Drain() {
+        if (!launched_) return;
+        launched_ = false;
+        GpuSection section;
+        pc_track_solve_result unused;
+        (void)pc_track_frame_finish(s_.ctx, s_.set, &unused);
+    }
 
    private:
     const Database& db_;
@@ -615,6 +627,10 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
         FrameSolver solvers[2] = {FrameSolver(database, camera_traj, model_matrix, accel_mesh, pnp_opts, scratch),
                                   FrameSolver(database, camera_traj, model_matrix, accel_mesh, pnp_opts, scratch)};
         int cur = 0;
+        bool fused_lost = false;
+        const char* lose_env = std::getenv("POLYCHASE_TRACK_TEST_LOSE_AT");   // read per run
+        const int lose_at = lose_env ? std::atoi(lose_env) : 0;
+        int finished = 0;
         request(first);
         {
             FlowPrefetcher::Batch* batch = prefetcher.Take(first);
@@ -631,7 +647,27 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
                 request(next + step);
                 then.Plan(next, batch, &frame);
             }
-            const std::optional<PnPResult> solved = now.Finish();
+            std::optional<PnPResult> solved;
+            try {
+                solved = now.Finish();
+                if (lose_at > 0 && ++finished == lose_at) throw CoResidencyLost{};   // POLYCHASE_TRACK_TEST_LOSE_AT: testing aid
+            } catch (const CoResidencyLost&) {
+                // The persistent LM launch needs all its workgroups on the GPU at once; another tenant of the GPU (an analysis
+                // running in the same host, say) can keep that from happening, and the launch then gives up after its time
+                // limit.  The frame is solved with the per-source building blocks instead (no such requirement), and so is
+                // the rest of this run.
+                fused_lost = true;
+            }
+            if (fused_lost) {
+                then.Drain();
+                for (int32_t f = frame; f != end; f += step) {
+                    const std::optional<PnPResult> r = SolveFrameUnfused(database, camera_traj, model_matrix, f, accel_mesh, pnp_opts, scratch, nullptr);
+                    if (!r) throw std::runtime_error("Could not track to frame: " + std::to_string(f) + ". Not enough features.");
+                    if (!report_and_store(f, *r)) return;
+                    camera_traj.Set(f, r->camera);
+                }
+                break;
+            }
             if (!solved) throw std::runtime_error("Could not track to frame: " + std::to_string(frame) + ". Not enough features.");
             // the pose goes in at once -- the next frame's launches need it -- and comes out again if the callback stops the run:
             // the pose of a frame the user stopped at is not stored (:179-186)

@@ -587,3 +587,88 @@ def test_ray_cast_from_python_while_a_tracker_thread_runs(core, tmp_path):
     assert done and sorted(got) == sorted(quiet) and casts >= 10
     for f in quiet:
         assert np.array_equal(got[f][0], quiet[f][0]) and np.array_equal(got[f][1], quiet[f][1]), f
+
+
+def test_pipelined_solve_frame_semantics(core, tmp_path, monkeypatch):
+    """Round 5: SolveFrame is one transfer + two launches + one wait, and the host runs one frame ahead of the GPU (the launches of
+    frame f + 1 are enqueued before the callback of frame f).  What the caller sees must be what the frame-by-frame loop of
+    cpp/tracker.cc:133-192 shows: the same poses as the per-source building blocks (POLYCHASE_TRACK_FUSED=0: the cross-check path),
+    a callback that stops the run at frame k (nothing after k is reported, the speculative launches of k + 1 are dropped, the next
+    run is clean), an exception out of the callback, and "Not enough features" at the frame that has no flows."""
+    verts, tris = grid_mesh()
+    model = np.diag([1.5, 1.5, 1.5, 1.0]).astype(np.float32)
+    n_frames = 16
+    path = str(tmp_path / "flow.db")
+    _build_flow_db(core, path, verts, tris, model, n_frames, noise=0.05)
+    mesh = core.AcceleratedMesh(verts, tris)
+    bo = core.BundleOptions()
+    bo.loss_type = core.LossType.Cauchy
+
+    def run(a, b, cb=None):
+        R0, t0 = true_pose(a)
+        st = core.SceneTransformations(model, view4(R0, t0), intr(core))
+        got = {}
+
+        def default_cb(r):
+            got[r.frame] = (np.array(r.pose.q, float), np.array(r.pose.t, float), r.inlier_ratio, r.bundle_stats.iterations)
+            return True if cb is None else cb(r)
+        core.track_sequence(path, a, b, st, mesh, default_cb, False, False, bo)
+        return got
+
+    for a, b in ((1, n_frames), (n_frames, 1)):
+        monkeypatch.delenv("POLYCHASE_TRACK_FUSED", raising=False)
+        fused = run(a, b)
+        again = run(a, b)
+        monkeypatch.setenv("POLYCHASE_TRACK_FUSED", "0")
+        blocks = run(a, b)
+        monkeypatch.delenv("POLYCHASE_TRACK_FUSED", raising=False)
+        assert sorted(fused) == sorted(blocks) and len(fused) == n_frames - 1
+        for f in fused:
+            assert np.array_equal(fused[f][0], again[f][0]) and np.array_equal(fused[f][1], again[f][1]), f      # deterministic
+            assert np.abs(fused[f][0] - blocks[f][0]).max() < 2e-6 and np.abs(fused[f][1] - blocks[f][1]).max() < 2e-5, f
+            assert abs(fused[f][2] - blocks[f][2]) < 1e-3
+    # the callback stops the run at frame 7: frames 2 .. 7 reported, nothing later (frame 8 was launched speculatively)
+    seen = run(1, n_frames, cb=lambda r: r.frame < 7)
+    assert sorted(seen) == [2, 3, 4, 5, 6, 7]
+    full = run(1, n_frames)
+    assert sorted(full) == list(range(2, n_frames + 1))
+    for f in seen:
+        assert np.array_equal(seen[f][0], full[f][0]) and np.array_equal(seen[f][1], full[f][1])
+    # an exception out of the callback travels to the caller; the next run is clean
+
+    class Boom(Exception):
+        pass
+
+    def boom(r):
+        if r.frame == 5:
+            raise Boom("stop")
+        return True
+    with pytest.raises(Exception, match="stop"):
+        run(1, n_frames, cb=boom)
+    after = run(1, n_frames)
+    assert all(np.array_equal(after[f][0], full[f][0]) for f in full)
+    # the persistent launch could not get its workgroups resident (another tenant holds the GPU): the frame and the rest of the run
+    # are solved with the per-source building blocks -- every frame reported once, same poses (POLYCHASE_TRACK_TEST_LOSE_AT: the
+    # 4th finished frame behaves as if its launch had timed out)
+    monkeypatch.setenv("POLYCHASE_TRACK_TEST_LOSE_AT", "4")
+    lost = run(1, n_frames)
+    monkeypatch.delenv("POLYCHASE_TRACK_TEST_LOSE_AT", raising=False)
+    assert sorted(lost) == sorted(full)
+    for f in full:
+        assert np.abs(lost[f][0] - full[f][0]).max() < 2e-6 and np.abs(lost[f][1] - full[f][1]).max() < 2e-5, f
+    for f in (2, 3, 4):
+        assert np.array_equal(lost[f][0], full[f][0])      # before the loss: the same path
+    # a frame without any flow into it: reported as in the reference, after the callbacks of the frames before it
+    db = core.Database(path)
+    import sqlite3
+    db.close()
+    con = sqlite3.connect(path)
+    con.execute("DELETE FROM optical_flow WHERE image_id_to = 9")
+    con.commit()
+    con.close()
+    seen = {}
+    with pytest.raises(RuntimeError, match="Could not track to frame: 9. Not enough features"):
+        R0, t0 = true_pose(1)
+        core.track_sequence(path, 1, n_frames, core.SceneTransformations(model, view4(R0, t0), intr(core)), mesh,
+                            lambda r: seen.update({r.frame: 1}) or True, False, False, bo)
+    assert sorted(seen) == [2, 3, 4, 5, 6, 7, 8]
