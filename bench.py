@@ -241,7 +241,7 @@ def c5_block():
 
     t0 = time.perf_counter()
     r = c5_endtoend.run(width=1920, height=1080, frames=300, oracle_frames=0, oracle_stride=29, refine_iterations=30, oracle_workers=10,
-                        refine_oracle_frames=10)
+                        refine_oracle_frames=6)
     tr, rf = r["tracking"], r["refinement"]
     s = tr.get("vs_cpu_reference_sampled", {})
     st = tr.get("stages", {})

@@ -566,18 +566,8 @@ int pc_context_create(int device_index, pc_context** out) {
     {
         const char* v = getenv("POLYCHASE_DETECT_STREAMS");
         c->n_detect = v ? std::max(0, std::min(2, atoi(v))) : 0;
-        // POLYCHASE_DETECT_CUMASK=1 (experiment): created with a (full) CU mask a stream owns its hardware queue instead of
-        // sharing one of the runtime's pool of GPU_MAX_HW_QUEUES (4)
-        const bool masked = getenv("POLYCHASE_DETECT_CUMASK") != nullptr;
-        for (int k = 0; k < c->n_detect && e == hipSuccess; k++) {
-            if (masked) {
-                uint32_t mask[8];
-                for (uint32_t& m : mask) m = 0xffffffffu;
-                e = hipExtStreamCreateWithCUMask(&c->detect_stream[k], 8, mask);
-            } else {
-                e = hipStreamCreateWithFlags(&c->detect_stream[k], hipStreamNonBlocking);
-            }
-        }
+        for (int k = 0; k < c->n_detect && e == hipSuccess; k++)
+            e = hipStreamCreateWithFlags(&c->detect_stream[k], hipStreamNonBlocking);
     }
     c->work = c->stream;
     {

@@ -579,8 +579,10 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
     pnp_opts.optimize_principal_point = optimize_principal_point;
 
     const int32_t step = frame_from < frame_to_inclusive ? 1 : -1;
-    Scratch scratch;
+    // (in this order: the scratch -- whose destructor waits for every stream of the correspondence set, the copy stream included --
+    // goes first, the prefetcher with the page-locked blocks those copies read from after it)
     FlowPrefetcher prefetcher(database.Path());
+    Scratch scratch;
     std::vector<int32_t> next_sources, wanted;
     // what frame `next` will need, read ahead: flows from the frames that have a pose by then -- filled now, or tracked
     // before it in this run -- and the keypoints of the frame tracked just before it (the one array no cache holds yet)
