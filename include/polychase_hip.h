@@ -510,6 +510,20 @@ typedef struct pc_refine_camera {
 
 int pc_refine_problem_create(pc_context* ctx, const pc_mesh* mesh, const pc_refine_desc* desc,
                              pc_refine_problem** out);
+/* The same problem with its three large arrays handed over in pieces: the keypoints and the residuals of consecutive runs of
+ * frames (what the reader threads of CachedDatabase's replacement each hold -- a 300-frame 1080p segment is 1.2 GB, and joining
+ * the pieces on the host first costs as much as reading them).  desc->kp_xy, res_src_kp and res_tgt_xy must be NULL; the parts,
+ * in order, make up kp_offset[n_frames] keypoints and edge_offset[n_edges] residuals.  A residual that names a keypoint its
+ * source frame does not have is found on the device and refused like pc_refine_problem_create refuses it. */
+typedef struct pc_refine_part {
+    const float* kp_xy;           /* n_keypoints (x, y) */
+    int64_t n_keypoints;
+    const uint32_t* res_src_kp;   /* n_residuals */
+    const float* res_tgt_xy;      /* n_residuals (x, y) */
+    int64_t n_residuals;
+} pc_refine_part;
+int pc_refine_problem_create_parts(pc_context* ctx, const pc_mesh* mesh, const pc_refine_desc* desc, const pc_refine_part* parts,
+                                   int n_parts, pc_refine_problem** out);
 void pc_refine_problem_destroy(pc_refine_problem* prob);
 /* LevMarqSparseSolver::TotalCost (lev_marq.h:773-824) over RefinementProblemBase::Evaluate
  * (refiner.cc:274-361); updates the per-keypoint triangle cache like the reference does. */
@@ -522,6 +536,11 @@ int pc_refine_total_cost(pc_context* ctx, pc_refine_problem* prob, const pc_refi
  * semi-definite to rounding (long weakly-damped chains need it). */
 int pc_refine_normal_equations(pc_context* ctx, pc_refine_problem* prob, const pc_refine_camera* cameras,
                                int loss_type, float loss_scale, double* edge_blocks, int* edge_valid);
+
+/* GPU time of the sweeps of this problem so far: HIP events on the context's stream around the kernel of every
+ * pc_refine_total_cost / pc_refine_normal_equations call (launches, summed milliseconds).  Any pointer may be NULL. */
+int pc_refine_problem_timing(const pc_refine_problem* prob, int* cost_launches, double* cost_ms, int* normal_eq_launches,
+                             double* normal_eq_ms);
 
 /* ---- record exchange between the ranks of a multi-GPU analysis (one process per GPU) --------------------------------
  * The stitch of the flow database (the reference's store, cpp/opticalflow.cc:149-151, sharded): a rank exports a

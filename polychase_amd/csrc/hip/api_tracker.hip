@@ -1,5 +1,7 @@
 // api_tracker.hip -- C ABI of the tracking and refinement paths: meshes + LBVH ray casting, PnP accumulation
 // (reference cpp/tracker.cc, cpp/pnp/*), and the refiner's per-edge sweeps (cpp/refiner.cc, cpp/pnp/lev_marq.h).
+#include <limits>
+
 #include "api_internal.hpp"
 #include "pnp_lm.hpp"
 
@@ -897,6 +899,10 @@ struct pc_refine_problem {
     DevBuf<float2> kp_xy, res_tgt_xy;
     DevBuf<double2> edge_cost;
     DevBuf<uint32_t> res_src_kp, prim_cache;
+    DevBuf<float4> tri_plane, tri_verts;
+    hipEvent_t sweep_begin = nullptr, sweep_end = nullptr;   // around the kernel of every sweep
+    int cost_launches = 0, neq_launches = 0;
+    double cost_ms = 0.0, neq_ms = 0.0;
     DevBuf<float> edge_weight;
     DevBuf<double> edge_blocks;
     DevBuf<uint8_t> frame_fixed;
@@ -923,6 +929,8 @@ pc::RefineProblemView refine_view(const pc_refine_problem* p) {
     v.edge_weight = p->edge_weight.p;
     v.frame_fixed = p->frame_fixed.p;
     v.prim_cache = p->prim_cache.p;
+    v.tri_plane = p->tri_plane.p;
+    v.tri_verts = p->tri_verts.p;
     v.verts = p->mesh->verts.p;
     v.tris = p->mesh->tris.p;
     v.mask = p->mesh->mask.p;
@@ -961,21 +969,37 @@ hipError_t upload(DevBuf<T>& dst, const U* src, size_t n, hipStream_t s) {
 
 extern "C" {
 
-int pc_refine_problem_create(pc_context* ctx, const pc_mesh* mesh, const pc_refine_desc* d, pc_refine_problem** out) {
-    if (!ctx || !mesh || !d || !out) return fail(PC_E_INVALID, "null argument");
+int pc_refine_problem_create_parts(pc_context* ctx, const pc_mesh* mesh, const pc_refine_desc* d, const pc_refine_part* parts,
+                                   int n_parts, pc_refine_problem** out) {
+    if (!ctx || !mesh || !d || !out || (n_parts > 0 && !parts) || n_parts < 0) return fail(PC_E_INVALID, "null argument");
     *out = nullptr;
     if (d->n_frames < 3) return fail(PC_E_INVALID, "a segment needs more than 2 frames");  // CHECK(traj.Count() > 2)
     if (d->n_edges < 0 || (d->block_len != 6 && d->block_len != 9)) return fail(PC_E_INVALID, "bad problem description");
     if (!d->kp_offset || !d->edge_offset || (d->n_edges > 0 && (!d->edge_src || !d->edge_tgt || !d->edge_weight)))
         return fail(PC_E_INVALID, "null array");
+    if (d->kp_xy || d->res_src_kp || d->res_tgt_xy) return fail(PC_E_INVALID, "the large arrays come in the parts: leave them NULL in the description");
+    if (d->kp_offset[0] != 0 || d->edge_offset[0] != 0) return fail(PC_E_INVALID, "offsets start at 0");
+    for (int f = 0; f < d->n_frames; f++)
+        if (d->kp_offset[f + 1] < d->kp_offset[f]) return fail(PC_E_INVALID, "kp_offset decreases at frame %d", f);
     const size_t n_kp = (size_t)d->kp_offset[d->n_frames], n_res = (size_t)d->edge_offset[d->n_edges];
     for (int e = 0; e < d->n_edges; e++) {
         if (d->edge_src[e] < 0 || d->edge_src[e] >= d->n_frames || d->edge_tgt[e] < 0 || d->edge_tgt[e] >= d->n_frames ||
             d->edge_src[e] == d->edge_tgt[e])
             return fail(PC_E_INVALID, "edge %d connects invalid frames", e);
-        const size_t src_kps = (size_t)(d->kp_offset[d->edge_src[e] + 1] - d->kp_offset[d->edge_src[e]]);
-        for (int r = d->edge_offset[e]; r < d->edge_offset[e + 1]; r++)
-            if (d->res_src_kp[r] >= src_kps) return fail(PC_E_INVALID, "edge %d references keypoint %u of %zu", e, d->res_src_kp[r], src_kps);
+        if (d->edge_offset[e + 1] < d->edge_offset[e]) return fail(PC_E_INVALID, "edge_offset decreases at edge %d", e);
+    }
+    {
+        size_t kp_sum = 0, res_sum = 0;
+        for (int t = 0; t < n_parts; t++) {
+            const pc_refine_part& part = parts[t];
+            if (part.n_keypoints < 0 || part.n_residuals < 0 || (part.n_keypoints > 0 && !part.kp_xy) ||
+                (part.n_residuals > 0 && (!part.res_src_kp || !part.res_tgt_xy)))
+                return fail(PC_E_INVALID, "part %d: null array or negative count", t);
+            kp_sum += (size_t)part.n_keypoints;
+            res_sum += (size_t)part.n_residuals;
+        }
+        if (kp_sum != n_kp || res_sum != n_res)
+            return fail(PC_E_INVALID, "the parts hold %zu keypoints and %zu residuals, the offsets say %zu and %zu", kp_sum, res_sum, n_kp, n_res);
     }
     PC_HIP(hipSetDevice(ctx->device));
     pc_refine_problem* p = new (std::nothrow) pc_refine_problem();
@@ -996,14 +1020,29 @@ int pc_refine_problem_create(pc_context* ctx, const pc_mesh* mesh, const pc_refi
     const int B2 = 2 * d->block_len, nacc = B2 * (B2 + 1) / 2 + B2;
     hipStream_t s = ctx->stream;
     hipError_t e = upload(p->kp_offset, d->kp_offset, (size_t)d->n_frames + 1, s);
-    if (e == hipSuccess) e = upload(p->kp_xy, d->kp_xy, n_kp, s);
     if (e == hipSuccess) e = upload(p->edge_src, d->edge_src, (size_t)d->n_edges, s);
     if (e == hipSuccess) e = upload(p->edge_tgt, d->edge_tgt, (size_t)d->n_edges, s);
     if (e == hipSuccess) e = upload(p->edge_offset, d->edge_offset, (size_t)d->n_edges + 1, s);
-    if (e == hipSuccess) e = upload(p->res_src_kp, d->res_src_kp, n_res, s);
-    if (e == hipSuccess) e = upload(p->res_tgt_xy, d->res_tgt_xy, n_res, s);
     if (e == hipSuccess) e = upload(p->edge_weight, d->edge_weight, (size_t)d->n_edges, s);
     if (e == hipSuccess) e = upload(p->frame_fixed, fixed.data(), fixed.size(), s);
+    if (e == hipSuccess) e = p->kp_xy.ensure(n_kp ? n_kp : 1);
+    if (e == hipSuccess) e = p->res_src_kp.ensure(n_res ? n_res : 1);
+    if (e == hipSuccess) e = p->res_tgt_xy.ensure(n_res ? n_res : 1);
+    {   // Every part to its place.  The pieces are pageable host memory: the runtime page-locks the source of a large copy on
+        // the fly, which is what bounds this (17 GB/s from 4-KiB pages, 38-44 GB/s from 2-MiB pages: the host side allocates
+        // its parts with MADV_HUGEPAGE).  Measured and not better: hipHostRegister around the copies, several threads with a
+        // stream each, a hand-made staging pipeline through page-locked blocks (tools/probes/pageable_upload_probe.hip).
+        size_t kp_at = 0, res_at = 0;
+        for (int t = 0; t < n_parts && e == hipSuccess; t++) {
+            const pc_refine_part& part = parts[t];
+            const size_t nk = (size_t)part.n_keypoints, nr = (size_t)part.n_residuals;
+            if (nk) e = hipMemcpyAsync(p->kp_xy.p + kp_at, part.kp_xy, nk * sizeof(float2), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess && nr) e = hipMemcpyAsync(p->res_src_kp.p + res_at, part.res_src_kp, nr * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess && nr) e = hipMemcpyAsync(p->res_tgt_xy.p + res_at, part.res_tgt_xy, nr * sizeof(float2), hipMemcpyHostToDevice, s);
+            kp_at += nk;
+            res_at += nr;
+        }
+    }
     if (e == hipSuccess) e = p->prim_cache.ensure(n_kp ? n_kp : 1);
     if (e == hipSuccess) e = hipMemsetAsync(p->prim_cache.p, 0xff, (n_kp ? n_kp : 1) * sizeof(uint32_t), s);
     if (e == hipSuccess) e = p->edge_cost.ensure((size_t)std::max(1, d->n_edges));
@@ -1011,14 +1050,58 @@ int pc_refine_problem_create(pc_context* ctx, const pc_mesh* mesh, const pc_refi
     if (e == hipSuccess) e = p->edge_valid.ensure((size_t)std::max(1, d->n_edges));
     if (e == hipSuccess) e = p->edge_blocks.ensure((size_t)std::max(1, d->n_edges) * nacc);
     if (e == hipSuccess) e = p->cams.ensure((size_t)d->n_frames);
+    if (e == hipSuccess) e = hipEventCreate(&p->sweep_begin);
+    if (e == hipSuccess) e = hipEventCreate(&p->sweep_end);
+    if (e == hipSuccess) e = p->tri_plane.ensure(2 * (size_t)std::max(1, mesh->n_triangles));
+    if (e == hipSuccess) e = p->tri_verts.ensure(3 * (size_t)std::max(1, mesh->n_triangles));
+    if (e == hipSuccess) {
+        pc::launch_refine_tri_planes(refine_view(p), p->tri_plane.p, s);
+        pc::launch_refine_tri_verts(refine_view(p), p->tri_verts.p, s);
+        e = hipGetLastError();
+    }
+    // the residuals' keypoint indices are checked where they now are (edge_valid is free until the first sweep)
+    int bad[2] = {std::numeric_limits<int>::max(), 0};
+    if (e == hipSuccess && d->n_edges > 0) {
+        e = p->edge_valid.ensure((size_t)std::max(2, d->n_edges));
+        if (e == hipSuccess) e = hipMemcpyAsync(p->edge_valid.p, bad, sizeof(bad), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            pc::launch_refine_validate(refine_view(p), p->edge_valid.p, s);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(bad, p->edge_valid.p, sizeof(bad), hipMemcpyDeviceToHost, s);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
         pc_refine_problem_destroy(p);
         return fail(PC_E_HIP, "refine problem upload failed: %s", hipGetErrorString(e));
     }
+    if (bad[0] != std::numeric_limits<int>::max()) {
+        const int edge = bad[0];
+        const int src_kps = d->kp_offset[d->edge_src[edge] + 1] - d->kp_offset[d->edge_src[edge]];
+        pc_refine_problem_destroy(p);
+        return fail(PC_E_INVALID, "edge %d references a keypoint (up to %d) its source frame does not have (%d keypoints)", edge, bad[1], src_kps);
+    }
     p->h_edge_weight.assign(d->edge_weight, d->edge_weight + d->n_edges);
     *out = p;
     return PC_OK;
+}
+
+int pc_refine_problem_create(pc_context* ctx, const pc_mesh* mesh, const pc_refine_desc* d, pc_refine_problem** out) {
+    if (!ctx || !mesh || !d || !out) return fail(PC_E_INVALID, "null argument");
+    *out = nullptr;
+    if (d->n_frames < 3) return fail(PC_E_INVALID, "a segment needs more than 2 frames");
+    if (d->n_edges < 0 || !d->kp_offset || !d->edge_offset) return fail(PC_E_INVALID, "bad problem description");
+    pc_refine_part whole{};
+    whole.kp_xy = d->kp_xy;
+    whole.n_keypoints = d->kp_offset[d->n_frames];
+    whole.res_src_kp = d->res_src_kp;
+    whole.res_tgt_xy = d->res_tgt_xy;
+    whole.n_residuals = d->edge_offset[d->n_edges];
+    pc_refine_desc small = *d;
+    small.kp_xy = nullptr;
+    small.res_src_kp = nullptr;
+    small.res_tgt_xy = nullptr;
+    return pc_refine_problem_create_parts(ctx, mesh, &small, &whole, 1, out);
 }
 
 void pc_refine_problem_destroy(pc_refine_problem* p) {
@@ -1037,6 +1120,10 @@ void pc_refine_problem_destroy(pc_refine_problem* p) {
     p->edge_cost.release();
     p->res_src_kp.release();
     p->prim_cache.release();
+    p->tri_plane.release();
+    if (p->sweep_begin) (void)hipEventDestroy(p->sweep_begin);
+    if (p->sweep_end) (void)hipEventDestroy(p->sweep_end);
+    p->tri_verts.release();
     p->edge_weight.release();
     p->edge_blocks.release();
     p->frame_fixed.release();
@@ -1054,9 +1141,15 @@ int pc_refine_total_cost(pc_context* ctx, pc_refine_problem* p, const pc_refine_
     if (rc != PC_OK) return rc;
     *cost = 0.0;
     if (p->n_edges == 0) return PC_OK;
+    PC_HIP(hipEventRecord(p->sweep_begin, ctx->stream));
     pc::launch_refine_cost(refine_view(p), p->cams.p, loss_type, loss_scale, p->edge_cost.p, ctx->stream);
+    PC_HIP(hipEventRecord(p->sweep_end, ctx->stream));
     PC_HIP(hipMemcpyAsync(p->h_edge_cost.p, p->edge_cost.p, (size_t)p->n_edges * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
     PC_HIP(hipStreamSynchronize(ctx->stream));
+    {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p->sweep_begin, p->sweep_end) == hipSuccess) p->cost_ms += ms, p->cost_launches++;
+    }
     // cost = sum_e edge_weight * (edge loss sum / valid)   (lev_marq.h:812-820), fixed edge order
     double total = 0.0;
     for (int e = 0; e < p->n_edges; e++) {
@@ -1079,12 +1172,27 @@ int pc_refine_normal_equations(pc_context* ctx, pc_refine_problem* p, const pc_r
     if (rc != PC_OK) return rc;
     if (p->n_edges == 0) return PC_OK;
     const int B2 = 2 * p->block_len, nacc = B2 * (B2 + 1) / 2 + B2;
+    PC_HIP(hipEventRecord(p->sweep_begin, ctx->stream));
     pc::launch_refine_normal_eq(refine_view(p), p->cams.p, loss_type, loss_scale, p->block_len, p->opt_f, p->opt_pp,
                                 p->edge_blocks.p, p->edge_valid.p, ctx->stream);
+    PC_HIP(hipEventRecord(p->sweep_end, ctx->stream));
     PC_HIP(hipMemcpyAsync(edge_blocks, p->edge_blocks.p, (size_t)p->n_edges * nacc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (edge_valid)
         PC_HIP(hipMemcpyAsync(edge_valid, p->edge_valid.p, (size_t)p->n_edges * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PC_HIP(hipStreamSynchronize(ctx->stream));
+    {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p->sweep_begin, p->sweep_end) == hipSuccess) p->neq_ms += ms, p->neq_launches++;
+    }
+    return PC_OK;
+}
+
+int pc_refine_problem_timing(const pc_refine_problem* p, int* cost_launches, double* cost_ms, int* normal_eq_launches, double* normal_eq_ms) {
+    if (!p) return fail(PC_E_INVALID, "null argument");
+    if (cost_launches) *cost_launches = p->cost_launches;
+    if (cost_ms) *cost_ms = p->cost_ms;
+    if (normal_eq_launches) *normal_eq_launches = p->neq_launches;
+    if (normal_eq_ms) *normal_eq_ms = p->neq_ms;
     return PC_OK;
 }
 

@@ -274,12 +274,21 @@ struct RefineProblemView {
     const float* edge_weight;
     const uint8_t* frame_fixed;    // first / last frame of the segment: no Jacobian (refiner.cc:611-612)
     uint32_t* prim_cache;          // per keypoint: cached triangle or 0xffffffff (refiner.cc:547-559)
+    const float4* tri_plane;       // per triangle: world-space normal, world-space first vertex (launch_refine_tri_planes)
+    const float4* tri_verts;       // per triangle: its three vertices, object space (launch_refine_tri_verts)
     const float* verts;
     const uint32_t* tris;
     const uint32_t* mask;
     BvhView bvh;                   // closest-hit ray casts when the cached triangle is missed
     float model[16], model_inv[16];
 };
+// bad[0] = lowest edge index (or INT_MAX) with a residual that names a keypoint its source frame does not have, bad[1] = one such
+// keypoint index of that launch (bad must hold {INT_MAX, 0} before)
+void launch_refine_validate(const RefineProblemView& P, int* bad, hipStream_t s);
+// plane[2 t], plane[2 t + 1] = world-space normal and first vertex of triangle t (what EvaluateWithJacobian intersects with)
+void launch_refine_tri_planes(const RefineProblemView& P, float4* plane, hipStream_t s);
+// tri_verts[3 t + k] = vertex k of triangle t
+void launch_refine_tri_verts(const RefineProblemView& P, float4* tri_verts, hipStream_t s);
 // edge_out[e] = {sum of losses over valid residuals, valid count}, accumulated in fp64
 void launch_refine_cost(const RefineProblemView& P, const RefineCamera* cams, int loss_type, float loss_scale,
                         double2* edge_out, hipStream_t s);

@@ -227,6 +227,19 @@ bool Database::ReadKeypointsInto(int32_t image_id, const std::function<float*(si
     return true;
 }
 
+bool Database::VisitKeypoints(int32_t image_id, const std::function<void(size_t rows, const void* xy)>& visit) const {
+    sqlite3_stmt* stmt = Stmt(kReadKeypoints);
+    Resetter reset{stmt};
+    SQL_OK(sqlite3_bind_int(stmt, 1, image_id));
+    if (SQL_OK(sqlite3_step(stmt)) != SQLITE_ROW) return false;
+    const int rows = sqlite3_column_int(stmt, 0);
+    CHECK(rows >= 0);
+    const void* blob = sqlite3_column_blob(stmt, 1);
+    CHECK_EQ(static_cast<size_t>(rows) * sizeof(Keypoint), static_cast<size_t>(sqlite3_column_bytes(stmt, 1)));
+    visit(static_cast<size_t>(rows), blob);
+    return true;
+}
+
 Keypoints Database::ReadKeypoints(int32_t image_id) const {
     Keypoints k;
     ReadKeypoints(image_id, k);
@@ -294,6 +307,24 @@ bool Database::ReadImagePairMatchesInto(int32_t from, int32_t to,
     if (idx_bytes) std::memcpy(idx, sqlite3_column_blob(stmt, 1), idx_bytes);
     if (tgt_bytes) std::memcpy(tgt, sqlite3_column_blob(stmt, 2), tgt_bytes);
     if (rows_out) *rows_out = rows;
+    return true;
+}
+
+bool Database::VisitImagePairMatches(int32_t from, int32_t to,
+                                     const std::function<void(size_t rows, const void* idx, const void* tgt_xy)>& visit) const {
+    sqlite3_stmt* stmt = Stmt(kReadMatches);
+    Resetter reset{stmt};
+    SQL_OK(sqlite3_bind_int(stmt, 1, from));
+    SQL_OK(sqlite3_bind_int(stmt, 2, to));
+    if (SQL_OK(sqlite3_step(stmt)) != SQLITE_ROW) return false;
+    const size_t rows = static_cast<size_t>(sqlite3_column_int(stmt, 0));
+    // both pointers first, then the sizes: a later sqlite3_column_blob() may not move an earlier one's memory, but a type
+    // conversion could -- there is none here (blob columns read as blobs)
+    const void* idx = sqlite3_column_blob(stmt, 1);
+    const void* tgt = sqlite3_column_blob(stmt, 2);
+    CHECK_EQ(rows * sizeof(uint32_t), static_cast<size_t>(sqlite3_column_bytes(stmt, 1)));
+    CHECK_EQ(rows * sizeof(Keypoint), static_cast<size_t>(sqlite3_column_bytes(stmt, 2)));
+    visit(rows, idx, tgt);
     return true;
 }
 

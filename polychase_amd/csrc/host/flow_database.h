@@ -55,6 +55,9 @@ class Database {
     // Not in the reference: the blob straight into memory the caller chooses once the row count is known (the tracker's
     // page-locked staging buffers: one copy from SQLite's page cache instead of two).  false if the row is absent.
     bool ReadKeypointsInto(int32_t image_id, const std::function<float*(size_t rows)>& place, size_t* rows_out) const;
+    // ... or not copied at all: `visit` sees the blob where SQLite holds it (valid during the call only; no alignment promised:
+    // read it with memcpy).  The refiner filters a frame's keypoints straight out of it.
+    bool VisitKeypoints(int32_t image_id, const std::function<void(size_t rows, const void* xy)>& visit) const;
     void WriteKeypoints(int32_t image_id, const Keypoints& keypoints);
     void WriteKeypoints(int32_t image_id, const float* xy, size_t rows);
     int32_t GetMinImageIdWithKeypoints() const;
@@ -70,6 +73,8 @@ class Database {
     // ... and straight into caller-chosen memory: place(rows, &idx, &tgt) names where the two columns go
     bool ReadImagePairMatchesInto(int32_t image_id_from, int32_t image_id_to,
                                   const std::function<void(size_t rows, uint32_t** idx, float** tgt_xy)>& place, size_t* rows_out) const;
+    bool VisitImagePairMatches(int32_t image_id_from, int32_t image_id_to,
+                               const std::function<void(size_t rows, const void* idx, const void* tgt_xy)>& visit) const;
     void WriteImagePairFlow(const ImagePairFlow& flow);
     void WriteImagePairFlow(int32_t image_id_from, int32_t image_id_to, const KeypointsIndices& src_kps_indices,
                             const Keypoints& tgt_kps, const FlowErrors& flow_errors);

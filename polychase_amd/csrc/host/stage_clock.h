@@ -36,10 +36,10 @@ class StageClock {
         std::chrono::steady_clock::time_point t0_;
     };
     // a duration measured elsewhere (e.g. by a kernel), or a count, under the same report
-    static void Add(const char* label, double value) {
+    static void Add(const char* label, double value, int calls = 1) {
         auto& e = Running()[label];
         e.first += value;
-        e.second += 1;
+        e.second += calls;
     }
     // the calling thread's totals become the report `title`; the thread starts from zero again
     static void Report(const char* title) {

@@ -10,11 +10,15 @@
 
 #include "stage_clock.h"
 
+#include <sys/mman.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <exception>
 #include <memory>
+#include <new>
 #include <stdexcept>
 #include <thread>
 #include <utility>
@@ -29,52 +33,92 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // segment data
 // ---------------------------------------------------------------------------------------------
-// std::allocator whose resize() leaves trivially constructible elements uninitialised: the gigabyte-sized arrays of
-// a segment are filled by the reader threads right after they are sized, and those threads should be the first to
-// touch the pages
+// A growing array of trivially copyable elements in anonymous memory that asks for transparent huge pages.  The
+// gigabyte-sized arrays of a segment are appended to by their reader thread, handed to the GPU once and given back: with 4-KiB
+// pages the kernel faults in, page-locks (the runtime pins the source of a large pageable copy) and unmaps 300 000 pages --
+// measured at 300 frames of 1080p: 78 ms for the copy and 163 ms for the release; 2-MiB pages divide the page count by 512
+// (tools/probes/pinned_alloc_probe.hip; the box runs transparent_hugepage=madvise).  Growth remaps the pages instead of
+// copying them.  New elements are not initialised: the thread that appends is the first to touch the pages.
 template <class T>
-struct NoInitAllocator : std::allocator<T> {
-    template <class U>
-    struct rebind {
-        using other = NoInitAllocator<U>;
-    };
-    template <class U, class... Args>
-    void construct(U* p, Args&&... args) {
-        if constexpr (sizeof...(Args) == 0) ::new (static_cast<void*>(p)) U;
-        else ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+class GrowArray {
+   public:
+    GrowArray() = default;
+    GrowArray(GrowArray&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr, o.n_ = o.cap_ = 0; }
+    GrowArray& operator=(GrowArray&& o) noexcept {
+        if (this != &o) {
+            Release();
+            p_ = o.p_, n_ = o.n_, cap_ = o.cap_;
+            o.p_ = nullptr, o.n_ = o.cap_ = 0;
+        }
+        return *this;
     }
+    GrowArray(const GrowArray&) = delete;
+    GrowArray& operator=(const GrowArray&) = delete;
+    ~GrowArray() { Release(); }
+    // room for `more` further elements; returns where the next one goes
+    T* Room(size_t more) {
+        if (n_ + more > cap_) {
+            const size_t want_bytes = RoundUp(std::max((n_ + more) * sizeof(T), cap_ * sizeof(T) * 3 / 2));
+            void* q = p_ ? mremap(p_, cap_ * sizeof(T), want_bytes, MREMAP_MAYMOVE)
+                         : mmap(nullptr, want_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (q == MAP_FAILED) throw std::bad_alloc();
+            (void)madvise(q, want_bytes, MADV_HUGEPAGE);   // advice: refused where the kernel has no THP, harmless then
+            p_ = static_cast<T*>(q);
+            cap_ = want_bytes / sizeof(T);
+        }
+        return p_ + n_;
+    }
+    void Grew(size_t by) { n_ += by; }
+    const T* data() const { return p_; }
+    size_t size() const { return n_; }
+    // The pages are dropped with MADV_DONTNEED first: that runs under the shared address-space lock, so several threads give
+    // their arrays back side by side (munmap alone holds the lock exclusively while the kernel clears the pages).
+    void Release() {
+        if (p_) {
+            (void)madvise(p_, cap_ * sizeof(T), MADV_DONTNEED);
+            munmap(p_, cap_ * sizeof(T));
+        }
+        p_ = nullptr, n_ = cap_ = 0;
+    }
+
+   private:
+    static constexpr size_t kChunk = size_t{32} << 20;   // multiples of 32 MiB (virtual: untouched pages cost nothing)
+    static size_t RoundUp(size_t bytes) { return (bytes + kChunk - 1) / kChunk * kChunk; }
+    T* p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
 };
 
+// what one reader thread brings back: a run of consecutive frames, offsets relative to the part
+struct SegmentPart {
+    std::vector<int32_t> kp_count;                 // per frame of the part
+    std::vector<int32_t> edge_src, edge_tgt, edge_count;
+    std::vector<float> edge_weight;
+    GrowArray<float> kp_xy;                        // bbox-filtered keypoints, x y
+    GrowArray<uint32_t> res_src_kp;                // per residual: keypoint index within its (filtered) source frame
+    GrowArray<float> res_tgt_xy;
+};
+
+// The segment as the GPU problem wants it (CSR over frames and over edges).  The three large arrays stay in the parts they
+// were read into: pc_refine_problem_create_parts puts every part at its place on the device, the host never joins them.
 struct Segment {
     int32_t first_frame = 0;
     int32_t n_frames = 0;
     std::vector<int32_t> kp_offset;   // n_frames + 1
-    std::vector<float, NoInitAllocator<float>> kp_xy;
     std::vector<int32_t> edge_src, edge_tgt, edge_offset;
-    std::vector<uint32_t, NoInitAllocator<uint32_t>> res_src_kp;
-    std::vector<float, NoInitAllocator<float>> res_tgt_xy;
     std::vector<float> edge_weight;
+    std::vector<SegmentPart> parts;
     int32_t NumEdges() const { return static_cast<int32_t>(edge_src.size()); }
+    int32_t NumResiduals() const { return edge_offset.back(); }
 };
 
 struct Box2 {
     float lo[2], hi[2];
-    bool Contains(const Keypoint& p) const { return p[0] > lo[0] && p[1] > lo[1] && p[0] < hi[0] && p[1] < hi[1]; }
+    bool Contains(float x, float y) const { return x > lo[0] && y > lo[1] && x < hi[0] && y < hi[1]; }
 };
 
 // image-space bounding box of the mesh's bounding box seen from `state`, padded by 20 px
 // (TransformBbox + ComputeBbox, refiner.cc:18-72)
-Box2 ProjectedMeshBox(const Mesh& mesh, const CameraState& state, const Mat4f& model_matrix) {
-    float pmin[3], pmax[3];
-    for (int a = 0; a < 3; a++) {
-        pmin[a] = std::numeric_limits<float>::max();
-        pmax[a] = std::numeric_limits<float>::lowest();
-    }
-    for (size_t v = 0; v < mesh.NumVertices(); v++)
-        for (int a = 0; a < 3; a++) {
-            pmin[a] = std::min(pmin[a], mesh.vertices[3 * v + a]);
-            pmax[a] = std::max(pmax[a], mesh.vertices[3 * v + a]);
-        }
+Box2 ProjectedMeshBox(const float pmin[3], const float pmax[3], const CameraState& state, const Mat4f& model_matrix) {
     const CameraIntrinsics& in = state.intrinsics;
     const Mat4f K = {in.fx, 0, in.cx, 0, 0, in.fy, in.cy, 0, 0, 0, -(110.0f / 90.0f), -2.0f * 100.0f * 10.0f / 90.0f, 0, 0, 1, 0};
     const Mat4f mvp = MatMul4(MatMul4(K, state.pose.Rt4x4()), model_matrix);
@@ -98,34 +142,49 @@ Box2 ProjectedMeshBox(const Mesh& mesh, const CameraState& state, const Mat4f& m
     return box;
 }
 
-// frames [frame_lo, frame_hi] of the segment, offsets relative to the part
-Segment LoadSegmentPart(const Database& db, const CameraTrajectory& traj, const Mesh& mesh, const Mat4f& model_matrix,
-                        int32_t frame_lo, int32_t frame_hi) {
+void MeshBounds(const Mesh& mesh, float pmin[3], float pmax[3]) {
+    for (int a = 0; a < 3; a++) {
+        pmin[a] = std::numeric_limits<float>::max();
+        pmax[a] = std::numeric_limits<float>::lowest();
+    }
+    for (size_t v = 0; v < mesh.NumVertices(); v++)
+        for (int a = 0; a < 3; a++) {
+            pmin[a] = std::min(pmin[a], mesh.vertices[3 * v + a]);
+            pmax[a] = std::max(pmax[a], mesh.vertices[3 * v + a]);
+        }
+}
+
+// frames [frame_lo, frame_hi] of the segment.  Keypoints and matches are filtered straight out of the blobs SQLite holds.
+SegmentPart LoadSegmentPart(const Database& db, const CameraTrajectory& traj, const float pmin[3], const float pmax[3],
+                            const Mat4f& model_matrix, int32_t frame_lo, int32_t frame_hi) {
     constexpr uint32_t kDropped = std::numeric_limits<uint32_t>::max();
-    Segment seg;
-    seg.first_frame = traj.FirstFrame();
-    seg.n_frames = frame_hi - frame_lo + 1;
-    seg.kp_offset.push_back(0);
-    seg.edge_offset.push_back(0);
-    Keypoints kps;
+    SegmentPart part;
     std::vector<uint32_t> remap;
     std::vector<int32_t> targets;
-    KeypointsIndices src_indices;
-    Keypoints tgt_kps;
     for (int32_t frame = frame_lo; frame <= frame_hi; frame++) {
         // keypoints inside the projected mesh box, order preserved (FilterKeypoints, refiner.cc:162-186)
-        kps.clear();
-        db.ReadKeypoints(frame, kps);
-        const Box2 box = ProjectedMeshBox(mesh, *traj.Get(frame), model_matrix);
-        remap.assign(kps.size(), kDropped);
+        const Box2 box = ProjectedMeshBox(pmin, pmax, *traj.Get(frame), model_matrix);
         uint32_t kept = 0;
-        for (size_t j = 0; j < kps.size(); j++) {
-            if (!box.Contains(kps[j])) continue;
-            remap[j] = kept++;
-            seg.kp_xy.push_back(kps[j][0]);
-            seg.kp_xy.push_back(kps[j][1]);
-        }
-        seg.kp_offset.push_back(seg.kp_offset.back() + static_cast<int32_t>(kept));
+        remap.clear();
+        db.VisitKeypoints(frame, [&](size_t rows, const void* blob) {
+            remap.resize(rows);
+            float* out = part.kp_xy.Room(2 * rows);
+            const char* in = static_cast<const char*>(blob);
+            for (size_t j = 0; j < rows; j++) {
+                float xy[2];
+                std::memcpy(xy, in + j * sizeof(Keypoint), sizeof xy);
+                if (!box.Contains(xy[0], xy[1])) {
+                    remap[j] = kDropped;
+                    continue;
+                }
+                remap[j] = kept;
+                out[2 * kept] = xy[0];
+                out[2 * kept + 1] = xy[1];
+                kept++;
+            }
+            part.kp_xy.Grew(2 * static_cast<size_t>(kept));
+        });
+        part.kp_count.push_back(static_cast<int32_t>(kept));
 
         // flows to frames inside the segment, restricted to the kept keypoints (LoadFrameFlows, :117-160)
         targets.clear();
@@ -133,36 +192,52 @@ Segment LoadSegmentPart(const Database& db, const CameraTrajectory& traj, const 
         const float dist = static_cast<float>(std::min(frame - traj.FirstFrame(), traj.LastFrame() - frame));
         for (int32_t to : targets) {
             if (!traj.IsValidFrame(to)) continue;
-            db.ReadImagePairMatches(frame, to, src_indices, tgt_kps);   // flow_errors are not used (refiner.cc:117-160)
-            CHECK_EQ(src_indices.size(), tgt_kps.size());
-            const size_t before = seg.res_src_kp.size();
-            for (size_t j = 0; j < tgt_kps.size(); j++) {
-                const uint32_t src = src_indices[j];
-                CHECK_LT(static_cast<size_t>(src), remap.size());
-                if (remap[src] == kDropped) continue;
-                seg.res_src_kp.push_back(remap[src]);
-                seg.res_tgt_xy.push_back(tgt_kps[j][0]);
-                seg.res_tgt_xy.push_back(tgt_kps[j][1]);
-            }
-            if (seg.res_src_kp.size() == before) continue;
-            seg.edge_src.push_back(frame - seg.first_frame);
-            seg.edge_tgt.push_back(to - seg.first_frame);
-            seg.edge_offset.push_back(static_cast<int32_t>(seg.res_src_kp.size()));
-            seg.edge_weight.push_back(1.0f / (dist + 1.0f));  // FrameWeight(image_id_from), refiner.cc:249-256
+            size_t added = 0;
+            // flow_errors are not used (refiner.cc:117-160)
+            db.VisitImagePairMatches(frame, to, [&](size_t rows, const void* idx_blob, const void* tgt_blob) {
+                uint32_t* out_kp = part.res_src_kp.Room(rows);
+                float* out_xy = part.res_tgt_xy.Room(2 * rows);
+                const char* idx_in = static_cast<const char*>(idx_blob);
+                const char* tgt_in = static_cast<const char*>(tgt_blob);
+                for (size_t j = 0; j < rows; j++) {
+                    uint32_t src;
+                    std::memcpy(&src, idx_in + j * sizeof(uint32_t), sizeof src);
+                    CHECK_LT(static_cast<size_t>(src), remap.size());
+                    if (remap[src] == kDropped) continue;
+                    out_kp[added] = remap[src];
+                    std::memcpy(out_xy + 2 * added, tgt_in + j * sizeof(Keypoint), sizeof(Keypoint));
+                    added++;
+                }
+                part.res_src_kp.Grew(added);
+                part.res_tgt_xy.Grew(2 * added);
+            });
+            if (added == 0) continue;
+            CHECK_LT(added, static_cast<size_t>(std::numeric_limits<int32_t>::max()));
+            part.edge_src.push_back(frame - traj.FirstFrame());
+            part.edge_tgt.push_back(to - traj.FirstFrame());
+            part.edge_count.push_back(static_cast<int32_t>(added));
+            part.edge_weight.push_back(1.0f / (dist + 1.0f));  // FrameWeight(image_id_from), refiner.cc:249-256
         }
     }
-    return seg;
+    return part;
 }
 
 // The whole segment (CachedDatabase, refiner.cc:71-197).  A 300-frame 1080p clip holds 1.5 GB of blobs: the frames
 // are dealt out to reader threads, each with its own read connection (the file is in WAL mode: readers do not
-// block each other), and the parts are joined in frame order -- the result does not depend on the thread count.
+// block each other); the small per-frame and per-edge arrays are joined in frame order, the large ones stay where they were
+// read -- the result does not depend on the thread count.
 Segment LoadSegment(const std::string& database_path, const CameraTrajectory& traj, const Mesh& mesh, const Mat4f& model_matrix) {
     const int32_t n = static_cast<int32_t>(traj.Count());
-    int n_threads = static_cast<int>(std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())));
+    // 16 connections read 1.2 GB in 24 ms on the GPU box (8: 34 ms; 32 and more queue up behind each other in Open())
+    int n_threads = static_cast<int>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
     if (const char* env = std::getenv("POLYCHASE_DB_READERS")) n_threads = std::max(1, std::atoi(env));
     n_threads = std::max(1, std::min(n_threads, n / 8));   // short segments: not worth a second connection
-    std::vector<Segment> parts(static_cast<size_t>(n_threads));
+    float pmin[3], pmax[3];
+    MeshBounds(mesh, pmin, pmax);
+    Segment seg;
+    seg.first_frame = traj.FirstFrame();
+    seg.n_frames = n;
+    seg.parts.resize(static_cast<size_t>(n_threads));
     std::vector<std::exception_ptr> errors(static_cast<size_t>(n_threads));
     // opened one after the other: Open() issues pragmas and CREATE TABLE IF NOT EXISTS, which take the write lock
     std::vector<std::unique_ptr<Database>> connections;
@@ -175,7 +250,7 @@ Segment LoadSegment(const std::string& database_path, const CameraTrajectory& tr
             const Database& db = *connections[static_cast<size_t>(t)];
             const int32_t lo = traj.FirstFrame() + static_cast<int32_t>(static_cast<int64_t>(n) * t / n_threads);
             const int32_t hi = traj.FirstFrame() + static_cast<int32_t>(static_cast<int64_t>(n) * (t + 1) / n_threads) - 1;
-            parts[static_cast<size_t>(t)] = LoadSegmentPart(db, traj, mesh, model_matrix, lo, hi);
+            seg.parts[static_cast<size_t>(t)] = LoadSegmentPart(db, traj, pmin, pmax, model_matrix, lo, hi);
         } catch (...) {
             errors[static_cast<size_t>(t)] = std::current_exception();
         }
@@ -187,54 +262,27 @@ Segment LoadSegment(const std::string& database_path, const CameraTrajectory& tr
         work(0);
         for (auto& th : threads) th.join();
     }
+    {
+        StageClock::Scope sc("refine/load: close connections");
+        connections.clear();
+    }
     for (const auto& e : errors)
         if (e) std::rethrow_exception(e);
-    if (n_threads == 1) {
-        parts[0].n_frames = n;
-        return std::move(parts[0]);
-    }
-    // join: sizes first, then every thread copies its part to its place
-    StageClock::Scope sc_join("refine/load: join parts");
-    Segment seg;
-    seg.first_frame = traj.FirstFrame();
-    seg.n_frames = n;
-    size_t n_kp = 0, n_res = 0, n_edges = 0;
-    std::vector<size_t> kp_base, res_base, edge_base;
-    for (const Segment& p : parts) {
-        kp_base.push_back(n_kp);
-        res_base.push_back(n_res);
-        edge_base.push_back(n_edges);
-        n_kp += p.kp_xy.size() / 2;
-        n_res += p.res_src_kp.size();
-        n_edges += p.edge_src.size();
-    }
-    CHECK_LT(n_res, static_cast<size_t>(std::numeric_limits<int32_t>::max()));
     seg.kp_offset.push_back(0);
     seg.edge_offset.push_back(0);
-    for (size_t t = 0; t < parts.size(); t++) {
-        const Segment& p = parts[t];
-        for (size_t f = 1; f < p.kp_offset.size(); f++) seg.kp_offset.push_back(static_cast<int32_t>(kp_base[t]) + p.kp_offset[f]);
-        for (size_t e = 1; e < p.edge_offset.size(); e++) seg.edge_offset.push_back(static_cast<int32_t>(res_base[t]) + p.edge_offset[e]);
+    int64_t n_res = 0;
+    for (const SegmentPart& p : seg.parts) {
+        for (int32_t c : p.kp_count) seg.kp_offset.push_back(seg.kp_offset.back() + c);
+        for (int32_t c : p.edge_count) {
+            n_res += c;
+            CHECK_LT(n_res, static_cast<int64_t>(std::numeric_limits<int32_t>::max()));
+            seg.edge_offset.push_back(static_cast<int32_t>(n_res));
+        }
         seg.edge_src.insert(seg.edge_src.end(), p.edge_src.begin(), p.edge_src.end());
         seg.edge_tgt.insert(seg.edge_tgt.end(), p.edge_tgt.begin(), p.edge_tgt.end());
         seg.edge_weight.insert(seg.edge_weight.end(), p.edge_weight.begin(), p.edge_weight.end());
     }
-    seg.kp_xy.resize(2 * n_kp);
-    seg.res_src_kp.resize(n_res);
-    seg.res_tgt_xy.resize(2 * n_res);
-    auto place = [&](int t) {
-        const Segment& p = parts[static_cast<size_t>(t)];
-        std::copy(p.kp_xy.begin(), p.kp_xy.end(), seg.kp_xy.begin() + static_cast<ptrdiff_t>(2 * kp_base[static_cast<size_t>(t)]));
-        // keypoint indices are relative to their frame: they do not move
-        std::copy(p.res_src_kp.begin(), p.res_src_kp.end(), seg.res_src_kp.begin() + static_cast<ptrdiff_t>(res_base[static_cast<size_t>(t)]));
-        std::copy(p.res_tgt_xy.begin(), p.res_tgt_xy.end(), seg.res_tgt_xy.begin() + static_cast<ptrdiff_t>(2 * res_base[static_cast<size_t>(t)]));
-    };
-    {
-        std::vector<std::thread> threads;
-        for (int t = 1; t < n_threads; t++) threads.emplace_back(place, t);
-        place(0);
-        for (auto& th : threads) th.join();
-    }
+    CHECK_EQ(seg.kp_offset.size(), static_cast<size_t>(n) + 1);
     return seg;
 }
 
@@ -310,26 +358,45 @@ class RefineSession {
         desc.n_frames = seg_.n_frames;
         desc.n_edges = seg_.NumEdges();
         desc.kp_offset = seg_.kp_offset.data();
-        desc.kp_xy = seg_.kp_xy.data();
         desc.edge_src = seg_.edge_src.data();
         desc.edge_tgt = seg_.edge_tgt.data();
         desc.edge_offset = seg_.edge_offset.data();
-        desc.res_src_kp = seg_.res_src_kp.data();
-        desc.res_tgt_xy = seg_.res_tgt_xy.data();
         desc.edge_weight = seg_.edge_weight.data();
         std::copy(model_matrix.begin(), model_matrix.end(), desc.model_matrix);
         std::copy(model_inv.begin(), model_inv.end(), desc.model_matrix_inv);
         desc.block_len = block_;
         desc.optimize_focal_length = opt_f ? 1 : 0;
         desc.optimize_principal_point = opt_pp ? 1 : 0;
-        // Evaluate ray casts with check_mask = true (refiner.cc:335): send the current mask bits
-        GpuSection section;   // mask upload + problem upload: one section on the shared context (gpu_context.h)
-        if (pc_mesh_set_mask(ctx_, mesh.Gpu(), mesh.Inner().masked_triangles.data(),
-                             static_cast<int>(mesh.Inner().masked_triangles.size())) != PC_OK)
-            ThrowHip("pc_mesh_set_mask");
+        std::vector<pc_refine_part> parts;
+        for (const SegmentPart& p : seg_.parts) {
+            pc_refine_part part{};
+            part.kp_xy = p.kp_xy.data();
+            part.n_keypoints = static_cast<int64_t>(p.kp_xy.size() / 2);
+            part.res_src_kp = p.res_src_kp.data();
+            part.res_tgt_xy = p.res_tgt_xy.data();
+            part.n_residuals = static_cast<int64_t>(p.res_src_kp.size());
+            parts.push_back(part);
+        }
         {
+            // Evaluate ray casts with check_mask = true (refiner.cc:335): send the current mask bits
+            GpuSection section;   // mask upload + problem upload: one section on the shared context (gpu_context.h)
+            if (pc_mesh_set_mask(ctx_, mesh.Gpu(), mesh.Inner().masked_triangles.data(),
+                                 static_cast<int>(mesh.Inner().masked_triangles.size())) != PC_OK)
+                ThrowHip("pc_mesh_set_mask");
             StageClock::Scope sc("refine/upload");
-            if (pc_refine_problem_create(ctx_, mesh.Gpu(), &desc, &gpu_.p) != PC_OK) ThrowHip("pc_refine_problem_create");
+            if (pc_refine_problem_create_parts(ctx_, mesh.Gpu(), &desc, parts.data(), static_cast<int>(parts.size()), &gpu_.p) != PC_OK)
+                ThrowHip("pc_refine_problem_create_parts");
+        }
+        {
+            // The device holds the large arrays now.  This kernel clears pages when they are freed (1.2 GB: 70 ms on one
+            // core, tools/probes/pageable_upload_probe.hip), so every part is given back by a thread of its own.  (Doing it
+            // behind the solver's back was measured too: the first sweeps slow down by as much as this takes.)
+            StageClock::Scope sc("refine/release host copy");
+            std::vector<std::thread> threads;
+            for (size_t t = 1; t < seg_.parts.size(); t++) threads.emplace_back([part = &seg_.parts[t]] { *part = SegmentPart(); });
+            if (!seg_.parts.empty()) seg_.parts[0] = SegmentPart();
+            for (auto& th : threads) th.join();
+            seg_.parts.clear();
         }
 
         // J^T J pattern (lev_marq.h:421-487): diagonal blocks + one off-diagonal block per connected pair
@@ -341,6 +408,16 @@ class RefineSession {
         diag.assign(NumParams(), 0.0);
         const int pair = 2 * block_;
         edge_blocks_.resize(static_cast<size_t>(std::max(1, seg_.NumEdges())) * (pair * (pair + 1) / 2 + pair));
+    }
+
+    // the kernels' own durations (HIP events) into the stage report, beside the host's view of the same calls
+    void ReportGpuTimes() const {
+        int cost_n = 0, neq_n = 0;
+        double cost_ms = 0.0, neq_ms = 0.0;
+        if (pc_refine_problem_timing(gpu_.p, &cost_n, &cost_ms, &neq_n, &neq_ms) != PC_OK) return;
+        StageClock::Add("refine/cost sweep: kernel (GPU clock)", cost_ms, cost_n);
+        StageClock::Add("refine/normal equations: kernel (GPU clock)", neq_ms, neq_n);
+        StageClock::Add("refine/residuals (count, not ms)", static_cast<double>(seg_.NumResiduals()), 1);
     }
 
     int BlockLength() const { return block_; }
@@ -512,6 +589,7 @@ void RefineTrajectory(const std::string& database_path, CameraTrajectory& traj, 
         if (!report(stats)) break;
     }
     report(stats);
+    session.ReportGpuTimes();
     StageClock::Report("RefineTrajectory");
 }
 
@@ -526,7 +604,7 @@ RefinementSystem EvaluateRefinementSystem(const std::string& database_path, cons
     out.num_params = n;
     out.block_length = session.BlockLength();
     out.num_edges = session.Data().NumEdges();
-    out.num_residuals = static_cast<int>(session.Data().res_src_kp.size());
+    out.num_residuals = session.Data().NumResiduals();
     out.num_keypoints = session.Data().kp_offset.back();
     out.JtJ.assign(static_cast<size_t>(n) * n, 0.f);
     for (int r = 0; r < n; r++)

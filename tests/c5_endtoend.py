@@ -42,12 +42,14 @@ def main(argv=None) -> int:
                          "its source frames and the GPU's pose of the frame before it as the initial guess")
     ap.add_argument("--oracle-workers", type=int, default=1, help="threads over the sampled frames of --oracle-stride")
     ap.add_argument("--refine-iterations", type=int, default=30)
+    ap.add_argument("--refine-intrinsics", action="store_true", help="the refinement also optimises focal length and principal point (9 parameters per camera)")
     ap.add_argument("--refine-oracle-frames", type=int, default=0,
                     help="> 2: the float64 CPU restatement of the refinement sweeps (oracle/refine_oracle.py) is timed on a "
                          "sub-segment of that many frames in the middle of the clip (a CPU baseline; checker leg)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args(argv)
-    out = run(a.width, a.height, a.frames, a.oracle_frames, a.oracle_stride, a.refine_iterations, a.oracle_workers, a.refine_oracle_frames)
+    out = run(a.width, a.height, a.frames, a.oracle_frames, a.oracle_stride, a.refine_iterations, a.oracle_workers, a.refine_oracle_frames,
+              a.refine_intrinsics)
     print(json.dumps(out))
     sys.path.insert(0, os.path.join(ROOT, "polychase_amd", "core"))
     import polychase_core
@@ -91,11 +93,12 @@ def _oracle_pose_check(job):
 
 
 def run(width=1920, height=1080, frames=300, oracle_frames=6, oracle_stride=0, refine_iterations=30, oracle_workers=1,
-        refine_oracle_frames=0) -> dict:
+        refine_oracle_frames=0, refine_intrinsics=False) -> dict:
     """the whole of C5 -> the result object (bench.py's "c5" block calls this; main() prints it)"""
     import types
     a = types.SimpleNamespace(width=width, height=height, frames=frames, oracle_frames=oracle_frames, oracle_stride=oracle_stride,
-                              refine_iterations=refine_iterations, oracle_workers=oracle_workers, refine_oracle_frames=refine_oracle_frames)
+                              refine_iterations=refine_iterations, oracle_workers=oracle_workers, refine_oracle_frames=refine_oracle_frames,
+                              refine_intrinsics=refine_intrinsics)
 
     import torch
     import torch.nn.functional as Fn
@@ -269,7 +272,8 @@ def run(width=1920, height=1080, frames=300, oracle_frames=6, oracle_stride=0, r
     bo2.max_iterations = a.refine_iterations
     last = []
     t0 = time.time()
-    core.refine_trajectory(path, traj_c, np.eye(4, dtype=np.float32), mesh, False, False, lambda u: last.append(u.stats) or True, bo2)
+    core.refine_trajectory(path, traj_c, np.eye(4, dtype=np.float32), mesh, a.refine_intrinsics, a.refine_intrinsics,
+                           lambda u: last.append(u.stats) or True, bo2)
     dt = time.time() - t0
     refined = {f: (np.array(traj_c.get(f).pose.q, float), np.array(traj_c.get(f).pose.t, float)) for f in range(2, n + 1)}
     out["refinement"] = {"seconds": round(dt, 3), "iterations": last[-1].iterations if last else 0,

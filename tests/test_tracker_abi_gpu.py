@@ -308,3 +308,136 @@ def test_solve_frame_in_one_call_against_its_building_blocks(env):
     assert rc != 0 and b"at most" in L.pc_last_error()
     L.pc_corr_set_destroy.argtypes = [VP]
     L.pc_corr_set_destroy(s)
+
+
+# ---- "Refine Sequence" problem handed over in parts ------------------------------------------------------------------------
+class RefineDesc(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("n_edges", C.c_int), ("kp_offset", VP), ("kp_xy", VP), ("edge_src", VP), ("edge_tgt", VP),
+                ("edge_offset", VP), ("res_src_kp", VP), ("res_tgt_xy", VP), ("edge_weight", VP), ("model_matrix", C.c_float * 16),
+                ("model_matrix_inv", C.c_float * 16), ("block_len", C.c_int), ("optimize_focal_length", C.c_int),
+                ("optimize_principal_point", C.c_int)]
+
+
+class RefinePart(C.Structure):
+    _fields_ = [("kp_xy", VP), ("n_keypoints", C.c_int64), ("res_src_kp", VP), ("res_tgt_xy", VP), ("n_residuals", C.c_int64)]
+
+
+class RefineCamera(C.Structure):
+    _fields_ = [("R", C.c_float * 9), ("t", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("aspect_ratio", C.c_float), ("unproject_sign", C.c_float), ("reserved", C.c_float * 2)]
+
+
+def _refine_problem(rng, n_frames=5, n_kp=40):
+    """keypoints over the quad of `env` seen from z = -5 (OpenCV), every frame tracked into its two neighbours"""
+    kp_offset = np.arange(n_frames + 1, dtype=np.int32) * n_kp
+    kp_xy = (rng.uniform(-150, 150, (n_frames * n_kp, 2)) + [320, 240]).astype(np.float32)
+    src, tgt, off, res_kp, res_xy = [], [], [0], [], []
+    for f in range(n_frames):
+        for g in (f - 1, f + 1):
+            if not 0 <= g < n_frames:
+                continue
+            take = np.sort(rng.choice(n_kp, n_kp - 7, replace=False)).astype(np.uint32)
+            src.append(f)
+            tgt.append(g)
+            res_kp.append(take)
+            res_xy.append(kp_xy[f * n_kp + take] + rng.normal(0, 0.5, (len(take), 2)).astype(np.float32))
+            off.append(off[-1] + len(take))
+    arrays = dict(kp_offset=kp_offset, kp_xy=kp_xy, edge_src=np.array(src, np.int32), edge_tgt=np.array(tgt, np.int32),
+                  edge_offset=np.array(off, np.int32), res_src_kp=np.concatenate(res_kp), res_tgt_xy=np.concatenate(res_xy).astype(np.float32),
+                  edge_weight=np.ones(len(src), np.float32))
+    cams = (RefineCamera * n_frames)()
+    for f in range(n_frames):
+        cams[f].R[:] = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+        cams[f].t[:] = [0.01 * f, 0, 5]
+        cams[f].fx = cams[f].fy = 500.0
+        cams[f].cx, cams[f].cy, cams[f].aspect_ratio, cams[f].unproject_sign = 320.0, 240.0, 1.0, 1.0
+    return arrays, cams
+
+
+def _refine_desc(a, with_large_arrays):
+    d = RefineDesc()
+    d.n_frames, d.n_edges = len(a["kp_offset"]) - 1, len(a["edge_src"])
+    for name in ("kp_offset", "edge_src", "edge_tgt", "edge_offset", "edge_weight"):
+        setattr(d, name, _p(a[name]))
+    if with_large_arrays:
+        for name in ("kp_xy", "res_src_kp", "res_tgt_xy"):
+            setattr(d, name, _p(a[name]))
+    eye = np.eye(4, dtype=np.float32).ravel()
+    d.model_matrix[:] = eye
+    d.model_matrix_inv[:] = eye
+    d.block_len = 6
+    return d
+
+
+def _refine_parts(a, cut_frames):
+    """the large arrays cut after the given frames (a part = a run of frames with the edges that start in them)"""
+    bounds = [0] + list(cut_frames) + [len(a["kp_offset"]) - 1]
+    parts = (RefinePart * (len(bounds) - 1))()
+    keep = []
+    for k in range(len(bounds) - 1):
+        f0, f1 = bounds[k], bounds[k + 1]
+        edges = np.nonzero((a["edge_src"] >= f0) & (a["edge_src"] < f1))[0]
+        r0, r1 = (a["edge_offset"][edges[0]], a["edge_offset"][edges[-1] + 1]) if len(edges) else (0, 0)
+        kp = np.ascontiguousarray(a["kp_xy"][a["kp_offset"][f0]:a["kp_offset"][f1]])
+        rk = np.ascontiguousarray(a["res_src_kp"][r0:r1])
+        rx = np.ascontiguousarray(a["res_tgt_xy"][r0:r1])
+        keep += [kp, rk, rx]
+        parts[k].kp_xy, parts[k].n_keypoints = _p(kp), len(kp)
+        parts[k].res_src_kp, parts[k].res_tgt_xy, parts[k].n_residuals = _p(rk), _p(rx), len(rk)
+    return parts, keep
+
+
+def test_refine_problem_in_parts_equals_the_whole_and_checks_its_indices(env):
+    L, ctx, mesh, _cam = env
+    L.pc_refine_problem_create.argtypes = [VP, VP, C.POINTER(RefineDesc), C.POINTER(VP)]
+    L.pc_refine_problem_create_parts.argtypes = [VP, VP, C.POINTER(RefineDesc), C.POINTER(RefinePart), C.c_int, C.POINTER(VP)]
+    L.pc_refine_total_cost.argtypes = [VP, VP, C.POINTER(RefineCamera), C.c_int, C.c_float, C.POINTER(C.c_double)]
+    L.pc_refine_normal_equations.argtypes = [VP, VP, C.POINTER(RefineCamera), C.c_int, C.c_float, VP, VP]
+    L.pc_refine_problem_destroy.argtypes = [VP]
+    a, cams = _refine_problem(np.random.default_rng(3))
+    n_edges = len(a["edge_src"])
+
+    def evaluate(prob):
+        cost = C.c_double()
+        assert L.pc_refine_total_cost(ctx._h, prob, cams, 2, 1.0, C.byref(cost)) == 0
+        blocks = np.zeros(n_edges * (12 * 13 // 2 + 12))
+        valid = np.zeros(n_edges, np.int32)
+        assert L.pc_refine_normal_equations(ctx._h, prob, cams, 2, 1.0, _p(blocks), _p(valid)) == 0
+        return cost.value, blocks, valid
+
+    whole = VP()
+    d = _refine_desc(a, True)
+    assert L.pc_refine_problem_create(ctx._h, mesh, C.byref(d), C.byref(whole)) == 0, L.pc_last_error()
+    want = evaluate(whole)
+    L.pc_refine_problem_destroy(whole)
+    assert want[0] > 0 and want[2].min() > 20
+    d = _refine_desc(a, False)
+    for cuts in ((), (2,), (1, 2, 4), (0, 3, 3)):          # also empty parts
+        parts, keep = _refine_parts(a, cuts)
+        prob = VP()
+        assert L.pc_refine_problem_create_parts(ctx._h, mesh, C.byref(d), parts, len(parts), C.byref(prob)) == 0, L.pc_last_error()
+        got = evaluate(prob)
+        L.pc_refine_problem_destroy(prob)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+        del keep
+
+    # refused: large arrays in the description, parts that do not add up, a residual naming a keypoint its frame does not have
+    prob = VP()
+    parts, keep = _refine_parts(a, (2,))
+    d_bad = _refine_desc(a, True)
+    assert L.pc_refine_problem_create_parts(ctx._h, mesh, C.byref(d_bad), parts, 2, C.byref(prob)) != 0 and not prob.value
+    assert L.pc_refine_problem_create_parts(ctx._h, mesh, C.byref(d), parts, 1, C.byref(prob)) != 0 and not prob.value
+    assert b"parts hold" in L.pc_last_error()
+    b = dict(a)
+    b["res_src_kp"] = a["res_src_kp"].copy()
+    edge = 3
+    b["res_src_kp"][a["edge_offset"][edge] + 5] = 40          # frames have keypoints 0..39
+    for make in ("whole", "parts"):
+        if make == "whole":
+            d_b = _refine_desc(b, True)
+            rc = L.pc_refine_problem_create(ctx._h, mesh, C.byref(d_b), C.byref(prob))
+        else:
+            parts_b, keep_b = _refine_parts(b, (1, 3))
+            rc = L.pc_refine_problem_create_parts(ctx._h, mesh, C.byref(d), parts_b, 3, C.byref(prob))
+        assert rc != 0 and not prob.value
+        assert b"edge 3 references a keypoint" in L.pc_last_error(), L.pc_last_error()
