@@ -350,7 +350,7 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
     CHECK(frame_accessor);
     const double t_begin = Now();
     std::unique_ptr<Database> db;
-    if (!database_path.empty()) db = std::make_unique<Database>(database_path);
+    if (!database_path.empty()) db = std::make_unique<Database>(database_path, /*bulk_writer=*/true);
     // Bulk load: rows go in under a rollback journal and the file is put back into WAL mode on every way out (done,
     // cancelled, exception) -- 2.3x the insert rate of WAL mode on this workload (tools/dbprobe/dbbench.py), same
     // file format in the end.  A process that dies in between leaves a rollback-journal database with a hot
@@ -726,7 +726,7 @@ size_t GenerateOpticalFlowRecords(const VideoInfo& video_info, FrameAccessorFunc
 struct OpticalFlowRecordWriter::Impl {
     Database db;
     bool bulk = false;
-    explicit Impl(const std::string& path) : db(path) {
+    explicit Impl(const std::string& path) : db(path, /*bulk_writer=*/true) {
         const char* env = std::getenv("POLYCHASE_DB_BULK_LOAD");
         bulk = !(env && env[0] == '0') && db.SetJournalMode("TRUNCATE") == "truncate";   // see RunAnalysis
     }

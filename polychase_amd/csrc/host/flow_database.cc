@@ -2,6 +2,8 @@
 // file format and therefore identical to the reference (cpp/database.cc:76-135, :353-399).
 #include "flow_database.h"
 
+#include "async_write_vfs.h"
+
 #include <cctype>
 
 #include <cstdlib>
@@ -113,11 +115,12 @@ void Database::Exec(const char* sql, int line) const {
     }
 }
 
-void Database::Open(const std::string& path) {
+void Database::Open(const std::string& path, bool bulk_writer) {
     Close();
     path_ = path;
     // NOMUTEX like the reference: callers serialise access (one writer thread here)
-    SQL_OK(sqlite3_open_v2(path.c_str(), &db_, SQLITE_OPEN_READWRITE | SQLITE_OPEN_CREATE | SQLITE_OPEN_NOMUTEX, nullptr));
+    SQL_OK(sqlite3_open_v2(path.c_str(), &db_, SQLITE_OPEN_READWRITE | SQLITE_OPEN_CREATE | SQLITE_OPEN_NOMUTEX,
+                           bulk_writer ? AsyncWriteVfsName() : nullptr));
     // another connection may be in the middle of a commit (the analysis bulk-loads under a rollback journal, so a reader
     // that opens the file meanwhile meets a locked database): wait instead of failing with SQLITE_BUSY
     sqlite3_busy_timeout(db_, 10000);

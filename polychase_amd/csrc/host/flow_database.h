@@ -38,13 +38,15 @@ struct ImagePairFlow {
 
 class Database {
    public:
-    explicit Database(const std::string& path) { Open(path); }
+    // bulk_writer (not in the reference): the connection of the analysis that inserts the rows -- its page writes to the
+    // database file are carried out by worker threads (async_write_vfs.h; POLYCHASE_DB_WRITE_THREADS=0: like any other)
+    explicit Database(const std::string& path, bool bulk_writer = false) { Open(path, bulk_writer); }
     Database(Database&& other) noexcept;
     Database(const Database&) = delete;
     Database& operator=(const Database&) = delete;
     ~Database();
 
-    void Open(const std::string& path);
+    void Open(const std::string& path, bool bulk_writer = false);
     void Close();
     const std::string& Path() const { return path_; }   // what Open() was given (a second read connection can be opened on it)
 

@@ -9,6 +9,7 @@
 
 #include "../../../include/polychase_hip.h"
 #include "../host/debug_images.h"
+#include "../host/async_write_vfs.h"
 #include "../host/flow_database.h"
 #include "../host/analysis.h"
 #include "../host/frame_pool.h"
@@ -263,11 +264,27 @@ PYBIND11_MODULE(polychase_core, m) {
         m.attr("_gpu_max_hw_queues") = queues;
     }
 
+    m.def("_async_write_counters", [] {   // not in the reference (tests, diagnostics): totals of csrc/host/async_write_vfs.h
+        const AsyncWriteVfsCounters c = AsyncWriteVfsTotals();
+        py::dict d;
+        d["deferred_writes"] = c.deferred_writes;
+        d["deferred_bytes"] = c.deferred_bytes;
+        d["direct_writes"] = c.direct_writes;
+        d["drains"] = c.drains;
+        d["drains_that_waited"] = c.drains_that_waited;
+        d["waits_for_a_slab"] = c.waits_for_a_slab;
+        return d;
+    });
     py::class_<Database>(m, "Database")
         .def(py::init<const std::string&>(), py::arg("path"))
-        .def("open", &Database::Open, py::arg("path"))
+        // not in the reference (tests): the connection mode of the analysis' writer, csrc/host/async_write_vfs.h
+        .def_static("_open_bulk_writer", [](const std::string& path) { return std::make_unique<Database>(path, true); }, py::arg("path"))
+        .def("open", [](Database& db, const std::string& path) { db.Open(path); }, py::arg("path"))
         .def("close", &Database::Close)
         .def("_set_journal_mode", &Database::SetJournalMode, py::arg("mode"))   // not in the reference (tests)
+        .def("_begin", &Database::Begin)                                          // ... explicit transactions (tests)
+        .def("_commit", &Database::Commit)
+        .def("_rollback", &Database::Rollback)
         .def("read_keypoints", [](const Database& db, int32_t id) { return VecToNumpy<2>(db.ReadKeypoints(id)); },
              py::arg("image_id"))
         .def("write_keypoints",

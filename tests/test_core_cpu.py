@@ -174,3 +174,79 @@ def test_bulk_load_journal_mode_round_trip(core, tmp_path):
     assert db2._set_journal_mode("WAL") == "wal"
     db2.close()
     con.close()
+
+
+def test_bulk_writer_connection_writes_the_same_file(core, tmp_path):
+    """The analysis' writer connection hands its page writes to worker threads (csrc/host/async_write_vfs.h).  The same
+    inserts through it and through a plain connection give byte-identical files; rows written earlier in a transaction can be
+    read back inside it (a read of the file waits for the pending pages); a rollback leaves nothing; the WAL switch at the end
+    and a reader on the default VFS see everything."""
+    rng = np.random.default_rng(5)
+    frames = []
+    for f in range(1, 13):
+        n = int(rng.integers(9000, 12000))          # ~90 KB of keypoints, 4 x ~130 KB of flows per frame: well over a page
+        kp = rng.random((n, 2), dtype=np.float32) * 1000
+        flows = []
+        for to in (f - 2, f - 1, f + 1, f + 2):
+            m = int(rng.integers(n // 2, n))
+            flows.append((to, np.sort(rng.choice(n, m, replace=False)).astype(np.uint32), rng.random((m, 2), dtype=np.float32), rng.random(m, dtype=np.float32)))
+        frames.append((f, kp, flows))
+
+    def fill(db, check_reads):
+        assert db._set_journal_mode("TRUNCATE") == "truncate"
+        for start in range(0, len(frames), 5):                      # transactions of 5, 5 and 2 frames
+            db._begin()
+            for f, kp, flows in frames[start:start + 5]:
+                db.write_keypoints(f, kp)
+                for to, idx, tgt, err in flows:
+                    db.write_image_pair_flow(f, to, idx, tgt, err)
+                if check_reads and f % 4 == 0:                       # inside the transaction, pages of it already spilled
+                    assert np.array_equal(db.read_keypoints(f), kp)
+                    got = db.read_image_pair_flow(f, flows[2][0])
+                    assert np.array_equal(got.src_kps_indices, flows[2][1]) and np.array_equal(got.tgt_kps, flows[2][2])
+            db._commit()
+        # a transaction that is rolled back: nothing of it may stay
+        db._begin()
+        db.write_keypoints(99, frames[0][1])
+        db.write_image_pair_flow(99, 98, *frames[0][2][0][1:])
+        db._rollback()
+        assert not db.keypoints_exist(99)
+        assert db._set_journal_mode("WAL") == "wal"
+        db.close()
+
+    before = core._async_write_counters()
+    fill(core.Database._open_bulk_writer(str(tmp_path / "a.db")), True)
+    after = core._async_write_counters()
+    fill(core.Database(str(tmp_path / "b.db")), False)
+    assert core._async_write_counters()["deferred_writes"] == after["deferred_writes"]     # the plain connection defers nothing
+    a, b = open(tmp_path / "a.db", "rb").read(), open(tmp_path / "b.db", "rb").read()
+    assert len(a) > 12 * 500_000 and a == b
+    assert after["deferred_writes"] - before["deferred_writes"] > len(a) // 65536 // 2    # most pages went through the workers
+    assert after["deferred_bytes"] - before["deferred_bytes"] >= (after["deferred_writes"] - before["deferred_writes"]) * 4096
+    con = sqlite3.connect(str(tmp_path / "a.db"))
+    assert con.execute("PRAGMA integrity_check").fetchone()[0] == "ok"
+    assert con.execute("select count(*), sum(rows) from keypoints").fetchone() == (12, sum(len(k) for _, k, _ in frames))
+    row = con.execute("select src_keypoints_indices, tgt_keypoints, flow_errors from optical_flow where image_id_from=7 and image_id_to=8").fetchone()
+    to, idx, tgt, err = frames[6][2][2]
+    assert to == 8 and row[0] == idx.tobytes() and row[1] == tgt.tobytes() and row[2] == err.tobytes()
+    con.close()
+
+    # a second bulk-writer connection on a file that already has one is an ordinary connection (no second set of workers)
+    first = core.Database._open_bulk_writer(str(tmp_path / "c.db"))
+    second = core.Database._open_bulk_writer(str(tmp_path / "c.db"))
+    first.write_keypoints(1, frames[0][1])
+    assert np.array_equal(second.read_keypoints(1), frames[0][1])
+    second.close()
+    first.close()
+
+    # POLYCHASE_DB_WRITE_THREADS=0: the bulk writer is an ordinary connection too
+    os.environ["POLYCHASE_DB_WRITE_THREADS"] = "0"
+    try:
+        c0 = core._async_write_counters()["deferred_writes"]
+        db = core.Database._open_bulk_writer(str(tmp_path / "d.db"))
+        db._set_journal_mode("TRUNCATE")
+        db.write_keypoints(1, frames[0][1])
+        db.close()
+        assert core._async_write_counters()["deferred_writes"] == c0
+    finally:
+        del os.environ["POLYCHASE_DB_WRITE_THREADS"]

@@ -41,15 +41,19 @@ def main():
                                  ("host_frames_sqlite", host, os.path.join(td, "a.db")),
                                  ("device_frames_sqlite", dev, os.path.join(td, "b.db"))]:
             core.generate_optical_flow_database(core.VideoInfo(w, h, 1, 12), lambda f: frames[f - 1], None, "", core.GFTTOptions(), fo)
+            c0 = core._async_write_counters()
             t0 = time.perf_counter()
             st = core.generate_optical_flow_database(vi, lambda f: frames[f - 1], None, db, core.GFTTOptions(), fo)
             dt = time.perf_counter() - t0
+            c1 = core._async_write_counters()
             out[name] = {"fps": a.frames / dt, "fps_without_setup": a.frames / (dt - st.seconds_setup), "seconds_db": st.seconds_db,
                          "db_bytes": os.path.getsize(db) if db else 0,
                          # the driver thread's stage clock, ms per frame
                          "driver_ms_per_frame": {k: round(1e3 * getattr(st, "seconds_" + k) / a.frames, 4)
                                                  for k in ("accessor", "put", "submit", "collect", "writer_wait")},
-                         "setup_ms": round(1e3 * st.seconds_setup, 1)}
+                         "setup_ms": round(1e3 * st.seconds_setup, 1),
+                         # page writes of the database file: handed to the worker threads / carried out by SQLite's own thread
+                         "db_page_writes": {k: c1[k] - c0[k] for k in c1}}
     print(json.dumps({"config": a.config, "frames": a.frames, **out}))
 
 
