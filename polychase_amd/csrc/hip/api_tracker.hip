@@ -1,5 +1,6 @@
 // api_tracker.hip -- C ABI of the tracking and refinement paths: meshes + LBVH ray casting, PnP accumulation
 // (reference cpp/tracker.cc, cpp/pnp/*), and the refiner's per-edge sweeps (cpp/refiner.cc, cpp/pnp/lev_marq.h).
+#include <chrono>
 #include <limits>
 
 #include "api_internal.hpp"
@@ -96,6 +97,7 @@ struct pc_corr_set {
     DevBuf<float4> t_pts;
     DevBuf<float> t_partials;
     PinBuf<pc::TrackLmOut> t_out;
+    uint32_t t_seq = 0;   // number of the LM launch in flight (TrackLmOut::seq)
     bool t_sync_zero = false;
 };
 
@@ -783,6 +785,7 @@ int pc_track_frame_launch(pc_context* ctx, pc_corr_set* s, const pc_mesh* mesh, 
     la.partials = s->t_partials.p;
     la.sync = s->t_sync.p;
     la.out = s->t_out.p;
+    la.seq = ++s->t_seq;
     la.max_rounds = o->max_iterations + 3;   // the initial sweep, one per iteration, one more for the 3-point case
     la.bad_index = s->counter.p + 1;         // zero unless an earlier call found a bad index and has not been cleared
     s->t_out.p->status = -1;
@@ -799,7 +802,28 @@ int pc_track_frame_finish(pc_context* ctx, pc_corr_set* s, pc_track_solve_result
     result->n_matches = s->t_n;
     if (s->t_n == 0) return PC_OK;
     PC_HIP(hipSetDevice(ctx->device));
-    PC_HIP(hipStreamSynchronize(ctx->stream));
+    {
+        // The kernel writes its result into page-locked host memory and its launch number last (system-scope release): poll
+        // that word instead of waiting for the stream -- the pose is here before the other workgroups have left the GPU and the
+        // queue has signalled, and the next frame's launches are already on their way by then.  The stream wait stays as the
+        // fall-back (a kernel that died never writes the word).
+        const uint32_t* word = &s->t_out.p->seq;
+        bool seen = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0; !seen; spins++) {
+            seen = __atomic_load_n(word, __ATOMIC_ACQUIRE) == s->t_seq;
+            if (seen) break;
+            __builtin_ia32_pause();
+            if ((spins & 0x3ffu) == 0x3ffu && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        }
+        if (!seen) {
+            PC_HIP(hipStreamSynchronize(ctx->stream));
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != s->t_seq) {
+                s->t_sync_zero = false;
+                return fail(PC_E_STATE, "the PnP solver's launch ended without a result");
+            }
+        }
+    }
     const pc::TrackLmOut& out = *s->t_out.p;
     if (out.status == 2 || out.status < 0) {
         s->t_sync_zero = false;   // the barrier words are in an unknown state

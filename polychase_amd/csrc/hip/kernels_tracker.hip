@@ -841,8 +841,12 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
         tick(5);
         if (done) break;
     }
+    auto hand_over = [&]() { __hip_atomic_store(&a.out->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); };
     if (aborted) {
-        if (blockIdx.x == 0 && tid == 0) a.out->status = 2;
+        if (blockIdx.x == 0 && tid == 0) {
+            a.out->status = 2;
+            hand_over();
+        }
         return;
     }
     // ---- inlier pass on the accepted parameters (solvers.cc:31-47; pnp_cost_body's terms) ----
@@ -873,7 +877,10 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
     if (blockIdx.x != 0) return;
     wait_for_all(a.sync, round + 1u, &s_ok);
     if (!s_ok) {
-        if (tid == 0) a.out->status = 2;
+        if (tid == 0) {
+            a.out->status = 2;
+            hand_over();
+        }
         return;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -900,6 +907,7 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
         for (int k = 0; k < kTrackTickPhases; k++) o->ticks[k] = (uint32_t)tk[k];
         o->status = h.status;
         o->bad_index = *a.bad_index;
+        hand_over();
     }
 }
 

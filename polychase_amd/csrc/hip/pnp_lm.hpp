@@ -59,6 +59,10 @@ struct TrackLmOut {
     // 100 MHz ticks of workgroup 0, summed over the rounds: [0] sweep + publish, [1] waiting for the other workgroups, [2] adding
     // the partials, [3] the decision (one lane), [4] publishing it, [5] fetching the next parameters, [6] inlier pass, [7] launch
     uint32_t ticks[kTrackTickPhases];
+    // written LAST, with a system-scope release: TrackLmArgs::seq of the launch.  The host polls this word in its page-locked
+    // memory instead of waiting for the stream (the result is out before the other workgroups have left and the queue has
+    // signalled completion)
+    uint32_t seq;
 };
 struct TrackLmArgs {
     const float4* pts;        // track_cast_kernel's output
@@ -69,6 +73,7 @@ struct TrackLmArgs {
     float* partials;          // 56 x track_lm_blocks(n)
     uint32_t* sync;           // kTrackSyncWords
     TrackLmOut* out;          // device-visible host memory
+    uint32_t seq;             // this launch's number (TrackLmOut::seq)
     const int* bad_index;     // track_cast_kernel's flag, passed on to `out`
     int max_rounds;
 };
