@@ -250,3 +250,52 @@ def test_bulk_writer_connection_writes_the_same_file(core, tmp_path):
         assert core._async_write_counters()["deferred_writes"] == c0
     finally:
         del os.environ["POLYCHASE_DB_WRITE_THREADS"]
+
+
+def test_bulk_writer_reports_a_failed_deferred_write_at_the_commit(tmp_path):
+    """A page write that fails on the worker thread (file size limit here) must fail the transaction: the commit raises, the
+    journal rolls the file back, and the database is intact with exactly the rows committed before.  In a subprocess: the
+    limit is per process."""
+    import subprocess
+    import textwrap
+    script = textwrap.dedent("""
+        import os, resource, signal, sqlite3, sys
+        import numpy as np
+        sys.path.insert(0, os.path.join(%r, "polychase_amd", "core"))
+        import polychase_core as core
+        path = sys.argv[1]
+        signal.signal(signal.SIGXFSZ, signal.SIG_IGN)          # write(2) then fails with EFBIG instead of killing the process
+        kp = (np.arange(2 * 30000, dtype=np.float32).reshape(-1, 2))          # 240 KB per row
+        db = core.Database._open_bulk_writer(path)
+        assert db._set_journal_mode("TRUNCATE") == "truncate"
+        db._begin(); db.write_keypoints(1, kp); db.write_keypoints(2, kp); db._commit()
+        before = core._async_write_counters()["deferred_writes"]
+        resource.setrlimit(resource.RLIMIT_FSIZE, (2 * 1024 * 1024, resource.getrlimit(resource.RLIMIT_FSIZE)[1]))
+        failed = False
+        try:
+            db._begin()
+            for f in range(3, 40):                                           # 9 MB: far beyond the limit
+                db.write_keypoints(f, kp)
+            db._commit()
+        except Exception as e:
+            failed = True
+            print("raised:", str(e)[:120])
+        assert failed, "the commit went through although the pages could not be written"
+        assert core._async_write_counters()["deferred_writes"] > before
+        try:
+            db._rollback()
+        except Exception:
+            pass
+        try:
+            db.close()
+        except Exception:
+            pass
+        resource.setrlimit(resource.RLIMIT_FSIZE, (resource.RLIM_INFINITY, resource.getrlimit(resource.RLIMIT_FSIZE)[1]))
+        con = sqlite3.connect(path)
+        assert con.execute("PRAGMA integrity_check").fetchone()[0] == "ok"
+        assert [r[0] for r in con.execute("select image_id from keypoints order by image_id")] == [1, 2]
+        assert con.execute("select keypoints from keypoints where image_id = 2").fetchone()[0] == kp.tobytes()
+        print("intact")
+    """) % ROOT
+    r = subprocess.run([sys.executable, "-c", script, str(tmp_path / "full.db")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "intact" in r.stdout, r.stdout + r.stderr
