@@ -454,6 +454,7 @@ typedef struct pc_track_solve_result {
      * partials, [3] the decision (9x9 algebra, one lane), [4] publishing it, [5] fetching the next parameters,
      * [6] inlier pass, [7] the whole launch */
     unsigned lm_ticks[8];
+    unsigned long long lm_begin_tick, lm_end_tick;   /* the GPU's 100 MHz clock when the LM kernel began / handed over its result */
 } pc_track_solve_result;
 int pc_track_solve_frame(pc_context* ctx, pc_corr_set* set, const pc_mesh* mesh, const float* model_matrix, int check_mask,
                          const pc_track_source* sources, int n_sources, const void* matches, size_t matches_bytes,

@@ -837,6 +837,8 @@ int pc_track_frame_finish(pc_context* ctx, pc_corr_set* s, pc_track_solve_result
     result->n_correspondences = out.n_valid;
     result->rounds = out.rounds;
     for (int k = 0; k < 8; k++) result->lm_ticks[k] = out.ticks[k];
+    result->lm_begin_tick = out.begin_tick;
+    result->lm_end_tick = out.end_tick;
     if (out.status == 1) return PC_OK;   // fewer than 3 correspondences: nothing solved
     read_lm_camera(out.cam, &result->pnp.camera);
     result->pnp.iterations = out.iterations;

@@ -905,6 +905,8 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
         tick(6);
         tk[7] = wall_clock64() - t_begin;
         for (int k = 0; k < kTrackTickPhases; k++) o->ticks[k] = (uint32_t)tk[k];
+        o->begin_tick = (unsigned long long)t_begin;
+        o->end_tick = (unsigned long long)wall_clock64();
         o->status = h.status;
         o->bad_index = *a.bad_index;
         hand_over();

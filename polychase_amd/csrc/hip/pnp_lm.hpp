@@ -59,6 +59,7 @@ struct TrackLmOut {
     // 100 MHz ticks of workgroup 0, summed over the rounds: [0] sweep + publish, [1] waiting for the other workgroups, [2] adding
     // the partials, [3] the decision (one lane), [4] publishing it, [5] fetching the next parameters, [6] inlier pass, [7] launch
     uint32_t ticks[kTrackTickPhases];
+    unsigned long long begin_tick, end_tick;   // wall_clock64 (100 MHz) when workgroup 0 started / wrote this: idle time between launches
     // written LAST, with a system-scope release: TrackLmArgs::seq of the launch.  The host polls this word in its page-locked
     // memory instead of waiting for the stream (the result is out before the other workgroups have left and the queue has
     // signalled completion)

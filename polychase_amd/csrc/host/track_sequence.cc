@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -244,6 +245,7 @@ struct Scratch {
     uint64_t clock = 0;
     MatchBlock own_matches[2];   // alternating: the block of the frame on the GPU stays untouched while the next one is read
     int own_turn = 0;
+    unsigned long long last_end_tick = 0;   // the previous frame's hand-over on the GPU's clock (stage report)
 
     Scratch() : ctx(SharedGpuContext()) {
         GpuSection section;
@@ -491,6 +493,11 @@ class FrameSolver {
                                             "track/lm kernel: decision", "track/lm kernel: publish decision", "track/lm kernel: fetch parameters",
                                             "track/lm kernel: inlier pass", "track/lm kernel: whole launch"};
             for (int k = 0; k < 8; k++) StageClock::Add(kPhase[k], sr.lm_ticks[k] * 1e-5);   // 100 MHz ticks -> ms
+            // from the result of one frame to the first instruction of the next frame's LM kernel, on the GPU's clock: the turn-
+            // around through the host (poll, pose, enqueue) + launch latency + the ray-cast kernel
+            if (s_.last_end_tick && sr.lm_begin_tick > s_.last_end_tick)
+                StageClock::Add("track/gpu: result of a frame -> LM kernel of the next", static_cast<double>(sr.lm_begin_tick - s_.last_end_tick) * 1e-5);
+            s_.last_end_tick = sr.lm_end_tick;
             StageClock::Add("track/lm kernel: rounds (count, not ms)", sr.rounds);
             StageClock::Add("track/matches (count, not ms)", sr.n_matches);
             StageClock::Add("track/correspondences (count, not ms)", sr.n_correspondences);
@@ -578,11 +585,15 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
     pnp_opts.optimize_focal_length = optimize_focal_length;
     pnp_opts.optimize_principal_point = optimize_principal_point;
 
+    const auto t_entry = std::chrono::steady_clock::now();
     const int32_t step = frame_from < frame_to_inclusive ? 1 : -1;
     // (in this order: the scratch -- whose destructor waits for every stream of the correspondence set, the copy stream included --
     // goes first, the prefetcher with the page-locked blocks those copies read from after it)
+    auto since_entry = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count(); };
     FlowPrefetcher prefetcher(database.Path());
+    StageClock::Add("track/start-up: read-ahead thread and connection at (ms)", since_entry());
     Scratch scratch;
+    StageClock::Add("track/start-up: correspondence set at (ms)", since_entry());
     std::vector<int32_t> next_sources, wanted;
     // what frame `next` will need, read ahead: flows from the frames that have a pose by then -- filled now, or tracked
     // before it in this run -- and the keypoints of the frame tracked just before it (the one array no cache holds yet)
@@ -637,8 +648,11 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
         {
             FlowPrefetcher::Batch* batch = prefetcher.Take(first);
             request(first + step);
+            StageClock::Add("track/start-up: first batch read at (ms)", since_entry());
             solvers[cur].Plan(first, batch, nullptr);
+            StageClock::Add("track/start-up: first frame uploaded at (ms)", since_entry());
             solvers[cur].Launch();
+            StageClock::Add("track/start-up: first frame launched at (ms)", since_entry());
         }
         for (int32_t frame = first; frame != end; frame += step) {
             const int32_t next = frame + step;
@@ -671,6 +685,8 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
                 break;
             }
             if (!solved) throw std::runtime_error("Could not track to frame: " + std::to_string(frame) + ". Not enough features.");
+            if (frame == first)   // connections, page-locked blocks, the device's arrays, the first batch read: paid once per call
+                StageClock::Add("track/from the call to the first pose", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count());
             // the pose goes in at once -- the next frame's launches need it -- and comes out again if the callback stops the run:
             // the pose of a frame the user stopped at is not stored (:179-186)
             const std::optional<CameraState> before = camera_traj.Get(frame);

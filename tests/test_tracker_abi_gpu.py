@@ -154,7 +154,8 @@ class TrackSource(C.Structure):
 
 
 class TrackResult(C.Structure):
-    _fields_ = [("pnp", SolveResult), ("n_matches", C.c_int), ("n_correspondences", C.c_int), ("rounds", C.c_int), ("lm_ticks", C.c_uint * 8)]
+    _fields_ = [("pnp", SolveResult), ("n_matches", C.c_int), ("n_correspondences", C.c_int), ("rounds", C.c_int), ("lm_ticks", C.c_uint * 8),
+                ("lm_begin_tick", C.c_ulonglong), ("lm_end_tick", C.c_ulonglong)]
 
 
 def _block(flows):
@@ -271,7 +272,7 @@ def test_solve_frame_in_one_call_against_its_building_blocks(env):
         assert np.allclose(list(a.camera.t), [0, 0, 5], atol=5e-2 if opt_f else 5e-3)
         # the same call again on the same set: bit-identical (the barrier words came back zero, sums in a fixed order)
         rc, rr = _solve_frame(L, ctx, s, mesh, cams, kps_list, flows, init, o, keys=[11, 12, 13])
-        assert rc == 0 and bytes(rr)[:C.sizeof(TrackResult) - 32] == bytes(r)[:C.sizeof(TrackResult) - 32]   # all but the tick counters
+        assert rc == 0 and bytes(rr)[:C.sizeof(TrackResult) - 48] == bytes(r)[:C.sizeof(TrackResult) - 48]   # all but the tick counters
     o = SolveOptions(max_iterations=100, initial_lambda=1e-5, min_lambda=1e-10, max_lambda=1e10, gradient_tol=1e-10, step_tol=1e-8,
                      loss_type=0, loss_scale=1.0, optimize_focal_length=1, optimize_principal_point=1, f_low=10, f_high=5000, cx_low=0,
                      cx_high=640, cy_low=0, cy_high=480, max_inlier_error=2.0, rounds_hint=0)
