@@ -79,6 +79,75 @@ C4_FRAMES = 2400            # BASELINE.json configs[3]: 3840x2160, 2400 frames o
 RANK_ID_STRIDE = 1 << 20   # rank r owns frame ids 1 + r * stride ...: disjoint, ordered shards like analyze.py's
 
 
+# ---- N > 1 safety net ------------------------------------------------------------------------------------------------
+# Nothing of the N > 1 path has ever run between two GPUs (no multi-GPU box was leased to this project).  So that the
+# first such run cannot end without a line: (i) every rank first times the K steps on the N = 1 code path (no device
+# log, no stitch, no data-path collective) and rank 0 keeps a minimal line built from it; (ii) a watchdog thread on
+# every rank ends the job when nothing has progressed for POLYCHASE_BENCH_WATCHDOG_S seconds (a hung peer mapping, a
+# collective that never returns) or when the launcher asks the rank to terminate because another rank died: rank 0
+# prints the best line it has, marked "incomplete", and every rank leaves with exit code 0 if it has one, 3 otherwise.
+_WD = {"last": None, "stage": "start", "fallback": None, "armed": False, "rank": 0, "done": False}
+
+
+def wd_tick(stage=None):
+    _WD["last"] = time.monotonic()
+    if stage is not None:
+        _WD["stage"] = stage
+
+
+def wd_bail(why):
+    """ends this rank now: rank 0 prints the best line it has"""
+    if _WD["done"]:
+        return
+    _WD["done"] = True
+    if _WD.get("printed"):   # the full line is out: only the shutdown of the process group is stuck
+        os._exit(0)
+    line = _WD["fallback"]
+    print(f"[bench] rank {_WD['rank']}: {why} (stage: {_WD['stage']}); leaving with "
+          f"{'the line measured so far' if line is not None else 'no line'}", file=sys.stderr, flush=True)
+    if _WD["rank"] == 0 and line is not None:
+        line = dict(line)
+        line["incomplete"] = f"{why} (stage: {_WD['stage']}): the fields of the full line that were still to be measured are missing"
+        print(json.dumps(line), flush=True)
+    os._exit(0 if line is not None or _WD["rank"] != 0 else 3)
+
+
+def wd_start(rank, limit_s):
+    """one thread per rank: no progress for limit_s seconds, or SIGTERM from the launcher -> wd_bail"""
+    import signal
+    import threading
+
+    _WD["rank"] = rank
+    wd_tick("start")
+    rfd, wfd = os.pipe()
+    os.set_blocking(wfd, False)
+    os.set_blocking(rfd, False)
+    try:
+        # the C-level handler writes the signal number into the pipe at once, whatever the main thread is blocked in
+        signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
+        signal.signal(signal.SIGTERM, lambda *_: wd_bail("terminated by the launcher (another rank ended)"))
+    except (ValueError, OSError):
+        pass
+
+    def run():
+        import select
+
+        while not _WD["done"]:
+            r, _, _ = select.select([rfd], [], [], 2.0)
+            if r:
+                try:
+                    got = os.read(rfd, 64)
+                except OSError:
+                    got = b""
+                if bytes([signal.SIGTERM]) in got:
+                    wd_bail("terminated by the launcher (another rank ended)")
+            if time.monotonic() - _WD["last"] > limit_s:
+                wd_bail(f"no progress for {limit_s:.0f} s")
+
+    threading.Thread(target=run, name="bench-watchdog", daemon=True).start()
+    _WD["armed"] = True
+
+
 def level_pixels(w, h, max_level, win=10):
     s, lw, lh = 0, w, h
     for _ in range(max_level + 1):
@@ -345,10 +414,12 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e, arith=None
     import torch
     import torch.distributed as dist
 
+    from polychase_amd import distributed as D
     from polychase_amd import hip, synth
     from polychase_amd.pipeline import ClipAnalyzer
 
     w, h, max_level, label = CONFIGS[cfg]
+    wd_tick(f"{cfg}: set-up")
     clip = synth.NoiseClip(w, h, CLIP_FRAMES, device=str(dev))
     clip_frames = [clip.frame_torch(t) for t in range(CLIP_FRAMES)]
     torch.cuda.synchronize()
@@ -408,10 +479,11 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e, arith=None
     stitches = {}      # mode -> stitch object
     unavailable = {}   # mode -> why
     modes = ["n1"]
-    if dist_path:
+
+    def make_stitches():
+        nonlocal log, modes
         # device-resident record log: the stitch all-gathers these bytes, no host copy of the payload
-        from polychase_amd import distributed as D
-        max_kp = int(1.5 * max(n_kps)) + 4096
+        max_kp = int(1.5 * max(n_kps + [kp_hint])) + 4096
         log = torch.empty(D.log_capacity_bytes(K + 2, max_kp), dtype=torch.uint8, device=dev)
         side = None
         if dist.is_initialized():
@@ -449,6 +521,7 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e, arith=None
         stitch = stitches.get(mode)
         res = {"region_s": [], "lk_avg": [], "lk_busy": [], "lk_launches": 0, "rank_dt": [], "finish_ms": [], "log_bytes": []}
         for region in range(regions):
+            wd_tick(f"{cfg} {arith_name}: mode {mode}, region {region + 1} of {regions}")
             timed = range(nxt, nxt + K)
             nxt += K
             if stitch is not None:
@@ -528,9 +601,34 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e, arith=None
         res["mid"] = int(order[len(order) // 2])      # the median region
         return res
 
+    kp_hint = max(n_kps)
     n_kps.clear()
     n_rows.clear()
-    results = {m: run_regions(m) for m in modes}
+    results = {}
+    if dist_path:
+        if not light:
+            # first the N = 1 code path on every rank (no log, no stitch): the line the watchdog falls back to
+            wd_tick(f"{cfg} {arith_name}: the N = 1 code path on all ranks")
+            results["n1"] = run_regions("n1")
+            if rank == 0 and _WD["fallback"] is None:
+                r1 = results["n1"]
+                dt1 = r1["region_s"][r1["mid"]]
+                _WD["fallback"] = {
+                    "metric": "optical-flow frames/sec", "value": world * K / dt1, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+                    "ms_per_step": dt1 / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "u8/int32 fixed-point + f32 2x2 solve", "data": "synthetic",
+                    "config": {"workload": label, "width": w, "height": h, "max_level": max_level, "window": 10, "pairs_per_frame": 8,
+                               "frames_per_gpu": K, "arith": arith_name, "parallelism": f"frame-shard x{world}" if world > 1 else "single GPU",
+                               "stitch": "none: the analysis-only rate (every rank's records delivered to its host, no all-gather)",
+                               "timed_regions": len(r1["region_s"])}}
+        wd_tick(f"{cfg} {arith_name}: creating the device log and the stitches")
+        if os.environ.get("POLYCHASE_BENCH_TEST_HANG") == "stitch":   # tests/test_bench_gpu.py: the watchdog's own test
+            time.sleep(1e6)
+        make_stitches()
+    for m in modes:
+        if m not in results:
+            results[m] = run_regions(m)
+    wd_tick(f"{cfg} {arith_name}: after the timed regions")
     gc.enable()
     stitch_names = {m: st.name for m, st in stitches.items()}
     for st in stitches.values():
@@ -805,6 +903,8 @@ def main():
     # communicator, and every collective of the N > 1 path (barrier, all_reduce, all_gather, all_gather_into_tensor of the
     # log pieces) goes through RCCL on the one GPU a test box has -- the calls, dtypes and buffer shapes of --gpus N
     rccl_world1 = world == 1 and args.force_dist_path and os.environ.get("POLYCHASE_BENCH_RCCL_WORLD1") == "1"
+    if world > 1 or os.environ.get("POLYCHASE_BENCH_TEST_HANG"):
+        wd_start(rank, float(os.environ.get("POLYCHASE_BENCH_WATCHDOG_S", "300")))
     if world > 1:
         if share_gpu:
             dist.init_process_group("gloo")
@@ -857,8 +957,11 @@ def main():
             out["c5"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
+    _WD["printed"] = True
+    wd_tick("shutting the process group down")
     if dist.is_initialized():
         dist.destroy_process_group()
+    _WD["done"] = True
 
 
 if __name__ == "__main__":

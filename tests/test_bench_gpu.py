@@ -23,6 +23,21 @@ def test_forced_dist_path_runs_several_regions():
     assert out["config"]["timed_regions"] > 1, "the short C1 regions must repeat (the case that reuses the stitch)"
 
 
+def test_watchdog_prints_the_line_measured_so_far_when_the_stitch_hangs():
+    """The N > 1 path has never run between two GPUs: a rank that stops progressing (here: a simulated hang where the
+    stitches are created) must not leave the job without a line.  The ranks time the N = 1 code path first; the watchdog
+    prints that line, marked incomplete, and the process leaves with exit code 0."""
+    env = dict(os.environ, POLYCHASE_BENCH_TEST_HANG="stitch", POLYCHASE_BENCH_WATCHDOG_S="5")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist-path", "--no-cpu-baseline", "--no-c3",
+                        "--no-end-to-end", "--no-breakdown", "--config", "c1", "--steps", "16", "--warmup", "4"],
+                       text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["steps"] == 16 and "no progress" in out["incomplete"] and "stitch" in out["incomplete"]
+    assert out["metric"] == "optical-flow frames/sec" and out["config"]["stitch"].startswith("none")
+
+
 @pytest.mark.parametrize("stitch", ["peer", "rccl", "peer-broken"])
 def test_two_ranks_on_one_gpu_over_gloo(stitch):
     """bench.py exactly as the driver launches it for --gpus 2 (torch.distributed.run, two processes), except that both
