@@ -21,6 +21,11 @@ HIP_SOURCES = ["kernels_image.hip", "kernels_pyramid.hip", "kernels_gftt.hip", "
 # -ffp-contract=off: the float stages must match the oracle bit-for-bit (no FMA fusion).
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
              "-Wno-unused-function"]
+# Per-source additions.  The LK kernel with LLVM's max-ILP scheduling strategy: the same instructions (VALU / LDS counts and the
+# 136-VGPR allocation unchanged, 9 % fewer s_nop / s_waitcnt), same bits, 1-1.5 % off the step at C2 and C3 in alternating
+# runs against the default strategy, max-memory-clause, no post-RA scheduler, -O2 and the AMDGPU pressure trackers
+# (tools/probes/flag_ab.sh, profiles/r05_lk_compiler_flags.jsonl).
+HIP_SOURCE_FLAGS = {"kernels_lk3.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _newer(target: str, deps: list[str]) -> bool:
@@ -54,7 +59,7 @@ def build_hip(force: bool = False) -> str:
     def compile_one(pair):
         src, obj = pair
         if force or not _newer(obj, [src] + headers):
-            _run(["hipcc", *HIP_FLAGS, "-c", src, "-o", obj])
+            _run(["hipcc", *HIP_FLAGS, *HIP_SOURCE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj])
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(compile_one, zip(srcs, objs)))

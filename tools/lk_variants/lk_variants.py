@@ -30,7 +30,7 @@ def build_hip_variant(tag, extra_flags):
     srcs = [os.path.join(b.HIP_DIR, s) for s in b.HIP_SOURCES]
     objs = [os.path.join(odir, os.path.splitext(s)[0] + ".o") for s in b.HIP_SOURCES]
     with ThreadPoolExecutor(max_workers=8) as ex:
-        list(ex.map(lambda so: subprocess.check_call(["hipcc", *b.HIP_FLAGS, *extra_flags, "-c", so[0], "-o", so[1]]), zip(srcs, objs)))
+        list(ex.map(lambda so: subprocess.check_call(["hipcc", *b.HIP_FLAGS, *b.HIP_SOURCE_FLAGS.get(os.path.basename(so[0]), []), *extra_flags, "-c", so[0], "-o", so[1]]), zip(srcs, objs)))
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs])
     return out
 
