@@ -131,3 +131,39 @@ def test_4k_filtered_equals_raw(setup):
     (idx, fxy, ferr), = hip.lk_track_filtered(ctx, a, [b], hip.flow_options(max_level=ML))
     keep = np.nonzero(st[0] == 1)[0].astype(np.uint32)
     assert np.array_equal(idx, keep) and np.array_equal(fxy, xy[0][keep]) and np.array_equal(ferr, err[0][keep])
+
+
+def test_8k_frame_detection_pyramid_and_lk():
+    """Beyond BASELINE's sizes: a 7680x4320 frame (max_level 5: six levels; 650 k keypoints out of 1.4 M candidates).  The gray
+    plane and every pyramid / Scharr plane bit-exact, the keypoints equal to the oracle's over the WHOLE frame in value and
+    order (the bucket sort, the suppression and the ordered compaction at four times the 4K counts), LK bit-exact on a
+    random subset of 3000 keypoints."""
+    w, h, ml = 7680, 4320, 5
+    ctx = hip.Context(0)
+    clip = synth.NoiseClip(w, h, 16, device="cuda")
+    f0, f1 = clip.frame_torch(12), clip.frame_torch(14)
+    a, b = hip.Frame(ctx, w, h, 10, ml), hip.Frame(ctx, w, h, 10, ml)
+    try:
+        a.set_rgb(f0)
+        b.set_rgb(f1)
+        a.detect()
+        kps = a.keypoints()
+        g0 = oracle.rgb2gray(f0.cpu().numpy())
+        assert np.array_equal(a.gray(), g0)
+        p0, p1 = oracle.Pyramid(g0, 10, ml), oracle.Pyramid(oracle.rgb2gray(f1.cpu().numpy()), 10, ml)
+        assert a.num_levels == p0.num_levels == 6
+        for l in range(6):
+            assert np.array_equal(a.level(l), p0.image(l)) and np.array_equal(a.deriv(l), p0.deriv(l))
+        assert len(kps) > 400_000 and np.array_equal(np.asarray(oracle.gftt(g0, oracle.gftt_options())), kps)
+        xy, st, err = hip.lk_track(ctx, a, [b], hip.flow_options(max_level=ml))
+        sel = np.sort(np.random.default_rng(0).choice(len(kps), 3000, replace=False))
+        oxy, ost, oerr = oracle.lk(p0, p1, kps[sel], oracle.flow_options(max_level=ml))
+        assert np.array_equal(st[0][sel], ost)
+        m = ost == 1
+        assert m.mean() > 0.97
+        assert np.array_equal(xy[0][sel][m].view(np.uint32), oxy[m].view(np.uint32))
+        assert np.array_equal(err[0][sel][m].view(np.uint32), oerr[m].view(np.uint32))
+    finally:
+        a.close()
+        b.close()
+        ctx.close()
