@@ -541,7 +541,7 @@ void launch_pnp_cost(const float* X, const float* x, const float* w, int n, cons
 // another workgroup will read is written with agent-scope atomic stores and read either with agent-scope atomic loads (the
 // round word, the parameters) or with plain loads behind ONE acquire fence in the reading workgroup (the partials).
 // Co-residency: at most 256 workgroups of 256 lanes (one per CU of this chip), 12 KB of LDS each: every workgroup of the launch
-// is resident as long as half of every CU's registers are free, and nothing else on the GPU waits for this kernel.  The spin
+// is resident as long as 272 of every SIMD's 512 registers are free (the kernel holds 270 per lane: a lane's correspondences live in registers), and nothing else on the GPU waits for this kernel.  The spin
 // loops sleep between polls and give up after kTrackSpinLimit ticks (status 2) instead of hanging: the host then solves the
 // frame -- and the rest of the run -- with the per-source building blocks (csrc/host/track_sequence.cc).
 // ------------------------------------------------------------------------------------------------
@@ -639,16 +639,29 @@ __device__ __forceinline__ bool spin_until(Ready ready, uint32_t* sync) {
 }
 
 // wave sums -> LDS -> lanes k < NV publish the workgroup's sum of value k (value-major like pnp_normal_eq_body)
+// the wavefront's sum of v, in lane 63: six additions with a DPP operand (neighbour, other pair, other quad, other half of the row
+// of 16, then the rows' totals handed on by row_bcast 15 / 31) -- the six ds_bpermute + add + wait of a shuffle butterfly cost
+// the sweep of 56 values a microsecond per round
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_term(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp((int)0x80000000u, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));   // lanes the pattern leaves out add -0.0f: the identity of the addition, which lets the compiler fold the move into v_add_f32_dpp
+}
+__device__ __forceinline__ float wave_sum_in_lane63(float v) {
+    v += dpp_term<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v += dpp_term<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v += dpp_term<0x141, 0xf>(v);   // row_half_mirror
+    v += dpp_term<0x140, 0xf>(v);   // row_mirror: every lane of a row holds the row's sum
+    v += dpp_term<0x142, 0xa>(v);   // row_bcast 15 into rows 1 and 3
+    v += dpp_term<0x143, 0xc>(v);   // row_bcast 31 into rows 2 and 3
+    return v;
+}
 template <int NV>
 __device__ __forceinline__ void block_reduce_publish(float (&v)[NV], float (*s_part)[NV], float* __restrict__ partials) {
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d);
-    }
+    for (int k = 0; k < NV; k++) v[k] = wave_sum_in_lane63(v[k]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();   // the previous round's readers of s_part are done
-    if (lane == 0)
+    if (lane == 63)
 #pragma unroll
         for (int k = 0; k < NV; k++) s_part[wave][k] = v[k];
     __syncthreads();
@@ -755,6 +768,22 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
 #pragma unroll
         for (int k = 0; k < kParamWords; k++) pw[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)pw[k]);   // uniform: scalar registers
     }
+    // This lane's first kTrackKeep correspondences stay in registers for the whole launch (150 k matches over 65 536 lanes: all
+    // of them): the ~12 sweeps of a frame then start with arithmetic instead of a trip to the L2.  The order in which a lane
+    // adds its terms is unchanged.
+    constexpr int kTrackKeep = 3;
+    float4 keepP[kTrackKeep];
+    float2 keepO[kTrackKeep];
+#pragma unroll
+    for (int k = 0; k < kTrackKeep; k++) {
+        const size_t i = gtid + (size_t)k * T;
+        keepP[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        keepO[k] = make_float2(0.f, 0.f);
+        if (i < (size_t)a.n) {
+            keepP[k] = a.pts[i];
+            keepO[k] = a.obs[i];
+        }
+    }
     uint32_t round = 0;
     bool aborted = false;
     // where the launch's time goes, measured by workgroup 0 (100 MHz ticks, TrackLmOut::ticks): its own sweep + publish,
@@ -774,7 +803,10 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
         float acc[PNP_ACC];
 #pragma unroll
         for (int k = 0; k < PNP_ACC; k++) acc[k] = 0.f;
-        for (size_t i = gtid; i < (size_t)a.n; i += T) {
+#pragma unroll
+        for (int k = 0; k < kTrackKeep; k++)
+            if (keepP[k].w != 0.0f) pnp_accumulate(keepP[k].x, keepP[k].y, keepP[k].z, keepO[k].x, keepO[k].y, 1.0f, p, acc);
+        for (size_t i = gtid + (size_t)kTrackKeep * T; i < (size_t)a.n; i += T) {
             const float4 P = a.pts[i];
             if (P.w == 0.0f) continue;
             const float2 o = a.obs[i];
@@ -852,10 +884,7 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
     // ---- inlier pass on the accepted parameters (solvers.cc:31-47; pnp_cost_body's terms) ----
     {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (size_t i = gtid; i < (size_t)a.n; i += T) {
-            const float4 P = a.pts[i];
-            if (P.w == 0.0f) continue;
-            const float2 o = a.obs[i];
+        auto inlier_term = [&](const float4& P, const float2& o) {
             const float ax = p.R[0] * P.x + p.R[1] * P.y + p.R[2] * P.z + p.t[0];
             const float ay = p.R[3] * P.x + p.R[4] * P.y + p.R[5] * P.z + p.t[1];
             const float az = p.R[6] * P.x + p.R[7] * P.y + p.R[8] * P.z + p.t[2];
@@ -870,6 +899,14 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
             if (r2n < a.cfg.max_inlier_err_sq) acc[2] += 1.0f;
             acc[0] += loss_value(p.loss_type, p.loss_scale, r2n);
             acc[1] += 1.0f;
+        };
+#pragma unroll
+        for (int k = 0; k < kTrackKeep; k++)
+            if (keepP[k].w != 0.0f) inlier_term(keepP[k], keepO[k]);
+        for (size_t i = gtid + (size_t)kTrackKeep * T; i < (size_t)a.n; i += T) {
+            const float4 P = a.pts[i];
+            if (P.w == 0.0f) continue;
+            inlier_term(P, a.obs[i]);
         }
         block_reduce_publish<4>(acc, reinterpret_cast<float(*)[4]>(&s_part[0][0]), a.partials);
         grid_arrive(a.sync, round + 1u);
@@ -914,7 +951,7 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
 }
 
 // At most ONE workgroup per CU (256 on this chip): the launch needs every workgroup resident at once, and with one per CU that
-// holds as long as half of every CU's registers are free -- two per CU (512 workgroups, 239 VGPRs each) left no room for anything
+// holds as long as 272 of every SIMD's 512 registers are free -- two per CU (512 workgroups, 239 VGPRs each) left no room for anything
 // else on the GPU.  Measured on C5 (150 k matches per frame): the sweep gets a third loop trip, the partial sums and flags halve.
 int track_lm_blocks(int n) {
     const int b = (n + 255) / 256;
