@@ -132,6 +132,17 @@ __device__ __forceinline__ int mad16_hh(int a, uint32_t b, int acc) {
     asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
     return d;
 }
+// hi16(a) * (int16)b.lo / b.hi: the same with a literal zero accumulator (no register for it)
+__device__ __forceinline__ int mul16_hl(int a, uint32_t b) {
+    int d;
+    asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ int mul16_hh(int a, uint32_t b) {
+    int d;
+    asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[1,1,0,0]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 
 __device__ __forceinline__ int half_sum3_i32(int v) {
     v = group_allreduce_add<16>(v);
@@ -290,25 +301,44 @@ __device__ __forceinline__ float dpp_add4(float acc, float v, int src_lane) {
     return acc;
 }
 
-// (ix, iy) of the pixel in slot k as one dword, out of the paired register layout of the iteration loop
-// (sel_lo / sel_hi: the v_perm selectors 0x05040100 / 0x07060302 as OPAQUE values of the calling iteration -- with literal
-// selectors these permutations are invariants of the iteration loop, and hoisted out of it they occupy a register each)
-template <int WIN, int K>
-__device__ __forceinline__ uint32_t x86_unpacked_dxy(const int (&Dxy)[K], int k, uint32_t sel_lo, uint32_t sel_hi) {
+// acc1 + d * ix, acc2 + d * iy for the pixel in slot k (d = the high half of R), the derivatives picked out of the paired
+// register layout of the iteration loop by the multiply-add's op_sel: no v_perm
+template <int WIN, int K, bool FIRST>
+__device__ __forceinline__ void x86_mad_dxy(int R, const int (&Dxy)[K], int k, int& acc1, int& acc2) {
     using G = LK3Geo<WIN>;
     constexpr int H1 = (WIN + 1) / 2, H2 = WIN - H1;
+    // FIRST: the accumulators are not read (a literal zero in the instruction)
+    auto hl = [](int a, uint32_t b, int acc) { return FIRST ? mul16_hl(a, b) : mad16_hl(a, b, acc); };
+    auto hh = [](int a, uint32_t b, int acc) { return FIRST ? mul16_hh(a, b) : mad16_hh(a, b, acc); };
     if (k < G::KM) {
         const int c = k / WIN, r = k - c * WIN;
-        if (r < H2) return __builtin_amdgcn_perm((uint32_t)Dxy[c * WIN + H1 + r], (uint32_t)Dxy[c * WIN + r], sel_lo);
-        if (r >= H1) return __builtin_amdgcn_perm((uint32_t)Dxy[c * WIN + r], (uint32_t)Dxy[c * WIN + r - H1], sel_hi);
-        return (uint32_t)Dxy[k];   // an odd window's middle row
+        if (r < H2) {
+            acc1 = hl(R, (uint32_t)Dxy[c * WIN + r], acc1);
+            acc2 = hl(R, (uint32_t)Dxy[c * WIN + H1 + r], acc2);
+        } else if (r >= H1) {
+            acc1 = hh(R, (uint32_t)Dxy[c * WIN + r - H1], acc1);
+            acc2 = hh(R, (uint32_t)Dxy[c * WIN + r], acc2);
+        } else {   // an odd window's middle row: (ix, iy) in one register
+            acc1 = hl(R, (uint32_t)Dxy[k], acc1);
+            acc2 = hh(R, (uint32_t)Dxy[k], acc2);
+        }
+        return;
     }
     const int e = k - G::KM;
     if (G::KE > 1 && G::RUNS) {
-        if ((e & 1) == 0 && e + 1 < G::KE) return __builtin_amdgcn_perm((uint32_t)Dxy[k + 1], (uint32_t)Dxy[k], sel_lo);
-        if (e & 1) return __builtin_amdgcn_perm((uint32_t)Dxy[k], (uint32_t)Dxy[k - 1], sel_hi);
+        if ((e & 1) == 0 && e + 1 < G::KE) {
+            acc1 = hl(R, (uint32_t)Dxy[k], acc1);
+            acc2 = hl(R, (uint32_t)Dxy[k + 1], acc2);
+            return;
+        }
+        if (e & 1) {
+            acc1 = hh(R, (uint32_t)Dxy[k - 1], acc1);
+            acc2 = hh(R, (uint32_t)Dxy[k], acc2);
+            return;
+        }
     }
-    return (uint32_t)Dxy[k];
+    acc1 = hl(R, (uint32_t)Dxy[k], acc1);
+    acc2 = hh(R, (uint32_t)Dxy[k], acc2);
 }
 
 // The mismatch vector of one iteration in the x86 order (see above).  Returns the raw sums (b * 2^20) in all lanes of the group.
@@ -317,48 +347,57 @@ __device__ __forceinline__ void x86_mismatch_ordered(const uint32_t* jq, int lg,
                                                      int e_off, const int (&offE)[KEA], float& b1, float& b2) {
     using G = LK3Geo<WIN>;
     using X = X86Geo<WIN>;
-    constexpr int H1 = (WIN + 1) / 2, H2 = WIN - H1;
-    uint32_t sel_lo = 0x05040100u, sel_hi = 0x07060302u;
-    asm volatile("" : "+v"(sel_lo), "+v"(sel_hi));   // see x86_unpacked_dxy
     float q1 = 0.f, q2 = 0.f;   // this vector lane's accumulators
     if constexpr (X::SIMD_W == 8) {
         const uint32_t* cb0 = jq + lg;
         const uint32_t* cb1 = jq + lg + G::GL;
-        uint32_t top0 = cb0[0], top1 = cb1[0];
+        // q += (float)(int32 pair sum of columns c and c + 4), one term per row: two multiply-adds per quantity (op_sel picks
+        // the derivative's half), one conversion, one addition.  Rows go in pairs between scheduling barriers (the second
+        // row's multiply-adds fill the wait states of the first's) with the LDS reads of the next pair issued ahead of the
+        // arithmetic; the barriers keep the pairs in place: left to itself the scheduler forms all pair sums first and
+        // holds them in registers the kernel does not have.
+        uint32_t rowA[2] = {cb0[0], cb1[0]}, rowB[2] = {cb0[G::PITCH], cb1[G::PITCH]}, rowC[2] = {0u, 0u};
+        if (WIN > 1) {
+            rowC[0] = cb0[2 * G::PITCH];
+            rowC[1] = cb1[2 * G::PITCH];
+        }
 #pragma unroll
-        for (int r = 0; r < WIN; r++) {
-            const uint32_t bot0 = cb0[(r + 1) * G::PITCH], bot1 = cb1[(r + 1) * G::PITCH];
-            const int R0 = interp_r(top0, bot0, wJ, Bias[r]), R1 = interp_r(top1, bot1, wJ, Bias[WIN + r]);
-            top0 = bot0;
-            top1 = bot1;
-            const uint32_t Rp = __builtin_amdgcn_perm((uint32_t)R1, (uint32_t)R0, 0x07060302u);   // (diff of column c, diff of column c + 4)
-            uint32_t IX, IY;
-            if (r < H2) {
-                IX = __builtin_amdgcn_perm((uint32_t)Dxy[WIN + r], (uint32_t)Dxy[r], sel_lo);
-                IY = __builtin_amdgcn_perm((uint32_t)Dxy[WIN + H1 + r], (uint32_t)Dxy[H1 + r], sel_lo);
-            } else if (r >= H1) {
-                IX = __builtin_amdgcn_perm((uint32_t)Dxy[WIN + r - H1], (uint32_t)Dxy[r - H1], sel_hi);
-                IY = __builtin_amdgcn_perm((uint32_t)Dxy[WIN + r], (uint32_t)Dxy[r], sel_hi);
-            } else {
-                IX = __builtin_amdgcn_perm((uint32_t)Dxy[WIN + r], (uint32_t)Dxy[r], sel_lo);
-                IY = __builtin_amdgcn_perm((uint32_t)Dxy[WIN + r], (uint32_t)Dxy[r], sel_hi);
+        for (int r = 0; r < WIN; r += 2) {
+            const bool two = r + 1 < WIN;
+            uint32_t nxtB[2] = {0u, 0u}, nxtC[2] = {0u, 0u};   // rows r + 3 and r + 4 of the region: the bottoms of the next pair
+            if (r + 2 < WIN) {
+                nxtB[0] = cb0[(r + 3) * G::PITCH];
+                nxtB[1] = cb1[(r + 3) * G::PITCH];
+                if (r + 3 < WIN) {
+                    nxtC[0] = cb0[(r + 4) * G::PITCH];
+                    nxtC[1] = cb1[(r + 4) * G::PITCH];
+                }
             }
-            // q += (float)(int32 pair sum), one term per row.  ONE volatile statement per row: the additions are a dependent
-            // chain per accumulator, and left to itself the scheduler computes all 2 * WIN pair sums ahead of them and holds
-            // them in registers the kernel does not have (177 VGPRs instead of 136).  (s_nop: a dot product's result needs a
-            // wait state before a dependent VALU read on this target; the compiler inserts the same in its own code.)
-            int t1, t2;
-            asm volatile(
-                "v_dot2_i32_i16 %2, %4, %5, 0\n\t"
-                "v_dot2_i32_i16 %3, %4, %6, 0\n\t"
-                "s_nop 1\n\t"
-                "v_cvt_f32_i32 %2, %2\n\t"
-                "v_cvt_f32_i32 %3, %3\n\t"
-                "s_nop 0\n\t"
-                "v_add_f32 %0, %0, %2\n\t"
-                "v_add_f32 %1, %1, %3"
-                : "+v"(q1), "+v"(q2), "=&v"(t1), "=&v"(t2)
-                : "v"(Rp), "v"(IX), "v"(IY));
+            __builtin_amdgcn_sched_barrier(0);
+            const int R0 = interp_r(rowA[0], rowB[0], wJ, Bias[r]), R1 = interp_r(rowA[1], rowB[1], wJ, Bias[WIN + r]);
+            int S0 = 0, S1 = 0;
+            if (two) {
+                S0 = interp_r(rowB[0], rowC[0], wJ, Bias[r + 1]);
+                S1 = interp_r(rowB[1], rowC[1], wJ, Bias[WIN + r + 1]);
+            }
+            int t1, t2, u1 = 0, u2 = 0;
+            x86_mad_dxy<WIN, K, true>(R0, Dxy, r, t1, t2);
+            if (two) x86_mad_dxy<WIN, K, true>(S0, Dxy, r + 1, u1, u2);
+            x86_mad_dxy<WIN, K, false>(R1, Dxy, WIN + r, t1, t2);
+            if (two) x86_mad_dxy<WIN, K, false>(S1, Dxy, WIN + r + 1, u1, u2);
+            q1 += (float)t1;
+            q2 += (float)t2;
+            if (two) {
+                q1 += (float)u1;
+                q2 += (float)u2;
+            }
+            rowA[0] = rowC[0];
+            rowA[1] = rowC[1];
+            rowB[0] = nxtB[0];
+            rowB[1] = nxtB[1];
+            rowC[0] = nxtC[0];
+            rowC[1] = nxtC[1];
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // the scalar chain: every lane converts the products of the pixels it owns, then the terms are added in row-major
@@ -372,9 +411,10 @@ __device__ __forceinline__ void x86_mismatch_ordered(const uint32_t* jq, int lg,
             const uint32_t bot = cb[(r + 1) * G::PITCH];
             const int R = interp_r(top, bot, wJ, Bias[r]);
             top = bot;
-            const uint32_t u = x86_unpacked_dxy<WIN, K>(Dxy, r, sel_lo, sel_hi);
-            f1[r] = (float)mad16_hl(R, u, 0);
-            f2[r] = (float)mad16_hh(R, u, 0);
+            int p1, p2;
+            x86_mad_dxy<WIN, K, true>(R, Dxy, r, p1, p2);
+            f1[r] = (float)p1;
+            f2[r] = (float)p2;
         }
     }
     if constexpr (G::KE > 0) {
@@ -386,9 +426,10 @@ __device__ __forceinline__ void x86_mismatch_ordered(const uint32_t* jq, int lg,
                 const uint32_t bot = cb[(e + 1) * G::PITCH];
                 const int R = interp_r(top, bot, wJ, Bias[G::KM + e]);
                 top = bot;
-                const uint32_t u = x86_unpacked_dxy<WIN, K>(Dxy, G::KM + e, sel_lo, sel_hi);
-                f1[X::KSC0 + e] = (float)mad16_hl(R, u, 0);
-                f2[X::KSC0 + e] = (float)mad16_hh(R, u, 0);
+                int p1, p2;
+                x86_mad_dxy<WIN, K, true>(R, Dxy, G::KM + e, p1, p2);
+                f1[X::KSC0 + e] = (float)p1;
+                f2[X::KSC0 + e] = (float)p2;
             }
         } else {
 #pragma unroll
@@ -453,7 +494,11 @@ __device__ __forceinline__ void x86_structure_tensor(uint32_t* wbase, const uint
         const int len = c < 4 ? X::CL : X::NS;
         const float* src = pa + k * NPX + c * X::CL;
         float acc = 0.f;
-#pragma unroll 4
+        // all LDS reads of the chain in flight, then the additions (unrolled by four the loop sat out an LDS latency per batch:
+        // ~0.7 iteration-equivalents per ordered tensor); the 11-px window has no registers for that (it would drop to two
+        // wavefronts per SIMD)
+        constexpr int kUnroll = WIN <= 10 ? MAXL : 4;
+#pragma unroll kUnroll
         for (int i = 0; i < MAXL; i++) {
             const float v = src[i < len ? i : 0];
             acc = i < len ? v + acc : acc;
