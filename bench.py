@@ -399,8 +399,9 @@ def hard_content_block():
     import x86_cost_probe
     rows = x86_cost_probe.measure(("c2 texture", "edges + texture", "checkerboard", "binary blocks"), reps=20)
     out = {"what": "isolated LK launch, 1920x1080, 8 targets, lk_x86 vs canonical arithmetic; ms per launch",
-           "model": "ratio ~ 1 + 0.09 (the exactness proof, every iteration) + 0.085 x (share of ordered structure tensors) + 0.5 x (share of "
-                    "ordered iterations): fitted to these rows (DESIGN.md section 4)"}
+           "model": "ratio ~ 1 + 0.06 (the exactness proof, every iteration) + 0.03 x (share of ordered structure tensors) + 0.3 x (share of "
+                    "ordered iterations): a rough fit to these rows (DESIGN.md section 4; before the ordered iteration was rewritten in "
+                    "round 5: 0.09 / 0.085 / 0.5)"}
     for r in rows:
         out[r["content"]] = {"keypoints": r["keypoints"], "canonical_ms": r["canonical_ms"], "x86_ms": r["lk_x86_ms"],
                              "x86_over_canonical": r["x86_over_canonical"], "iterations_in_x86_order": r["iterations_in_x86_order"],
