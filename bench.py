@@ -86,7 +86,8 @@ RANK_ID_STRIDE = 1 << 20   # rank r owns frame ids 1 + r * stride ...: disjoint,
 # every rank ends the job when nothing has progressed for POLYCHASE_BENCH_WATCHDOG_S seconds (a hung peer mapping, a
 # collective that never returns) or when the launcher asks the rank to terminate because another rank died: rank 0
 # prints the best line it has, marked "incomplete", and every rank leaves with exit code 0 if it has one, 3 otherwise.
-_WD = {"last": None, "stage": "start", "fallback": None, "armed": False, "rank": 0, "done": False}
+_WD = {"last": None, "stage": "start", "fallback": None, "rank": 0, "done": False}
+_WD_LOCK = __import__("threading").Lock()   # the watchdog thread and the SIGTERM handler may both want to end the rank
 
 
 def wd_tick(stage=None):
@@ -97,7 +98,7 @@ def wd_tick(stage=None):
 
 def wd_bail(why):
     """ends this rank now: rank 0 prints the best line it has"""
-    if _WD["done"]:
+    if _WD["done"] or not _WD_LOCK.acquire(blocking=False):
         return
     _WD["done"] = True
     if _WD.get("printed"):   # the full line is out: only the shutdown of the process group is stuck
@@ -145,7 +146,6 @@ def wd_start(rank, limit_s):
                 wd_bail(f"no progress for {limit_s:.0f} s")
 
     threading.Thread(target=run, name="bench-watchdog", daemon=True).start()
-    _WD["armed"] = True
 
 
 def level_pixels(w, h, max_level, win=10):

@@ -541,7 +541,8 @@ void launch_pnp_cost(const float* X, const float* x, const float* w, int n, cons
 // another workgroup will read is written with agent-scope atomic stores and read either with agent-scope atomic loads (the
 // round word, the parameters) or with plain loads behind ONE acquire fence in the reading workgroup (the partials).
 // Co-residency: at most 256 workgroups of 256 lanes (one per CU of this chip), 12 KB of LDS each: every workgroup of the launch
-// is resident as long as 272 of every SIMD's 512 registers are free (the kernel holds 270 per lane: a lane's correspondences live in registers), and nothing else on the GPU waits for this kernel.  The spin
+// is resident as long as 272 of every SIMD's 512 registers are free (the kernel holds 270 per lane: a lane's correspondences
+// live in registers), and nothing else on the GPU waits for this kernel.  The spin
 // loops sleep between polls and give up after kTrackSpinLimit ticks (status 2) instead of hanging: the host then solves the
 // frame -- and the rest of the run -- with the per-source building blocks (csrc/host/track_sequence.cc).
 // ------------------------------------------------------------------------------------------------
@@ -638,13 +639,13 @@ __device__ __forceinline__ bool spin_until(Ready ready, uint32_t* sync) {
     }
 }
 
-// wave sums -> LDS -> lanes k < NV publish the workgroup's sum of value k (value-major like pnp_normal_eq_body)
-// the wavefront's sum of v, in lane 63: six additions with a DPP operand (neighbour, other pair, other quad, other half of the row
-// of 16, then the rows' totals handed on by row_bcast 15 / 31) -- the six ds_bpermute + add + wait of a shuffle butterfly cost
-// the sweep of 56 values a microsecond per round
+// The wavefront's sum of v, in lane 63: six additions whose second operand comes over DPP (neighbour, other pair, other quad, other
+// half of the row of 16, then the rows' totals handed on by row_bcast 15 / 31) -- a v_mov_b32_dpp + v_add_f32 each; the
+// ds_bpermute + wait + add of a shuffle butterfly cost the sweep of 56 values a microsecond per round.  Lanes a pattern leaves
+// out receive -0.0f, the identity of the addition.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_term(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp((int)0x80000000u, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));   // lanes the pattern leaves out add -0.0f: the identity of the addition, which lets the compiler fold the move into v_add_f32_dpp
+    return __int_as_float(__builtin_amdgcn_update_dpp((int)0x80000000u, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
 __device__ __forceinline__ float wave_sum_in_lane63(float v) {
     v += dpp_term<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
@@ -655,6 +656,7 @@ __device__ __forceinline__ float wave_sum_in_lane63(float v) {
     v += dpp_term<0x143, 0xc>(v);   // row_bcast 31 into rows 2 and 3
     return v;
 }
+// wave sums -> LDS -> lanes k < NV publish the workgroup's sum of value k (value-major like pnp_normal_eq_body)
 template <int NV>
 __device__ __forceinline__ void block_reduce_publish(float (&v)[NV], float (*s_part)[NV], float* __restrict__ partials) {
 #pragma unroll
