@@ -350,6 +350,12 @@ typedef struct pc_corr_set pc_corr_set;
 int pc_corr_set_create(pc_context* ctx, pc_corr_set** out);
 void pc_corr_set_destroy(pc_corr_set* set);
 int pc_corr_set_clear(pc_context* ctx, pc_corr_set* set);
+/* Makes a set fit for an unrelated run without giving its device memory back: waits for the set's own work (its copy stream
+ * and the context's stream), forgets the cached keypoint arrays (they are keyed by frame id: another database may use the same
+ * ids) and empties the set.  The host side parks ONE set per process between TrackSequence calls (csrc/host/track_sequence.cc):
+ * creating the set's streams, page-locked words and device arrays is 6-8 ms of a call (cpp/tracker.cc:133-192 has no such
+ * state: the reference allocates per frame on the host). */
+int pc_corr_set_recycle(pc_context* ctx, pc_corr_set* set);
 /* keypoints_xy: n_keypoints x 2 of the source frame; src_idx / tgt_xy: the n_matches rows of the flow
  * (src_keypoints_indices, tgt_keypoints).  Host pointers (pinned memory from pc_host_buffer_alloc is copied
  * asynchronously: it must stay untouched until pc_corr_set_size or a PnP call has returned).  keypoints_key >= 0

@@ -332,6 +332,24 @@ int pc_corr_set_clear(pc_context* ctx, pc_corr_set* s) {
     return PC_OK;
 }
 
+int pc_corr_set_recycle(pc_context* ctx, pc_corr_set* s) {
+    if (!ctx || !s) return fail(PC_E_INVALID, "null argument");
+    if (s->t_stage == 2) return fail(PC_E_STATE, "a frame is in flight: pc_track_frame_finish first");
+    PC_HIP(hipSetDevice(ctx->device));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
+    if (s->copy_stream) PC_HIP(hipStreamSynchronize(s->copy_stream));
+    for (auto& c : s->cache) {
+        c.key = -1;
+        c.n = 0;
+        c.stamp = 0;
+    }
+    s->clock = 0;
+    s->t_stage = 0;
+    s->t_n = 0;
+    s->t_block_bytes = 0;
+    return pc_corr_set_clear(ctx, s);
+}
+
 // grow X / x to `need` correspondences, keeping what they hold
 static int corr_reserve(pc_context* ctx, pc_corr_set* s, size_t need) {
     if (need <= s->capacity) return PC_OK;

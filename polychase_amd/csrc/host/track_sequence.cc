@@ -18,6 +18,7 @@
 #include <optional>
 #include <stdexcept>
 #include <thread>
+#include <vector>
 
 #include "gpu_context.h"
 #include "pnp.h"
@@ -32,22 +33,85 @@ constexpr float kMaxInlierError = 12.0f;  // tracker.cc:123 ("FIXME: Make this c
 // Page-locked host memory (pc_host_buffer_alloc): what the database reader fills is fetched by the GPU's copy engine as
 // it is -- a pageable std::vector costs a staging copy on the calling thread for every transfer (round 4: 31 us per
 // source frame, a fifth of a tracked frame).
+// What a TrackSequence call keeps for the next one (POLYCHASE_TRACK_CACHE=0: nothing): creating page-locked blocks, the
+// correspondence set's streams and device arrays is 6-8 ms of every call -- a third of a 50-frame run, and Blender calls
+// once per user action.  Page-locked blocks go back to a small process-wide pool instead of to the driver; one correspondence
+// set is parked (ParkedSet below).  Both are leaked at process exit on purpose (no GPU call after the runtime's teardown has
+// begun); ReleaseTrackerCaches() -- polychase_core.release_cached_engine() -- gives the memory back earlier.
+bool TrackCacheEnabled() {
+    const char* e = std::getenv("POLYCHASE_TRACK_CACHE");
+    return !(e && e[0] == '0');
+}
+
+class PinnedPool {
+   public:
+    static PinnedPool& Get() {
+        static PinnedPool* pool = new PinnedPool;   // never destroyed
+        return *pool;
+    }
+    // a block of at least `bytes` (the smallest that fits), or nullptr
+    void* Take(size_t bytes, size_t* cap) {
+        std::lock_guard<std::mutex> lk(m_);
+        int best = -1;
+        for (int i = 0; i < static_cast<int>(blocks_.size()); i++)
+            if (blocks_[i].cap >= bytes && (best < 0 || blocks_[i].cap < blocks_[best].cap)) best = i;
+        if (best < 0) return nullptr;
+        void* p = blocks_[best].p;
+        *cap = blocks_[best].cap;
+        total_ -= blocks_[best].cap;
+        blocks_.erase(blocks_.begin() + best);
+        return p;
+    }
+    // false: the pool is full (or off), the caller frees the block
+    bool Give(void* p, size_t cap) {
+        if (!p || !TrackCacheEnabled()) return false;
+        std::lock_guard<std::mutex> lk(m_);
+        if (blocks_.size() >= kMaxBlocks || total_ + cap > kMaxBytes) return false;
+        blocks_.push_back({p, cap});
+        total_ += cap;
+        return true;
+    }
+    void Clear() {
+        std::vector<Block> drop;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            drop.swap(blocks_);
+            total_ = 0;
+        }
+        for (const Block& b : drop) pc_host_buffer_free(b.p);
+    }
+
+   private:
+    struct Block {
+        void* p;
+        size_t cap;
+    };
+    static constexpr size_t kMaxBlocks = 48, kMaxBytes = 256u << 20;
+    std::mutex m_;
+    std::vector<Block> blocks_;
+    size_t total_ = 0;
+};
+
 class PinnedBuffer {
    public:
     PinnedBuffer() = default;
     PinnedBuffer(const PinnedBuffer&) = delete;
     PinnedBuffer& operator=(const PinnedBuffer&) = delete;
-    ~PinnedBuffer() { pc_host_buffer_free(p_); }
+    ~PinnedBuffer() { Drop(p_, cap_); }
     // at least `bytes`; `keep` bytes of the old contents survive a reallocation
     void Reserve(size_t bytes, size_t keep = 0) {
         if (bytes <= cap_) return;
-        const size_t want = bytes + bytes / 2 + 65536;   // pinned allocations take tens of milliseconds: grow rarely
-        void* q = nullptr;
-        if (pc_host_buffer_alloc(want, &q) != PC_OK) ThrowHip("pc_host_buffer_alloc");
+        const size_t want = bytes + bytes / 2 + 65536;   // pinned allocations take milliseconds: grow rarely
+        size_t got = 0;
+        void* q = PinnedPool::Get().Take(bytes, &got);
+        if (!q) {
+            if (pc_host_buffer_alloc(want, &q) != PC_OK) ThrowHip("pc_host_buffer_alloc");
+            got = want;
+        }
         if (keep) std::memcpy(q, p_, keep);
-        pc_host_buffer_free(p_);
+        Drop(p_, cap_);
         p_ = q;
-        cap_ = want;
+        cap_ = got;
     }
     uint8_t* data() const { return static_cast<uint8_t*>(p_); }
     void swap(PinnedBuffer& o) {
@@ -56,6 +120,9 @@ class PinnedBuffer {
     }
 
    private:
+    static void Drop(void* p, size_t cap) {
+        if (p && !PinnedPool::Get().Give(p, cap)) pc_host_buffer_free(p);
+    }
     void* p_ = nullptr;
     size_t cap_ = 0;
 };
@@ -247,15 +314,53 @@ struct Scratch {
     int own_turn = 0;
     unsigned long long last_end_tick = 0;   // the previous frame's hand-over on the GPU's clock (stage report)
 
+    // ONE correspondence set per process is parked between runs (its copy stream, event, page-locked result words and the
+    // device arrays a frame needs: 1.5-2 ms to create, more to grow to a clip's size).  A run that ended normally hands its
+    // set over through pc_corr_set_recycle (waits for the set's streams, forgets the keypoint arrays cached by frame id --
+    // the next run may read another database); a run that ended with an exception destroys it as before.
+    struct ParkedSet {
+        std::mutex m;
+        pc_corr_set* set = nullptr;
+    };
+    static ParkedSet& Parked() {
+        static ParkedSet* parked = new ParkedSet;   // never destroyed
+        return *parked;
+    }
+    bool reusable = false;   // set by the run when it has ended normally
+
     Scratch() : ctx(SharedGpuContext()) {
         GpuSection section;
-        if (pc_corr_set_create(ctx, &set) != PC_OK) throw std::runtime_error(std::string("pc_corr_set_create: ") + pc_last_error());
+        if (TrackCacheEnabled()) {
+            std::lock_guard<std::mutex> lk(Parked().m);
+            set = Parked().set;
+            Parked().set = nullptr;
+        }
+        if (!set && pc_corr_set_create(ctx, &set) != PC_OK) throw std::runtime_error(std::string("pc_corr_set_create: ") + pc_last_error());
     }
     Scratch(const Scratch&) = delete;
     Scratch& operator=(const Scratch&) = delete;
     ~Scratch() {
         GpuSection section;
+        if (reusable && TrackCacheEnabled() && pc_corr_set_recycle(ctx, set) == PC_OK) {
+            std::lock_guard<std::mutex> lk(Parked().m);
+            if (!Parked().set) {
+                Parked().set = set;
+                set = nullptr;
+            }
+        }
         pc_corr_set_destroy(set);
+    }
+    static void ReleaseParked() {
+        pc_corr_set* drop = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(Parked().m);
+            drop = Parked().set;
+            Parked().set = nullptr;
+        }
+        if (drop) {
+            GpuSection section;
+            pc_corr_set_destroy(drop);
+        }
     }
 
     const PinnedKeypoints& KeypointsOf(const Database& db, int32_t frame, FlowPrefetcher::Batch* batch) {
@@ -629,9 +734,13 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
             request(frame + step);
             const std::optional<PnPResult> solved = SolveFrameUnfused(database, camera_traj, model_matrix, frame, accel_mesh, pnp_opts, scratch, batch);
             if (!solved) throw std::runtime_error("Could not track to frame: " + std::to_string(frame) + ". Not enough features.");
-            if (!report_and_store(frame, *solved)) return;  // the pose of a frame the user stopped at is not stored (:179-186)
+            if (!report_and_store(frame, *solved)) {   // the pose of a frame the user stopped at is not stored (:179-186)
+                scratch.reusable = true;
+                return;
+            }
             camera_traj.Set(frame, solved->camera);
         }
+        scratch.reusable = true;
         StageClock::Report("TrackCameraTrajectory");
         return;
     }
@@ -703,12 +812,21 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
                 }
             } restore{camera_traj, frame, before};
             if (next != end) then.Launch();
-            if (!report_and_store(frame, *solved)) return;   // (`then`'s destructor waits for the launches that are no longer wanted)
+            if (!report_and_store(frame, *solved)) {   // (`then`'s destructor waits for the launches that are no longer wanted)
+                scratch.reusable = true;
+                return;
+            }
             restore.armed = false;
             cur ^= 1;
         }
     }
+    scratch.reusable = true;   // ended normally: the correspondence set is parked for the next run (Scratch)
     StageClock::Report("TrackCameraTrajectory");
+}
+
+void ReleaseTrackerCaches() {
+    Scratch::ReleaseParked();
+    PinnedPool::Get().Clear();
 }
 
 void TrackSequence(const std::string& database_path, int32_t frame_from, int32_t frame_to_inclusive,

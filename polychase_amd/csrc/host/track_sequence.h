@@ -24,6 +24,10 @@ void TrackSequence(const std::string& database_path, int32_t frame_from, int32_t
                    TrackingCallback callback, bool optimize_focal_length, bool optimize_principal_point,
                    BundleOptions opts);
 
+// Gives back what a run keeps for the next one: the parked correspondence set (device memory, a stream) and the pool of
+// page-locked blocks (track_sequence.cc; POLYCHASE_TRACK_CACHE=0 keeps nothing in the first place).
+void ReleaseTrackerCaches();
+
 // The 3D-2D correspondences SolveFrame (tracker.cc:36-97) would hand to PnP for `frame` under the poses in
 // camera_traj -- built on the GPU like in TrackCameraTrajectory, then downloaded (tests / debugging).
 void FrameCorrespondences(const Database& database, const CameraTrajectory& camera_traj, const Mat4f& model_matrix,

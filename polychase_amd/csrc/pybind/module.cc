@@ -16,6 +16,7 @@
 #include "../host/analysis_thread.h"
 #include "../host/multi_gpu.h"
 #include "../host/stage_clock.h"
+#include "../host/track_sequence.h"
 #include "np_helpers.h"
 
 #ifdef PC_WITH_TRACKER
@@ -419,7 +420,12 @@ PYBIND11_MODULE(polychase_core, m) {
         for (const auto& kv : StageClock::Last(title)) d[py::str(kv.first)] = py::make_tuple(kv.second.first, kv.second.second);
         return d;
     });
-    m.def("release_cached_engine", &ReleaseCachedEngine);   // not in the reference: gives the parked GPU engine's memory back
+    // not in the reference: gives back what the calls keep for the next one -- the parked analysis engine, the tracker's parked
+    // correspondence set and its pool of page-locked blocks
+    m.def("release_cached_engine", [] {
+        ReleaseCachedEngine();
+        ReleaseTrackerCaches();
+    });
     m.def("generate_optical_flow_shard", &GenerateOpticalFlowShardPy, py::arg("video_info"), py::arg("frame_accessor_function"),
           py::arg("callback"), py::arg("database_path"), py::arg("shard_begin"), py::arg("shard_end"), py::arg("device_log") = 0,
           py::arg("capacity_bytes") = 0, py::arg("log_buffers") = 1, py::arg("piece_frames") = 0, py::arg("on_piece") = py::none(),

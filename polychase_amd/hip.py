@@ -39,7 +39,7 @@ SYMBOLS = [
     "pc_comm_unique_id", "pc_comm_create", "pc_comm_destroy", "pc_comm_world_size", "pc_comm_rank", "pc_comm_all_gather_log",
     "pc_comm_send", "pc_comm_recv",
     "pc_mesh_create", "pc_mesh_set_mask", "pc_mesh_destroy", "pc_raycast_pixels", "pc_raycast_pixels_sweep",
-    "pc_corr_set_create", "pc_corr_set_destroy", "pc_corr_set_clear", "pc_corr_set_append", "pc_corr_set_size",
+    "pc_corr_set_create", "pc_corr_set_destroy", "pc_corr_set_clear", "pc_corr_set_recycle", "pc_corr_set_append", "pc_corr_set_size",
     "pc_corr_set_download", "pc_pnp_problem_from_set",
     "pc_pnp_problem_create", "pc_pnp_problem_destroy", "pc_pnp_normal_equations", "pc_pnp_normal_equations_cost",
     "pc_pnp_solve", "pc_pnp_total_cost", "pc_track_solve_frame", "pc_track_frame_upload", "pc_track_frame_launch", "pc_track_frame_finish",

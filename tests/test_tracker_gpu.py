@@ -672,3 +672,59 @@ def test_pipelined_solve_frame_semantics(core, tmp_path, monkeypatch):
         core.track_sequence(path, 1, n_frames, core.SceneTransformations(model, view4(R0, t0), intr(core)), mesh,
                             lambda r: seen.update({r.frame: 1}) or True, False, False, bo)
     assert sorted(seen) == [2, 3, 4, 5, 6, 7, 8]
+
+
+def test_what_a_run_keeps_for_the_next_one_does_not_leak_into_it(core, tmp_path, monkeypatch):
+    """A TrackSequence call that ends normally parks its correspondence set (device arrays, a stream, and -- inside the set -- the
+    keypoint arrays of its source frames CACHED BY FRAME ID) and its page-locked blocks for the next call (track_sequence.cc:
+    Scratch::ParkedSet, PinnedPool; pc_corr_set_recycle).  The next call may read ANOTHER database with the same frame ids:
+    its poses must be those of a process that kept nothing -- after a run on a different database, after a stopped run, after an
+    exception -- bit for bit, and POLYCHASE_TRACK_CACHE=0 / release_cached_engine() must give the same again."""
+    verts, tris = grid_mesh()
+    model = np.diag([1.5, 1.5, 1.5, 1.0]).astype(np.float32)
+    n_frames = 12
+    path_a, path_b = str(tmp_path / "a.db"), str(tmp_path / "b.db")
+    _build_flow_db(core, path_a, verts, tris, model, n_frames, n_kp=300, noise=0.05, seed=3)
+    _build_flow_db(core, path_b, verts, tris, model, n_frames, n_kp=340, noise=0.05, seed=11)   # other keypoints under the same ids
+    mesh = core.AcceleratedMesh(verts, tris)
+    bo = core.BundleOptions()
+    bo.loss_type = core.LossType.Cauchy
+
+    def run(path, cb=None):
+        R0, t0 = true_pose(1)
+        st = core.SceneTransformations(model, view4(R0, t0), intr(core))
+        got = {}
+
+        def default_cb(r):
+            got[r.frame] = (np.array(r.pose.q, float), np.array(r.pose.t, float), r.inlier_ratio, r.bundle_stats.iterations)
+            return True if cb is None else cb(r)
+        core.track_sequence(path, 1, n_frames, st, mesh, default_cb, False, False, bo)
+        return got
+
+    def same(x, y):
+        return sorted(x) == sorted(y) and all(np.array_equal(x[f][0], y[f][0]) and np.array_equal(x[f][1], y[f][1]) and x[f][2:] == y[f][2:] for f in x)
+
+    core.release_cached_engine()
+    fresh_b = run(path_b)
+    core.release_cached_engine()
+    fresh_a = run(path_a)                       # parks a set that holds A's keypoints under the frame ids 1 .. 12
+    assert not same(fresh_a, fresh_b)
+    assert same(run(path_b), fresh_b)           # ... which B must not see
+    assert same(run(path_a), fresh_a)
+    run(path_a, cb=lambda r: r.frame < 6)       # a stopped run (its speculative launch dropped) parks too
+    assert same(run(path_b), fresh_b)
+
+    class Boom(Exception):
+        pass
+
+    def boom(r):
+        raise Boom("stop")
+    with pytest.raises(Exception, match="stop"):
+        run(path_a, cb=boom)                    # an exception: the set is destroyed, not parked
+    assert same(run(path_b), fresh_b)
+    monkeypatch.setenv("POLYCHASE_TRACK_CACHE", "0")
+    assert same(run(path_b), fresh_b) and same(run(path_a), fresh_a)
+    monkeypatch.delenv("POLYCHASE_TRACK_CACHE")
+    assert same(run(path_b), fresh_b)
+    core.release_cached_engine()
+    assert same(run(path_a), fresh_a)
