@@ -720,10 +720,8 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ partia
 #pragma unroll
     for (int q = 0; q < PER_WAVE; q++) {
         const int k = wave + 4 * q;
-        float s = (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-        if (lane == 0 && k < NV) s_out[k] = s;
+        const float s = wave_sum_in_lane63((v[q][0] + v[q][1]) + (v[q][2] + v[q][3]));
+        if (lane == 63 && k < NV) s_out[k] = s;
     }
 }
 
