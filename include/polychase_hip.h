@@ -34,7 +34,8 @@ extern "C" {
 
 #define PC_MAX_TARGETS 8      /* the reference tracks each frame into <= 8 neighbours (opticalflow.cc:76-77) */
 #define PC_MAX_LEVELS 8
-#define PC_MAX_WINDOW 16
+#define PC_MAX_WINDOW 31      /* OpticalFlowOptions.window_size is free in the reference (opticalflow.h:27-33); OpenCV's own default is 21.
+                                 3: lk4, 4..11: the two-keypoint kernel (lk3), 12..31: lk4 (one keypoint per wavefront, 8 lanes per target) */
 
 typedef struct pc_context pc_context;
 typedef struct pc_frame pc_frame;

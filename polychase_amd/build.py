@@ -17,7 +17,7 @@ LIB_DIR = os.path.join(PKG, "lib")
 OBJ_DIR = os.path.join(PKG, "lib", "obj")
 HIP_DIR = os.path.join(PKG, "csrc", "hip")
 
-HIP_SOURCES = ["kernels_image.hip", "kernels_pyramid.hip", "kernels_gftt.hip", "kernels_lk.hip", "kernels_lk3.hip", "kernels_tracker.hip", "kernels_refiner.hip", "kernels_bvh.hip", "api.hip", "api_analyzer.hip", "api_tracker.hip", "api_comm.hip"]
+HIP_SOURCES = ["kernels_image.hip", "kernels_pyramid.hip", "kernels_gftt.hip", "kernels_lk.hip", "kernels_lk3.hip", "kernels_lk4a.hip", "kernels_lk4b.hip", "kernels_lk4c.hip", "kernels_tracker.hip", "kernels_refiner.hip", "kernels_bvh.hip", "api.hip", "api_analyzer.hip", "api_tracker.hip", "api_comm.hip"]
 # -ffp-contract=off: the float stages must match the oracle bit-for-bit (no FMA fusion).
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall",
              "-Wno-unused-function"]
@@ -61,7 +61,7 @@ def build_hip(force: bool = False) -> str:
         if force or not _newer(obj, [src] + headers):
             _run(["hipcc", *HIP_FLAGS, *HIP_SOURCE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj])
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(compile_one, zip(srcs, objs)))
     _run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs])
     return out

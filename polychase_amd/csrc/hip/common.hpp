@@ -10,8 +10,9 @@
 
 namespace pc {
 
-// Left padding (bytes) of every pyramid plane: >= window, and 16 so interior rows are 16-B aligned.
-constexpr int kPadX = 16;
+// Left padding (bytes) of every pyramid plane: >= PC_MAX_WINDOW + 1 (an LK region starts one position left of its window,
+// which may start a window's width left of the image), and a multiple of 16 so that interior rows are 16-B aligned.
+constexpr int kPadX = 32;
 
 // One pyramid level resident in HBM.  `img` / `der` point at the INTERIOR origin (x=0, y=0); the
 // padding (win rows above/below, kPadX bytes left, >= win bytes right) is addressable with negative

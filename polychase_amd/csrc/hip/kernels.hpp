@@ -142,6 +142,11 @@ constexpr int kRecStride = 8;   // records per slot (= PC_MAX_TARGETS)
 bool launch_lk(const LKParams& p, int win, hipStream_t s);
 // two keypoints per wavefront on the uint16 planes, dword-per-position LDS regions (kernels_lk3.hip); windows 4..11
 bool launch_lk3(const LKParams& p, int win, hipStream_t s);
+// one keypoint per wavefront, 8 lanes per target, on the uint16 planes (lk4_kernel.hpp); windows 3 and 12..31, spread over
+// three translation units (kernels_lk4{a,b,c}.hip)
+bool launch_lk4a(const LKParams& p, int win, hipStream_t s);
+bool launch_lk4b(const LKParams& p, int win, hipStream_t s);
+bool launch_lk4c(const LKParams& p, int win, hipStream_t s);
 bool lk_profile_enabled();   // library compiled with -DPC_LK_PROFILE: LKParams::prof takes 16 words per wavefront
 // counting sort of keypoint indices by 64x64 tile -> perm[n]; hist: bin_num_tiles(w, h) words of scratch
 int bin_num_tiles(int w, int h);

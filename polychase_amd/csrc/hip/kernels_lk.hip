@@ -389,9 +389,11 @@ static void launch_lk_t(const LKParams& p0, hipStream_t s) {
     else hipLaunchKernelGGL((lk_kernel<WIN, false>), dim3((unsigned)p.blocks_per_xcd * 8u), dim3(256), 0, s, p);
 }
 
-// POLYCHASE_LK_VARIANT=1 forces the one-keypoint-per-wavefront kernel (round 1's two-keypoint kernel on the u8 planes,
-// kernels_lk2.hip, was removed in round 3 after its last measurement: profiles/r03_c2_lk_variants.jsonl);
-// default: the two-keypoint kernel on the uint16 planes (kernels_lk3.hip) where the window allows it
+// POLYCHASE_LK_VARIANT=1 forces the generic one-keypoint-per-wavefront kernel of this file (windows up to 16: the cross-check of
+// the two product kernels; round 1's two-keypoint kernel on the u8 planes, kernels_lk2.hip, was removed in round 3 after its last
+// measurement: profiles/r03_c2_lk_variants.jsonl);
+// default: the two-keypoint kernel on the uint16 planes (kernels_lk3.hip) for windows 4..11, the eight-lanes-per-target kernel
+// (lk4_kernel.hpp) for window 3 and windows 12..31
 static int lk_variant() {
     static const int v = [] {
         const char* e = getenv("POLYCHASE_LK_VARIANT");
@@ -403,6 +405,7 @@ static int lk_variant() {
 bool launch_lk(const LKParams& p, int win, hipStream_t s) {
     const int v = lk_variant();
     if ((v == 0 || v == 3) && launch_lk3(p, win, s)) return true;
+    if ((v != 1 || win > 16) && (launch_lk4a(p, win, s) || launch_lk4b(p, win, s) || launch_lk4c(p, win, s))) return true;
     switch (win) {
 #define PC_LK_CASE(W) case W: launch_lk_t<W>(p, s); return true;
         PC_LK_CASE(3) PC_LK_CASE(4) PC_LK_CASE(5) PC_LK_CASE(6) PC_LK_CASE(7) PC_LK_CASE(8) PC_LK_CASE(9)

@@ -73,10 +73,12 @@ def test_x86_lk_order_is_bit_exact_on_step_edges_and_differs_from_canonical(ctx)
 
 
 @pytest.mark.parametrize("win,max_level,n_targets", [(10, 3, 8), (7, 2, 2), (13, 3, 3), (16, 1, 1), (4, 2, 2), (8, 3, 5), (5, 2, 3), (6, 3, 8),
-                                                      (9, 2, 4), (11, 3, 7), (3, 1, 2), (12, 2, 1)])
+                                                      (9, 2, 4), (11, 3, 7), (3, 1, 2), (12, 2, 1), (14, 2, 3), (15, 3, 8), (17, 2, 2), (20, 1, 3),
+                                                      (21, 3, 8), (24, 2, 2), (27, 1, 1), (29, 2, 3), (31, 2, 4)])
 def test_x86_lk_order_every_window_geometry(ctx, win, max_level, n_targets):
     """(win / 8) * 8 vector columns + scalar rest: 0 + 3 ... 0 + 7, 8 + 0 ... 8 + 5, 16 + 0 columns; windows 4-11 run on the
-    two-keypoint kernel (kernels_lk3.hip, X86 = true), the others on the generic one"""
+    two-keypoint kernel (kernels_lk3.hip, X86 = true), 3 and 12-31 on the eight-lanes-per-target kernel (lk4_kernel.hpp: up to
+    three 8-column blocks of vector lanes + up to 7 scalar columns)"""
     frames = synth.checkerboard_clip(16, w=320, h=240)
     _lk_both(ctx, [frames[6]] + [frames[6 + k + 1] for k in range(n_targets)], hip.ARITH_LK_X86_ORDER, oracle.EMU_LK_SIMD, win, max_level)
     clip = synth.NoiseClip(320, 240, 12)

@@ -219,10 +219,13 @@ def test_lk_bit_exact_odd_size_and_windows(ctx):
     _lk_case(ctx, 333, 211, 5, [7], max_level=4, win=13)
 
 
-@pytest.mark.parametrize("win,n_targets", [(3, 2), (4, 1), (5, 3), (6, 8), (8, 5), (9, 7), (11, 4), (12, 2), (16, 3)])
+@pytest.mark.parametrize("win,n_targets", [(3, 2), (4, 1), (5, 3), (6, 8), (8, 5), (9, 7), (11, 4), (12, 2), (13, 8), (14, 1), (15, 5), (16, 3),
+                                           (17, 2), (18, 8), (19, 1), (20, 3), (21, 8), (22, 2), (23, 4), (24, 1), (25, 6), (26, 2), (27, 1),
+                                           (28, 3), (29, 2), (30, 1), (31, 8)])
 def test_lk_every_window_size_and_target_count(ctx, win, n_targets):
-    """Windows 4..11 run the two-keypoints-per-wavefront kernel (chains + remainder columns differ per size),
-    the others the one-keypoint kernel; target counts below 8 leave groups idle."""
+    """Windows 4..11 run the two-keypoints-per-wavefront kernel (chains + remainder columns differ per size), 3 and 12..31
+    (PC_MAX_WINDOW; OpenCV's own default is 21) the one-keypoint, eight-lanes-per-target kernel (lk4_kernel.hpp: one to four
+    column chains per lane, entries in registers up to 16 px and in LDS above); target counts below 8 leave groups idle."""
     ts = [11, 12, 14, 18, 9, 8, 6, 2][:n_targets]
     _lk_case(ctx, 320, 200, 10, ts, max_level=2, win=win)
 
@@ -254,6 +257,14 @@ def test_lk_bit_exact_1080p(ctx):
     _lk_case(ctx, 1920, 1080, 15, [16, 23], n=30)
 
 
+@pytest.mark.parametrize("win", [17, 21, 31])
+def test_lk_large_windows_odd_size_and_1080p(ctx, win):
+    """OpticalFlowOptions.window_size above 16 (cpp/opticalflow.h:27-33 accepts any; OpenCV's default is 21): bit-exact at an odd
+    frame size (levels end early: the next level would be <= the window) and at 1920x1080"""
+    _lk_case(ctx, 333, 211, 5, [6, 4, 9], max_level=3, win=win)
+    _lk_case(ctx, 1920, 1080, 15, [16, 11], n=30, win=win)
+
+
 def test_lk_border_features(ctx):
     """Keypoints within a window of the border exercise the REFLECT_101 / zero paddings and the
     out-of-range status paths."""
@@ -280,8 +291,10 @@ def test_lk_border_features(ctx):
 def test_errors(ctx):
     with pytest.raises(hip.PolychaseHipError):
         hip.Frame(ctx, 64, 64, window_size=2)
+    hip.Frame(ctx, 64, 64, window_size=17).close()            # windows up to PC_MAX_WINDOW = 31 run
+    hip.Frame(ctx, 64, 64, window_size=31).close()
     with pytest.raises(hip.PolychaseHipError):
-        hip.Frame(ctx, 64, 64, window_size=17)
+        hip.Frame(ctx, 64, 64, window_size=32)
     f = hip.Frame(ctx, 64, 64)
     g = hip.Frame(ctx, 64, 64)
     f.set_gray(np.zeros((64, 64), np.uint8))

@@ -46,7 +46,7 @@ def test_random_configuration(ctx, seed):
     rng = np.random.default_rng(1000 + seed)
     w, h = int(rng.integers(24, 260)), int(rng.integers(24, 200))
     kind = ["noise", "blocks", "smooth"][seed % 3]
-    win = int(rng.integers(3, 17))
+    win = int(rng.integers(3, 32))
     max_level = int(rng.integers(0, 6))
     gk = dict(quality_level=float(rng.choice([0.001, 0.01, 0.05, 0.3])), min_distance=float(rng.choice([0.0, 1.0, 2.5, 5.0, 11.0])),
               max_corners=int(rng.choice([0, 0, 7, 300])), grid_rows=int(rng.integers(1, 7)), grid_cols=int(rng.integers(1, 7)))
@@ -100,7 +100,7 @@ def test_random_clip_through_the_analyzer(ctx, seed):
     w, h = int(rng.integers(48, 200)), int(rng.integers(48, 160))
     n, first = int(rng.integers(1, 27)), int(rng.integers(-3, 40))
     kind = ["noise", "blocks", "smooth"][seed % 3]
-    win, max_level = int(rng.integers(4, 14)), int(rng.integers(0, 4))
+    win, max_level = int(rng.integers(3, 26)), int(rng.integers(0, 4))
     gk = dict(quality_level=float(rng.choice([0.01, 0.05])), min_distance=float(rng.choice([0.0, 3.0, 5.0])),
               max_corners=int(rng.choice([0, 40])), grid_rows=int(rng.integers(1, 5)), grid_cols=int(rng.integers(1, 5)))
     fk = dict(window_size=win, max_level=max_level, term_max_iters=int(rng.choice([5, 30])))
@@ -141,7 +141,7 @@ def test_random_detector_branch_and_arithmetic_mode(ctx, seed):
     rng = np.random.default_rng(9000 + seed)
     w, h = int(rng.integers(40, 300)), int(rng.integers(40, 220))
     kind = ["noise", "blocks", "smooth"][seed % 3]
-    win, max_level = int(rng.integers(3, 17)), int(rng.integers(0, 4))
+    win, max_level = int(rng.integers(3, 32)), int(rng.integers(0, 4))
     block = int(rng.choice([1, 2, 3, 3, 4, 5, 7]))
     harris = bool(rng.random() < 0.35)
     arith = int(rng.choice([hip.ARITH_CANONICAL, hip.ARITH_LK_X86_ORDER, hip.ARITH_SOBEL_FMA, hip.ARITH_OPENCV_X86,
