@@ -33,7 +33,8 @@ extern "C" {
 #define PC_E_STATE (-5)       /* call sequence error (e.g. frame has no keypoints) */
 
 #define PC_MAX_TARGETS 8      /* the reference tracks each frame into <= 8 neighbours (opticalflow.cc:76-77) */
-#define PC_MAX_LEVELS 8
+#define PC_MAX_LEVELS 16      /* a pyramid ends where the next level would be <= the window (>= 3 px): 14 levels at most for the
+                                 2^30 pixels a frame may have; any max_level >= 0 is accepted (OpenCV: maxLevel is free) */
 #define PC_MAX_WINDOW 31      /* OpticalFlowOptions.window_size is free in the reference (opticalflow.h:27-33); OpenCV's own default is 21.
                                  3: lk4, 4..11: the two-keypoint kernel (lk3), 12..31: lk4 (one keypoint per wavefront, 8 lanes per target) */
 
@@ -60,7 +61,7 @@ typedef struct pc_gftt_options {
 /* OpticalFlowOptions, cpp/opticalflow.h:27-33 */
 typedef struct pc_flow_options {
     int window_size;            /* 10  (3..PC_MAX_WINDOW) */
-    int max_level;              /* 3   (0..PC_MAX_LEVELS-1) */
+    int max_level;              /* 3   (any value >= 0: the pyramid ends where the next level would be <= the window, as in OpenCV) */
     int term_max_iters;         /* 30 */
     double term_epsilon;        /* 0.01 */
     double min_eigen_threshold; /* 1e-4 */

@@ -463,7 +463,8 @@ static void scharr_deriv(const uint8_t* src, int sstride, int w, int h, int16_t*
 }
 
 pco_pyramid* pco_pyramid_build(const uint8_t* gray, int w, int h, int win, int max_level) {
-    if (win <= 2 || max_level < 0 || max_level >= PCO_MAX_LEVELS || w < 1 || h < 1) return NULL;
+    if (win <= 2 || max_level < 0 || w < 1 || h < 1) return NULL;
+    if (max_level >= PCO_MAX_LEVELS) max_level = PCO_MAX_LEVELS - 1; /* no frame of <= 2^30 pixels has that many levels (loop below) */
     pco_pyramid* p = (pco_pyramid*)calloc(1, sizeof(pco_pyramid));
     p->win = win;
     int lw = w, lh = h;

@@ -140,7 +140,8 @@ int validate_gftt(const pc_gftt_options* opt, int w, int h, pc::GfttGrid* g) {
     // cornerEigenValsVecs: Sobel apertures 3 / 5 / 7 or Scharr (-1) (gftt.cc:31-36)
     if (opt->gradient_size != 3 && opt->gradient_size != 5 && opt->gradient_size != 7 && opt->gradient_size != -1)
         return fail(PC_E_INVALID, "gradient_size must be 3, 5, 7 (Sobel) or -1 (Scharr)");
-    if (opt->block_size < 1 || opt->block_size > 31) return fail(PC_E_INVALID, "block_size must be in [1,31] on the HIP path");
+    // cornerMinEigenVal / cornerHarris take any block size (boxFilter); 2 * block_size reads per pixel from kBoxRowsFromBlock on
+    if (opt->block_size < 1) return fail(PC_E_INVALID, "block_size must be >= 1");
     if (opt->min_distance > 64.0) return fail(PC_E_INVALID, "min_distance > 64 is not supported on the HIP path");
     g->rows = std::max(1, opt->grid_rows);
     g->cols = std::max(1, opt->grid_cols);
@@ -162,7 +163,9 @@ static int corner_response(pc_context* ctx, const pc_frame* f, DetectScratch& d,
         return PC_OK;
     }
     PC_HIP(d.cov.ensure((size_t)3 * f->w * f->h));
-    if (!pc::launch_corner_response(f->levels[0], d.eig.p, d.cov.p, grid, cell_max, opt.block_size, opt.gradient_size, opt.use_harris != 0, opt.harris_k,
+    const bool two_pass = opt.block_size >= pc::kBoxRowsFromBlock;
+    if (two_pass) PC_HIP(d.box_rows.ensure((size_t)3 * f->w * f->h));
+    if (!pc::launch_corner_response(f->levels[0], d.eig.p, d.cov.p, two_pass ? d.box_rows.p : nullptr, grid, cell_max, opt.block_size, opt.gradient_size, opt.use_harris != 0, opt.harris_k,
                                     fma, ctx->work))
         return fail(PC_E_INVALID, "gradient_size must be 3, 5, 7 (Sobel) or -1 (Scharr)");
     return PC_OK;
@@ -796,7 +799,10 @@ int pc_frame_create(pc_context* ctx, int width, int height, int window_size, int
     if (width < 1 || height < 1) return fail(PC_E_INVALID, "bad frame size %dx%d", width, height);
     // buildOpticalFlowPyramid: CV_Assert(winSize.width > 2 && winSize.height > 2)
     if (window_size < 3 || window_size > PC_MAX_WINDOW) return fail(PC_E_INVALID, "window_size must be in [3,%d]", PC_MAX_WINDOW);
-    if (max_level < 0 || max_level >= PC_MAX_LEVELS) return fail(PC_E_INVALID, "max_level must be in [0,%d]", PC_MAX_LEVELS - 1);
+    if (max_level < 0) return fail(PC_E_INVALID, "max_level must be >= 0");
+    // OpenCV takes any maxLevel and stops where the next level would be <= winSize: with windows >= 3 px and frames <= 2^30 pixels
+    // no pyramid reaches PC_MAX_LEVELS levels, so clamping the request changes nothing
+    max_level = std::min(max_level, PC_MAX_LEVELS - 1);
     if ((long long)width * height > (1ll << 30)) return fail(PC_E_INVALID, "frame too large");
     PC_HIP(hipSetDevice(ctx->device));
     pc_frame* f = new (std::nothrow) pc_frame();

@@ -18,6 +18,8 @@
 #include "../../../include/polychase_hip.h"
 #include "kernels.hpp"
 
+static_assert(pc::kMaxLevels == PC_MAX_LEVELS, "LKParams holds PC_MAX_LEVELS levels");
+
 namespace pc {
 
 std::string& last_error();
@@ -110,6 +112,7 @@ struct DetectScratch {
     DevBuf<unsigned long long> keys, keys_bucketed, keys_sorted;
     DevBuf<float> eig;                     // min-eig map (K2 -> K3, K5)
     DevBuf<float> cov;                     // covariance planes of the general corner response (block_size != 3 / Harris), on demand
+    DevBuf<double> box_rows;               // row sums of the box filter for large block sizes (kernels.hpp kBoxRowsFromBlock), on demand
     DevBuf<uint8_t> cstate;                // 0 no candidate / 1 candidate / 2 accepted / 3 rejected
     // [0] candidates, [1] keypoints, [2] stuck lanes, [3] fast-path overflow bits, [4] sort range hi, [5] sort shift, [6..7] pad,
     // [8 ..] cell max [kMaxGridCells], bucket counts [kSortBuckets], bucket cursors [kSortBuckets]
@@ -129,6 +132,7 @@ struct DetectScratch {
         keys_sorted.release();
         eig.release();
         cov.release();
+        box_rows.release();
         cstate.release();
         counters.release();
         bucket_offsets.release();

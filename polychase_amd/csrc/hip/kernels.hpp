@@ -56,8 +56,10 @@ constexpr int kMaxGridCells = 256;
 // bit 1: the row pass of Dy as a fused chain (PC_ARITH_SOBEL_ROW_FMA)
 void launch_min_eig(const Level& l0, float* eig, const GfttGrid& g, uint32_t* cell_max, int sobel_fma, hipStream_t s);
 // K2 for any block_size, any gradient_size (3, 5, 7: Sobel; -1: Scharr) and for cornerHarris (gftt.cc:31-36): two plain kernels;
-// cov = 3 * w * h floats of scratch.  false: not an aperture OpenCV has
-bool launch_corner_response(const Level& l0, float* eig, float* cov, const GfttGrid& g, uint32_t* cell_max, int block_size, int gradient_size,
+// cov = 3 * w * h floats of scratch; box_rows = 3 * w * h doubles (the box filter's row sums: block^2 -> 2 * block reads per pixel,
+// the same additions in the same order) or null.  false: not an aperture OpenCV has
+constexpr int kBoxRowsFromBlock = 12;   // callers pass box_rows from this block size on
+bool launch_corner_response(const Level& l0, float* eig, float* cov, double* box_rows, const GfttGrid& g, uint32_t* cell_max, int block_size, int gradient_size,
                             bool harris, double harris_k, int sobel_fma, hipStream_t s);
 // K3: per-cell THRESH_TOZERO + 3x3 dilate + strict-interior local maxima -> 64-bit keys
 // (ordered(value) << 32 | y*w+x) appended to `keys` (capacity `cap`), count in *counter; cstate (w*h bytes): 1 at
@@ -98,10 +100,11 @@ hipError_t sort_keys_desc(void* temp, size_t& temp_bytes, unsigned long long* ke
                           unsigned long long* keys_out, uint32_t n, hipStream_t s);
 
 // ---- kernels_lk.hip ----
+constexpr int kMaxLevels = 16;   // == PC_MAX_LEVELS (internal.hpp asserts it)
 struct LKParams {
-    Level src[8];             // frame1 levels
-    const uint8_t* tgt[8][8]; // [target][level] interior origins (same geometry as src)
-    const uint16_t* tgt16[8][8];  // the same levels as uint16 (pixel << 7) planes (Level::img16)
+    Level src[kMaxLevels];             // frame1 levels
+    const uint8_t* tgt[8][kMaxLevels]; // [target][level] interior origins (same geometry as src)
+    const uint16_t* tgt16[8][kMaxLevels];  // the same levels as uint16 (pixel << 7) planes (Level::img16)
     int n_targets;
     int max_level;            // effective (min over pyramids)
     int n;                    // number of keypoints

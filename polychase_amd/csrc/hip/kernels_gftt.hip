@@ -521,7 +521,27 @@ __global__ __launch_bounds__(256) void cov_kernel(const uint8_t* __restrict__ im
     cov[2 * n + i] = dy * dy;
 }
 
-__global__ __launch_bounds__(256) void box_response_kernel(const float* __restrict__ cov, int w, int h, int block, int harris, double harris_k,
+// Large blocks: the row sums of the box filter once per pixel (RowSum), three fp64 planes; box_response_kernel then adds
+// `block` of them per pixel (ColumnSum) instead of block^2 products -- the same additions in the same order, the same bits.
+__global__ __launch_bounds__(256) void box_rows_kernel(const float* __restrict__ cov, int w, int h, int block, double* __restrict__ rows, int hi_prio) {
+    helper_priority(hi_prio);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const size_t n = (size_t)w * h, row = (size_t)y * w;
+    const int a0 = block / 2;
+    double rxx = 0, rxy = 0, ryy = 0;
+    for (int i = 0; i < block; i++) {
+        const size_t at = row + reflect101(x + i - a0, w);
+        rxx += (double)cov[at];
+        rxy += (double)cov[n + at];
+        ryy += (double)cov[2 * n + at];
+    }
+    rows[row + x] = rxx;
+    rows[n + row + x] = rxy;
+    rows[2 * n + row + x] = ryy;
+}
+
+__global__ __launch_bounds__(256) void box_response_kernel(const float* __restrict__ cov, const double* __restrict__ rows, int w, int h, int block, int harris, double harris_k,
                                                            float* __restrict__ eig, GfttGrid g, uint32_t* __restrict__ cell_max, int hi_prio) {
     helper_priority(hi_prio);
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -531,18 +551,27 @@ __global__ __launch_bounds__(256) void box_response_kernel(const float* __restri
     // the oracle's order (RowSum then ColumnSum): each window row left to right, the row sums top to bottom.  Exact for
     // 8-bit inputs in the canonical arithmetic; under PC_ARITH_SOBEL_FMA the order defines the last bit of ~1 pixel in 10^5.
     double sxx = 0, sxy = 0, syy = 0;
-    for (int j = 0; j < block; j++) {
-        const size_t row = (size_t)reflect101(y + j - a0, h) * w;
-        double rxx = 0, rxy = 0, ryy = 0;
-        for (int i = 0; i < block; i++) {
-            const size_t at = row + reflect101(x + i - a0, w);
-            rxx += (double)cov[at];
-            rxy += (double)cov[n + at];
-            ryy += (double)cov[2 * n + at];
+    if (rows) {
+        for (int j = 0; j < block; j++) {
+            const size_t at = (size_t)reflect101(y + j - a0, h) * w + x;
+            sxx += rows[at];
+            sxy += rows[n + at];
+            syy += rows[2 * n + at];
         }
-        sxx += rxx;
-        sxy += rxy;
-        syy += ryy;
+    } else {
+        for (int j = 0; j < block; j++) {
+            const size_t row = (size_t)reflect101(y + j - a0, h) * w;
+            double rxx = 0, rxy = 0, ryy = 0;
+            for (int i = 0; i < block; i++) {
+                const size_t at = row + reflect101(x + i - a0, w);
+                rxx += (double)cov[at];
+                rxy += (double)cov[n + at];
+                ryy += (double)cov[2 * n + at];
+            }
+            sxx += rxx;
+            sxy += rxy;
+            syy += ryy;
+        }
     }
     float e;
     if (harris) {
@@ -577,7 +606,7 @@ __global__ __launch_bounds__(256) void box_response_kernel(const float* __restri
     }
 }
 
-bool launch_corner_response(const Level& l0, float* eig, float* cov, const GfttGrid& g, uint32_t* cell_max, int block_size, int gradient_size,
+bool launch_corner_response(const Level& l0, float* eig, float* cov, double* box_rows, const GfttGrid& g, uint32_t* cell_max, int block_size, int gradient_size,
                             bool harris, double harris_k, int sobel_fma, hipStream_t s) {
     SobelTaps T;
     int taps = 0;
@@ -589,7 +618,8 @@ bool launch_corner_response(const Level& l0, float* eig, float* cov, const GfttG
         hipLaunchKernelGGL(cov_kernel<5>, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, cov, T, sobel_fma, helper_prio_arg());
     else
         hipLaunchKernelGGL(cov_kernel<7>, grid, dim3(256), 0, s, l0.img, l0.pitch, l0.w, l0.h, cov, T, sobel_fma, helper_prio_arg());
-    hipLaunchKernelGGL(box_response_kernel, grid, dim3(256), 0, s, cov, l0.w, l0.h, block_size, harris ? ((sobel_fma & 1) ? 2 : 1) : 0, harris_k, eig, g, cell_max,
+    if (box_rows) hipLaunchKernelGGL(box_rows_kernel, grid, dim3(256), 0, s, cov, l0.w, l0.h, block_size, box_rows, helper_prio_arg());
+    hipLaunchKernelGGL(box_response_kernel, grid, dim3(256), 0, s, cov, (const double*)box_rows, l0.w, l0.h, block_size, harris ? ((sobel_fma & 1) ? 2 : 1) : 0, harris_k, eig, g, cell_max,
                        helper_prio_arg());
     return true;
 }

@@ -157,6 +157,28 @@ def test_sync_binding_with_options_and_errors(core, tmp_path):
                                             str(tmp_path / "s.db"))
 
 
+@pytest.mark.parametrize("win,arith", [(17, "opencv_x86"), (21, "opencv_x86"), (31, "opencv_x86"), (21, "canonical"), (31, "canonical"), (3, "opencv_x86")])
+def test_large_windows_through_generate_optical_flow_database(core, tmp_path, monkeypatch, win, arith):
+    """OpticalFlowOptions.window_size is a free attribute in the reference (cpp/opticalflow.h:27-33, polychase_pybind.cc:138-145)
+    and OpenCV's own default is 21: windows above 16 (and 3) through the binding, database byte-equal to the reference-shaped
+    CPU path in the default and the canonical arithmetic"""
+    monkeypatch.setenv("POLYCHASE_ARITH", arith)
+    clip = synth.NoiseClip(333, 211, 11)
+    frames = [clip.frame(t) for t in range(11)]
+    fo = core.OpticalFlowOptions()
+    fo.window_size = win
+    fo.max_level = 3
+    path = str(tmp_path / f"w{win}.db")
+    stats = core.generate_optical_flow_database(core.VideoInfo(333, 211, 1, 11), lambda fid: frames[fid - 1], None, path,
+                                                core.GFTTOptions(), fo)
+    assert stats.frames_processed == 11
+    emu = (oracle.EMU_LK_SIMD | oracle.EMU_SOBEL_FMA) if arith == "opencv_x86" else 0
+    with oracle.emulation(emu):
+        ek, ef = _expect(frames, 1, fopt=oracle.flow_options(window_size=win, max_level=3))
+    k, f = _dump(path)
+    assert k == ek and f == ef
+
+
 def test_device_resident_frames_through_the_binding(core, tmp_path):
     import torch
     clip = synth.NoiseClip(256, 192, 10)

@@ -129,11 +129,13 @@ def test_gftt_options(ctx):
 @pytest.mark.parametrize("kw", [dict(use_harris=1), dict(use_harris=1, harris_k=0.15), dict(block_size=5), dict(block_size=2),
                                 dict(block_size=1), dict(block_size=7, use_harris=1), dict(block_size=4, min_distance=3.0, grid_rows=2),
                                 dict(gradient_size=5), dict(gradient_size=7), dict(gradient_size=-1), dict(gradient_size=5, use_harris=1),
-                                dict(gradient_size=7, block_size=2), dict(gradient_size=-1, block_size=5, use_harris=1, harris_k=0.08)],
+                                dict(gradient_size=7, block_size=2), dict(gradient_size=-1, block_size=5, use_harris=1, harris_k=0.08),
+                                dict(block_size=12), dict(block_size=33), dict(block_size=40, use_harris=1, gradient_size=5)],
                          ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
 def test_harris_and_other_block_sizes(ctx, kw):
     """The detector's other branches (reference cpp/feature_detection/gftt.cc:31-36: cornerHarris, any block_size, and since
-    round 5 every gradient_size the bound GFTTOptions can carry -- Sobel 5 / 7, Scharr = -1), which the addon never selects:
+    round 5 every gradient_size the bound GFTTOptions can carry -- Sobel 5 / 7, Scharr = -1; block sizes from 12 on take the
+    two-pass box filter, any size runs), which the addon never selects:
     response map and keypoints -- value and order -- bit-exact against the oracle, on sizes that do not divide the kernels'
     tiles (odd, so that every border reflection of the 7-tap aperture is exercised); also through the analyzer."""
     for (w, h) in ((333, 211), (640, 360)):
@@ -146,7 +148,7 @@ def test_harris_and_other_block_sizes(ctx, kw):
         want = oracle.corner_harris(g, bs, ks, k) if kw.get("use_harris") else oracle.min_eigen_val(g, bs, ks)
         assert np.array_equal(f.min_eig().view(np.uint32), want.view(np.uint32)), "response map"
         xy = oracle.gftt(g, oracle.gftt_options(**kw))
-        assert len(xy) > 50 and np.array_equal(f.keypoints(), xy), "keypoints must match in value AND order"
+        assert len(xy) > 10 and np.array_equal(f.keypoints(), xy), "keypoints must match in value AND order"
         f.close()
     from polychase_amd.pipeline import ClipAnalyzer
     clip = synth.NoiseClip(320, 240, 6)

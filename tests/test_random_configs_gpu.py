@@ -142,7 +142,7 @@ def test_random_detector_branch_and_arithmetic_mode(ctx, seed):
     w, h = int(rng.integers(40, 300)), int(rng.integers(40, 220))
     kind = ["noise", "blocks", "smooth"][seed % 3]
     win, max_level = int(rng.integers(3, 32)), int(rng.integers(0, 4))
-    block = int(rng.choice([1, 2, 3, 3, 4, 5, 7]))
+    block = int(rng.choice([1, 2, 3, 3, 4, 5, 7, 13, 34]))
     harris = bool(rng.random() < 0.35)
     arith = int(rng.choice([hip.ARITH_CANONICAL, hip.ARITH_LK_X86_ORDER, hip.ARITH_SOBEL_FMA, hip.ARITH_OPENCV_X86,
                             hip.ARITH_SOBEL_FMA | hip.ARITH_SOBEL_ROW_FMA, hip.ARITH_OPENCV_X86 | hip.ARITH_SOBEL_ROW_FMA, hip.ARITH_SOBEL_ROW_FMA]))
