@@ -469,13 +469,27 @@ int pc_track_solve_frame(pc_context* ctx, pc_corr_set* set, const pc_mesh* mesh,
                          const pc_pnp_camera* initial, const pc_pnp_solve_options* options, pc_track_solve_result* result);
 /* The same in three steps, so that a caller overlaps the host's part and the transfer of frame f + 1 with the launches of
  * frame f (csrc/host/track_sequence.cc): upload = the matches block (and the keypoints of sources the set has not cached yet)
- * on the set's own copy stream, into the second of two device blocks -- callable while a frame is in flight, before the
+ * on the set's own copy stream, into the next of three device blocks -- callable while frames are in flight, before the
  * cameras of its sources are known; launch = the two launches behind that upload, for the block uploaded last; finish =
  * wait + result.  `matches` and the keypoint arrays must stay untouched until the frame's finish. */
 int pc_track_frame_upload(pc_context* ctx, pc_corr_set* set, const void* matches, size_t matches_bytes, const pc_track_source* sources,
                           int n_sources);
 int pc_track_frame_launch(pc_context* ctx, pc_corr_set* set, const pc_mesh* mesh, const float* model_matrix, int check_mask,
                           const pc_track_source* sources, int n_sources, const pc_pnp_camera* initial, const pc_pnp_solve_options* options);
+/* The launch with its inputs taken from the launch enqueued JUST BEFORE it on this set, on the device: up to TWO frames may be in
+ * flight (finished in launch order), so that the GPU goes from frame f to frame f + 1 without the host in between -- SolveFrame of
+ * f + 1 needs the pose of f twice (tracker.cc:43-50: f is one of its source frames; :111-119: f's pose is its initial guess), and
+ * both are left on the device by f's launch.
+ *   chained_source  index into `sources` of the source frame whose camera (pc_track_source::cam is ignored for it) is the result
+ *                   of the previous launch, or -1;
+ *   chain_initial   != 0: the initial camera is the previous launch's result (`initial` is ignored);
+ * both require that a launch of this set has run since it was created / recycled.  Sources of a second frame in flight must
+ * have keypoints_key >= 0.  If the previous launch fails, this one runs on whatever it left (bounded by max_iterations) and the
+ * caller, who learns of the failure first, drops its result. */
+int pc_track_frame_launch_chained(pc_context* ctx, pc_corr_set* set, const pc_mesh* mesh, const float* model_matrix, int check_mask,
+                                  const pc_track_source* sources, int n_sources, int chained_source, const pc_pnp_camera* initial,
+                                  int chain_initial, const pc_pnp_solve_options* options);
+/* waits for the OLDEST frame in flight */
 int pc_track_frame_finish(pc_context* ctx, pc_corr_set* set, pc_track_solve_result* result);
 /* debugging / tests: (world x, y, z, hit ? 1 : 0) of the first n matches of the last pc_track_solve_frame, in match order
  * (source after source). */

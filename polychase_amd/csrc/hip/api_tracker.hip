@@ -76,7 +76,7 @@ struct pc_corr_set {
         uint64_t stamp = 0;
         DevBuf<float2> xy;
     };
-    Cached cache[16];
+    Cached cache[32];   // two frames in flight + the one being uploaded, up to 8 sources each
     DevBuf<float2> uncached_kps[pc::kTrackMaxSources];
     uint64_t clock = 0;
     // PnP scratch shared by the problems made from this set
@@ -85,19 +85,28 @@ struct pc_corr_set {
     DevBuf<pc::LmState> lm_state;
     PinBuf<pc::LmState> lm_host;
     // pc_track_solve_frame: all matches of the frame (device copies), their world points, the solver's barrier words
-    DevBuf<uint8_t> t_block[2];   // the matches of the frame being solved and of the next one (uploaded while the first is solved)
+    DevBuf<uint8_t> t_block[3];   // the matches of the (up to two) frames in flight and of the one uploaded behind them
     int t_cur = 0;                // the block of the last pc_track_frame_upload
     size_t t_block_bytes = 0;
     hipStream_t copy_stream = nullptr;
     hipEvent_t upload_done = nullptr;
-    int t_stage = 0;              // 0 idle, 1 uploaded, 2 launched
-    int t_n = 0;                  // matches of the launched frame
+    // Up to TWO frames in flight, finished in launch order: the second one's launches sit behind the first one's on the stream and
+    // may take the first one's camera from the device (pc_track_frame_launch_chained), so the GPU goes from one frame to the next
+    // without waiting for the host to see a pose.
+    struct Flight {
+        int n = 0;                // matches (0: nothing was launched, finish reports "no correspondences")
+        uint32_t seq = 0;         // TrackLmOut::seq of its LM launch; the result is in t_out[seq & 1]
+    };
+    Flight t_flight[2];
+    int t_inflight = 0;           // entries of t_flight in use, oldest first
+    bool t_chain_valid = false;   // the launch enqueued last wrote t_chain
+    DevBuf<pc::TrackChainSlot> t_chain;
     DevBuf<uint32_t> t_sync;
     DevBuf<float2> t_obs;
     DevBuf<float4> t_pts;
     DevBuf<float> t_partials;
-    PinBuf<pc::TrackLmOut> t_out;
-    uint32_t t_seq = 0;   // number of the LM launch in flight (TrackLmOut::seq)
+    PinBuf<pc::TrackLmOut> t_out;   // two: launch `seq` reports into t_out[seq & 1]
+    uint32_t t_seq = 0;   // number of the LM launch enqueued last (TrackLmOut::seq)
     bool t_sync_zero = false;
 };
 
@@ -321,6 +330,7 @@ void pc_corr_set_destroy(pc_corr_set* s) {
     s->t_pts.release();
     s->t_partials.release();
     s->t_out.release();
+    s->t_chain.release();
     delete s;
 }
 
@@ -334,7 +344,7 @@ int pc_corr_set_clear(pc_context* ctx, pc_corr_set* s) {
 
 int pc_corr_set_recycle(pc_context* ctx, pc_corr_set* s) {
     if (!ctx || !s) return fail(PC_E_INVALID, "null argument");
-    if (s->t_stage == 2) return fail(PC_E_STATE, "a frame is in flight: pc_track_frame_finish first");
+    if (s->t_inflight > 0) return fail(PC_E_STATE, "a frame is in flight: pc_track_frame_finish first");
     PC_HIP(hipSetDevice(ctx->device));
     PC_HIP(hipStreamSynchronize(ctx->stream));
     if (s->copy_stream) PC_HIP(hipStreamSynchronize(s->copy_stream));
@@ -344,8 +354,7 @@ int pc_corr_set_recycle(pc_context* ctx, pc_corr_set* s) {
         c.stamp = 0;
     }
     s->clock = 0;
-    s->t_stage = 0;
-    s->t_n = 0;
+    s->t_chain_valid = false;
     s->t_block_bytes = 0;
     return pc_corr_set_clear(ctx, s);
 }
@@ -722,7 +731,7 @@ int pc_track_frame_upload(pc_context* ctx, pc_corr_set* s, const void* matches, 
         PC_HIP(hipEventCreateWithFlags(&s->upload_done, hipEventDisableTiming));
     }
     // the other block: the launch that reads the current one may still be running
-    s->t_cur ^= 1;
+    s->t_cur = (s->t_cur + 1) % 3;
     s->t_block_bytes = matches_bytes;
     PC_HIP(s->t_block[s->t_cur].ensure(std::max<size_t>(matches_bytes, 16)));
     if (matches_bytes) PC_HIP(hipMemcpyAsync(s->t_block[s->t_cur].p, matches, matches_bytes, hipMemcpyHostToDevice, s->copy_stream));
@@ -734,29 +743,45 @@ int pc_track_frame_upload(pc_context* ctx, pc_corr_set* s, const void* matches, 
         if (rc != PC_OK) return rc;
     }
     PC_HIP(hipEventRecord(s->upload_done, s->copy_stream));
-    if (s->t_stage == 0) s->t_stage = 1;   // (an upload while a frame is in flight leaves it in flight)
     return PC_OK;
 }
 
 int pc_track_frame_launch(pc_context* ctx, pc_corr_set* s, const pc_mesh* mesh, const float* model_matrix, int check_mask,
                           const pc_track_source* sources, int n_sources, const pc_pnp_camera* initial, const pc_pnp_solve_options* o) {
+    return pc_track_frame_launch_chained(ctx, s, mesh, model_matrix, check_mask, sources, n_sources, -1, initial, 0, o);
+}
+
+int pc_track_frame_launch_chained(pc_context* ctx, pc_corr_set* s, const pc_mesh* mesh, const float* model_matrix, int check_mask,
+                                  const pc_track_source* sources, int n_sources, int chained_source, const pc_pnp_camera* initial,
+                                  int chain_initial, const pc_pnp_solve_options* o) {
     if (!ctx || !s || !mesh || !model_matrix || !initial || !o) return fail(PC_E_INVALID, "bad argument");
     if (o->loss_type < 0 || o->loss_type > 2) return fail(PC_E_INVALID, "Unknown loss type: %d", o->loss_type);
-    if (s->t_stage == 2) return fail(PC_E_STATE, "a frame is in flight: pc_track_frame_finish first");
+    if (s->t_inflight >= 2) return fail(PC_E_STATE, "two frames are in flight: pc_track_frame_finish first");
     if (!s->copy_stream) return fail(PC_E_STATE, "pc_track_frame_upload first");
+    if (chained_source >= n_sources) return fail(PC_E_INVALID, "chained_source %d of %d sources", chained_source, n_sources);
+    if ((chained_source >= 0 || chain_initial) && !s->t_chain_valid)
+        return fail(PC_E_STATE, "nothing to chain to: no launch of this set has left its camera on the device");
     size_t total = 0;
     int rc = check_track_sources(sources, n_sources, s->t_block_bytes, &total);
     if (rc != PC_OK) return rc;
-    s->t_n = (int)total;
-    s->t_stage = 2;
-    if (total == 0) return PC_OK;   // no correspondences: finish reports "not enough features"
+    pc_corr_set::Flight& fl = s->t_flight[s->t_inflight];
+    if (total == 0) {   // no correspondences: finish reports "not enough features"
+        fl.n = 0;
+        fl.seq = 0;
+        s->t_inflight++;
+        return PC_OK;
+    }
+    for (int k = 0; k < n_sources; k++)
+        if (s->t_inflight > 0 && sources[k].n_matches > 0 && sources[k].keypoints_key < 0)
+            return fail(PC_E_STATE, "a second frame in flight needs keyed keypoint arrays (keypoints_key >= 0)");
     PC_HIP(hipSetDevice(ctx->device));
     const int n = (int)total;
     const int nb = pc::track_lm_blocks(n);
     PC_HIP(s->t_obs.ensure(total));
     PC_HIP(s->t_pts.ensure(total));
     PC_HIP(s->t_partials.ensure((size_t)nb * 56));
-    PC_HIP(s->t_out.ensure(1));
+    PC_HIP(s->t_out.ensure(2));
+    PC_HIP(s->t_chain.ensure(1));
     PC_HIP(s->t_sync.ensure((size_t)pc::kTrackSyncWords));
     if (!s->t_sync_zero) {
         PC_HIP(hipMemsetAsync(s->t_sync.p, 0, pc::kTrackSyncWords * sizeof(uint32_t), ctx->stream));
@@ -776,6 +801,7 @@ int pc_track_frame_launch(pc_context* ctx, pc_corr_set* s, const pc_mesh* mesh, 
         if (q.n_matches == 0) continue;
         pc::TrackSource& t = ca.src[used];
         to_ray_camera(&q.cam, &t.cam);
+        t.cam_dev = (k == chained_source) ? &s->t_chain.p->ray : nullptr;
         rc = corr_keypoints(ctx, s, q.keypoints_key, q.keypoints_xy, q.n_keypoints, &t.kps, used);   // cached by the upload, else sent now
         if (rc != PC_OK) return rc;
         t.idx = reinterpret_cast<const uint32_t*>(block + q.idx_offset);
@@ -800,51 +826,69 @@ int pc_track_frame_launch(pc_context* ctx, pc_corr_set* s, const pc_mesh* mesh, 
     la.n = n;
     fill_lm_config(o, &la.cfg);
     fill_lm_camera(initial, &la.cam);
+    la.chain_in = chain_initial ? s->t_chain.p : nullptr;
+    la.chain_out = s->t_chain.p;
+    {   // the model matrix as 4x4 (the caller passes its rows 0-2 as the first 12 floats of a row-major 4x4)
+        std::memcpy(la.model, model_matrix, 16 * sizeof(float));
+    }
     la.partials = s->t_partials.p;
     la.sync = s->t_sync.p;
-    la.out = s->t_out.p;
-    la.seq = ++s->t_seq;
+    la.seq = s->t_seq + 1u;
+    pc::TrackLmOut* const slot = s->t_out.p + (la.seq & 1u);
+    la.out = slot;
     la.max_rounds = o->max_iterations + 3;   // the initial sweep, one per iteration, one more for the 3-point case
     la.bad_index = s->counter.p + 1;         // zero unless an earlier call found a bad index and has not been cleared
-    s->t_out.p->status = -1;
-    s->t_out.p->bad_index = 0;
+    slot->status = -1;
+    slot->bad_index = 0;
+    slot->seq = la.seq ^ 0x80000000u;        // anything but this launch's number (the word was never initialised)
     pc::launch_track_lm(la, ctx->stream);
+    // both launches are enqueued: only now is the frame in flight (an error return above used to leave it so)
+    s->t_seq = la.seq;
+    s->t_chain_valid = true;
+    fl.n = n;
+    fl.seq = la.seq;
+    s->t_inflight++;
     return PC_OK;
 }
 
 int pc_track_frame_finish(pc_context* ctx, pc_corr_set* s, pc_track_solve_result* result) {
     if (!ctx || !s || !result) return fail(PC_E_INVALID, "null argument");
-    if (s->t_stage != 2) return fail(PC_E_STATE, "no frame is in flight");
-    s->t_stage = 0;
+    if (s->t_inflight < 1) return fail(PC_E_STATE, "no frame is in flight");
+    const pc_corr_set::Flight fl = s->t_flight[0];   // the oldest
+    s->t_flight[0] = s->t_flight[1];
+    s->t_inflight--;
     std::memset(result, 0, sizeof(*result));
-    result->n_matches = s->t_n;
-    if (s->t_n == 0) return PC_OK;
+    result->n_matches = fl.n;
+    if (fl.n == 0) return PC_OK;
     PC_HIP(hipSetDevice(ctx->device));
+    const pc::TrackLmOut* const slot = s->t_out.p + (fl.seq & 1u);
     {
         // The kernel writes its result into page-locked host memory and its launch number last (system-scope release): poll
         // that word instead of waiting for the stream -- the pose is here before the other workgroups have left the GPU and the
         // queue has signalled, and the next frame's launches are already on their way by then.  The stream wait stays as the
         // fall-back (a kernel that died never writes the word).
-        const uint32_t* word = &s->t_out.p->seq;
+        const uint32_t* word = &slot->seq;
         bool seen = false;
         const auto t0 = std::chrono::steady_clock::now();
         for (uint32_t spins = 0; !seen; spins++) {
-            seen = __atomic_load_n(word, __ATOMIC_ACQUIRE) == s->t_seq;
+            seen = __atomic_load_n(word, __ATOMIC_ACQUIRE) == fl.seq;
             if (seen) break;
             __builtin_ia32_pause();
-            if ((spins & 0x3ffu) == 0x3ffu && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+            if ((spins & 0x3ffu) == 0x3ffu && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500)) break;
         }
         if (!seen) {
             PC_HIP(hipStreamSynchronize(ctx->stream));
-            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != s->t_seq) {
+            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != fl.seq) {
                 s->t_sync_zero = false;
+                s->t_chain_valid = false;
                 return fail(PC_E_STATE, "the PnP solver's launch ended without a result");
             }
         }
     }
-    const pc::TrackLmOut& out = *s->t_out.p;
+    const pc::TrackLmOut& out = *slot;
     if (out.status == 2 || out.status < 0) {
         s->t_sync_zero = false;   // the barrier words are in an unknown state
+        s->t_chain_valid = false;
         return fail(PC_E_STATE, "the PnP solver's workgroups did not all become resident (status %d)", out.status);
     }
     if (out.bad_index) {
@@ -875,13 +919,10 @@ int pc_track_solve_frame(pc_context* ctx, pc_corr_set* s, const pc_mesh* mesh, c
                          const pc_pnp_camera* initial, const pc_pnp_solve_options* o, pc_track_solve_result* result) {
     if (!result) return fail(PC_E_INVALID, "null argument");
     std::memset(result, 0, sizeof(*result));
-    if (s && s->t_stage == 2) return fail(PC_E_STATE, "a frame is in flight: pc_track_frame_finish first");
+    if (s && s->t_inflight > 0) return fail(PC_E_STATE, "a frame is in flight: pc_track_frame_finish first");
     int rc = pc_track_frame_upload(ctx, s, matches, matches_bytes, sources, n_sources);
     if (rc == PC_OK) rc = pc_track_frame_launch(ctx, s, mesh, model_matrix, check_mask, sources, n_sources, initial, o);
-    if (rc != PC_OK) {
-        if (s) s->t_stage = 0;
-        return rc;
-    }
+    if (rc != PC_OK) return rc;
     return pc_track_frame_finish(ctx, s, result);
 }
 

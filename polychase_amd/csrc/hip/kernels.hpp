@@ -231,6 +231,9 @@ constexpr int kTrackMaxSources = 8;     // flows into a frame: the skips -8 .. +
 constexpr int kTrackSyncWords = 64 + 256; // barrier words of track_lm_kernel: zero before the launch, left zero by it
 struct TrackSource {                    // one source frame of the frame being solved
     RayCamera cam;                      // the source's camera, object space (GetRayObjectSpace, ray_casting.h:53-63)
+    const RayCamera* cam_dev;           // or null.  Not null: the camera is read from device memory -- the source is the frame whose
+                                        // LM launch sits in FRONT of this one on the stream and leaves its camera there
+                                        // (TrackChainSlot::ray): the host has not seen that pose yet
     const float2* kps;                  // its keypoints (device)
     const uint32_t* idx;                // its matches (device): src_keypoints_indices ...
     const float2* tgt;                  // ... and tgt_keypoints of the flow source -> frame

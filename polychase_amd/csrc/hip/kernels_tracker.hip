@@ -8,6 +8,8 @@
 //        cpp/pnp/lev_marq.h:231-356), deterministic two-stage reduction.
 // fp32 throughout like the reference (Float = float, cpp/eigen_typedefs.h).
 #include "bvh.hpp"
+#include <algorithm>
+
 #include "pnp_lm.hpp"
 #include "kernels.hpp"
 
@@ -563,7 +565,8 @@ __global__ __launch_bounds__(RC_BLOCK) void track_cast_kernel(TrackCastArgs a) {
     if (k >= (uint32_t)S.n_kps) {
         atomicExch(a.bad_index, 1);   // CHECK_LT(idx, keypoints.size()), tracker.cc:61
     } else {
-        const RayCamera& cam = S.cam;
+        RayCamera cam = S.cam;
+        if (S.cam_dev) cam = *S.cam_dev;   // uniform: the camera the LM launch in front of this one left on the device
         const float2 p = S.kps[k];
         const float ux = cam.sign * ((p.x - cam.cx) / cam.fx), uy = cam.sign * ((p.y - cam.cy) / cam.fy), uz = cam.sign;
         const float dx = cam.m[0] * ux + cam.m[1] * uy + cam.m[2] * uz;
@@ -611,7 +614,10 @@ static_assert(sizeof(PnPParams) % sizeof(uint32_t) == 0, "PnPParams travels word
 //   [kSyncFlags + b]            workgroup b has published its partial sums of round r: r + 1
 constexpr int kSyncAbort = 0, kSyncParams = 2, kSyncFlags = 64;
 static_assert(kSyncParams + 2 * (kParamWords + 1) <= kSyncFlags && kSyncFlags + 256 <= kTrackSyncWords, "sync layout");
-constexpr long long kTrackSpinLimit = 500000000ll;   // wall_clock64 ticks (100 MHz): 5 s
+// wall_clock64 ticks (100 MHz) a wait may last: 100 ms.  A launch whose workgroups do not all become resident (a renderer on the
+// same GPU -- the addon's normal life -- holds the registers) gives the CUs back after that time; the host retries once and then
+// solves with the per-source building blocks (track_sequence.cc).  Round 5 spun for 5 s.
+constexpr long long kTrackSpinLimit = 10000000ll;
 
 __device__ __forceinline__ uint32_t peek(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long peek64(const unsigned long long* p) {
@@ -727,6 +733,77 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ partia
 
 }  // namespace
 
+// SourceCamera (csrc/host/track_sequence.cc) on the device, for TrackChainSlot::ray: Pose::Rt4x4 (types.h; the rotation by
+// Quatf::ToRotationMatrix = lm_make_params' R), MatMul4(view, model) in float, Inverse4 in double with partial pivoting
+// (linalg.h) -- the host's operations in the host's order, so the bits are the host's.  Static indices only (the pivot row is
+// picked with selects): nothing goes to scratch memory.  One lane, once per launch.
+__device__ __forceinline__ void track_source_camera(const LmCamera& c, const float* model, RayCamera* out) {
+    const float tx = 2 * c.qx, ty = 2 * c.qy, tz = 2 * c.qz;
+    const float twx = tx * c.qw, twy = ty * c.qw, twz = tz * c.qw;
+    const float txx = tx * c.qx, txy = ty * c.qx, txz = tz * c.qx;
+    const float tyy = ty * c.qy, tyz = tz * c.qy, tzz = tz * c.qz;
+    const float view[16] = {1 - (tyy + tzz), txy - twz, txz + twy, c.t[0], txy + twz, 1 - (txx + tzz), tyz - twx, c.t[1],
+                            txz - twy,       tyz + twx, 1 - (txx + tyy), c.t[2], 0.f, 0.f, 0.f, 1.f};
+    double a[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) s += view[4 * i + k] * model[4 * k + j];
+            a[i][j] = (double)s;
+            a[i][4 + j] = (i == j) ? 1.0 : 0.0;
+        }
+#pragma unroll
+    for (int col = 0; col < 4; col++) {
+        int piv = col;
+        double best = fabs(a[col][col]);
+#pragma unroll
+        for (int r = col + 1; r < 4; r++) {
+            const double v = fabs(a[r][col]);
+            if (v > best) {
+                best = v;
+                piv = r;
+            }
+        }
+        // (a singular view * model: the host throws when it makes this camera; here the launch that reads the slot runs on
+        // garbage for at most max_rounds rounds and the host reports the error when it gets to the frame)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            double pr = a[col][j];
+#pragma unroll
+            for (int r = col + 1; r < 4; r++) pr = (piv == r) ? a[r][j] : pr;
+#pragma unroll
+            for (int r = col + 1; r < 4; r++) a[r][j] = (piv == r) ? a[col][j] : a[r][j];
+            a[col][j] = pr;
+        }
+        const double inv = 1.0 / a[col][col];
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[col][j] *= inv;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (r == col) continue;
+            const double f = a[r][col];
+            if (f != 0.0) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) a[r][j] -= f * a[col][j];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) out->m[3 * r + cc] = (float)a[r][4 + cc];
+        out->origin[r] = (float)a[r][7];
+    }
+    out->fx = c.fx;
+    out->fy = c.fy;
+    out->cx = c.cx;
+    out->cy = c.cy;
+    out->sign = c.convention_opencv ? 1.0f : -1.0f;
+}
+
 // the decision of one round on top of lm_consume: the correspondence count is only known once the first sweep has
 // counted the valid entries (PnPProblem's n: pnp_problem.h:34-35, solvers.cc:54-55, tracker.cc:95-97)
 __device__ __forceinline__ void track_consume(LmState& s, const float* out56, int round, int max_rounds) {
@@ -762,7 +839,11 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
     const int tid = threadIdx.x, G = gridDim.x;
     const size_t T = (size_t)G * 256, gtid = (size_t)blockIdx.x * 256 + tid;
     PnPParams p;
-    lm_make_params(a.cam, a.cfg, &p);   // round 0: the initial parameters, from the launch arguments
+    // round 0: the initial parameters, from the launch arguments -- or from what the launch in front of this one left on the device
+    // (uniform loads; that kernel has ended: its stores are visible)
+    LmCamera cam0 = a.cam;
+    if (a.chain_in) cam0 = a.chain_in->cam;
+    lm_make_params(cam0, a.cfg, &p);
     {
         uint32_t* pw = reinterpret_cast<uint32_t*>(&p);
 #pragma unroll
@@ -830,8 +911,8 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
                     uint32_t* z = reinterpret_cast<uint32_t*>(&h);
                     for (int i = 0; i < (int)(sizeof(LmState) / sizeof(uint32_t)); i++) z[i] = 0u;
                     h.cfg = a.cfg;
-                    h.cam = a.cam;
-                    h.cam_new = a.cam;
+                    h.cam = cam0;
+                    h.cam_new = cam0;
                     h.lambda = a.cfg.initial_lambda;
                     h.v = 2.0f;
                     h.grad_norm = -1.0f;
@@ -947,15 +1028,33 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
         o->status = h.status;
         o->bad_index = *a.bad_index;
         hand_over();
+        if (a.chain_out) {   // after the hand-over: the host does not wait for this, the next launch on the stream does
+            a.chain_out->cam = h.cam;
+            track_source_camera(h.cam, a.model, &a.chain_out->ray);
+        }
     }
 }
 
-// At most ONE workgroup per CU (256 on this chip): the launch needs every workgroup resident at once, and with one per CU that
-// holds as long as 272 of every SIMD's 512 registers are free -- two per CU (512 workgroups, 239 VGPRs each) left no room for anything
-// else on the GPU.  Measured on C5 (150 k matches per frame): the sweep gets a third loop trip, the partial sums and flags halve.
+// At most ONE workgroup per CU: the launch needs every workgroup resident at once, and with one per CU that holds as long as 272
+// of every SIMD's 512 registers are free -- two per CU (512 workgroups, 239 VGPRs each) left no room for anything else on the GPU.
+// Measured on C5 (150 k matches per frame): the sweep gets a third loop trip, the partial sums and flags halve.  The cap is the
+// device's own CU count (a partitioned GPU -- CPX / NPS modes -- or a smaller part has fewer than this chip's 256, and a
+// grid that cannot be resident spins until the time limit).
+static int track_lm_max_blocks() {
+    static int cap[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (cap[dev] == 0) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, track_lm_kernel, 256, 0) != hipSuccess) per_cu = 1;
+        cap[dev] = per_cu < 1 ? 1 : std::min(256, cus);   // (kSyncFlags holds 256 flags)
+    }
+    return cap[dev];
+}
 int track_lm_blocks(int n) {
-    const int b = (n + 255) / 256;
-    return b < 1 ? 1 : (b > 256 ? 256 : b);
+    const int b = (n + 255) / 256, cap = track_lm_max_blocks();
+    return b < 1 ? 1 : (b > cap ? cap : b);
 }
 void launch_track_lm(const TrackLmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(track_lm_kernel, dim3(track_lm_blocks(a.n)), dim3(256), 0, s, a);

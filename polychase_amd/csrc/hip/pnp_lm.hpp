@@ -65,12 +65,24 @@ struct TrackLmOut {
     // signalled completion)
     uint32_t seq;
 };
+// What a tracked frame leaves on the device for the launches of the NEXT frame, which are enqueued before the host has seen this
+// frame's pose (csrc/host/track_sequence.cc: the frame after the one on the GPU is always queued behind it): the solved camera
+// (the next frame's initial guess, tracker.cc:111-119) and the same camera as a ray-cast source (SourceCamera of
+// track_sequence.cc = GetRayObjectSpace, ray_casting.h:53-63, computed with the host's operations in the host's order: the
+// next frame's world points are the same bits whichever side made the camera).
+struct TrackChainSlot {
+    LmCamera cam;
+    RayCamera ray;
+};
 struct TrackLmArgs {
     const float4* pts;        // track_cast_kernel's output
     const float2* obs;        // tracked positions, same rows
     int n;
     LmConfig cfg;
     LmCamera cam;             // initial guess
+    const TrackChainSlot* chain_in;   // not null: the initial guess is chain_in->cam (left there by the launch in front of this one)
+    TrackChainSlot* chain_out;        // not null: the solved camera goes there as well (with `model`: its ray-cast form)
+    float model[16];                  // the model matrix (row-major 4x4), for chain_out->ray
     float* partials;          // 56 x track_lm_blocks(n)
     uint32_t* sync;           // kTrackSyncWords
     TrackLmOut* out;          // device-visible host memory

@@ -52,6 +52,9 @@ class StageClock {
         std::lock_guard<std::mutex> lk(Mutex());
         Reports()[title] = std::move(t);
     }
+    // the calling thread starts from zero: the entry of a call that will Report (a call that left without reporting -- stopped by
+    // the callback, an exception -- must not leak its totals into the next report of this thread)
+    static void Begin() { Running().clear(); }
     static Totals Last(const std::string& title) {
         std::lock_guard<std::mutex> lk(Mutex());
         auto it = Reports().find(title);

@@ -9,6 +9,7 @@
 #include "track_sequence.h"
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <chrono>
@@ -310,7 +311,7 @@ struct Scratch {
     };
     CachedKeypoints cache[16];
     uint64_t clock = 0;
-    MatchBlock own_matches[2];   // alternating: the block of the frame on the GPU stays untouched while the next one is read
+    MatchBlock own_matches[3];   // in turn: the blocks of the (up to two) frames on the GPU stay untouched while the next one is read
     int own_turn = 0;
     unsigned long long last_end_tick = 0;   // the previous frame's hand-over on the GPU's clock (stage report)
 
@@ -405,23 +406,29 @@ CameraState InitialGuess(const CameraTrajectory& traj, int32_t frame) {
 
 // the flows into `frame` whose source already has a pose (:43-50), in the database's order; their matches in `block`
 // (the prefetched one, or read now)
-// `pending`: a frame whose solve is in flight counts as filled (its pose is there before anything that uses it is launched)
+// `pending`: frames whose solve is in flight count as filled (their poses are there -- on the host or, for the launch directly in
+// front, on the device -- before anything that uses them runs)
+struct PendingFrames {
+    int n = 0;
+    int32_t frame[2] = {0, 0};
+    bool Has(int32_t f) const { return (n > 0 && frame[0] == f) || (n > 1 && frame[1] == f); }
+};
 const MatchBlock& GatherMatches(const Database& db, const CameraTrajectory& traj, int32_t frame, Scratch& s,
-                                FlowPrefetcher::Batch* batch, std::vector<int32_t>& used_sources, const int32_t* pending = nullptr) {
+                                FlowPrefetcher::Batch* batch, std::vector<int32_t>& used_sources, const PendingFrames& pending = PendingFrames{}) {
     StageClock::Scope sc("track/db read");
     s.sources.clear();
     db.FindOpticalFlowsToImage(frame, s.sources);
     used_sources.clear();
     for (int32_t source : s.sources) {
         CHECK_NE(source, frame);
-        if (traj.IsFrameFilled(source) || (pending && source == *pending)) used_sources.push_back(source);   // only frames that already have a pose (:48)
+        if (traj.IsFrameFilled(source) || pending.Has(source)) used_sources.push_back(source);   // only frames that already have a pose (:48)
     }
     if (batch) {
         bool complete = true;
         for (int32_t source : used_sources) complete = complete && batch->matches.Find(source) != nullptr;
         if (complete) return batch->matches;
     }
-    MatchBlock& own = s.own_matches[s.own_turn ^= 1];
+    MatchBlock& own = s.own_matches[s.own_turn = (s.own_turn + 1) % 3];
     own.Clear();
     for (int32_t source : used_sources) own.Append(db, source, frame);
     return own;
@@ -504,15 +511,23 @@ class FrameSolver {
     }
 
     // host-only part + transfer: which flows end in `frame`, where their matches and the sources' keypoints are
-    void Plan(int32_t frame, FlowPrefetcher::Batch* batch, const int32_t* pending) {
+    void Plan(int32_t frame, FlowPrefetcher::Batch* batch, const PendingFrames& pending) {
         frame_ = frame;
         n_sources_ = 0;
+        too_many_ = false;
         std::vector<int32_t>& used = used_;
         const MatchBlock& block = GatherMatches(db_, traj_, frame, s_, batch, used, pending);
         for (int32_t source : used) {
             const MatchBlock::Flow* f = block.Find(source);
             if (!f || f->rows == 0) continue;
-            CHECK(n_sources_ < 8);   // the skips of cpp/opticalflow.cc:76-77: at most 8 flows end in a frame
+            if (n_sources_ == 8) {
+                // More flows into a frame than the skips of cpp/opticalflow.cc:76-77 make (a database written with another skip
+                // set): SolveFrame takes any number (tracker.cc:43-50) -- this frame and the ones after it go to the per-source
+                // building blocks, which do too (this used to be a CHECK).
+                too_many_ = true;
+                n_sources_ = 0;
+                return;
+            }
             const PinnedKeypoints& kps = s_.KeypointsOf(db_, source, batch);
             source_frames_[n_sources_] = source;
             pc_track_source& q = sources_[n_sources_++];
@@ -531,12 +546,32 @@ class FrameSolver {
             ThrowHip("pc_track_frame_upload");
     }
 
-    // the sources' poses are all there now: cameras, initial guess (tracker.cc:111-119), the two launches
-    void Launch() {
+    // The sources' poses are all there now -- on the host, or (`prev`: the solver whose launches were enqueued just before, still
+    // in flight) on the device: cameras, initial guess (tracker.cc:111-119), the two launches.  With `prev` the intrinsics must
+    // not be under optimisation (the caller checks): the camera `prev` will report then has prev's own initial intrinsics.
+    void Launch(const FrameSolver* prev = nullptr) {
         if (n_sources_ == 0) return;
         StageClock::Scope sc("track/launch (enqueue)");
-        for (int k = 0; k < n_sources_; k++) SourceCamera(*traj_.Get(source_frames_[k]), model_, &sources_[k].cam);
-        guess_ = InitialGuess(traj_, frame_);
+        int chained_source = -1;
+        for (int k = 0; k < n_sources_; k++) {
+            if (prev && source_frames_[k] == prev->frame_) chained_source = k;
+            else SourceCamera(*traj_.Get(source_frames_[k]), model_, &sources_[k].cam);
+        }
+        // "The solution should be very close to the previous/next pose" (:111-119): this frame's own pose, else frame - 1's, else
+        // frame + 1's -- a frame in flight counts as filled
+        bool chain_initial = false;
+        guess_ = CameraState{};
+        for (int32_t candidate : {frame_, frame_ - 1, frame_ + 1}) {
+            if (prev && candidate == prev->frame_) {
+                chain_initial = true;
+                guess_ = prev->guess_;   // its intrinsics (not optimised: the result's too); the pose is on the device
+                break;
+            }
+            if (traj_.IsFrameFilled(candidate)) {
+                guess_ = *traj_.Get(candidate);
+                break;
+            }
+        }
         const BundleOptions& bo = opts_.bundle_opts;
         const CameraIntrinsics::Bounds bounds = guess_.intrinsics.GetBounds();
         pc_pnp_camera init;
@@ -572,7 +607,8 @@ class FrameSolver {
         so.rounds_hint = 0;
         GpuSection section;
         mesh_.SyncMask();   // the mask can be edited between frames through inner_mut(): the current bits (sent when they changed)
-        if (pc_track_frame_launch(s_.ctx, s_.set, mesh_.Gpu(), model_.data(), /*check_mask=*/1, sources_, n_sources_, &init, &so) != PC_OK)
+        if (pc_track_frame_launch_chained(s_.ctx, s_.set, mesh_.Gpu(), model_.data(), /*check_mask=*/1, sources_, n_sources_, chained_source,
+                                          &init, chain_initial ? 1 : 0, &so) != PC_OK)
             ThrowHip("pc_track_frame_launch");
         launched_ = true;
     }
@@ -633,6 +669,7 @@ class FrameSolver {
         return result;
     }
     int32_t frame() const { return frame_; }
+    bool too_many_sources() const { return too_many_; }
     // waits for whatever this solver has in flight and forgets it
     void Drain() {
         if (!launched_) return;
@@ -656,11 +693,27 @@ class FrameSolver {
     std::vector<int32_t> used_;
     CameraState guess_;
     bool launched_ = false;
+    bool too_many_ = false;
 };
+
+// Process-wide memory of a lost co-residency: the persistent LM launch needs every workgroup on the GPU at once; when a
+// run has given up on it twice (the launch, then its one retry -- 100 ms each), the runs of the next
+// POLYCHASE_TRACK_FUSED_BACKOFF_S seconds (30) start on the per-source building blocks at once instead of stalling again: Blender
+// calls TrackSequence once per user action, and whatever held the GPU a moment ago (a render) is probably still there.
+std::atomic<long long> g_fused_lost_until_ms{0};
+long long SteadyNowMs() {
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+void RememberCoResidencyLost() {
+    const char* env = std::getenv("POLYCHASE_TRACK_FUSED_BACKOFF_S");
+    const double seconds = env ? std::atof(env) : 30.0;
+    g_fused_lost_until_ms.store(SteadyNowMs() + static_cast<long long>(seconds * 1000.0), std::memory_order_relaxed);
+}
 
 bool FusedSolve() {
     const char* env = std::getenv("POLYCHASE_TRACK_FUSED");   // read per call: the tests flip it
-    return !(env && env[0] == '0');
+    if (env && env[0] == '0') return false;
+    return SteadyNowMs() >= g_fused_lost_until_ms.load(std::memory_order_relaxed);
 }
 
 }  // namespace
@@ -690,6 +743,7 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
     pnp_opts.optimize_focal_length = optimize_focal_length;
     pnp_opts.optimize_principal_point = optimize_principal_point;
 
+    StageClock::Begin();
     const auto t_entry = std::chrono::steady_clock::now();
     const int32_t step = frame_from < frame_to_inclusive ? 1 : -1;
     // (in this order: the scratch -- whose destructor waits for every stream of the correspondence set, the copy stream included --
@@ -745,79 +799,168 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
         return;
     }
     if (first != end) {
-        // two solvers take turns: one holds the frame on the GPU, the other plans the next
-        FrameSolver solvers[2] = {FrameSolver(database, camera_traj, model_matrix, accel_mesh, pnp_opts, scratch),
+        // Three solvers take turns.  With `lead` = 2 (the default whenever the intrinsics are not being optimised) the frame
+        // AFTER the one on the GPU is always enqueued behind it: its launches take the pose of the frame in front -- one of its
+        // source cameras and its initial guess -- from where that frame's LM launch leaves it on the device
+        // (pc_track_frame_launch_chained), so the GPU goes from frame to frame without waiting for the host to see a pose
+        // (round 5: 56-116 us of turn-around per frame, a third of a frame's time on a slow host).  While the GPU solves `frame`
+        // and holds `frame + step`, the host plans `frame + 2 step` (which flows, where their blobs are; the upload) and, when
+        // the pose of `frame` arrives, enqueues it.  lead = 1 (POLYCHASE_TRACK_CHAIN=0, or intrinsics under optimisation: the
+        // bounds of a frame's solve derive from the intrinsics the frame before it ENDED with): round 5's schedule.
+        FrameSolver solvers[3] = {FrameSolver(database, camera_traj, model_matrix, accel_mesh, pnp_opts, scratch),
+                                  FrameSolver(database, camera_traj, model_matrix, accel_mesh, pnp_opts, scratch),
                                   FrameSolver(database, camera_traj, model_matrix, accel_mesh, pnp_opts, scratch)};
-        int cur = 0;
-        bool fused_lost = false;
+        const char* chain_env = std::getenv("POLYCHASE_TRACK_CHAIN");   // read per run
+        const bool chain = !(chain_env && chain_env[0] == '0') && !optimize_focal_length && !optimize_principal_point;
+        const int lead = chain ? 2 : 1;
+        bool fused_lost = false, too_many = false;
         const char* lose_env = std::getenv("POLYCHASE_TRACK_TEST_LOSE_AT");   // read per run
         const int lose_at = lose_env ? std::atoi(lose_env) : 0;
+        const char* twice_env = std::getenv("POLYCHASE_TRACK_TEST_LOSE_TWICE");
+        const bool lose_twice = twice_env && twice_env[0] == '1';
         int finished = 0;
+        // solver of frame number k of this run (0 = first): k % 3
+        auto solver_of = [&](int32_t f) -> FrameSolver& { return solvers[((f - first) * step) % 3]; };
+        auto in_range = [&](int32_t f) { return step > 0 ? (f >= first && f < end) : (f <= first && f > end); };
+        // frames [launched_to - ..., launched_to) are in flight; `launched_to` = the next frame to enqueue
+        int32_t launched_to = first;
+        // plans `f` (the frames in flight count as filled) -- false: more sources than the fused path holds
+        auto plan = [&](int32_t f, FlowPrefetcher::Batch* batch, int32_t oldest_in_flight) {
+            PendingFrames pending;
+            for (int32_t q = oldest_in_flight; q != f; q += step) pending.frame[pending.n++] = q;
+            solver_of(f).Plan(f, batch, pending);
+            return !solver_of(f).too_many_sources();
+        };
         request(first);
         {
             FlowPrefetcher::Batch* batch = prefetcher.Take(first);
             request(first + step);
             StageClock::Add("track/start-up: first batch read at (ms)", since_entry());
-            solvers[cur].Plan(first, batch, nullptr);
+            if (!plan(first, batch, first)) too_many = true;
             StageClock::Add("track/start-up: first frame uploaded at (ms)", since_entry());
-            solvers[cur].Launch();
+            if (!too_many) {
+                solver_of(first).Launch();
+                launched_to = first + step;
+            }
             StageClock::Add("track/start-up: first frame launched at (ms)", since_entry());
+            // the second frame behind it, chained
+            if (!too_many && lead == 2 && in_range(launched_to)) {
+                FlowPrefetcher::Batch* b2 = prefetcher.Take(launched_to);
+                request(launched_to + step);
+                if (plan(launched_to, b2, first)) {
+                    solver_of(launched_to).Launch(&solver_of(first));
+                    launched_to += step;
+                } else {
+                    too_many = true;
+                }
+            }
         }
-        for (int32_t frame = first; frame != end; frame += step) {
-            const int32_t next = frame + step;
-            FrameSolver& now = solvers[cur];
-            FrameSolver& then = solvers[cur ^ 1];
-            if (next != end) {   // while the GPU solves `frame`
-                FlowPrefetcher::Batch* batch = prefetcher.Take(next);
-                request(next + step);
-                then.Plan(next, batch, &frame);
+        // the frames from `f` on with the per-source building blocks (no co-residency requirement, any number of sources)
+        auto run_unfused_from = [&](int32_t f) {
+            for (; f != end; f += step) {
+                const std::optional<PnPResult> r = SolveFrameUnfused(database, camera_traj, model_matrix, f, accel_mesh, pnp_opts, scratch, nullptr);
+                if (!r) throw std::runtime_error("Could not track to frame: " + std::to_string(f) + ". Not enough features.");
+                if (!report_and_store(f, *r)) return false;
+                camera_traj.Set(f, r->camera);
             }
-            std::optional<PnPResult> solved;
-            try {
-                solved = now.Finish();
-                if (lose_at > 0 && ++finished == lose_at) throw CoResidencyLost{};   // POLYCHASE_TRACK_TEST_LOSE_AT: testing aid
-            } catch (const CoResidencyLost&) {
-                // The persistent LM launch needs all its workgroups on the GPU at once; another tenant of the GPU (an analysis
-                // running in the same host, say) can keep that from happening, and the launch then gives up after its time
-                // limit.  The frame is solved with the per-source building blocks instead (no such requirement), and so is
-                // the rest of this run.
-                fused_lost = true;
-            }
-            if (fused_lost) {
-                then.Drain();
-                for (int32_t f = frame; f != end; f += step) {
-                    const std::optional<PnPResult> r = SolveFrameUnfused(database, camera_traj, model_matrix, f, accel_mesh, pnp_opts, scratch, nullptr);
-                    if (!r) throw std::runtime_error("Could not track to frame: " + std::to_string(f) + ". Not enough features.");
-                    if (!report_and_store(f, *r)) return;
-                    camera_traj.Set(f, r->camera);
+            return true;
+        };
+        auto drain_all = [&]() {
+            for (auto& sv : solvers) sv.Drain();   // (pc_track_frame_finish returns the oldest first whoever asks: results are dropped)
+        };
+        if (too_many && launched_to == first) {
+            if (!run_unfused_from(first)) return;
+        } else {
+            for (int32_t frame = first; frame != end; frame += step) {
+                FrameSolver& now = solver_of(frame);
+                // while the GPU works: plan the frame that goes behind what is in flight
+                const int32_t target = launched_to;
+                bool planned = false;
+                if (!too_many && in_range(target)) {
+                    FlowPrefetcher::Batch* batch = prefetcher.Take(target);
+                    request(target + step);
+                    planned = plan(target, batch, frame);
+                    if (!planned) too_many = true;
                 }
-                break;
-            }
-            if (!solved) throw std::runtime_error("Could not track to frame: " + std::to_string(frame) + ". Not enough features.");
-            if (frame == first)   // connections, page-locked blocks, the device's arrays, the first batch read: paid once per call
-                StageClock::Add("track/from the call to the first pose", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count());
-            // the pose goes in at once -- the next frame's launches need it -- and comes out again if the callback stops the run:
-            // the pose of a frame the user stopped at is not stored (:179-186)
-            const std::optional<CameraState> before = camera_traj.Get(frame);
-            camera_traj.Set(frame, solved->camera);
-            struct Restore {
-                CameraTrajectory& traj;
-                int32_t frame;
-                const std::optional<CameraState>& before;
-                bool armed = true;
-                ~Restore() {
-                    if (!armed) return;
-                    if (before) traj.Set(frame, *before);
-                    else traj.Clear(frame);
+                std::optional<PnPResult> solved;
+                auto finish = [&](bool retry) {
+                    solved = now.Finish();
+                    // POLYCHASE_TRACK_TEST_LOSE_AT=N: the N-th finished frame behaves as if its launch had timed out;
+                    // POLYCHASE_TRACK_TEST_LOSE_TWICE=1: and so does its retry (testing aids)
+                    if (!retry && lose_at > 0 && ++finished == lose_at) throw CoResidencyLost{};
+                    if (retry && lose_twice) throw CoResidencyLost{};
+                };
+                try {
+                    finish(false);
+                } catch (const CoResidencyLost&) {
+                    // The persistent LM launch needs all its workgroups on the GPU at once; another tenant of the GPU (a render in
+                    // the same Blender, an analysis in the same host) can keep that from happening, and the launch then gives the
+                    // CUs back after its time limit (100 ms).  Whatever is queued behind it ran on what it left: dropped.  ONE
+                    // retry of the frame; if that is lost too, the frame and the rest of this run are solved with the per-source
+                    // building blocks (no such requirement), and the next runs start there for a while (RememberCoResidencyLost).
+                    StageClock::Add("track/co-residency lost (count, not ms)", 1);
+                    drain_all();
+                    launched_to = frame;
+                    planned = false;
+                    try {
+                        if (!plan(frame, nullptr, frame)) throw CoResidencyLost{};
+                        now.Launch();
+                        launched_to = frame + step;
+                        finish(true);
+                    } catch (const CoResidencyLost&) {
+                        drain_all();
+                        fused_lost = true;
+                        RememberCoResidencyLost();
+                    }
                 }
-            } restore{camera_traj, frame, before};
-            if (next != end) then.Launch();
-            if (!report_and_store(frame, *solved)) {   // (`then`'s destructor waits for the launches that are no longer wanted)
-                scratch.reusable = true;
-                return;
+                if (fused_lost) {
+                    if (!run_unfused_from(frame)) return;
+                    break;
+                }
+                if (!solved) throw std::runtime_error("Could not track to frame: " + std::to_string(frame) + ". Not enough features.");
+                if (frame == first)   // connections, page-locked blocks, the device's arrays, the first batch read: paid once per call
+                    StageClock::Add("track/from the call to the first pose", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count());
+                // the pose goes in at once -- the next launches need it -- and comes out again if the callback stops the run:
+                // the pose of a frame the user stopped at is not stored (:179-186)
+                const std::optional<CameraState> before = camera_traj.Get(frame);
+                camera_traj.Set(frame, solved->camera);
+                struct Restore {
+                    CameraTrajectory& traj;
+                    int32_t frame;
+                    const std::optional<CameraState>& before;
+                    bool armed = true;
+                    ~Restore() {
+                        if (!armed) return;
+                        if (before) traj.Set(frame, *before);
+                        else traj.Clear(frame);
+                    }
+                } restore{camera_traj, frame, before};
+                // enqueue what was planned: behind frame + step if that one is in flight (then its pose comes from the device)
+                if (planned) {
+                    solver_of(target).Launch(target != frame + step ? &solver_of(target - step) : nullptr);
+                    launched_to += step;
+                }
+                // after a retry nothing is planned and nothing is in flight: the pipeline is filled again (synchronous reads)
+                while (!too_many && in_range(launched_to) && (launched_to - (frame + step)) * step < lead) {
+                    const int32_t f = launched_to;
+                    if (!plan(f, nullptr, frame + step)) {
+                        too_many = true;
+                        break;
+                    }
+                    solver_of(f).Launch(f != frame + step ? &solver_of(f - step) : nullptr);
+                    launched_to += step;
+                }
+                if (!report_and_store(frame, *solved)) {   // (the solvers' destructors wait for the launches that are no longer wanted)
+                    scratch.reusable = true;
+                    drain_all();
+                    return;
+                }
+                restore.armed = false;
+                if (too_many && launched_to == frame + step) {   // nothing in flight any more: the rest on the building blocks
+                    if (!run_unfused_from(frame + step)) return;
+                    break;
+                }
             }
-            restore.armed = false;
-            cur ^= 1;
         }
     }
     scratch.reusable = true;   // ended normally: the correspondence set is parked for the next run (Scratch)
@@ -825,6 +968,7 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
 }
 
 void ReleaseTrackerCaches() {
+    g_fused_lost_until_ms.store(0, std::memory_order_relaxed);
     Scratch::ReleaseParked();
     PinnedPool::Get().Clear();
 }

@@ -622,6 +622,16 @@ def test_pipelined_solve_frame_semantics(core, tmp_path, monkeypatch):
         monkeypatch.setenv("POLYCHASE_TRACK_FUSED", "0")
         blocks = run(a, b)
         monkeypatch.delenv("POLYCHASE_TRACK_FUSED", raising=False)
+        # round 6: by default the frame after the one on the GPU is enqueued behind it and takes that frame's pose -- a source camera
+        # and the initial guess -- from the device (pc_track_frame_launch_chained); POLYCHASE_TRACK_CHAIN=0 is round 5's schedule
+        # (every camera made on the host): the same bits, forward and backward
+        monkeypatch.setenv("POLYCHASE_TRACK_CHAIN", "0")
+        unchained = run(a, b)
+        monkeypatch.delenv("POLYCHASE_TRACK_CHAIN", raising=False)
+        assert sorted(fused) == sorted(unchained)
+        for f in fused:
+            assert np.array_equal(fused[f][0], unchained[f][0]) and np.array_equal(fused[f][1], unchained[f][1]), f
+            assert fused[f][2] == unchained[f][2] and fused[f][3] == unchained[f][3], f
         assert sorted(fused) == sorted(blocks) and len(fused) == n_frames - 1
         for f in fused:
             assert np.array_equal(fused[f][0], again[f][0]) and np.array_equal(fused[f][1], again[f][1]), f      # deterministic
@@ -647,12 +657,33 @@ def test_pipelined_solve_frame_semantics(core, tmp_path, monkeypatch):
         run(1, n_frames, cb=boom)
     after = run(1, n_frames)
     assert all(np.array_equal(after[f][0], full[f][0]) for f in full)
-    # the persistent launch could not get its workgroups resident (another tenant holds the GPU): the frame and the rest of the run
-    # are solved with the per-source building blocks -- every frame reported once, same poses (POLYCHASE_TRACK_TEST_LOSE_AT: the
-    # 4th finished frame behaves as if its launch had timed out)
+    # the persistent launch could not get its workgroups resident (another tenant holds the GPU; it gives the CUs back after 100 ms):
+    # ONE retry of the frame (POLYCHASE_TRACK_TEST_LOSE_AT: the 4th finished frame behaves as if its launch had timed out) -- what
+    # was queued behind it is dropped, the pipeline starts again: every frame reported once, the same bits
     monkeypatch.setenv("POLYCHASE_TRACK_TEST_LOSE_AT", "4")
+    retried = run(1, n_frames)
+    assert sorted(retried) == sorted(full)
+    for f in full:
+        assert np.array_equal(retried[f][0], full[f][0]) and np.array_equal(retried[f][1], full[f][1]), f
+    # ... and if the retry is lost as well (POLYCHASE_TRACK_TEST_LOSE_TWICE), the frame and the rest of the run are solved with the
+    # per-source building blocks -- every frame reported once, same poses --, and the runs of the next
+    # POLYCHASE_TRACK_FUSED_BACKOFF_S seconds start there
+    monkeypatch.setenv("POLYCHASE_TRACK_TEST_LOSE_TWICE", "1")
+    monkeypatch.setenv("POLYCHASE_TRACK_FUSED_BACKOFF_S", "600")
     lost = run(1, n_frames)
     monkeypatch.delenv("POLYCHASE_TRACK_TEST_LOSE_AT", raising=False)
+    monkeypatch.delenv("POLYCHASE_TRACK_TEST_LOSE_TWICE", raising=False)
+    backed_off = run(1, n_frames)                      # no injected loss, but inside the back-off: the building blocks from frame 2 on
+    monkeypatch.setenv("POLYCHASE_TRACK_FUSED", "0")
+    blocks = run(1, n_frames)
+    monkeypatch.delenv("POLYCHASE_TRACK_FUSED", raising=False)
+    for f in full:
+        assert np.array_equal(backed_off[f][0], blocks[f][0]) and np.array_equal(backed_off[f][1], blocks[f][1]), f
+    core.release_cached_engine()                       # forgets the back-off
+    monkeypatch.delenv("POLYCHASE_TRACK_FUSED_BACKOFF_S", raising=False)
+    fused_again = run(1, n_frames)
+    for f in full:
+        assert np.array_equal(fused_again[f][0], full[f][0]) and np.array_equal(fused_again[f][1], full[f][1]), f
     assert sorted(lost) == sorted(full)
     for f in full:
         assert np.abs(lost[f][0] - full[f][0]).max() < 2e-6 and np.abs(lost[f][1] - full[f][1]).max() < 2e-5, f
