@@ -148,6 +148,53 @@ def wd_start(rank, limit_s):
     threading.Thread(target=run, name="bench-watchdog", daemon=True).start()
 
 
+def host_block(dev_index=0):
+    """what a reader needs to compare this line with one from another box -- the CPU, its sockets / NUMA nodes, the
+    node the GPU hangs off, where the library put its own threads (csrc/host/numa_pin.h), and the file system the databases of the
+    end-to-end blocks were written to."""
+    import platform
+    import tempfile
+    out = {"python_process_affinity_cpus": len(os.sched_getaffinity(0)), "cpu_count": os.cpu_count(), "kernel": platform.release()}
+    try:
+        model, sockets = None, set()
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            if line.startswith("physical id"):
+                sockets.add(line.split(":", 1)[1].strip())
+        out["cpu_model"] = model
+        out["sockets"] = len(sockets) or None
+    except OSError:
+        pass
+    try:
+        nodes = sorted(d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
+        out["numa_nodes"] = {d: open(f"/sys/devices/system/node/{d}/cpulist").read().strip() for d in nodes}
+    except OSError:
+        out["numa_nodes"] = None
+    try:
+        import json as _json
+        sys.path.insert(0, os.path.join(ROOT, "polychase_amd", "core"))
+        import polychase_core
+        out["thread_placement"] = _json.loads(polychase_core._thread_placement())
+    except Exception as e:   # the module is optional for the kernel benchmark
+        out["thread_placement"] = {"error": str(e)}
+    try:
+        tmp = os.path.realpath(tempfile.gettempdir())
+        best = ("", "?", "?")
+        for line in open("/proc/mounts"):
+            dev, mnt, fs = line.split()[:3]
+            if (tmp == mnt or tmp.startswith(mnt.rstrip("/") + "/")) and len(mnt) >= len(best[0]):
+                best = (mnt, fs, dev)
+        out["temp_dir"] = {"path": tmp, "mount": best[0], "file_system": best[1], "device": best[2]}
+    except OSError:
+        pass
+    try:
+        out["transparent_hugepage"] = open("/sys/kernel/mm/transparent_hugepage/enabled").read().strip()
+    except OSError:
+        pass
+    return out
+
+
 def level_pixels(w, h, max_level, win=10):
     s, lw, lh = 0, w, h
     for _ in range(max_level + 1):
@@ -784,7 +831,12 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e, arith=None
                                           f"16 / {fpg} of the pyramid kernel's time per shard (kernel_ms_per_frame.pyramid), not in the steady-state step"}
         out = {
             "metric": "optical-flow frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+            "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+            # the dominant kernel's GPU-busy time per step (one LK launch per step; the union of the overlapping launches' intervals
+            # of the two-lane pipeline / launches): <= ms_per_step.  (roofline.kernel_avg_duration_ms -- one launch ALONE, from the
+            # one-lane pass -- may exceed ms_per_step by the overlap: the launches of consecutive steps share the GPU in their tails.)
+            "gpu_busy_ms_per_step": lk_busy_ms,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 fixed-point + f32 2x2 solve",
             "data": "synthetic",
             "config": {"workload": workload, "width": w, "height": h, "max_level": max_level,
@@ -803,6 +855,12 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e, arith=None
         if dist.is_initialized():
             out["collectives_backend"] = dist.get_backend()   # "nccl" = RCCL; "gloo" only under the SHARE_GPU testing aid
             out["world_size"] = dist.get_world_size()
+        if world > 1 or modes[0] != "n1":
+            # every N > 1 figure is the ANALYSIS-ONLY rate -- detection + LK + the stitch of the records, no SQLite
+            # insert.  The product call with the insert is bound by its single writer (one connection, one pwrite thread: DESIGN.md
+            # section 5) whatever N is: product_rate_with_insert below is that rate, measured on rank 0 of this job.
+            out["claim"] = ("analysis-only (no insert): frames analysed and their records stitched per second over all ranks; the "
+                            "end-to-end product rate with the SQLite insert does not scale with N (one writer) -- see product_rate_with_insert")
         if modes[0] != "n1":
             out["config"]["stitch"] = stitch_names[modes[0]]
             if not light:
@@ -821,6 +879,15 @@ def run_config(cfg, K, W, args, rank, world, dev, with_cpu, with_e2e, arith=None
                 out["end_to_end"] = end_to_end(cfg, clip_frames, 300 if cfg != "c3" else 100)
             except Exception as e:   # the module is optional for the kernel benchmark
                 out["end_to_end"] = {"error": str(e)}
+        elif world > 1 and not light and not args.no_end_to_end:
+            try:   # the writer-bound rate the N > 1 figure must be read beside (rank 0 alone; the other ranks wait at the next barrier)
+                e2e = end_to_end(cfg, clip_frames, 100 if cfg != "c3" else 50)
+                out["product_rate_with_insert"] = {"value": e2e.get("host_frames_over_pcie_sqlite_fps"), "unit": "frames/s", "n_gpus_that_matter": 1,
+                                                   "what": "generate_optical_flow_database with the SQLite insert, one GPU + one writer: the ceiling "
+                                                           "of the multi-GPU product call (polychase_amd/analyze.py) whatever the number of GPUs",
+                                                   "frames": e2e.get("frames"), "sqlite_insert_ms_per_frame": e2e.get("sqlite_insert_ms_per_frame")}
+            except Exception as e:
+                out["product_rate_with_insert"] = {"error": str(e)}
     ctx.close()
     del clip_frames, clip
     torch.cuda.empty_cache()
@@ -959,6 +1026,10 @@ def main():
         except Exception as e:
             out["c5"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
+        try:
+            out["host"] = host_block()
+        except Exception as e:
+            out["host"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     _WD["printed"] = True
     wd_tick("shutting the process group down")

@@ -88,6 +88,8 @@ int pc_runtime_init(int* runtime_was_up, int* hw_queues);
 int pc_context_create(int device_index, pc_context** out);
 void pc_context_destroy(pc_context* ctx);
 int pc_context_synchronize(pc_context* ctx);
+/* "0000:c1:00.0" of the context's GPU (hipDeviceGetPCIBusId): the host side looks up the GPU's NUMA node with it (csrc/host/numa_pin.h) */
+int pc_context_pci_bus_id(pc_context* ctx, char* buf, int len);
 /* Arithmetic mode: where OpenCV's result depends on how the host executes it, which execution the GPU reproduces.
  *   PC_ARITH_CANONICAL      no FMA anywhere; the LK sums (structure tensor, mismatch vector) exact in integers, rounded once
  *   PC_ARITH_LK_X86_ORDER   the LK sums in fp32 in the order of LKTrackerInvoker's CV_SIMD128 path on x86 (four vector lanes
@@ -476,6 +478,11 @@ int pc_track_frame_upload(pc_context* ctx, pc_corr_set* set, const void* matches
                           int n_sources);
 int pc_track_frame_launch(pc_context* ctx, pc_corr_set* set, const pc_mesh* mesh, const float* model_matrix, int check_mask,
                           const pc_track_source* sources, int n_sources, const pc_pnp_camera* initial, const pc_pnp_solve_options* options);
+/* Allocates what the first tracked frame of a clip with up to n_matches matches per frame and n_keypoints keypoints per source
+ * frame would otherwise allocate inside pc_track_frame_upload / _launch (the set's copy stream and event, the three match blocks,
+ * the per-match arrays, the barrier words, the page-locked result words, `n_cached` keypoint arrays): 6-8 ms of a process's
+ * first TrackSequence call.  Everything still grows on demand. */
+int pc_corr_set_reserve(pc_context* ctx, pc_corr_set* set, int n_matches, int n_keypoints, int n_cached);
 /* The launch with its inputs taken from the launch enqueued JUST BEFORE it on this set, on the device: up to TWO frames may be in
  * flight (finished in launch order), so that the GPU goes from frame f to frame f + 1 without the host in between -- SolveFrame of
  * f + 1 needs the pose of f twice (tracker.cc:43-50: f is one of its source frames; :111-119: f's pose is its initial guess), and

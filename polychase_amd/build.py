@@ -121,7 +121,7 @@ def build_multi_gpu_tool(force: bool = False) -> str:
     the multi-GPU analysis (csrc/host/multi_gpu.cc) as a plain C++ program: no Python, no torch."""
     src = os.path.join(ROOT, "tools", "multi_gpu", "multi_gpu_analyze.cc")
     out = multi_gpu_tool_path()
-    need = ["analysis_driver", "flow_database", "async_write_vfs", "frame_pool", "debug_images", "gpu_context", "multi_gpu"]
+    need = ["analysis_driver", "flow_database", "async_write_vfs", "frame_pool", "debug_images", "gpu_context", "multi_gpu", "numa_pin"]
     objs = [os.path.join(OBJ_DIR, f"core_{n}.o") for n in need]
     if not force and _newer(out, [src, hip_library_path()] + objs):
         return out

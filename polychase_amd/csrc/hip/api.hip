@@ -781,6 +781,12 @@ int pc_debug_lk_x86_stats(pc_context* c, int enable, unsigned long long* out) {
     return PC_OK;
 }
 
+int pc_context_pci_bus_id(pc_context* c, char* buf, int len) {
+    if (!c || !buf || len < 16) return fail(PC_E_INVALID, "bad argument");
+    PC_HIP(hipDeviceGetPCIBusId(buf, len, c->device));
+    return PC_OK;
+}
+
 int pc_context_reset_timing(pc_context* c) {
     if (!c) return fail(PC_E_INVALID, "null context");
     int rc = collect_timing(c);

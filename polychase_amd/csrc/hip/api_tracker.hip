@@ -1,6 +1,7 @@
 // api_tracker.hip -- C ABI of the tracking and refinement paths: meshes + LBVH ray casting, PnP accumulation
 // (reference cpp/tracker.cc, cpp/pnp/*), and the refiner's per-edge sweeps (cpp/refiner.cc, cpp/pnp/lev_marq.h).
 #include <chrono>
+#include <mutex>
 #include <limits>
 
 #include "api_internal.hpp"
@@ -716,6 +717,33 @@ static int check_track_sources(const pc_track_source* sources, int n_sources, si
     }
     if (total > (size_t)1 << 30) return fail(PC_E_INVALID, "too many matches");
     *total_out = total;
+    return PC_OK;
+}
+
+int pc_corr_set_reserve(pc_context* ctx, pc_corr_set* s, int n_matches, int n_keypoints, int n_cached) {
+    if (!ctx || !s || n_matches < 0 || n_keypoints < 0 || n_cached < 0) return fail(PC_E_INVALID, "bad argument");
+    if (s->t_inflight > 0) return fail(PC_E_STATE, "a frame is in flight: pc_track_frame_finish first");
+    PC_HIP(hipSetDevice(ctx->device));
+    if (!s->copy_stream) {
+        PC_HIP(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+        PC_HIP(hipEventCreateWithFlags(&s->upload_done, hipEventDisableTiming));
+    }
+    const size_t total = (size_t)n_matches;
+    for (auto& b : s->t_block) PC_HIP(b.ensure(total * 12 + 16 * 2 * pc::kTrackMaxSources + 16));   // per source: uint32 indices + float2 targets, 16-byte aligned
+    PC_HIP(s->t_obs.ensure(total));
+    PC_HIP(s->t_pts.ensure(total));
+    PC_HIP(s->t_partials.ensure((size_t)pc::track_lm_blocks(n_matches) * 56));
+    PC_HIP(s->t_out.ensure(2));
+    PC_HIP(s->t_chain.ensure(1));
+    PC_HIP(s->t_sync.ensure((size_t)pc::kTrackSyncWords));
+    if (!s->t_sync_zero) {
+        PC_HIP(hipMemsetAsync(s->t_sync.p, 0, pc::kTrackSyncWords * sizeof(uint32_t), ctx->stream));
+        s->t_sync_zero = true;
+    }
+    int k = 0;
+    for (auto& c : s->cache)
+        if (k++ < n_cached) PC_HIP(c.xy.ensure((size_t)std::max(n_keypoints, 1)));
+    PC_HIP(hipStreamSynchronize(ctx->stream));
     return PC_OK;
 }
 

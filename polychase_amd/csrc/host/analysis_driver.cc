@@ -8,6 +8,7 @@
 // :298-302) and kept in a 17-slot ring on the GPU; frame1 jobs are pipelined through pc_analyzer,
 // and the 8 pairs of a frame run as one LK launch instead of 8 TBB tasks.
 #include "analysis.h"
+#include "numa_pin.h"
 
 #include <chrono>
 #include <condition_variable>
@@ -245,6 +246,7 @@ class RecordWriter {
     // finished frames: the file is rolled back to the last commit and a resumed run recomputes exactly those rows
     // (cpp/opticalflow.cc:168-178, :286: rows that exist are skipped), bit for bit.
     void Run() {
+        numa::PinThisThreadNearGpu(nullptr, "analysis: database writer");
         bool in_transaction = false;
         int in_batch = 0;
         auto fail = [&](std::exception_ptr e) {
@@ -417,6 +419,9 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
             ThrowHip("pc_analyzer_create");
     }
     Engine& eng = *engine;
+    // the threads that feed this GPU stay on its NUMA node (numa_pin.h): this one for the duration of the call, the writer and its
+    // page-write worker (started below / when the database opens its file) for their lives
+    numa::ScopedPin near_gpu(eng.ctx, "analysis: calling thread");
     // The shard's device log: `log_buffers` equal parts of the caller's buffer, filled in turn; a part is handed to
     // on_piece when every job submitted into it has been collected, and reused `log_buffers` pieces later.
     const bool with_log = shard && shard->device_log != nullptr;

@@ -1,6 +1,8 @@
 // async_write_vfs.cc -- see async_write_vfs.h.
 #include "async_write_vfs.h"
 
+#include "numa_pin.h"
+
 #include <sqlite3.h>
 #include <sys/mman.h>
 
@@ -36,7 +38,23 @@ class Writer {
         slabs_ = static_cast<char*>(p);
         slab_bytes_ = bytes;
         for (int i = n_slabs - 1; i >= 0; i--) free_.push_back(i);
-        for (Lane& lane : lanes_) lane.thread = std::thread([this, &lane] { Run(lane); });
+        try {
+            for (Lane& lane : lanes_) lane.thread = std::thread([this, &lane] { Run(lane); });
+        } catch (...) {
+            // a thread could not be created: the lanes that did start are stopped and joined -- destroying a joinable
+            // std::thread terminates the process
+            for (Lane& lane : lanes_) {
+                if (!lane.thread.joinable()) continue;
+                {
+                    std::lock_guard<std::mutex> lk(lane.m);
+                    lane.stop = true;
+                }
+                lane.cv.notify_one();
+                lane.thread.join();
+            }
+            munmap(slabs_, slab_bytes_);
+            throw;
+        }
     }
     ~Writer() {
         (void)Drain();
@@ -134,6 +152,7 @@ class Writer {
         std::thread thread;
     };
     void Run(Lane& lane) {
+        numa::PinThisThreadNearGpu(nullptr, "analysis: database page writer");
         for (;;) {
             Job job;
             {
@@ -295,7 +314,12 @@ int XUnlock(sqlite3_file* file, int level) {
 int XCheckReservedLock(sqlite3_file* file, int* out) { return Self(file)->real->pMethods->xCheckReservedLock(Self(file)->real, out); }
 int XFileControl(sqlite3_file* file, int op, void* arg) { return Self(file)->real->pMethods->xFileControl(Self(file)->real, op, arg); }
 int XSectorSize(sqlite3_file* file) { return Self(file)->real->pMethods->xSectorSize(Self(file)->real); }
-int XDeviceCharacteristics(sqlite3_file* file) { return Self(file)->real->pMethods->xDeviceCharacteristics(Self(file)->real); }
+// Without SQLITE_IOCAP_BATCH_ATOMIC: on a file system that offers it (F2FS), SQLite commits with the
+// BEGIN / COMMIT_ATOMIC_WRITE file controls and no journal -- controls that would pass straight to the real file while the page
+// writes they cover are still queued here.  Masked out, SQLite takes the rollback-journal path this VFS is written for.
+int XDeviceCharacteristics(sqlite3_file* file) {
+    return Self(file)->real->pMethods->xDeviceCharacteristics(Self(file)->real) & ~SQLITE_IOCAP_BATCH_ATOMIC;
+}
 int XShmMap(sqlite3_file* file, int page, int page_size, int extend, void volatile** out) {
     return Self(file)->real->pMethods->xShmMap(Self(file)->real, page, page_size, extend, out);
 }

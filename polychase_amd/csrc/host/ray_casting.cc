@@ -4,6 +4,8 @@
 
 #include "gpu_context.h"
 
+void WarmTrackerCaches();   // track_sequence.cc
+
 AcceleratedMesh::AcceleratedMesh(std::vector<float> vertices, std::vector<uint32_t> triangles,
                                  std::vector<uint32_t> masked_triangles)
     : mesh_(std::move(vertices), std::move(triangles), std::move(masked_triangles)) {
@@ -12,6 +14,8 @@ AcceleratedMesh::AcceleratedMesh(std::vector<float> vertices, std::vector<uint32
     if (pc_mesh_create(ctx, mesh_.vertices.data(), static_cast<int>(mesh_.NumVertices()), mesh_.triangles.data(),
                        static_cast<int>(mesh_.NumTriangles()), &gpu_) != PC_OK)
         throw std::runtime_error(std::string("pc_mesh_create: ") + pc_last_error());
+    // tracking always follows the construction of a mesh: what its first call would allocate is allocated now (track_sequence.h)
+    WarmTrackerCaches();
 }
 
 AcceleratedMesh::~AcceleratedMesh() {

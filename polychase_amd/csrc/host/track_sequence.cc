@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "gpu_context.h"
+#include "numa_pin.h"
 #include "pnp.h"
 #include "stage_clock.h"
 
@@ -250,6 +251,7 @@ class FlowPrefetcher {
 
    private:
     void Run() {
+        numa::PinThisThreadNearGpu(nullptr, "tracking: read-ahead thread");
         for (;;) {
             int32_t frame, kp_frame;
             std::vector<int32_t> sources;
@@ -744,6 +746,7 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
     pnp_opts.optimize_principal_point = optimize_principal_point;
 
     StageClock::Begin();
+    numa::ScopedPin near_gpu(SharedGpuContext(), "tracking: calling thread (polls the result words)");   // numa_pin.h
     const auto t_entry = std::chrono::steady_clock::now();
     const int32_t step = frame_from < frame_to_inclusive ? 1 : -1;
     // (in this order: the scratch -- whose destructor waits for every stream of the correspondence set, the copy stream included --
@@ -967,7 +970,39 @@ void TrackCameraTrajectory(const Database& database, CameraTrajectory& camera_tr
     StageClock::Report("TrackCameraTrajectory");
 }
 
+namespace {
+std::atomic<bool> g_warmed{false};
+}
+
+void WarmTrackerCaches() {
+    const char* env = std::getenv("POLYCHASE_TRACK_WARM");
+    if (!TrackCacheEnabled() || (env && env[0] == '0')) return;
+    if (g_warmed.exchange(true)) return;
+    try {
+        {
+            // sizes: a 1080p clip's frame has ~40 k keypoints and ~150 k matches into it (8 flows); everything grows on demand
+            Scratch scratch;   // takes the parked set if there is one (then this only tops it up), parks it again on the way out
+            GpuSection section;
+            if (pc_corr_set_reserve(scratch.ctx, scratch.set, 256 * 1024, 64 * 1024, 12) == PC_OK) scratch.reusable = true;
+        }
+        // page-locked blocks: the match blocks of the read-ahead batches and of the synchronous reads, the keypoint arrays
+        for (int k = 0; k < 6; k++) {
+            void* p = nullptr;
+            if (pc_host_buffer_alloc(size_t(4) << 20, &p) != PC_OK) break;
+            if (!PinnedPool::Get().Give(p, size_t(4) << 20)) pc_host_buffer_free(p);
+        }
+        for (int k = 0; k < 20; k++) {
+            void* p = nullptr;
+            if (pc_host_buffer_alloc(size_t(512) << 10, &p) != PC_OK) break;
+            if (!PinnedPool::Get().Give(p, size_t(512) << 10)) pc_host_buffer_free(p);
+        }
+    } catch (...) {
+        // no device, no memory: the first TrackSequence call reports it
+    }
+}
+
 void ReleaseTrackerCaches() {
+    g_warmed.store(false, std::memory_order_relaxed);
     g_fused_lost_until_ms.store(0, std::memory_order_relaxed);
     Scratch::ReleaseParked();
     PinnedPool::Get().Clear();

@@ -28,6 +28,13 @@ void TrackSequence(const std::string& database_path, int32_t frame_from, int32_t
 // page-locked blocks (track_sequence.cc; POLYCHASE_TRACK_CACHE=0 keeps nothing in the first place).
 void ReleaseTrackerCaches();
 
+// Creates, at a moment when nobody waits for a pose (the construction of an AcceleratedMesh: tracking always follows one), what the
+// first TrackSequence call of a process would otherwise create while the caller waits for its first pose: the correspondence set
+// with its stream, device arrays and page-locked result words (parked like a finished run's), and a handful of page-locked blocks
+// in the pool -- 6-8 ms, a tenth of a 300-frame run.  Once per process (again after ReleaseTrackerCaches); POLYCHASE_TRACK_CACHE=0
+// or POLYCHASE_TRACK_WARM=0: nothing.
+void WarmTrackerCaches();
+
 // The 3D-2D correspondences SolveFrame (tracker.cc:36-97) would hand to PnP for `frame` under the poses in
 // camera_traj -- built on the GPU like in TrackCameraTrajectory, then downloaded (tests / debugging).
 void FrameCorrespondences(const Database& database, const CameraTrajectory& camera_traj, const Mat4f& model_matrix,

@@ -27,6 +27,7 @@
 #include "band_matrix.h"
 #include "flow_database.h"
 #include "gpu_context.h"
+#include "numa_pin.h"
 
 namespace {
 
@@ -486,6 +487,8 @@ class RefineSession {
 void RefineTrajectory(const std::string& database_path, CameraTrajectory& traj, const Mat4f& model_matrix,
                       const AcceleratedMesh& mesh, bool optimize_focal_length, bool optimize_principal_point,
                       RefineTrajectoryCallback callback, BundleOptions opts) {
+    StageClock::Begin();
+    numa::ScopedPin near_gpu(SharedGpuContext(), "refinement: calling thread");   // numa_pin.h
     RefineSession session(database_path, traj, model_matrix, mesh, optimize_focal_length, optimize_principal_point, opts);
     const int B = session.BlockLength(), n_params = session.NumParams();
     const CameraIntrinsics::Bounds bounds = traj.Get(traj.FirstFrame())->intrinsics.GetBounds();  // refiner.cc:690

@@ -16,6 +16,7 @@
 #include "../host/analysis_thread.h"
 #include "../host/multi_gpu.h"
 #include "../host/stage_clock.h"
+#include "../host/numa_pin.h"
 #include "../host/track_sequence.h"
 #include "np_helpers.h"
 
@@ -420,6 +421,8 @@ PYBIND11_MODULE(polychase_core, m) {
         for (const auto& kv : StageClock::Last(title)) d[py::str(kv.first)] = py::make_tuple(kv.second.first, kv.second.second);
         return d;
     });
+    // measurement aid (not in the reference): where the library's host threads were put (csrc/host/numa_pin.h), as a JSON string
+    m.def("_thread_placement", [] { return numa::Placement(); });
     // not in the reference: gives back what the calls keep for the next one -- the parked analysis engine, the tracker's parked
     // correspondence set and its pool of page-locked blocks
     m.def("release_cached_engine", [] {

@@ -42,7 +42,7 @@ SYMBOLS = [
     "pc_corr_set_create", "pc_corr_set_destroy", "pc_corr_set_clear", "pc_corr_set_recycle", "pc_corr_set_append", "pc_corr_set_size",
     "pc_corr_set_download", "pc_pnp_problem_from_set",
     "pc_pnp_problem_create", "pc_pnp_problem_destroy", "pc_pnp_normal_equations", "pc_pnp_normal_equations_cost",
-    "pc_pnp_solve", "pc_pnp_total_cost", "pc_track_solve_frame", "pc_track_frame_upload", "pc_track_frame_launch", "pc_track_frame_launch_chained", "pc_track_frame_finish",
+    "pc_pnp_solve", "pc_pnp_total_cost", "pc_track_solve_frame", "pc_track_frame_upload", "pc_track_frame_launch", "pc_track_frame_launch_chained", "pc_corr_set_reserve", "pc_context_pci_bus_id", "pc_track_frame_finish",
     "pc_track_download_points",
     "pc_refine_problem_create", "pc_refine_problem_create_parts", "pc_refine_problem_destroy", "pc_refine_total_cost", "pc_refine_normal_equations", "pc_refine_problem_timing",
 ]

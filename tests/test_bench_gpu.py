@@ -66,6 +66,10 @@ def _check_multi_gpu_keys(out, n, peer, peer_wanted):
     """what ONE N-GPU run must return: both stitches and the analysis-only rate of the same job,
     per-rank step times, the exposed stitch time, bytes per second per peer link, world size and backend"""
     assert out["world_size"] == n and out["collectives_backend"] in ("nccl", "gloo")
+    # VERDICT r05 #8: the N > 1 figure is labelled analysis-only and carries the writer-bound product rate beside it
+    assert out["claim"].startswith("analysis-only (no insert)")
+    assert out["product_rate_with_insert"].get("value", 0) > 0, out["product_rate_with_insert"]
+    assert "host" in out and "thread_placement" in out["host"] and out["gpu_busy_ms_per_step"] > 0
     assert out["config"]["arith"] == "opencv_x86" and set(out["arith_modes"]) >= {"opencv_x86", "canonical"}
     ab = out["stitch_ab"]
     assert "rccl" in ab and ab["rccl"]["stitch"].startswith("rccl all_gather")
