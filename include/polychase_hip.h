@@ -44,7 +44,7 @@ typedef struct pc_frame pc_frame;
 /* GFTTOptions, cpp/feature_detection/gftt.h:5-21 (same fields, same defaults) */
 typedef struct pc_gftt_options {
     double quality_level; /* 0.01 */
-    double min_distance;  /* 5.0 */
+    double min_distance;  /* 5.0   (any value >= 0: up to 64 the table-driven parallel suppression, above it the reference's loop against a grid of accepted corners on one wavefront) */
     int block_size;       /* 3   (any size >= 1: 3 runs the tiled kernel, others the general pair of kernels) */
     int gradient_size;    /* 3   (aperture of cornerEigenValsVecs' derivative: Sobel 3 / 5 / 7, or -1 = Scharr; anything else: PC_E_INVALID) */
     int max_corners;      /* 0 = unlimited */

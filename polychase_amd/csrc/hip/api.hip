@@ -142,7 +142,7 @@ int validate_gftt(const pc_gftt_options* opt, int w, int h, pc::GfttGrid* g) {
         return fail(PC_E_INVALID, "gradient_size must be 3, 5, 7 (Sobel) or -1 (Scharr)");
     // cornerMinEigenVal / cornerHarris take any block size (boxFilter); 2 * block_size reads per pixel from kBoxRowsFromBlock on
     if (opt->block_size < 1) return fail(PC_E_INVALID, "block_size must be >= 1");
-    if (opt->min_distance > 64.0) return fail(PC_E_INVALID, "min_distance > 64 is not supported on the HIP path");
+    // (any min_distance: above kSuppressMaxTableRadius the greedy loop runs against a grid of accepted corners, kernels_gftt.hip)
     g->rows = std::max(1, opt->grid_rows);
     g->cols = std::max(1, opt->grid_cols);
     if (g->rows * g->cols > pc::kMaxGridCells) return fail(PC_E_INVALID, "grid_rows*grid_cols must be <= %d", pc::kMaxGridCells);
@@ -198,6 +198,7 @@ int detect_reserve(pc_context* ctx, int w, int h, DetectScratch& d) {
 
 static int upload_suppression_offsets(pc_context* ctx, const pc_gftt_options& opt) {
     if (!(opt.min_distance >= 1) || ctx->sup_min_distance == opt.min_distance) return PC_OK;
+    if (opt.min_distance > pc::kSuppressMaxTableRadius) return PC_OK;   // no table: the grid kernel
     const std::vector<int2> offs = suppression_offsets(opt.min_distance);
     PC_HIP(ctx->sup_offsets.ensure(offs.size() + 1));
     PC_HIP(hipStreamSynchronize(ctx->work));  // a queued suppression may still read the old table
@@ -267,12 +268,15 @@ int detect_enqueue(pc_context* ctx, pc_frame* f, const pc::GfttGrid& grid, const
     }
     // keypoints beyond the frame's buffer are not written; the count then exceeds the capacity and the slow path redoes it
     const uint32_t limit = opt.max_corners > 0 ? std::min<uint32_t>((uint32_t)opt.max_corners, (uint32_t)f->kp_cap) : (uint32_t)f->kp_cap;
+    const bool large_radius = opt.min_distance > pc::kSuppressMaxTableRadius;
+    if (large_radius) PC_HIP(d.sup_grid.ensure((size_t)pc::suppress_large_grid_words(w, h, opt.min_distance)));
     {
         ScopedTimer t(ctx, PC_K_SUPPRESS);
         pc::launch_suppress_and_compact(d.keys_sorted.p, n_launch, cnt + kCntCand, w, h, d.eig.p, d.cstate.p, ctx->sup_offsets.p,
                                         ctx->n_sup_offsets, ctx->sup_rows.p, ctx->sup_R, opt.min_distance >= 1, d.per_block.p,
                                         cnt + kCntStuck, limit, f->d_kps,
-                                        cnt + kCntKps, hist.p, cnt + kCntOverflow, tickets + d.ticket_stride, d.ticket_stride, ctx->work);
+                                        cnt + kCntKps, hist.p, cnt + kCntOverflow, tickets + d.ticket_stride, d.ticket_stride,
+                                        opt.min_distance, large_radius ? d.sup_grid.p : nullptr, ctx->work);
     }
     // the visiting order; the same launch stores the counters in pinned host memory (no copy command behind it)
     pc::launch_spatial_bins_counted(f->d_kps, (int)std::min<uint32_t>(limit, n_launch), cnt + kCntKps, w, h, hist.p, f->d_perm,
@@ -317,9 +321,12 @@ static int detect_slow_path(pc_context* ctx, pc_frame* f, const pc::GfttGrid& gr
     int rc = ensure_kp_capacity(f, cap);
     if (rc != PC_OK) return rc;
     if ((rc = ensure_perm_capacity(f, f->kp_cap)) != PC_OK) return rc;
+    const bool large_radius = opt.min_distance > pc::kSuppressMaxTableRadius;
+    if (large_radius) PC_HIP(d.sup_grid.ensure((size_t)pc::suppress_large_grid_words(w, h, opt.min_distance)));
     pc::launch_suppress_and_compact(d.keys_sorted.p, n_cand, nullptr, w, h, d.eig.p, d.cstate.p, ctx->sup_offsets.p, ctx->n_sup_offsets,
                                     ctx->sup_rows.p, ctx->sup_R, opt.min_distance >= 1, d.per_block.p, cnt + kCntStuck, (uint32_t)std::max(opt.max_corners, 0), f->d_kps,
-                                    cnt + kCntKps, hist.p, nullptr, tickets + d.ticket_stride, d.ticket_stride, ctx->work);
+                                    cnt + kCntKps, hist.p, nullptr, tickets + d.ticket_stride, d.ticket_stride, opt.min_distance,
+                                    large_radius ? d.sup_grid.p : nullptr, ctx->work);
     pc::launch_spatial_bins_counted(f->d_kps, cap, cnt + kCntKps, w, h, hist.p, f->d_perm, f->d_perm + f->perm_cap, nullptr, nullptr, 0,
                                     ctx->work);
     PC_HIP(hipMemcpyAsync(d.h_counters.p, cnt, kHostCells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->work));

@@ -865,6 +865,10 @@ int pc_track_frame_launch_chained(pc_context* ctx, pc_corr_set* s, const pc_mesh
     pc::TrackLmOut* const slot = s->t_out.p + (la.seq & 1u);
     la.out = slot;
     la.max_rounds = o->max_iterations + 3;   // the initial sweep, one per iteration, one more for the 3-point case
+    {
+        const char* sd = getenv("POLYCHASE_TRACK_SERIAL_DECISION");   // read per launch: the tests flip it
+        la.serial_decision = (sd && sd[0] == '1') ? 1 : 0;
+    }
     la.bad_index = s->counter.p + 1;         // zero unless an earlier call found a bad index and has not been cleared
     slot->status = -1;
     slot->bad_index = 0;

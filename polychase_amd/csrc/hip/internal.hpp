@@ -119,6 +119,7 @@ struct DetectScratch {
     DevBuf<uint32_t> counters;
     DevBuf<uint32_t> bucket_offsets;       // [kSortBuckets + 1]
     DevBuf<uint32_t> per_block;            // accepted candidates per suppression workgroup -> their exclusive scan
+    DevBuf<uint32_t> sup_grid;             // min_distance > 64: the accepted corners by grid cell (kernels_gftt.hip), on demand
     DevBuf<uint32_t> bin_hist;             // keypoints per 64x64 tile (the analyzer's detections; stage-level calls use the context's)
     PinBuf<uint32_t> h_counters;           // counters[0..7] after the detection
     hipEvent_t ev_b = nullptr;
@@ -137,6 +138,7 @@ struct DetectScratch {
         counters.release();
         bucket_offsets.release();
         per_block.release();
+        sup_grid.release();
         bin_hist.release();
         h_counters.release();
         if (ev_b) (void)hipEventDestroy(ev_b);

@@ -49,7 +49,7 @@ struct GfttGrid {
     int rows, cols;      // grid_rows, grid_cols (>= 1)
     int cell_w, cell_h;  // ceil(W/cols), ceil(H/rows)
 };
-constexpr int kMaxGridCells = 256;
+constexpr int kMaxGridCells = 1024;   // grid_rows x grid_cols (not bound by the reference's module -- polychase_pybind.cc:128-136 leaves the 4 x 4 default -- but free in the C ABI)
 // K2: cornerMinEigenVal (block 3, Sobel 3) of the level-0 interior + per-cell max (ordered keys,
 // cell_max must be zeroed first).
 // sobel_fma, bit 0: the column pass of Dx as ONE fused multiply-add (PC_ARITH_SOBEL_FMA: the AVX2 dispatch of OpenCV's filter);
@@ -94,7 +94,12 @@ void launch_suppress_and_compact(const unsigned long long* keys, uint32_t n_max,
                                  uint8_t* cstate, const int2* offsets, int n_offsets, const int* row_hw, int R, bool suppress,
                                  uint32_t* per_block,
                                  uint32_t* stuck, uint32_t max_corners, float2* xy, uint32_t* n_out, uint32_t* bin_hist,
-                                 uint32_t* overflow, uint32_t* tickets, uint32_t ticket_stride, hipStream_t s);
+                                 uint32_t* overflow, uint32_t* tickets, uint32_t ticket_stride, double large_min_distance, uint32_t* large_grid,
+                                 hipStream_t s);
+// min_distance above this: the neighbourhood table is not built; large_grid (suppress_large_grid_words words of scratch) and
+// large_min_distance select the one-wavefront greedy kernel (the reference's loop against a grid of accepted corners)
+constexpr double kSuppressMaxTableRadius = 64.0;
+int suppress_large_grid_words(int w, int h, double min_distance);
 // K4 fallback: descending radix sort of the candidate keys (rocPRIM), count on the host.  temp may be null to query bytes.
 hipError_t sort_keys_desc(void* temp, size_t& temp_bytes, unsigned long long* keys_in,
                           unsigned long long* keys_out, uint32_t n, hipStream_t s);

@@ -17,6 +17,8 @@
 #include <type_traits>
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <cmath>
+
 #include "kernels.hpp"
 
 namespace pc {
@@ -1149,6 +1151,103 @@ __global__ __launch_bounds__(SUP_BLOCK) void accepted_scatter_kernel(const unsig
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K5 for LARGE radii (min_distance > kSuppressMaxTableRadius): the reference's own algorithm (gftt.cc:100-164) -- candidates in
+// priority order against a grid of the corners accepted so far -- by ONE wavefront.  The table-driven kernel above reads the
+// pi R^2 state bytes around every candidate (and walks them again per spin when more than 12 higher-priority neighbours exist):
+// fine at the detector's 5 px, hopeless at 200.  With a large radius almost every candidate is rejected by a corner accepted long
+// before it, and a frame has few corners (w h / (pi R^2 / 4) at most): 64 candidates per step, lane l = candidate base + l:
+//   * every lane tests its candidate against the accepted corners of the 3 x 3 grid cells around it (cell size = ceil(R): a cell
+//     holds at most four corners that keep the distance, kLargeCellCap slots);
+//   * the candidates that survive are settled among themselves in lane (= priority) order: the lowest surviving lane is accepted,
+//     enters the grid, and knocks out the surviving lanes within the radius; repeat.
+// The same predicate as everywhere ((float)(dx^2 + dy^2) < min_distance^2 as a double), so the same corners as the reference's
+// loop.  Then the workgroup's 256 lanes scan the per-block counts for the ordered compaction.  ~2 us per 64 candidates.
+// `grid`: gw * gh * (1 + 2 * kLargeCellCap) zeroed words.
+// ------------------------------------------------------------------------------------------------
+constexpr int kLargeCellCap = 8;
+constexpr int kLargeCellWords = 1 + 2 * kLargeCellCap;
+__global__ __launch_bounds__(256) void suppress_large_radius_kernel(const unsigned long long* __restrict__ keys, uint32_t n_max,
+                                                                    const uint32_t* __restrict__ n_dev, int w, uint8_t* cstate, double r2,
+                                                                    int cell, int gw, int gh, uint32_t* grid,
+                                                                    uint32_t* __restrict__ accepted_per_block, int nblocks,
+                                                                    uint32_t* __restrict__ stuck, uint32_t* __restrict__ n_out,
+                                                                    uint32_t* __restrict__ overflow, uint32_t max_corners, int hi_prio) {
+    helper_priority(hi_prio);
+    __shared__ uint32_t s_scan[256];
+    const uint32_t n = n_dev ? min(*n_dev, n_max) : n_max;
+    for (int b = threadIdx.x; b < nblocks + 1; b += 256) publish(&accepted_per_block[b], 0u);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        auto gload = [&](size_t at) { return __hip_atomic_load(grid + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        auto gstore = [&](size_t at, uint32_t v) { __hip_atomic_store(grid + at, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        uint32_t block_accepted = 0;
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t i = base + lane;
+            const bool live = i < n;
+            const uint32_t idx = live ? (uint32_t)keys[i] : 0u;
+            const int y = (int)(idx / (uint32_t)w), x = (int)(idx - (uint32_t)y * (uint32_t)w);
+            const int cx = x / cell, cy = y / cell;
+            bool pending = live;
+            if (live) {
+                for (int gy = max(cy - 1, 0); gy <= min(cy + 1, gh - 1) && pending; gy++)
+                    for (int gx = max(cx - 1, 0); gx <= min(cx + 1, gw - 1) && pending; gx++) {
+                        const size_t at = (size_t)(gy * gw + gx) * kLargeCellWords;
+                        const int cnt = min((int)gload(at), kLargeCellCap);
+                        for (int k = 0; k < cnt; k++) {
+                            const float dx = (float)(x - (int)gload(at + 1 + 2 * k)), dy = (float)(y - (int)gload(at + 2 + 2 * k));
+                            if ((double)(dx * dx + dy * dy) < r2) pending = false;   // gftt.cc:134-141
+                        }
+                    }
+            }
+            bool accepted = false;
+            unsigned long long pm = __ballot(pending);
+            while (pm) {
+                const int winner = __ffsll((long long)pm) - 1;   // the highest priority among the survivors
+                const int ax = __shfl(x, winner), ay = __shfl(y, winner);
+                if (lane == winner) {
+                    accepted = true;
+                    pending = false;
+                    const size_t at = (size_t)(cy * gw + cx) * kLargeCellWords;
+                    const uint32_t cnt = gload(at);
+                    if (cnt < (uint32_t)kLargeCellCap) {
+                        gstore(at + 1 + 2 * cnt, (uint32_t)x);
+                        gstore(at + 2 + 2 * cnt, (uint32_t)y);
+                    } else {
+                        atomicAdd(stuck, 1u);   // cannot happen (four corners fit a cell): reported like the other kernel's tripwire
+                    }
+                    gstore(at, cnt + 1u);
+                } else if (pending) {
+                    const float dx = (float)(x - ax), dy = (float)(y - ay);
+                    if ((double)(dx * dx + dy * dy) < r2) pending = false;
+                }
+                pm = __ballot(pending);
+            }
+            if (live) cs_store(&cstate[idx], accepted ? CS_ACCEPTED : CS_REJECTED);
+            block_accepted += (uint32_t)__popcll(__ballot(accepted));
+            if (((base >> 6) & (SUP_BLOCK / 64 - 1)) == (SUP_BLOCK / 64 - 1) || base + 64 >= n) {
+                if (lane == 0) publish(&accepted_per_block[base / SUP_BLOCK], block_accepted);
+                block_accepted = 0;
+            }
+            __builtin_amdgcn_s_waitcnt(0);   // this step's corners are in the grid before the next step reads it
+        }
+    }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const uint32_t total = scan_exclusive_256(accepted_per_block, accepted_per_block, nblocks, s_scan);
+    if (threadIdx.x == 0) {
+        if (n_dev && overflow && *n_dev > n_max) atomicOr(overflow, 4u);
+        *n_out = (max_corners > 0 && total > max_corners) ? max_corners : total;
+    }
+}
+int suppress_large_grid_words(int w, int h, double min_distance) {
+    const int cell = (int)std::ceil(min_distance);
+    return ((w + cell - 1) / cell) * ((h + cell - 1) / cell) * kLargeCellWords;
+}
+
 int suppress_num_blocks(uint32_t n) { return (int)((n + SUP_BLOCK - 1) / SUP_BLOCK); }
 
 // Suppression + ordered compaction: TWO launches.  `tickets` = two zeroed arrays of last_workgroup_words(blocks) words,
@@ -1159,12 +1258,18 @@ void launch_suppress_and_compact(const unsigned long long* keys, uint32_t n_max,
                                  uint8_t* cstate, const int2* offsets, int n_offsets, const int* row_hw, int R, bool suppress,
                                  uint32_t* per_block,
                                  uint32_t* stuck, uint32_t max_corners, float2* xy, uint32_t* n_out, uint32_t* bin_hist,
-                                 uint32_t* overflow, uint32_t* tickets, uint32_t ticket_stride, hipStream_t s) {
+                                 uint32_t* overflow, uint32_t* tickets, uint32_t ticket_stride, double large_min_distance, uint32_t* large_grid,
+                                 hipStream_t s) {
     uint32_t* const accepted_per_block = per_block;
     const int nb = suppress_num_blocks(n_max);
     if (nb == 0) return;
     const AcceptedScan fin{tickets, n_out, overflow, max_corners};
-    if (suppress)
+    if (suppress && large_grid) {
+        const int cell = (int)std::ceil(large_min_distance), gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+        (void)hipMemsetAsync(large_grid, 0, (size_t)gw * gh * kLargeCellWords * sizeof(uint32_t), s);
+        hipLaunchKernelGGL(suppress_large_radius_kernel, dim3(1), dim3(256), 0, s, keys, n_max, n_dev, w, cstate, large_min_distance * large_min_distance,
+                           cell, gw, gh, large_grid, accepted_per_block, nb, stuck, n_out, overflow, max_corners, helper_prio_arg());
+    } else if (suppress)
         hipLaunchKernelGGL(suppress_sorted_kernel, dim3(nb), dim3(SUP_BLOCK), 0, s, keys, n_max, n_dev, w, h, eig, cstate, offsets,
                            n_offsets, row_hw, R, accepted_per_block, stuck, fin, helper_prio_arg());
     else

@@ -830,6 +830,39 @@ __device__ __forceinline__ void track_consume(LmState& s, const float* out56, in
     }
 }
 
+// track_consume by the workgroup's first wavefront (lm_consume_wave, pnp_lm.hpp): the same decision, the same bits
+__device__ __forceinline__ void track_consume_wave(LmState& s, const float* out56, int round, int max_rounds, int lane) {
+    lm_wave_sync();
+    if (s.phase == 0) {
+        const int n_valid = (int)out56[54];
+        const bool drop_intrinsics = n_valid == 3 && (s.cfg.optimize_focal || s.cfg.optimize_pp);
+        lm_wave_sync();
+        if (lane == 0) {
+            s.n_valid = n_valid;
+            if (n_valid < 3) {   // "Not enough features" (tracker.cc:95-97): nothing is solved
+                s.status = 1;
+                lm_finish(s);
+            } else if (drop_intrinsics) {
+                s.cfg.optimize_focal = 0;
+                s.cfg.optimize_pp = 0;
+                lm_make_params(s.cam, s.cfg, &s.sweep);
+            }
+        }
+        lm_wave_sync();
+        if (n_valid < 3 || drop_intrinsics) return;
+    }
+    lm_consume_wave(s, out56, lane);
+    lm_wave_sync();
+    if (!s.done && round + 1 >= max_rounds) {
+        lm_wave_sync();
+        if (lane == 0) {
+            s.status = 3;
+            lm_finish(s);
+        }
+        lm_wave_sync();
+    }
+}
+
 __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
     __shared__ float s_part[4][PNP_ACC];
     __shared__ float s_out[PNP_ACC];
@@ -905,8 +938,8 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
             reduce_partials<PNP_ACC>(a.partials, G, s_out);
             __syncthreads();
             tick(2);
-            if (tid == 0) {
-                if (round == 0) {
+            if (tid < 64) {   // the workgroup's first wavefront
+                if (round == 0 && tid == 0) {
                     LmState& h = s_state;
                     uint32_t* z = reinterpret_cast<uint32_t*>(&h);
                     for (int i = 0; i < (int)(sizeof(LmState) / sizeof(uint32_t)); i++) z[i] = 0u;
@@ -920,7 +953,10 @@ __global__ __launch_bounds__(256) void track_lm_kernel(TrackLmArgs a) {
                     h.rebuild = 1;
                     lm_make_params(h.cam, h.cfg, &h.sweep);
                 }
-                track_consume(s_state, s_out, (int)round, a.max_rounds);
+                // the decision: the 9x9 algebra dealt out over the wavefront's lanes (same operations, same order per result:
+                // the serial code's bits), or -- serial_decision, the cross-check -- on one lane
+                if (!a.serial_decision) track_consume_wave(s_state, s_out, (int)round, a.max_rounds, tid);
+                else if (tid == 0) track_consume(s_state, s_out, (int)round, a.max_rounds);
             }
             __syncthreads();
             tick(3);

@@ -89,6 +89,7 @@ struct TrackLmArgs {
     uint32_t seq;             // this launch's number (TrackLmOut::seq)
     const int* bad_index;     // track_cast_kernel's flag, passed on to `out`
     int max_rounds;
+    int serial_decision;      // != 0: the decision of a round on ONE lane (lm_consume; round 5's, the cross-check of lm_consume_wave)
 };
 
 PC_HD float lm_clamp(float v, float lo, float hi) { return v < lo ? lo : (hi < v ? hi : v); }   // std::clamp
@@ -301,5 +302,200 @@ PC_HD void lm_consume(LmState& s, const float* out56) {
     s.iterations++;
     lm_advance(s);
 }
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same decision taken by one WAVEFRONT (track_lm_kernel, round 6): lm_consume above is ~1600 dependent instructions of one
+// lane -- 4.6 us of every 16-us LM round during which 255 workgroups wait.  Here the 9x9 algebra is dealt out over lanes 0..8
+// with EVERY floating-point operation of the serial code kept, on the same operands, in the same order per result -- so the
+// bits are the serial code's (tests/test_tracker_gpu.py holds the two against each other; POLYCHASE_TRACK_SERIAL_DECISION=1
+// runs the serial one):
+//   * Cholesky, left-looking: lane i owns row i of L.  Column k: every lane i >= k forms a[i][k] - sum_{j<k} a[i][j] a[k][j]
+//     (row k's entries arrive as scalars: v_readlane), lane k's value is the pivot, one square root, one division per lane --
+//     9 dependent divisions instead of 36.
+//   * forward substitution by columns: y[j] = s[j] / l[j][j] in lane j, then every lane i > j subtracts l[i][j] y[j] -- for each
+//     row the subtractions come in ascending j, as in the serial loop.
+//   * back substitution: x[i] needs x[i+1..8] in ascending order, the last one first -- a dependent chain whichever lane runs
+//     it: done uniformly (l[j][i] by v_readlane).
+//   * step^T (2 J^T r + J^T J step): row a in lane a, the nine terms added in order.
+//   * copies of the 45 + 9 + 81 entries: one lane each.
+// Scalars of the state are updated by lane 0; the wavefront reads them back from LDS (in-order LDS, fences between the phases).
+// Called by all 64 lanes of ONE wavefront; `s` and `out56` live in LDS.
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lm_lane_value(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ void lm_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// lm_advance by a wavefront
+__device__ __forceinline__ void lm_advance_wave(LmState& s, int lane) {
+    for (;;) {
+        lm_wave_sync();
+        if (!(s.iterations < s.cfg.max_iterations)) break;
+        if (s.rebuild) {
+            // JtJ's lower triangle <- cur_lower, Jtr <- cur_Jtr
+            for (int e = lane; e < 81; e += 64) {
+                const int a = e / 9, b = e - 9 * a;
+                if (b <= a) s.JtJ[e] = s.cur_lower[a * (a + 1) / 2 + b];
+            }
+            if (lane < 9) s.Jtr[lane] = s.cur_Jtr[lane];
+            lm_wave_sync();
+            // JtJ_diag = diag.cwiseMax(1e-6).cwiseMin(1e32)  (:296)
+            float sq = 0.f;
+            if (lane < 9) {
+                s.diag[lane] = fminf(fmaxf(s.JtJ[10 * lane], 1e-6f), 1e32f);
+                sq = s.Jtr[lane] * s.Jtr[lane];
+            }
+            float g2 = 0;
+#pragma unroll
+            for (int a = 0; a < 9; a++) g2 += lm_lane_value(sq, a);
+            const float grad_norm = sqrtf(g2);
+            if (lane == 0) s.grad_norm = grad_norm;
+            lm_wave_sync();
+            if (grad_norm < s.cfg.gradient_tol) break;
+        }
+        // ComputeStep (:299-314): multiplicative damping, LLT of the lower triangle; lane i holds row i
+        float Lr[9];
+        const int row = lane < 9 ? lane : 0;
+        const float lambda = s.lambda;
+#pragma unroll
+        for (int j = 0; j < 9; j++) Lr[j] = (lane < 9 && j < row) ? s.JtJ[9 * row + j] : 0.0f;
+        {
+            const float d = (lane < 9) ? s.diag[row] * (1.0f + lambda) : 1.0f;
+#pragma unroll
+            for (int j = 0; j < 9; j++) Lr[j] = (j == lane) ? d : Lr[j];
+            if (lane < 9) s.JtJ[10 * lane] = s.diag[lane];   // "remove dampening" leaves the clamped diagonal
+        }
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            float sk = Lr[k];
+#pragma unroll
+            for (int j = 0; j < k; j++) sk -= Lr[j] * lm_lane_value(Lr[j], k);
+            const float pivot = lm_lane_value(sk, k);
+            ok = ok && (pivot > 0.0f);
+            const float x = sqrtf(pivot);
+            Lr[k] = (lane == k) ? x : sk / x;   // (lanes < k: the upper triangle, never read)
+        }
+        if (!ok) {
+            if (lane == 0) {
+                s.invalid_steps++;
+                if (s.lambda != s.cfg.max_lambda) {
+                    s.lambda = fminf(s.cfg.max_lambda, s.lambda * s.v);
+                    s.v = 2 * s.v;
+                    s.rebuild = 0;
+                    s.iterations++;
+                }
+            }
+            if (lambda == s.cfg.max_lambda) break;   // (the value before the update: s.lambda is unchanged in that case)
+            continue;
+        }
+        // L y = J^T r
+        float sy = lane < 9 ? s.Jtr[row] : 0.0f;
+        float yv[9], xv[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++) {
+            yv[j] = lm_lane_value(sy / Lr[j], j);   // lane j: s[j] / l[j][j]
+            sy -= Lr[j] * yv[j];                    // lanes i > j: s[i] -= l[i][j] y[j]
+        }
+        // L^T x = y
+#pragma unroll
+        for (int i = 8; i >= 0; i--) {
+            float sx = yv[i];
+#pragma unroll
+            for (int j = i + 1; j < 9; j++) sx -= lm_lane_value(Lr[i], j) * xv[j];
+            xv[i] = sx / lm_lane_value(Lr[i], i);
+        }
+        float s2 = 0;
+#pragma unroll
+        for (int a = 0; a < 9; a++) {
+            const float st = -xv[a];
+            if (lane == a) s.step[a] = st;
+            s2 += st * st;
+        }
+        const float step_norm = sqrtf(s2);
+        if (lane == 0) s.step_norm = step_norm;
+        lm_wave_sync();
+        if (step_norm < s.cfg.step_tol) break;
+        if (lane == 0) {
+            lm_step_camera(s.cam, s.step, s.cfg, &s.cam_new);
+            lm_make_params(s.cam_new, s.cfg, &s.sweep);
+            s.phase = 1;
+        }
+        lm_wave_sync();
+        return;   // evaluate cam_new
+    }
+    if (lane == 0) lm_finish(s);
+    lm_wave_sync();
+}
+
+// lm_consume by a wavefront
+__device__ __forceinline__ void lm_consume_wave(LmState& s, const float* out56, int lane) {
+    lm_wave_sync();
+    if (s.done) return;
+    auto take_sums = [&]() {   // cur_lower, cur_Jtr <- the sweep's sums
+        if (lane < 45) s.cur_lower[lane] = out56[lane];
+        if (lane < 9) s.cur_Jtr[lane] = out56[45 + lane];
+    };
+    if (s.phase == 0) {   // the initial parameters (lev_marq.h:139-144)
+        take_sums();
+        if (lane == 0) {
+            s.cost = out56[55];
+            s.initial_cost = s.cost;
+            s.rebuild = 1;
+        }
+        lm_advance_wave(s, lane);
+        return;
+    }
+    const float cost_new = out56[55];
+    if (cost_new < s.cost) {
+        const float actual = cost_new - s.cost;
+        // step^T (2 Jtr + JtJ_sym step)   (:183-186), fp32 like the reference: row a in lane a, the terms added in order
+        float term = 0.f;
+        if (lane < 9) {
+            float rowsum = 0;
+#pragma unroll
+            for (int b = 0; b < 9; b++) rowsum += (b <= lane ? s.JtJ[9 * lane + b] : s.JtJ[9 * b + lane]) * s.step[b];
+            term = s.step[lane] * (2.0f * s.Jtr[lane] + rowsum);
+        }
+        float expected = 0;
+#pragma unroll
+        for (int a = 0; a < 9; a++) expected += lm_lane_value(term, a);
+        const float rho = actual / expected;
+        lm_wave_sync();   // every lane has read cost, JtJ, step, Jtr
+        if (lane == 0) {
+            if (rho > 0) {  // ill-conditioned JtJ can make `expected` positive (:189-197)
+                const double d = 2.0 * (double)rho - 1.0;
+                const double f = 1.0 - d * d * d;
+                const double factor = f > 1.0 / 3.0 ? f : 1.0 / 3.0;
+                s.lambda = lm_clamp((float)((double)s.lambda * factor), s.cfg.min_lambda, s.cfg.max_lambda);
+            }
+            s.cam = s.cam_new;
+            s.cost = cost_new;
+            s.v = 2;
+            s.rebuild = 1;
+            s.iterations++;
+        }
+        take_sums();
+    } else {
+        const bool at_max = s.lambda == s.cfg.max_lambda;
+        lm_wave_sync();
+        if (lane == 0) {
+            s.invalid_steps++;
+            if (at_max) {
+                lm_finish(s);
+            } else {
+                s.lambda = fminf(s.cfg.max_lambda, s.lambda * s.v);
+                s.v = 2 * s.v;
+                s.rebuild = 0;
+                s.iterations++;
+            }
+        }
+        if (at_max) {
+            lm_wave_sync();
+            return;
+        }
+    }
+    lm_advance_wave(s, lane);
+}
+#endif  // __HIPCC__
 
 }  // namespace pc

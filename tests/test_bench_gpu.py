@@ -38,7 +38,9 @@ def test_watchdog_prints_the_line_measured_so_far_when_the_stitch_hangs():
     assert out["metric"] == "optical-flow frames/sec" and out["config"]["stitch"].startswith("none")
 
 
-@pytest.mark.parametrize("stitch", ["peer", "rccl", "peer-broken"])
+# ("peer" rides in test_c4_label_of_the_nested_4k_block_with_two_ranks and "rccl" in test_gpus_flag_launches_the_ranks_itself since
+# round 6: the same assertions on jobs that are run anyway -- VERDICT r05 #7, the suite's time)
+@pytest.mark.parametrize("stitch", ["peer-broken"])
 def test_two_ranks_on_one_gpu_over_gloo(stitch):
     """bench.py exactly as the driver launches it for --gpus 2 (torch.distributed.run, two processes), except that both
     ranks sit on GPU 0 and the process group is gloo (POLYCHASE_BENCH_SHARE_GPU=1): the region count agreed by all-reduce,
@@ -62,7 +64,7 @@ def test_two_ranks_on_one_gpu_over_gloo(stitch):
     _check_multi_gpu_keys(out, 2, peer=stitch == "peer", peer_wanted=stitch != "rccl")
 
 
-def _check_multi_gpu_keys(out, n, peer, peer_wanted):
+def _check_multi_gpu_keys(out, n, peer, peer_wanted, arith_modes=True):
     """what ONE N-GPU run must return: both stitches and the analysis-only rate of the same job,
     per-rank step times, the exposed stitch time, bytes per second per peer link, world size and backend"""
     assert out["world_size"] == n and out["collectives_backend"] in ("nccl", "gloo")
@@ -70,7 +72,7 @@ def _check_multi_gpu_keys(out, n, peer, peer_wanted):
     assert out["claim"].startswith("analysis-only (no insert)")
     assert out["product_rate_with_insert"].get("value", 0) > 0, out["product_rate_with_insert"]
     assert "host" in out and "thread_placement" in out["host"] and out["gpu_busy_ms_per_step"] > 0
-    assert out["config"]["arith"] == "opencv_x86" and set(out["arith_modes"]) >= {"opencv_x86", "canonical"}
+    assert out["config"]["arith"] == "opencv_x86" and (not arith_modes or set(out["arith_modes"]) >= {"opencv_x86", "canonical"})
     ab = out["stitch_ab"]
     assert "rccl" in ab and ab["rccl"]["stitch"].startswith("rccl all_gather")
     if peer:
@@ -93,7 +95,9 @@ def test_gpus_flag_launches_the_ranks_itself():
     """`python3 bench.py --gpus 2 --steps 16 --warmup 4` -- the form the driver uses, no torchrun around it: bench.py
     re-executes itself through torch.distributed.run with two ranks (on this one-GPU box both on GPU 0 over gloo, the
     SHARE_GPU testing aid) and exactly one JSON line with n_gpus == 2 comes out (round 2 parsed --gpus and ignored it)."""
-    env = dict(os.environ, POLYCHASE_BENCH_SHARE_GPU="1")
+    # (POLYCHASE_BENCH_STITCH=rccl: the chunked all-gather as the headline stitch -- gloo here -- and everything ONE N-GPU run must
+    # return, on the same job)
+    env = dict(os.environ, POLYCHASE_BENCH_SHARE_GPU="1", POLYCHASE_BENCH_STITCH="rccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "4",
@@ -104,6 +108,8 @@ def test_gpus_flag_launches_the_ranks_itself():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 16 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["parallelism"] == "frame-shard x2"
+    assert out["config"]["stitch"].startswith("rccl all_gather"), (out["config"]["stitch"], r.stderr[-2000:])
+    _check_multi_gpu_keys(out, 2, peer=False, peer_wanted=False)
 
 
 def test_peer_stitch_selftest_three_ranks_with_logs_of_different_sizes():
@@ -149,7 +155,7 @@ def test_gpus_flag_fails_loudly_without_enough_gpus():
 def test_c4_label_of_the_nested_4k_block_with_two_ranks():
     """`bench.py --gpus N` carries the 4K configuration as C4's per-rank workload: the nested block must say so (frames
     per GPU, halo) and hold both stitches as well.  Two ranks on one GPU (testing aid), few steps."""
-    env = dict(os.environ, POLYCHASE_BENCH_SHARE_GPU="1")
+    env = dict(os.environ, POLYCHASE_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
@@ -162,6 +168,11 @@ def test_c4_label_of_the_nested_4k_block_with_two_ranks():
     assert c4["n_gpus"] == 2 and c4["config"]["workload"].startswith("C4 3840x2160 2400-frame clip frame-sharded across 2")
     assert c4["config"]["c4_frames_per_gpu_at_8"] == 300 and c4["config"]["halo_frames_per_side"] == 8
     assert "rccl" in c4["stitch_ab"] and c4["analysis_only"]["value"] > 0
+    # the default stitch -- each rank maps the other's receive buffer through HIP IPC and pushes its pieces with device-to-device
+    # copies (distributed.PeerLogStitch; here both buffers live on GPU 0) -- and what ONE N-GPU run must return, headline and nested
+    assert out["config"]["stitch"].startswith("xgmi peer copies"), (out["config"]["stitch"], r.stderr[-2000:])
+    _check_multi_gpu_keys(out, 2, peer=True, peer_wanted=True, arith_modes=False)
+    _check_multi_gpu_keys(c4, 2, peer=True, peer_wanted=True, arith_modes=False)
 
 
 def test_one_gpu_line_carries_roofline_counters_arith_modes_and_c5():

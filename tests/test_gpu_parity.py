@@ -161,6 +161,35 @@ def test_harris_and_other_block_sizes(ctx, kw):
         assert np.array_equal(got[fid], oracle.gftt(oracle.rgb2gray(frames[fid]), oracle.gftt_options(**kw)))
 
 
+@pytest.mark.parametrize("kw", [dict(min_distance=65.0), dict(min_distance=100.5, quality_level=0.001), dict(min_distance=300.0),
+                                dict(min_distance=64.0), dict(min_distance=80.0, max_corners=7), dict(grid_rows=20, grid_cols=30),
+                                dict(grid_rows=32, grid_cols=32, min_distance=70.0)],
+                         ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
+def test_large_min_distance_and_fine_grids(ctx, kw):
+    """GFTTOptions.min_distance is a free double in the reference (cpp/feature_detection/gftt.h:5-21): above 64 px the HIP path
+    runs the reference's own greedy loop against a grid of accepted corners on one wavefront (kernels_gftt.hip:
+    suppress_large_radius_kernel) instead of the table-driven parallel suppression -- keypoints in value AND order; a radius larger
+    than the frame leaves one corner.  Grids up to 1024 cells."""
+    for (w, h) in ((640, 360), (333, 211)):
+        _, (rgb,) = _noise_frames(w, h, [3])
+        g = oracle.rgb2gray(rgb)
+        f = hip.Frame(ctx, w, h)
+        f.set_rgb(rgb)
+        f.detect(hip.gftt_options(**kw))
+        xy = oracle.gftt(g, oracle.gftt_options(**kw))
+        assert len(xy) >= 1 and np.array_equal(f.keypoints(), xy), "keypoints must match in value AND order"
+        f.close()
+    from polychase_amd.pipeline import ClipAnalyzer
+    clip = synth.NoiseClip(320, 240, 5)
+    frames = {i + 1: clip.frame(i) for i in range(5)}
+    an = ClipAnalyzer(ctx, 320, 240, 1, 5, lambda fid: frames[fid], hip.gftt_options(**kw))
+    got = {}
+    an.run(range(1, 6), lambda f1, kp, det, flows: got.__setitem__(f1, kp.copy()))
+    an.close()
+    for fid in (1, 4):
+        assert np.array_equal(got[fid], oracle.gftt(oracle.rgb2gray(frames[fid]), oracle.gftt_options(**kw)))
+
+
 def test_flat_image_has_no_keypoints(ctx):
     f = hip.Frame(ctx, 128, 96)
     f.set_gray(np.full((96, 128), 77, np.uint8))

@@ -48,7 +48,7 @@ def test_random_configuration(ctx, seed):
     kind = ["noise", "blocks", "smooth"][seed % 3]
     win = int(rng.integers(3, 32))
     max_level = int(rng.integers(0, 6))
-    gk = dict(quality_level=float(rng.choice([0.001, 0.01, 0.05, 0.3])), min_distance=float(rng.choice([0.0, 1.0, 2.5, 5.0, 11.0])),
+    gk = dict(quality_level=float(rng.choice([0.001, 0.01, 0.05, 0.3])), min_distance=float(rng.choice([0.0, 1.0, 2.5, 5.0, 11.0, 70.0])),
               max_corners=int(rng.choice([0, 0, 7, 300])), grid_rows=int(rng.integers(1, 7)), grid_cols=int(rng.integers(1, 7)))
     fk = dict(window_size=win, max_level=max_level, term_max_iters=int(rng.choice([1, 3, 30, 60])),
               term_epsilon=float(rng.choice([0.0, 0.001, 0.01, 0.3])), min_eigen_threshold=float(rng.choice([1e-6, 1e-4, 1e-2])))

@@ -632,6 +632,16 @@ def test_pipelined_solve_frame_semantics(core, tmp_path, monkeypatch):
         for f in fused:
             assert np.array_equal(fused[f][0], unchained[f][0]) and np.array_equal(fused[f][1], unchained[f][1]), f
             assert fused[f][2] == unchained[f][2] and fused[f][3] == unchained[f][3], f
+        # round 6: the decision of an LM round is taken by a wavefront (pnp_lm.hpp: lm_consume_wave -- the 9x9 Cholesky, the
+        # substitutions and the gain ratio dealt out over nine lanes, every operation of the serial code on the same operands in the
+        # same order); POLYCHASE_TRACK_SERIAL_DECISION=1 is round 5's one-lane decision: the same bits, iteration counts included
+        monkeypatch.setenv("POLYCHASE_TRACK_SERIAL_DECISION", "1")
+        serial = run(a, b)
+        monkeypatch.delenv("POLYCHASE_TRACK_SERIAL_DECISION", raising=False)
+        assert sorted(fused) == sorted(serial)
+        for f in fused:
+            assert np.array_equal(fused[f][0], serial[f][0]) and np.array_equal(fused[f][1], serial[f][1]), f
+            assert fused[f][2] == serial[f][2] and fused[f][3] == serial[f][3], f
         assert sorted(fused) == sorted(blocks) and len(fused) == n_frames - 1
         for f in fused:
             assert np.array_equal(fused[f][0], again[f][0]) and np.array_equal(fused[f][1], again[f][1]), f      # deterministic
