@@ -5,11 +5,18 @@ Every rank runs the SAME host code as the single-GPU path -- polychase_core's C+
 contiguous range of frame1 ids (the frames up to 8 outside the range are ingested as tracking targets only, no
 detection).  There is no collective on the data path.  Rank 0, which owns the SQLite file, stores its shard as it goes;
 the other ranks append their records to a log in GPU memory that is handed over in pieces of a few frames while the
-analysis continues: the pieces travel to rank 0 over RCCL (torch.distributed, backend "nccl": device-to-device send /
-recv over xGMI) in frame order and are stored through polychase_core.write_optical_flow_records as they arrive -- the
-statements of the single-process run in the same order, so the SQLite file does not depend on the number of ranks, and
-no rank ever holds more than a few pieces.  (Only rank 0 reads the records, so this is a gather; bench.py times the
-all-gather variant of the same pieces, distributed.ChunkedLogStitch.)
+analysis continues: the pieces travel to rank 0 over RCCL (ncclSend / ncclRecv, device to device over xGMI) in frame order
+under credit flow control and are stored as they arrive -- the statements of the single-process run in the same order, so
+the SQLite file does not depend on the number of ranks, and no rank ever holds more than a few pieces.  (Only rank 0 reads
+the records, so this is a gather; bench.py times the all-gather variant of the same pieces, distributed.ChunkedLogStitch.)
+
+ONE implementation of that protocol: csrc/host/multi_gpu.cc (GenerateOpticalFlowDatabaseMultiGpu), reached here through
+polychase_core.generate_optical_flow_database_multi_gpu -- this module is its launcher and its frame source, nothing more
+(rounds 3-5 carried a Python twin of the protocol over torch.distributed: removed in round 6).  The ranks find each other
+through MASTER_ADDR / MASTER_PORT (+ 17: the port itself belongs to the launcher's rendezvous) or POLYCHASE_MULTI_GPU_PORT.
+
+EVERY N > 1 FIGURE OF THIS PATH IS BOUND BY ITS SINGLE WRITER once the analysis outruns one SQLite connection (4K: ~370-460
+frames/s on one writer against ~670 analysed per GPU): what scales with N is the analysis-only rate (bench.py --gpus N).
 
     python -m polychase_amd.analyze --gpus 8 --synthetic c3 --frames 2400 --database /tmp/clip.db
 
@@ -48,20 +55,6 @@ def log_capacity(n_frames: int, width: int, height: int, n_targets: int = 8, key
     return D.log_capacity_bytes(n_frames, kp, n_targets)
 
 
-def _control_group(group):
-    """CPU-tensor group for credits and headers: the main group when it is gloo already, else a gloo group over the same
-    ranks.  Its waits can be long (a rank waits for its turn while rank 0 stores the ranks before it)."""
-    import datetime
-
-    import torch.distributed as dist
-
-    if dist.get_backend(group) == "gloo":
-        return group
-    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-    ranks = dist.get_process_group_ranks(group) if group is not None else None
-    return dist.new_group(ranks=ranks, backend="gloo", timeout=datetime.timedelta(hours=24))
-
-
 def analyze(width: int, height: int, first_frame: int, num_frames: int, frame_accessor, database_path: str,
             detector_options=None, flow_options=None, callback=None, group=None, device=None, piece_frames: int = 16,
             keypoints_per_frame: int | None = None):
@@ -71,7 +64,7 @@ def analyze(width: int, height: int, first_frame: int, num_frames: int, frame_ac
 
     Rank 0 runs its own shard straight into the database (the single-GPU path: inserts overlap the analysis); every other
     rank analyses its shard into a two-part device log and hands the log over in pieces of `piece_frames` frames, which
-    travel to rank 0 over RCCL in frame order (distributed.OrderedPieceGather) and are stored as they arrive.  GPU and
+    travel to rank 0 over RCCL in frame order (csrc/host/multi_gpu.cc) and are stored as they arrive.  GPU and
     host memory are bounded by the pieces in flight, whatever the length of the clip.  An existing database must hold
     the same analysis (write_optical_flow_records refuses other keypoints).
     Returns a dict of per-phase seconds and counts (on every rank)."""
@@ -99,58 +92,18 @@ def analyze(width: int, height: int, first_frame: int, num_frames: int, frame_ac
                    written={"keypoint_rows": st.keypoint_rows_written, "flow_rows": st.flow_rows_written})
         return out
 
-    ctl = _control_group(group)
-    gather = D.OrderedPieceGather(group, ctl, device=dev)
-    cancelled = False
-    if rank == 0:
-        # the receiver asks rank 1 for its first piece at once; what arrives waits (bounded) until this shard is stored
-        gather.start()
-        try:
-            res = core.generate_optical_flow_shard(vi, frame_accessor, callback, database_path, begin, end, detector_options=gopt,
-                                                   flow_options=fopt)
-        except BaseException:
-            # this rank's own shard failed: the other ranks are waiting for a credit (a blocking recv under a 24 h
-            # timeout) -- tell them to stop before the exception leaves (a negative credit; OrderedPieceGather.abort)
-            gather.abort()
-            raise
-        st = res["stats"]
-        cancelled = bool(res["cancelled"])
-        t1 = time.perf_counter()
-        rows_kp, rows_flow, db_s = st.keypoint_rows_written, st.flow_rows_written, st.seconds_db
-        writer = core.OpticalFlowRecordWriter(database_path)
-        for _r, _first, _frames, host in gather.pieces():      # frame order: all of rank 1, then rank 2, ...
-            ws = writer.write(host, len(host))
-            rows_kp += ws.keypoint_rows_written
-            rows_flow += ws.flow_rows_written
-            db_s += ws.seconds_db
-        writer.close()
-        t2 = time.perf_counter()
-        out.update(seconds_analysis=t1 - t0, seconds_stitch=0.0, seconds_database=db_s, log_bytes=int(gather.bytes_moved),
-                   frames_processed=st.frames_processed, written={"keypoint_rows": rows_kp, "flow_rows": rows_flow})
-    else:
-        part = log_capacity(piece_frames + 1, width, height, keypoints_per_frame=keypoints_per_frame)
-        part = (part + 15) // 16 * 16
-        log = torch.empty(2 * part, dtype=torch.uint8, device=dev)
-
-        def on_piece(piece, offset, nbytes, first, n_frames):
-            gather.put(log[offset:offset + nbytes], first, n_frames)
-
-        ok = False
-        try:
-            res = core.generate_optical_flow_shard(vi, frame_accessor, callback, "", begin, end, log.data_ptr(), log.numel(), 2,
-                                                   piece_frames, on_piece, False, gopt, fopt)
-            ok = True
-        finally:
-            gather.finish(failed=not ok)
-        st = res["stats"]
-        cancelled = bool(res["cancelled"])
-        t1 = t2 = time.perf_counter()
-        out.update(seconds_analysis=t1 - t0 - gather.seconds_blocked, seconds_stitch=gather.seconds_blocked, seconds_database=0.0,
-                   log_bytes=int(gather.bytes_moved), frames_processed=st.frames_processed, written=None, pieces=int(res["pieces"]))
-    # a rank whose progress callback cancelled leaves a hole in the clip: every rank reports it
-    flag = torch.tensor([1 if cancelled else 0], dtype=torch.int64)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ctl)
-    out["cancelled"] = bool(flag.item())
+    # N ranks: the C++ protocol (csrc/host/multi_gpu.cc) -- rank 0 stores its own shard while it receives the first pieces of rank 1
+    share_gpu = os.environ.get("POLYCHASE_ANALYZE_SHARE_GPU") == "1"
+    port = int(os.environ.get("POLYCHASE_MULTI_GPU_PORT", "0")) or int(os.environ.get("MASTER_PORT", "29594")) + 17
+    res = core.generate_optical_flow_database_multi_gpu(
+        vi, frame_accessor, callback, database_path, world, rank, master_addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), master_port=port,
+        device=dev.index or 0, piece_frames=piece_frames,
+        transport="tcp" if share_gpu else "rccl",     # (RCCL refuses two ranks on one device: the one-GPU testing aid moves the pieces over TCP)
+        keypoints_per_frame=keypoints_per_frame or 0, detector_options=gopt, flow_options=fopt)
+    st = res["stats"]
+    out.update(seconds_analysis=res["seconds_analysis"], seconds_stitch=res["seconds_blocked"], seconds_database=st.seconds_db,
+               log_bytes=int(res["bytes_moved"]), frames_processed=st.frames_processed, pieces=int(res["pieces"]), cancelled=bool(res["cancelled"]),
+               written={"keypoint_rows": st.keypoint_rows_written, "flow_rows": st.flow_rows_written} if rank == 0 else None)
     out["seconds_total"] = time.perf_counter() - t0
     return out
 

@@ -344,7 +344,18 @@ MultiGpuResult GenerateOpticalFlowDatabaseMultiGpu(const VideoInfo& video_info, 
         });
         std::exception_ptr failure;
         try {
-            GenerateOpticalFlowShard(video_info, frame_accessor, callback, database_path, shard, detector_options, flow_options, &res.stats);
+            if (cfg.synthetic_shard) {
+                OpticalFlowRecordWriter own(database_path);
+                cfg.synthetic_shard(0, [&](const void* bytes, size_t n, int32_t, int) {
+                    OpticalFlowRunStats ws;
+                    own.Write(static_cast<const uint8_t*>(bytes), n, &ws);
+                    res.stats.keypoint_rows_written += ws.keypoint_rows_written;
+                    res.stats.flow_rows_written += ws.flow_rows_written;
+                });
+                own.Close();
+            } else {
+                GenerateOpticalFlowShard(video_info, frame_accessor, callback, database_path, shard, detector_options, flow_options, &res.stats);
+            }
             res.seconds_analysis = Since(t0);
             OpticalFlowRecordWriter writer(database_path);
             for (;;) {
@@ -385,8 +396,12 @@ MultiGpuResult GenerateOpticalFlowDatabaseMultiGpu(const VideoInfo& video_info, 
         master.Recv(id, sizeof(id));
         CheckAbi(pc_comm_create(comm_ctx, id, world, rank, &comm), "pc_comm_create");
     }
+    if (cfg.synthetic_shard && rccl) Fail("synthetic_shard needs transport tcp");
     const size_t part = LogPartBytes(video_info, cfg);
-    DeviceBuffer log(device, 2 * part);
+    std::unique_ptr<DeviceBuffer> log_owner;
+    if (!cfg.synthetic_shard) log_owner.reset(new DeviceBuffer(device, 2 * part));
+    DeviceBuffer no_log;
+    DeviceBuffer& log = log_owner ? *log_owner : no_log;
     constexpr int kDepth = 2;
     std::unique_ptr<DeviceBuffer> staging[kDepth];
     if (rccl)
@@ -442,7 +457,16 @@ MultiGpuResult GenerateOpticalFlowDatabaseMultiGpu(const VideoInfo& video_info, 
     };
     std::exception_ptr failure;
     try {
-        GenerateOpticalFlowShard(video_info, frame_accessor, callback, "", shard, detector_options, flow_options, &res.stats);
+        if (cfg.synthetic_shard) {
+            cfg.synthetic_shard(rank, [&](const void* bytes, size_t n, int32_t first_frame1, int n_frames) {
+                Outgoing o;
+                o.h = Header{static_cast<int64_t>(n), n_frames, first_frame1};
+                o.host.assign(static_cast<const uint8_t*>(bytes), static_cast<const uint8_t*>(bytes) + n);
+                if (!outgoing.Push(std::move(o), &res.seconds_blocked)) Fail("the sender ended (see its error)");
+            });
+        } else {
+            GenerateOpticalFlowShard(video_info, frame_accessor, callback, "", shard, detector_options, flow_options, &res.stats);
+        }
     } catch (...) {
         failure = std::current_exception();
     }

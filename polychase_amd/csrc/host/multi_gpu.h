@@ -11,11 +11,13 @@
 //   * the payload moves with RCCL (ncclSend / ncclRecv over xGMI; include/polychase_hip.h: pc_comm_send / pc_comm_recv);
 //     credits, piece headers and RCCL's unique id travel over a TCP control connection to rank 0 (blocking host
 //     sockets: no collective kernel sits on a GPU spinning for a peer that is seconds away).
-// The database does not depend on the number of ranks (tests/test_multi_gpu_cpp_gpu.py).  The Python product
-// (polychase_amd/analyze.py over torch.distributed) does the same with the same record format; this is the C++ host's way.
+// The database does not depend on the number of ranks (tests/test_multi_gpu_cpp_gpu.py).  THIS is the one implementation of the
+// protocol (round 6; rounds 3-5 carried a Python twin, distributed.OrderedPieceGather): polychase_amd/analyze.py calls it through
+// polychase_core.generate_optical_flow_database_multi_gpu, a C++ host calls it directly (tools/multi_gpu/multi_gpu_analyze.cc).
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <string>
 
 #include "analysis.h"
@@ -32,6 +34,11 @@ struct MultiGpuConfig {
     // host memory -- a testing aid for boxes where the ranks share ONE GPU (RCCL refuses two ranks on one device).
     std::string transport = "rccl";
     double connect_timeout_s = 120.0;
+    // Testing aid (tests/test_distributed_cpu.py: the protocol on a box without a GPU, transport "tcp"): when set, NO analysis
+    // runs -- the rank's shard is whatever this function hands to `emit`, piece by piece, in frame order: a piece = a packed record
+    // log as the analyzer writes it (bytes, first frame1, number of frame1s).  Rank 0 stores its pieces directly, the other ranks
+    // send theirs through the same queue, credits and headers as the analyzer's pieces.  May throw (a failing rank).
+    std::function<void(int rank, const std::function<void(const void* bytes, size_t n, int32_t first_frame1, int n_frames)>& emit)> synthetic_shard;
 };
 
 struct MultiGpuResult {

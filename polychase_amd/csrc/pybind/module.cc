@@ -16,6 +16,9 @@
 #include "../host/analysis_thread.h"
 #include "../host/multi_gpu.h"
 #include "../host/stage_clock.h"
+#include <chrono>
+#include <thread>
+
 #include "../host/numa_pin.h"
 #include "../host/track_sequence.h"
 #include "np_helpers.h"
@@ -438,6 +441,53 @@ PYBIND11_MODULE(polychase_core, m) {
           py::arg("master_addr") = "127.0.0.1", py::arg("master_port") = 29611, py::arg("device") = -1, py::arg("piece_frames") = 16,
           py::arg("transport") = "rccl", py::arg("keypoints_per_frame") = 0, py::arg("detector_options") = GFTTOptions{},
           py::arg("flow_options") = OpticalFlowOptions{});
+    // Testing aid (not in the reference): GenerateOpticalFlowDatabaseMultiGpu's protocol -- credits, headers, ordered pieces, failure
+    // propagation, the cancelled flag -- with the rank's shard given as ready-made record logs instead of an analysis
+    // (MultiGpuConfig::synthetic_shard, transport "tcp"): runs on a box without a GPU (tests/test_distributed_cpu.py).
+    // pieces: [(bytes-like log, first_frame1, n_frames)]; delay_ms: sleep before every piece; fail_after: raise after that many.
+    m.def("_multi_gpu_protocol_selftest",
+          [](int world_size, int rank, int master_port, const std::string& database_path, py::list pieces, int delay_ms, int fail_after) {
+              struct Piece {
+                  std::string bytes;
+                  int32_t first;
+                  int frames;
+              };
+              std::vector<Piece> ps;
+              for (const py::handle& h : pieces) {
+                  const py::tuple t = h.cast<py::tuple>();
+                  ps.push_back(Piece{t[0].cast<py::bytes>(), t[1].cast<int32_t>(), t[2].cast<int>()});
+              }
+              MultiGpuConfig cfg;
+              cfg.world_size = world_size;
+              cfg.rank = rank;
+              cfg.master_port = master_port;
+              cfg.transport = "tcp";
+              cfg.connect_timeout_s = 60.0;
+              cfg.synthetic_shard = [&](int, const std::function<void(const void*, size_t, int32_t, int)>& emit) {
+                  int sent = 0;
+                  for (const Piece& p : ps) {
+                      if (fail_after >= 0 && sent == fail_after) throw std::runtime_error("synthetic shard failed on purpose");
+                      if (delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
+                      emit(p.bytes.data(), p.bytes.size(), p.first, p.frames);
+                      sent++;
+                  }
+                  if (fail_after >= 0 && sent == fail_after) throw std::runtime_error("synthetic shard failed on purpose");
+              };
+              MultiGpuResult r;
+              {
+                  py::gil_scoped_release release;
+                  r = GenerateOpticalFlowDatabaseMultiGpu(VideoInfo{}, nullptr, nullptr, database_path, cfg);
+              }
+              py::dict out;
+              out["pieces"] = r.pieces;
+              out["bytes_moved"] = r.bytes_moved;
+              out["cancelled"] = r.cancelled;
+              out["keypoint_rows_written"] = r.stats.keypoint_rows_written;
+              out["flow_rows_written"] = r.stats.flow_rows_written;
+              return out;
+          },
+          py::arg("world_size"), py::arg("rank"), py::arg("master_port"), py::arg("database_path"), py::arg("pieces"),
+          py::arg("delay_ms") = 0, py::arg("fail_after") = -1);
     py::class_<OpticalFlowRecordWriter>(m, "OpticalFlowRecordWriter")
         .def(py::init<const std::string&>(), py::arg("database_path"))
         .def("write",

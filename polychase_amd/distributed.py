@@ -545,246 +545,10 @@ def make_log_stitch(log, group=None, side_group=None, prefer: str = "rccl"):
     return ChunkedLogStitch(log, group=group, side_group=side_group)
 
 
-class OrderedPieceGather:
-    """The stitch of the multi-rank analysis (polychase_amd/analyze.py): the pieces of every rank's record log travel to
-    rank 0, which receives them IN FRAME ORDER -- all of rank 1, then all of rank 2, ... -- while the analysis keeps
-    running (the store of cpp/opticalflow.cc:149-151 overlapped with the frame loop).  Memory is bounded everywhere: a
-    sender holds at most `depth` staged pieces, the receiver `depth` received ones; a rank whose pieces are not wanted
-    yet simply stops analysing (its on_piece call blocks).
-
-    Flow control is by CREDIT: rank 0 tells rank r "send your next piece" over the control group (gloo: CPU tensors, a
-    blocking host wait -- no RCCL kernel sits on a GPU spinning for a peer that is minutes away), rank r answers with a
-    header [bytes, frames, first_frame1] on the control group and the payload on the payload group (RCCL send / recv of
-    exactly `bytes` bytes, device to device over xGMI; under a gloo payload group the staging is host memory).
-    bytes == 0 ends a rank's stream, bytes < 0 reports its failure.
-
-        sender (rank > 0):   g.put(view_of_the_log, first_frame1, n_frames) per piece ... g.finish()
-        receiver (rank 0):   g.start() ... for rank, first_frame1, n_frames, host_bytes in g.pieces(): store(host_bytes)
-    """
-
-    def __init__(self, group=None, ctl_group=None, device=None, depth: int = 2):
-        import queue
-        import threading
-
-        import torch.distributed as dist
-
-        self.dist = dist
-        self.group, self.ctl = group, (ctl_group if ctl_group is not None else group)
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        self.on_host = dist.get_backend(group) != "nccl"      # gloo carries host tensors
-        self.device = device
-        self.depth = depth
-        self._q = queue.Queue(maxsize=depth)
-        self._free = queue.Queue()
-        self._thread = None
-        self._error = None
-        self._threading = threading
-        self.bytes_moved = 0
-        self.seconds_blocked = 0.0    # sender: on_piece waited for a staging slot (back-pressure from the store)
-
-    # ---------------------------------------------------------------- sender (rank > 0)
-    def _staging(self, nbytes: int):
-        import torch
-
-        try:
-            buf = self._free.get_nowait()
-        except Exception:
-            buf = None
-        if buf is None or buf.numel() < nbytes:
-            cap = int(nbytes * 1.25) + 4096
-            if self.on_host:
-                buf = torch.empty(cap, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
-            else:
-                buf = torch.empty(cap, dtype=torch.uint8, device=self.device)
-        return buf
-
-    def put(self, view, first_frame1: int, n_frames: int):
-        """view: uint8 tensor (a part of the device log whose records are complete).  Copied into a staging buffer and
-        queued; returns when the copy has finished (the log part may then be overwritten).  Blocks while `depth` pieces
-        are waiting for rank 0."""
-        import time
-
-        import torch
-
-        if self._error:
-            raise self._error
-        if self._thread is None:
-            self._allocated = 0
-            self._thread = self._threading.Thread(target=self._send_loop, daemon=True)
-            self._thread.start()
-        t0 = time.perf_counter()
-        while self._q.full():          # back-pressure: rank 0 has not asked for the earlier pieces yet
-            if self._error:
-                raise self._error
-            time.sleep(0.001)
-        self.seconds_blocked += time.perf_counter() - t0
-        n = int(view.numel())
-        buf = self._staging(n)
-        buf[:n].copy_(view)
-        if view.is_cuda:
-            torch.cuda.current_stream(view.device).synchronize()
-        self._q.put((buf, n, int(first_frame1), int(n_frames)))
-
-    def finish(self, failed: bool = False):
-        """No more pieces from this rank (failed: tell rank 0 the records are incomplete)."""
-        import queue
-        import time
-
-        if self.rank == 0:
-            return
-        if self._error:                       # the sender thread died (rank 0 is gone, a send failed): nothing more to say
-            raise self._error
-        if self._thread is None:
-            self._thread = self._threading.Thread(target=self._send_loop, daemon=True)
-            self._thread.start()
-        item = (None, -1 if failed else 0, 0, 0)
-        while True:
-            # never block on a full queue whose consumer has died: re-check the thread between short waits
-            if self._error:
-                raise self._error
-            if not self._thread.is_alive():
-                raise RuntimeError("the piece sender thread ended before the end-of-stream marker could be queued")
-            try:
-                self._q.put(item, timeout=0.05)
-                break
-            except queue.Full:
-                continue
-        while self._thread.is_alive():
-            self._thread.join(timeout=0.1)
-            if self._error:
-                break
-        if self._error:
-            raise self._error
-
-    def abort(self):
-        """Rank 0: its own part failed -- tell every rank still waiting for a credit to stop (a negative credit), so that
-        nobody sits in recv() until the process group's timeout.  Safe to call whether or not start() ran."""
-        import torch
-
-        if self.rank != 0:
-            return
-        self._aborted = True
-        if self._thread is not None:
-            # the receiver owns the control channel: it sends the negative credits itself.  It may be parked in a put() on the
-            # full output queue (nobody consumes while rank 0 works on its own shard): every put() of the loop is a timed one
-            # that re-checks _aborted, so it gets there within a tick -- wait for it, so that the other ranks have their
-            # answer before the caller's exception travels on (a caller that catches it keeps the process alive)
-            self._thread.join(timeout=30.0)
-            return
-        for r in range(1, self.world):
-            try:
-                self.dist.send(torch.full((1,), -1, dtype=torch.int64), dst=r, group=self.ctl)
-            except Exception:
-                pass
-
-    def _send_loop(self):
-        import torch
-
-        dist = self.dist
-        try:
-            if not self.on_host:
-                torch.cuda.set_device(self.device)     # a new thread starts on device 0
-            while True:
-                buf, n, first, frames = self._q.get()
-                credit = torch.zeros(1, dtype=torch.int64)
-                dist.recv(credit, src=0, group=self.ctl)                       # rank 0 wants the next piece
-                if int(credit.item()) < 0:
-                    raise RuntimeError("rank 0 aborted the run: its own part of the analysis failed")
-                dist.send(torch.tensor([n, frames, first], dtype=torch.int64), dst=0, group=self.ctl)
-                if buf is None:
-                    return
-                dist.send(buf[:n], dst=0, group=self.group)
-                if not self.on_host:
-                    torch.cuda.current_stream(buf.device).synchronize()
-                self.bytes_moved += n
-                self._free.put(buf)
-        except BaseException as e:     # surfaces in put() / finish()
-            self._error = e
-
-    # ---------------------------------------------------------------- receiver (rank 0)
-    def start(self):
-        """Rank 0: start receiving now (rank 1 is asked for its first piece at once); `pieces()` hands them out."""
-        import queue
-
-        import torch
-
-        assert self.rank == 0 and self._thread is None
-        out = self._out = queue.Queue(maxsize=self.depth)
-        dist = self.dist
-
-        def hand_over(item) -> bool:
-            """queue a received piece for pieces(); False when the run was aborted meanwhile (the piece is dropped).  Never a
-            blocking put: after rank 0's own failure nobody drains the queue any more"""
-            while not getattr(self, "_aborted", False):
-                try:
-                    out.put(item, timeout=0.05)
-                    return True
-                except queue.Full:
-                    continue
-            return False
-
-        def recv_loop():
-            try:
-                if not self.on_host:
-                    torch.cuda.set_device(self.device)
-                dev_buf = None
-                for r in range(1, self.world):
-                    while True:
-                        if getattr(self, "_aborted", False):
-                            # rank 0's own shard failed: a negative credit to this rank and every later one, then stop
-                            for rr in range(r, self.world):
-                                dist.send(torch.full((1,), -1, dtype=torch.int64), dst=rr, group=self.ctl)
-                            raise RuntimeError("aborted by rank 0")
-                        dist.send(torch.ones(1, dtype=torch.int64), dst=r, group=self.ctl)
-                        hdr = torch.zeros(3, dtype=torch.int64)
-                        dist.recv(hdr, src=r, group=self.ctl)
-                        n, frames, first = (int(v) for v in hdr)
-                        if n < 0:
-                            raise RuntimeError(f"rank {r} failed: its records are incomplete")
-                        if n == 0:
-                            break
-                        if self.on_host:
-                            host = torch.empty(n, dtype=torch.uint8)
-                            dist.recv(host, src=r, group=self.group)
-                        else:
-                            if dev_buf is None or dev_buf.numel() < n:
-                                dev_buf = torch.empty(int(n * 1.25) + 4096, dtype=torch.uint8, device=self.device)
-                            dist.recv(dev_buf[:n], src=r, group=self.group)
-                            host = torch.empty(n, dtype=torch.uint8, pin_memory=True)
-                            host.copy_(dev_buf[:n])
-                            torch.cuda.current_stream(dev_buf.device).synchronize()
-                        self.bytes_moved += n
-                        hand_over((r, first, frames, host.numpy()))   # (aborted: the next turn of the loop sends the negative credits)
-                if not hand_over(None):
-                    raise RuntimeError("aborted by rank 0")
-            except BaseException as e:
-                # the consumer must see the error, but must not be waited for: make room if the queue is full
-                while True:
-                    try:
-                        out.put_nowait(e)
-                        break
-                    except queue.Full:
-                        try:
-                            out.get_nowait()
-                        except queue.Empty:
-                            pass
-
-        self._thread = self._threading.Thread(target=recv_loop, daemon=True)
-        self._thread.start()
-
-    def pieces(self):
-        """Rank 0, after start(): generator over (rank, first_frame1, n_frames, numpy uint8 array) in frame order;
-        receiving the next piece overlaps whatever the consumer does with the current one."""
-        while True:
-            item = self._out.get()
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            yield item
-        self._thread.join()
-
-
+# (The ordered, credit-controlled hand-over of a rank's record log to rank 0 -- the PRODUCT's stitch -- lives in ONE place since round
+# 6: csrc/host/multi_gpu.cc, reached through polychase_core.generate_optical_flow_database_multi_gpu; rounds 3-5 also carried a
+# Python implementation of the same protocol here, OrderedPieceGather.  What stays in this module is the benchmark's side: the
+# all-gather stitches of bench.py --gpus N, and the record format's pack / parse helpers.)
 def parse_device_log(buf: np.ndarray, used: int):
     """buf: uint8 array of one rank's log.  -> records like pack_records' input."""
     out, o = [], 0

@@ -259,111 +259,76 @@ def test_record_log_roundtrip_and_corruption():
 
 
 # ----------------------------------------------------------------------------------------------
-# The streamed stitch of the product (polychase_amd/analyze.py): pieces of the ranks' logs travel to rank 0 in frame
-# order under credit flow control (distributed.OrderedPieceGather) and are stored as they arrive.
+# The streamed stitch of the PRODUCT (polychase_amd/analyze.py -> csrc/host/multi_gpu.cc: GenerateOpticalFlowDatabaseMultiGpu): pieces
+# of the ranks' logs travel to rank 0 in frame order under credit flow control and are stored as they arrive.  ONE implementation
+# since round 6 (the Python twin of rounds 3-5 is gone): these tests drive the C++ protocol itself on this GPU-less box through its
+# testing aid -- a rank's shard given as ready-made record logs, payload over the control connection (transport "tcp");
+# polychase_core._multi_gpu_protocol_selftest.  World sizes 2 and 3, one process per rank.
 # ----------------------------------------------------------------------------------------------
-def _gather_worker(rank, world, port, first, n, out_dir, per, delay_start):
-    import time
-
-    import torch
-    import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    b, e = D.shard_range(first, n, world, rank)
-    g = D.OrderedPieceGather(depth=2)
+def _protocol_worker(rank, world, port, first, n, out_dir, per, delay_ms, fail_rank, fail_after, q):
     core = _core()
-    if rank == 0:
-        if delay_start:
-            time.sleep(delay_start)            # the senders fill their queues and block meanwhile
-        g.start()
-        own = D.pack_device_log([fake_record(f, first, n) for f in range(b, e)])
-        w = core.OpticalFlowRecordWriter(os.path.join(out_dir, "streamed.db"))
-        w.write(own, len(own))
-        order = []
-        for r, piece_first, frames, host in g.pieces():
-            order.append((r, piece_first, frames))
-            w.write(host, len(host))
-        w.close()
-        # frame order: ranks ascending, within a rank the pieces ascending and contiguous
-        expect = []
-        for r in range(1, world):
-            rb, re_ = D.shard_range(first, n, world, r)
-            expect += [(r, f, min(per, re_ - f)) for f in range(rb, re_, per)]
-        assert order == expect, (order, expect)
-    else:
-        log_np, bounds = _fake_log(range(b, e), first, n)
-        log = torch.from_numpy(log_np) if len(log_np) else torch.zeros(0, dtype=torch.uint8)
-        for lo in range(0, e - b, per):
-            hi = min(lo + per, e - b)
-            g.put(log[bounds[lo]:bounds[hi]], b + lo, hi - lo)
-        g.finish()
-        if delay_start and (e - b + per - 1) // per > 3:
-            assert g.seconds_blocked > 0.2, "more pieces than the queue holds must have waited for rank 0"
-    dist.barrier()
-    dist.destroy_process_group()
+    b, e = D.shard_range(first, n, world, rank)
+    pieces = []
+    for lo in range(b, e, per):
+        hi = min(lo + per, e)
+        pieces.append((bytes(D.pack_device_log([fake_record(f, first, n) for f in range(lo, hi)])), lo, hi - lo))
+    try:
+        r = core._multi_gpu_protocol_selftest(world, rank, port, os.path.join(out_dir, "streamed.db"), pieces,
+                                              delay_ms=delay_ms if rank == 0 else 0, fail_after=fail_after if rank == fail_rank else -1)
+        q.put((rank, "ok", int(r["pieces"]), int(r["bytes_moved"]), bool(r["cancelled"])))
+    except RuntimeError as ex:
+        q.put((rank, "error", str(ex), 0, False))
 
 
-@pytest.mark.parametrize("world,n,per,delay", [(2, 21, 3, 0.0), (3, 31, 2, 1.0), (3, 2, 4, 0.0)])
-def test_ordered_piece_gather_streams_the_single_rank_database(tmp_path, world, n, per, delay):
-    import torch.multiprocessing as mp
+def _run_protocol(world, first, n, out_dir, per, delay_ms=0, fail_rank=-1, fail_after=-1):
+    import multiprocessing as mp
+    import time
+    ctx = mp.get_context("spawn")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_protocol_worker, args=(r, world, port, first, n, out_dir, per, delay_ms, fail_rank, fail_after, q))
+             for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=120)
+        got[item[0]] = item
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got, time.time() - t0
+
+
+@pytest.mark.parametrize("world,n,per,delay_ms", [(2, 21, 3, 0), (3, 31, 2, 60), (3, 2, 4, 0)])
+def test_multi_gpu_protocol_streams_the_single_rank_database(tmp_path, world, n, per, delay_ms):
+    """every rank's pieces reach rank 0 in frame order (ranks ascending, a rank's pieces ascending) whatever the timing -- rank 0
+    slow with its own shard (delay_ms per piece: the senders fill their two-deep queues and wait for credits meanwhile), a rank
+    with no frames at all (n = 2 over 3 ranks) -- and the database is the single-rank one, row for row"""
     first = 3
-    mp.spawn(_gather_worker, args=(world, port, first, n, str(tmp_path), per, delay), nprocs=world, join=True)
+    got, _ = _run_protocol(world, first, n, str(tmp_path), per, delay_ms=delay_ms)
+    assert all(v[1] == "ok" for v in got.values()), got
+    sent = sum(got[r][2] for r in range(1, world))
+    assert got[0][2] == sent and got[0][3] == sum(got[r][3] for r in range(1, world))      # pieces / bytes received == sent
+    expect_pieces = sum(len(range(*D.shard_range(first, n, world, r), per)) for r in range(1, world))
+    assert sent == expect_pieces
     core = _core()
     one = D.pack_device_log([fake_record(f, first, n) for f in range(first, first + n)])
     core.write_optical_flow_records(str(tmp_path / "single.db"), one, len(one))
     assert _db_dump(str(tmp_path / "streamed.db")) == _db_dump(str(tmp_path / "single.db"))
 
 
-def _abort_worker(rank, world, port, mode):
-    """rank 0's own shard fails (mode "abort_before_start": before its receiver runs; "abort_running": while it receives):
-    every other rank must come back with an error quickly instead of sitting in recv(credit)"""
-    import time
-
-    import torch
-    import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    g = D.OrderedPieceGather(depth=2)
-    t0 = time.time()
-    if rank == 0:
-        if mode in ("abort_running", "abort_full_queue"):
-            g.start()
-            # "abort_full_queue" (ADVICE r04): long enough for the receiver to have queued `depth` pieces and to be parked
-            # in the put() of the next one -- nobody consumes while rank 0 is busy with its own shard
-            time.sleep(1.5 if mode == "abort_full_queue" else 0.3)
-        if mode == "abort_full_queue":
-            assert g._out.full(), "the receiver should be blocked on the full output queue by now"
-        t_abort = time.time()
-        g.abort()
-        assert time.time() - t_abort < 5 and not g._thread.is_alive() if g._thread is not None else True
-        if mode in ("abort_running", "abort_full_queue"):
-            with pytest.raises(RuntimeError):
-                for _ in g.pieces():
-                    pass
-    else:
-        payload = torch.arange(64, dtype=torch.uint8)
-        with pytest.raises(RuntimeError, match="rank 0 aborted|sender thread"):
-            for k in range(50):                      # far more pieces than the queue holds: put() must not block for ever either
-                g.put(payload, 10 * rank + k, 1)
-            g.finish()
-        # the original error is reported again by finish(), at once, although the queue is full and nobody drains it
-        with pytest.raises(RuntimeError):
-            g.finish(failed=True)
-    assert time.time() - t0 < 20, "a rank waited for the process group's timeout"
-    dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("mode", ["abort_before_start", "abort_running", "abort_full_queue"])
-def test_ordered_piece_gather_rank0_failure_releases_the_other_ranks(mode):
-    """rank 0's shard throws while the other ranks wait for credits / sit on a full queue -- nobody may hang."""
-    import torch.multiprocessing as mp
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    mp.spawn(_abort_worker, args=(3, port, mode), nprocs=3, join=True)
+@pytest.mark.parametrize("fail_rank,fail_after", [(0, 0), (0, 2), (2, 1), (1, 0)])
+def test_multi_gpu_protocol_a_failing_rank_releases_every_rank(tmp_path, fail_rank, fail_after):
+    """a rank's shard throws -- rank 0 before or while it receives, another rank between two pieces -- while the
+    others wait for credits or sit on a full queue: EVERY rank comes back with an error, quickly, nobody hangs"""
+    got, seconds = _run_protocol(3, 1, 40, str(tmp_path), 2, delay_ms=20, fail_rank=fail_rank, fail_after=fail_after)
+    assert seconds < 60
+    assert all(v[1] == "error" for v in got.values()), got
+    assert "on purpose" in got[fail_rank][2]
 
 
 def test_record_writer_refuses_other_keypoints(tmp_path):
