@@ -543,7 +543,7 @@ void launch_pnp_cost(const float* X, const float* x, const float* w, int n, cons
 // another workgroup will read is written with agent-scope atomic stores and read either with agent-scope atomic loads (the
 // round word, the parameters) or with plain loads behind ONE acquire fence in the reading workgroup (the partials).
 // Co-residency: at most 256 workgroups of 256 lanes (one per CU of this chip), 12 KB of LDS each: every workgroup of the launch
-// is resident as long as 272 of every SIMD's 512 registers are free (the kernel holds 270 per lane: a lane's correspondences
+// is resident as long as 288 of every SIMD's 512 registers are free (the kernel holds 281 per lane: a lane's correspondences
 // live in registers), and nothing else on the GPU waits for this kernel.  The spin
 // loops sleep between polls and give up after kTrackSpinLimit ticks (status 2) instead of hanging: the host then solves the
 // frame -- and the rest of the run -- with the per-source building blocks (csrc/host/track_sequence.cc).

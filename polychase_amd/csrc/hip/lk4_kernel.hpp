@@ -183,7 +183,7 @@ static inline float lk4_division_threshold(float thr, float c) {
 }
 
 template <int WIN, bool X86>
-__global__ __launch_bounds__(64) void lk4_kernel(const LKParams p) {
+__global__ __launch_bounds__(64, (WIN <= 16 ? 3 : 1)) void lk4_kernel(const LKParams p) {
     using G = LK4Geo<WIN>;
     constexpr int GL = G::GL, NPX = G::NPX, NCH = G::NCH, H1 = G::H1, H2 = G::H2;
     constexpr int KW = (NPX + 63) / 64;   // pixels per lane in the wave-wide I-side pass

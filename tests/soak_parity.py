@@ -40,7 +40,7 @@ def main() -> int:
                 T.test_random_clip_through_the_analyzer(ctx, seed)
             if seed % 3 == 0:    # every third: the detector's other branches and the arithmetic modes
                 T.test_random_detector_branch_and_arithmetic_mode(ctx, seed)
-            if seed % 2 == 0:    # every second: the x86 summation order on the two-keypoint kernel, hard content, windows 4-11
+            if seed % 2 == 0:    # every second: the x86 summation order on hard content, every window 3..31 (both product kernels)
                 A.test_x86_order_on_the_two_keypoint_kernel_random(ctx, seed)
         except AssertionError as e:
             import traceback
@@ -80,7 +80,7 @@ def fan_out(args) -> int:
     out = {"first_seed": args.first, "cases": args.count, "jobs": len(procs), "mismatches": sum(p["mismatches"] for p in parts),
            "failures": [f for p in parts for f in p["failures"]], "seconds": round(time.time() - t0, 1),
            "what": "per seed: test_random_configuration (default arithmetic = opencv_x86); every 10th a whole clip through the analyzer; "
-                   "every 3rd the detector branches x arithmetic modes; every 2nd the x86 LK order on hard content, windows 4-11"}
+                   "every 3rd the detector branches x arithmetic modes; every 2nd the x86 LK order on hard content, windows 3-31"}
     print(json.dumps(out))
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)

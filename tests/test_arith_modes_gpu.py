@@ -145,15 +145,16 @@ def _hard(rng, w, h, kind):
     return np.repeat(np.clip(img, 0, 255).astype(np.uint8)[:, :, None], 3, axis=2)
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(106))
 def test_x86_order_on_the_two_keypoint_kernel_random(ctx, seed):
-    """Windows 4-11 in PC_ARITH_LK_X86_ORDER run the two-keypoint kernel: the canonical integer data path plus a proof that
-    the fp32 sums of the x86 order are exact, and the x86 order itself where the proof fails.  Random content of three
-    kinds (proof always fails / fails at edges / always holds), every window, 1-8 targets, odd keypoint counts -- bit for
-    bit against the oracle's emulation, and the diagnostics counters must add up."""
+    """Windows 4-11 in PC_ARITH_LK_X86_ORDER run the two-keypoint kernel, 3 and 12-31 the eight-lanes-per-target kernel (seeds from
+    48 on: every window 3..31 in turn): the canonical integer data path plus a proof that the fp32 sums of the x86 order are exact,
+    and the x86 order itself where the proof fails.  Random content of three kinds (proof always fails / fails at edges / always
+    holds), every window, 1-8 targets, odd keypoint counts -- bit for bit against the oracle's emulation, and the diagnostics
+    counters must add up."""
     rng = np.random.default_rng(77000 + seed)
-    win = 4 + seed % 8
-    kind = ["noise", "binary", "smooth"][(seed // 8) % 3]
+    win = 4 + seed % 8 if seed < 48 else 3 + (seed - 48) % 29
+    kind = ["noise", "binary", "smooth"][(seed // 8) % 3] if seed < 48 else ["noise", "binary", "smooth"][seed % 3]
     w, h = int(rng.integers(60, 260)), int(rng.integers(60, 200))
     max_level = int(rng.integers(0, 4))
     n_targets = int(rng.integers(1, 9))

@@ -64,14 +64,15 @@ def test_two_ranks_on_one_gpu_over_gloo(stitch):
     _check_multi_gpu_keys(out, 2, peer=stitch == "peer", peer_wanted=stitch != "rccl")
 
 
-def _check_multi_gpu_keys(out, n, peer, peer_wanted, arith_modes=True):
+def _check_multi_gpu_keys(out, n, peer, peer_wanted, arith_modes=True, top=True):
     """what ONE N-GPU run must return: both stitches and the analysis-only rate of the same job,
     per-rank step times, the exposed stitch time, bytes per second per peer link, world size and backend"""
     assert out["world_size"] == n and out["collectives_backend"] in ("nccl", "gloo")
     # VERDICT r05 #8: the N > 1 figure is labelled analysis-only and carries the writer-bound product rate beside it
     assert out["claim"].startswith("analysis-only (no insert)")
     assert out["product_rate_with_insert"].get("value", 0) > 0, out["product_rate_with_insert"]
-    assert "host" in out and "thread_placement" in out["host"] and out["gpu_busy_ms_per_step"] > 0
+    assert out["gpu_busy_ms_per_step"] > 0
+    assert not top or ("host" in out and "thread_placement" in out["host"])      # (the line's, not a nested block's)
     assert out["config"]["arith"] == "opencv_x86" and (not arith_modes or set(out["arith_modes"]) >= {"opencv_x86", "canonical"})
     ab = out["stitch_ab"]
     assert "rccl" in ab and ab["rccl"]["stitch"].startswith("rccl all_gather")
@@ -172,7 +173,7 @@ def test_c4_label_of_the_nested_4k_block_with_two_ranks():
     # copies (distributed.PeerLogStitch; here both buffers live on GPU 0) -- and what ONE N-GPU run must return, headline and nested
     assert out["config"]["stitch"].startswith("xgmi peer copies"), (out["config"]["stitch"], r.stderr[-2000:])
     _check_multi_gpu_keys(out, 2, peer=True, peer_wanted=True, arith_modes=False)
-    _check_multi_gpu_keys(c4, 2, peer=True, peer_wanted=True, arith_modes=False)
+    _check_multi_gpu_keys(c4, 2, peer=True, peer_wanted=True, arith_modes=False, top=False)
 
 
 def test_one_gpu_line_carries_roofline_counters_arith_modes_and_c5():

@@ -45,29 +45,15 @@ def _hash(extra_env, size=(416, 304, 26)):
 
 
 @pytest.fixture(scope="module")
-def all_hashes():
-    """every variant's process, four at a time (a process is ~3 s of interpreter + runtime start-up around a 26-frame clip: VERDICT
-    r05 #7, the suite's time); a variant that fails keeps its exception for its own test"""
-    from concurrent.futures import ThreadPoolExecutor
-
-    def one(v):
-        try:
-            return _hash(v)
-        except BaseException as e:   # noqa: BLE001 -- re-raised by the test of that variant
-            return e
-    jobs = [{}] + VARIANTS
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        got = list(ex.map(one, jobs))
-    return {tuple(sorted(j.items())): g for j, g in zip(jobs, got)}
+def reference_hash():
+    return _hash({})
 
 
+# (Round 6 tried the variants' processes four at a time to save suite time: 307 s instead of 48 -- processes that share the GPU
+# time-slice whole contexts, and the analyzer's stream gates spin meanwhile.  One after the other.)
 @pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
-def test_knob_does_not_change_the_database(all_hashes, variant):
-    ref, got = all_hashes[()], all_hashes[tuple(sorted(variant.items()))]
-    for h in (ref, got):
-        if isinstance(h, BaseException):
-            raise h
-    assert got == ref
+def test_knob_does_not_change_the_database(reference_hash, variant):
+    assert _hash(variant) == reference_hash
 
 
 def test_the_three_min_eig_kernels_agree_in_the_row_fma_mode():
