@@ -461,7 +461,7 @@ typedef struct pc_track_solve_result {
     int rounds;                   /* parameter sets evaluated by the persistent launch */
     /* where the persistent launch spent its time, measured by its deciding workgroup in 100 MHz ticks and summed over the
      * rounds: [0] residual sweep + publishing the partial sums, [1] waiting for the other workgroups, [2] adding the
-     * partials, [3] the decision (9x9 algebra, one lane), [4] publishing it, [5] fetching the next parameters,
+     * partials, [3] the decision (9x9 algebra; by a wavefront since round 6), [4] publishing it, [5] fetching the next parameters,
      * [6] inlier pass, [7] the whole launch */
     unsigned lm_ticks[8];
     unsigned long long lm_begin_tick, lm_end_tick;   /* the GPU's 100 MHz clock when the LM kernel began / handed over its result */

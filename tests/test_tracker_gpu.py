@@ -155,7 +155,7 @@ def test_pnp_intrinsics_refinement(core):
         core._solve_pnp_iterative(Xw[:2].astype(np.float32), x[:2].astype(np.float32), init, core.BundleOptions(), 12.0, False, False)
 
 
-def _build_flow_db(core, path, verts, tris, model, n_frames, n_kp=300, noise=0.0, seed=3):
+def _build_flow_db(core, path, verts, tris, model, n_frames, n_kp=300, noise=0.0, seed=3, skips=(-8, -4, -2, -1, 1, 2, 4, 8)):
     """keypoints at random pixels; flow f -> f+s = analytic reprojection of the mesh point under the
     keypoint (so the true trajectory explains every match exactly when noise == 0)."""
     rng = np.random.default_rng(seed)
@@ -172,7 +172,7 @@ def _build_flow_db(core, path, verts, tris, model, n_frames, n_kp=300, noise=0.0
         db.write_keypoints(f, xy)
     for f in range(1, n_frames + 1):
         pw, hit = world[f]
-        for s in (-8, -4, -2, -1, 1, 2, 4, 8):
+        for s in skips:
             g = f + s
             if g < 1 or g > n_frames:
                 continue
@@ -713,6 +713,34 @@ def test_pipelined_solve_frame_semantics(core, tmp_path, monkeypatch):
         core.track_sequence(path, 1, n_frames, core.SceneTransformations(model, view4(R0, t0), intr(core)), mesh,
                             lambda r: seen.update({r.frame: 1}) or True, False, False, bo)
     assert sorted(seen) == [2, 3, 4, 5, 6, 7, 8]
+
+
+def test_more_flows_into_a_frame_than_the_reference_skips_make(core, tmp_path, monkeypatch):
+    """SolveFrame takes ANY number of flows into a frame (tracker.cc:43-50); the fused path holds eight sources (the skips
+    of cpp/opticalflow.cc:76-77) and used to CHECK-fail on a database written with another skip set.  Eighteen skips: forward
+    tracking reaches nine filled sources at frame 13 -- from there on the per-source building blocks solve (no abort), every frame is
+    reported once, and the poses are those of a run that used the building blocks throughout (to the order of the fp32 sums)."""
+    verts, tris = grid_mesh()
+    model = np.diag([1.5, 1.5, 1.5, 1.0]).astype(np.float32)
+    n_frames = 18
+    path = str(tmp_path / "dense.db")
+    _build_flow_db(core, path, verts, tris, model, n_frames, noise=0.05, skips=(-12, -10, -8, -6, -5, -4, -3, -2, -1, 1, 2, 3, 4, 5, 6, 8, 10, 12))
+    mesh = core.AcceleratedMesh(verts, tris)
+    bo = core.BundleOptions()
+
+    def run():
+        R0, t0 = true_pose(1)
+        got = {}
+        core.track_sequence(path, 1, n_frames, core.SceneTransformations(model, view4(R0, t0), intr(core)), mesh,
+                            lambda r: got.update({r.frame: (np.array(r.pose.q, float), np.array(r.pose.t, float))}) or True, False, False, bo)
+        return got
+    fused = run()
+    monkeypatch.setenv("POLYCHASE_TRACK_FUSED", "0")
+    blocks = run()
+    monkeypatch.delenv("POLYCHASE_TRACK_FUSED", raising=False)
+    assert sorted(fused) == sorted(blocks) == list(range(2, n_frames + 1))
+    for f in fused:
+        assert np.abs(fused[f][0] - blocks[f][0]).max() < 5e-6 and np.abs(fused[f][1] - blocks[f][1]).max() < 5e-5, f
 
 
 def test_what_a_run_keeps_for_the_next_one_does_not_leak_into_it(core, tmp_path, monkeypatch):
