@@ -16,8 +16,9 @@
 //     the groups through LDS in the layout the iteration consumes: one 16-byte ENTRY per (chain, step, lane) =
 //     {bias of the upper-run pixel, bias of the lower-run pixel, (ix_upper, ix_lower), (iy_upper, iy_lower)} -- a chain is walked as
 //     two runs (rows 0 .. H1-1 and H1 .. WIN-1) whose step-s pixels share the v_perm + 2 v_dot2 that accumulate the mismatch
-//     vector (3 instructions per two pixels).  Windows up to 16 px keep their entries in REGISTERS for the level (64 VGPRs),
-//     larger ones read them with one ds_read_b128 per two pixels (a 31-px window would need 248 registers).
+//     vector (3 instructions per two pixels).  Windows up to 21 px keep their entries in REGISTERS for the level (64 VGPRs at
+//     16 px, 132 at 21), larger ones read them with one ds_read_b128 per two pixels (a 31-px window would need 248 registers;
+//     24 px in registers: one wavefront per SIMD, measured 4-12 % slower).
 //   * Sums are exact integers, reduced over the group with DPP adds, ONE rounding (== the oracle's (float)(int64)).
 //   * X86 (PC_ARITH_LK_X86_ORDER): the canonical data path plus the PROOF that OpenCV's fp32 lane sums would be exact
 //     (kernels_lk3.hip: S11, S22 < 2^24 per level, sum d^2 * max(S11, S22) <= 2^48 per iteration); where it fails, the sums
@@ -49,7 +50,7 @@ struct LK4Geo {
     static constexpr int I_DW = I_ROWS * I_PITCH;              // I window, same format
     static constexpr int D_PITCH = WIN + 1, D_DW = (((WIN + 1) * (WIN + 1)) + 3) & ~3;   // raw Scharr window
     static constexpr int X_DW = NCH * H1 * GL * 4;             // the entries (see the header)
-    static constexpr bool REG = WIN <= 16;                     // entries in registers for the level
+    static constexpr bool REG = WIN <= 21;                     // entries in registers for the level
     // x86 order
     static constexpr int SIMD_W = (WIN / 8) * 8, NB = SIMD_W / 8, NXS = WIN - SIMD_W, NS = NXS * WIN;
     static constexpr int CL = WIN * (SIMD_W / 4);              // terms of a vector lane's chain (structure tensor)
@@ -183,7 +184,7 @@ static inline float lk4_division_threshold(float thr, float c) {
 }
 
 template <int WIN, bool X86>
-__global__ __launch_bounds__(64, (WIN <= 16 ? 3 : 1)) void lk4_kernel(const LKParams p) {
+__global__ __launch_bounds__(64, (WIN <= 16 ? 3 : (WIN <= 21 ? 2 : 1))) void lk4_kernel(const LKParams p) {
     using G = LK4Geo<WIN>;
     constexpr int GL = G::GL, NPX = G::NPX, NCH = G::NCH, H1 = G::H1, H2 = G::H2;
     constexpr int KW = (NPX + 63) / 64;   // pixels per lane in the wave-wide I-side pass
