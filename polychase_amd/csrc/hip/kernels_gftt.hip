@@ -1243,8 +1243,14 @@ __global__ __launch_bounds__(256) void suppress_large_radius_kernel(const unsign
         *n_out = (max_corners > 0 && total > max_corners) ? max_corners : total;
     }
 }
+// cell size of the grid: ceil(min_distance), at most the frame's larger side (a radius beyond that: one cell -- and no overflow of
+// the conversion for absurd values)
+static int suppress_large_cell(int w, int h, double min_distance) {
+    const double side = (double)std::max(w, h);
+    return std::max(1, (int)std::ceil(std::min(min_distance, side)));
+}
 int suppress_large_grid_words(int w, int h, double min_distance) {
-    const int cell = (int)std::ceil(min_distance);
+    const int cell = suppress_large_cell(w, h, min_distance);
     return ((w + cell - 1) / cell) * ((h + cell - 1) / cell) * kLargeCellWords;
 }
 
@@ -1265,7 +1271,7 @@ void launch_suppress_and_compact(const unsigned long long* keys, uint32_t n_max,
     if (nb == 0) return;
     const AcceptedScan fin{tickets, n_out, overflow, max_corners};
     if (suppress && large_grid) {
-        const int cell = (int)std::ceil(large_min_distance), gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+        const int cell = suppress_large_cell(w, h, large_min_distance), gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
         (void)hipMemsetAsync(large_grid, 0, (size_t)gw * gh * kLargeCellWords * sizeof(uint32_t), s);
         hipLaunchKernelGGL(suppress_large_radius_kernel, dim3(1), dim3(256), 0, s, keys, n_max, n_dev, w, cstate, large_min_distance * large_min_distance,
                            cell, gw, gh, large_grid, accepted_per_block, nb, stuck, n_out, overflow, max_corners, helper_prio_arg());

@@ -82,6 +82,7 @@ struct OpticalFlowRunStats {
     double seconds_collect = 0;      // pc_analyzer_collect (waiting for the GPU)
     double seconds_writer_wait = 0;  // RecordWriter::Enqueue / Flush (waiting for SQLite)
     double seconds_callback = 0;     // progress callback + database look-ups of the loop
+    bool engine_reused = false;      // the call took the process's parked engine (context + analyzer) instead of creating one
 };
 
 // ---- entry point -------------------------------------------------------------------------------

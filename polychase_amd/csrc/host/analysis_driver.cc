@@ -405,6 +405,7 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
     if (shard && shard->device >= 0) device = shard->device;   // a rank of the multi-GPU analysis names its GPU itself
     else if (const char* env = std::getenv("POLYCHASE_DEVICE")) device = std::atoi(env);
     std::unique_ptr<Engine> engine = EngineCache::Take(device, video_info.width, video_info.height, gopt, fopt);
+    const bool engine_reused = engine != nullptr;
     if (!engine) {
         engine = std::make_unique<Engine>();
         engine->device = device;
@@ -447,6 +448,7 @@ static void RunAnalysis(const VideoInfo& video_info, FrameAccessorFunction frame
     }
     OpticalFlowRunStats local_stats;
     local_stats.seconds_setup = Now() - t_begin;
+    local_stats.engine_reused = engine_reused;
     struct StageClock {   // adds the time of a scope to one of the stage counters
         double* acc;
         double t0;

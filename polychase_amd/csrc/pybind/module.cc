@@ -374,6 +374,7 @@ PYBIND11_MODULE(polychase_core, m) {
         .def_readonly("seconds_total", &OpticalFlowRunStats::seconds_total)
         .def_readonly("seconds_db", &OpticalFlowRunStats::seconds_db)
         .def_readonly("seconds_setup", &OpticalFlowRunStats::seconds_setup)
+        .def_readonly("engine_reused", &OpticalFlowRunStats::engine_reused)
         .def_readonly("seconds_accessor", &OpticalFlowRunStats::seconds_accessor)
         .def_readonly("seconds_put", &OpticalFlowRunStats::seconds_put)
         .def_readonly("seconds_submit", &OpticalFlowRunStats::seconds_submit)

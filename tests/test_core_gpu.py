@@ -270,13 +270,15 @@ def test_parked_engine_is_reused_and_replaced(core, tmp_path):
     core.release_cached_engine()
     p1, s1 = run(fa, "a1.db")
     p2, s2 = run(fa, "a2.db", first=7)        # same geometry, other frame ids: a stale resident frame must not be found
-    assert s1.seconds_setup > 5 * s2.seconds_setup, (s1.seconds_setup, s2.seconds_setup)   # the second call found the engine
+    # the second call found the engine (the flag; the times -- 10-20 ms against < 1 -- only on a quiet box: round 6 saw 8.5 vs 9.3 ms
+    # of database creation on a busy one)
+    assert s2.engine_reused and not s1.engine_reused, (s1.seconds_setup, s2.seconds_setup)
     p3, _ = run(fb, "b.db")                   # other geometry: the parked engine is replaced
     p4, _ = run(fa, "a4.db", max_level=2)     # other options
     p5, _ = run(fa, "a5.db")
     core.release_cached_engine()
     p6, s6 = run(fa, "a6.db")
-    assert s6.seconds_setup > 5 * s2.seconds_setup
+    assert not s6.engine_reused
     assert _dump(p1) == _dump(p5) == _dump(p6)
     k1, k2 = _dump(p1)[0], _dump(p2)[0]
     assert {f + 6: kv for f, kv in k1.items()} == k2                          # the same keypoints under shifted ids
@@ -326,7 +328,7 @@ def test_parked_engine_is_given_back_after_the_idle_time(tmp_path):
         "from polychase_amd import synth\n"
         "clip = synth.NoiseClip(320, 240, 12); fr = [clip.frame(t) for t in range(12)]\n"
         "def run():\n"
-        "    return core.generate_optical_flow_database(core.VideoInfo(320, 240, 1, 12), lambda f: fr[f - 1], None, '', core.GFTTOptions(), core.OpticalFlowOptions()).seconds_setup\n"
+        "    return int(core.generate_optical_flow_database(core.VideoInfo(320, 240, 1, 12), lambda f: fr[f - 1], None, '', core.GFTTOptions(), core.OpticalFlowOptions()).engine_reused)\n"
         "t0 = core._engine_cache_timer_running()\n"
         "a = run(); t1 = core._engine_cache_timer_running(); b = run(); time.sleep(3.0); t2 = core._engine_cache_timer_running()\n"
         "c = run(); d = run(); t3 = core._engine_cache_timer_running(); core.release_cached_engine(); t4 = core._engine_cache_timer_running()\n"
@@ -336,9 +338,9 @@ def test_parked_engine_is_given_back_after_the_idle_time(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=env, text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     line = [l for l in r.stdout.splitlines() if l.startswith("SETUP")]
     assert r.returncode == 0 and line, r.stderr[-2000:]
-    a, b, c, d = map(float, line[0].split()[1:])
-    assert b < a / 5 and d < c / 5, (a, b, c, d)          # taken from the slot
-    assert c > 5 * b, (a, b, c, d)                        # created again: the idle timer had destroyed the parked engine
+    a, b, c, d = map(int, line[0].split()[1:])            # "the call took the parked engine"
+    assert (a, b) == (0, 1) and d == 1, (a, b, c, d)      # taken from the slot
+    assert c == 0, (a, b, c, d)                           # created again: the idle timer had destroyed the parked engine
     # the timer is a thread that exists only while an engine is parked: none before the first run, one while
     # parked, gone after the idle time fired, one again, joined by release_cached_engine()
     timer = [l for l in r.stdout.splitlines() if l.startswith("TIMER")][0].split()[1:]

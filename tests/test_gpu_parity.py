@@ -161,7 +161,7 @@ def test_harris_and_other_block_sizes(ctx, kw):
         assert np.array_equal(got[fid], oracle.gftt(oracle.rgb2gray(frames[fid]), oracle.gftt_options(**kw)))
 
 
-@pytest.mark.parametrize("kw", [dict(min_distance=65.0), dict(min_distance=100.5, quality_level=0.001), dict(min_distance=300.0),
+@pytest.mark.parametrize("kw", [dict(min_distance=65.0), dict(min_distance=100.5, quality_level=0.001), dict(min_distance=300.0), dict(min_distance=2000.0),
                                 dict(min_distance=64.0), dict(min_distance=80.0, max_corners=7), dict(grid_rows=20, grid_cols=30),
                                 dict(grid_rows=32, grid_cols=32, min_distance=70.0)],
                          ids=lambda kw: ",".join(f"{k}={v}" for k, v in kw.items()))
