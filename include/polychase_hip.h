@@ -36,7 +36,7 @@ extern "C" {
 #define PC_MAX_LEVELS 16      /* a pyramid ends where the next level would be <= the window (>= 3 px): 14 levels at most for the
                                  2^30 pixels a frame may have; any max_level >= 0 is accepted (OpenCV: maxLevel is free) */
 #define PC_MAX_WINDOW 31      /* OpticalFlowOptions.window_size is free in the reference (opticalflow.h:27-33); OpenCV's own default is 21.
-                                 3: lk4, 4..11: the two-keypoint kernel (lk3), 12..31: lk4 (one keypoint per wavefront, 8 lanes per target) */
+                                 3: lk4, 4..10: the two-keypoint kernel (lk3), 11..31: lk4 (one keypoint per wavefront, 8 lanes per target) */
 
 typedef struct pc_context pc_context;
 typedef struct pc_frame pc_frame;

@@ -148,9 +148,9 @@ constexpr int kRecStride = 8;   // records per slot (= PC_MAX_TARGETS)
 // K8-K10: pyramidal LK, one 16-lane DPP row per (keypoint, target).  Returns false if the window
 // size is unsupported.
 bool launch_lk(const LKParams& p, int win, hipStream_t s);
-// two keypoints per wavefront on the uint16 planes, dword-per-position LDS regions (kernels_lk3.hip); windows 4..11
+// two keypoints per wavefront on the uint16 planes, dword-per-position LDS regions (kernels_lk3.hip); windows 4..11 (launch_lk sends 11 to lk4)
 bool launch_lk3(const LKParams& p, int win, hipStream_t s);
-// one keypoint per wavefront, 8 lanes per target, on the uint16 planes (lk4_kernel.hpp); windows 3 and 12..31, spread over
+// one keypoint per wavefront, 8 lanes per target, on the uint16 planes (lk4_kernel.hpp); windows 3 and 11..31, spread over
 // three translation units (kernels_lk4{a,b,c}.hip)
 bool launch_lk4a(const LKParams& p, int win, hipStream_t s);
 bool launch_lk4b(const LKParams& p, int win, hipStream_t s);

@@ -392,8 +392,8 @@ static void launch_lk_t(const LKParams& p0, hipStream_t s) {
 // POLYCHASE_LK_VARIANT=1 forces the generic one-keypoint-per-wavefront kernel of this file (windows up to 16: the cross-check of
 // the two product kernels; round 1's two-keypoint kernel on the u8 planes, kernels_lk2.hip, was removed in round 3 after its last
 // measurement: profiles/r03_c2_lk_variants.jsonl);
-// default: the two-keypoint kernel on the uint16 planes (kernels_lk3.hip) for windows 4..11, the eight-lanes-per-target kernel
-// (lk4_kernel.hpp) for window 3 and windows 12..31
+// default: the two-keypoint kernel on the uint16 planes (kernels_lk3.hip) for windows 4..10, the eight-lanes-per-target kernel
+// (lk4_kernel.hpp) for window 3 and windows 11..31
 static int lk_variant() {
     static const int v = [] {
         const char* e = getenv("POLYCHASE_LK_VARIANT");
@@ -404,6 +404,9 @@ static int lk_variant() {
 
 bool launch_lk(const LKParams& p, int win, hipStream_t s) {
     const int v = lk_variant();
+    // window 11: the eight-lanes-per-target kernel (0.43 ms per C2 launch against 0.62 on the two-keypoint kernel, whose 11-px
+    // instance has no registers left for its unrolled ordered tensor and read-ahead; POLYCHASE_LK_VARIANT=3 keeps it reachable)
+    if (v == 0 && win == 11 && launch_lk4a(p, win, s)) return true;
     if ((v == 0 || v == 3) && launch_lk3(p, win, s)) return true;
     if ((v != 1 || win > 16) && (launch_lk4a(p, win, s) || launch_lk4b(p, win, s) || launch_lk4c(p, win, s))) return true;
     switch (win) {

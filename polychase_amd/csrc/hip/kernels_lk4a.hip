@@ -8,7 +8,7 @@ bool launch_lk4a(const LKParams& p, int win, hipStream_t s) {
     if (!p.src[0].img16) return false;
     switch (win) {
 #define PC_LK_CASE(W) case W: launch_lk4_t<W>(p, s); return true;
-        PC_LK_CASE(3) PC_LK_CASE(12) PC_LK_CASE(13) PC_LK_CASE(14) PC_LK_CASE(15) PC_LK_CASE(16)
+        PC_LK_CASE(3) PC_LK_CASE(11) PC_LK_CASE(12) PC_LK_CASE(13) PC_LK_CASE(14) PC_LK_CASE(15) PC_LK_CASE(16)
 #undef PC_LK_CASE
         default: return false;
     }

@@ -1,5 +1,5 @@
 // lk4_kernel.hpp -- pyramidal Lucas-Kanade (K8-K10) for the windows the two-keypoint kernel does not take: one keypoint per
-// wavefront, EIGHT lanes per target, on the uint16 planes.  Windows 3 and 12 .. PC_MAX_WINDOW (31).
+// wavefront, EIGHT lanes per target, on the uint16 planes.  Windows 3 and 11 .. PC_MAX_WINDOW (31).
 //
 // Same arithmetic and results as kernels_lk.hip / kernels_lk3.hip (bit for bit; all follow oracle/pc_oracle.c, which restates
 // cv::calcOpticalFlowPyrLK as called at reference cpp/opticalflow.cc:119-125 -- OpticalFlowOptions.window_size is a free
